@@ -1,0 +1,196 @@
+/*
+ * satrans_hip.h  --  C ABI of libsatrans_hip.so, the MI355X (gfx950) implementation of the
+ * SATrans scenario-adaptive attention path.
+ *
+ * The reference (qwerfdsaplking/SATrans) is pure Python on PyTorch: it has no FFI of its own, so
+ * the boundary a maintainer binds is the set of tensor-level operations its `SATrans.forward`,
+ * `BaseModel.fit` and `torch.optim.Adam` perform for this path.  Each entry point below names the
+ * reference lines it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless its name starts with `h_`;
+ *   - the caller owns all memory, passes workspaces in, and keeps buffers alive until the stream
+ *     has executed the call; nothing here allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); every kernel is enqueued on
+ *     it, so calls are re-entrant per stream and capturable into a hipGraph;
+ *   - return value: 0 on success, a negative SATRANS_E_* code otherwise; nothing throws across
+ *     the ABI.  `satrans_last_error()` returns a static description of the last failure of the
+ *     calling thread.
+ *   - tensors are dense row-major fp32 unless stated; sizes are in elements.
+ */
+#ifndef SATRANS_HIP_H
+#define SATRANS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SATRANS_ABI_VERSION 1
+
+/* error codes */
+#define SATRANS_OK 0
+#define SATRANS_E_BADARG (-1)      /* null pointer, negative size, unsupported dtype code          */
+#define SATRANS_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for (see below)     */
+#define SATRANS_E_LAUNCH (-3)      /* hipLaunch / runtime error                                    */
+#define SATRANS_E_WORKSPACE (-4)   /* workspace too small                                          */
+
+/* id dtypes accepted wherever ids are read out of the input matrix X */
+#define SATRANS_ID_F32 0 /* ids carried as floats and truncated, reference meta_basemodel.py:311,533-535 */
+#define SATRANS_ID_I32 1
+#define SATRANS_ID_I64 2
+
+/* layer flags (bit mask) */
+#define SATRANS_META_Q 1    /* 'Q' in meta_mode: MetaNet on the query projection, satrans.py:60-66     */
+#define SATRANS_META_K 2    /* 'K' in meta_mode: MetaNet on the key projection,   satrans.py:67-73     */
+#define SATRANS_RELU_OUT 4  /* flag 'relu': ReLU after Out_linear,                 satrans.py:91-92     */
+#define SATRANS_NO_RES 8    /* att_res=False                                                           */
+#define SATRANS_TRAIN 16    /* apply the four dropouts (p = drop_p)                                    */
+#define SATRANS_GATE 32     /* flag 'gate': q,k *= 2*vec instead of the MetaNet,   satrans.py:61-62,68-69 */
+#define SATRANS_BILINEAR 64 /* flag 'bilinear': per-head q_h @ M[s,h],             satrans.py:79-81     */
+
+const char* satrans_last_error(void);
+int satrans_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scenario bucketing.  Reads the scenario id column of X (reference satrans.py:203:
+ * `X[:, feature_index[domain_col][0]].long()`), writes
+ *   sid[B]     scenario row per sample (clamped into [0,S) is NOT done: an id outside [0,S) sets
+ *              status[0] = 1, the caller turns that into the IndexError the reference raises),
+ *   order[B]   sample indices stably grouped by scenario,
+ *   seg[S+1]   start of every scenario's run inside `order`.
+ * x_stride = elements between consecutive samples of X; col = column of the scenario id.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t satrans_bucket_workspace_bytes(int B, int S);
+int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_stride, int col, int B, int S,
+                             int32_t* sid, int32_t* order, int32_t* seg, int32_t* status, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-table embedding gather: reference meta_basemodel.py:533-535 (one nn.Embedding call per
+ * SparseFeat) + concat_fun(axis=1) at satrans.py:211.
+ *   arena      [total_rows, D] fp32: all tables back to back, table f starts at row row_off[f]
+ *   row_off    [F+1] int64 (device)
+ *   cols       [F] int32 (device): X column of field f
+ *   out        [B, F, D]
+ *   rows_out   optional [B, F] int32: arena row of every gathered id (kept for the backward pass)
+ *   status     [1] int32: set to 1 when an id falls outside its table
+ * Bit-exact: every output element is a copy.
+ * ---------------------------------------------------------------------------------------------- */
+int satrans_gather_fwd(const float* arena, const int64_t* row_off, const int32_t* cols, const void* X,
+                       int id_dtype, int64_t x_stride, int B, int F, int D, float* out,
+                       int32_t* rows_out, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One Meta_Transformer_Layer (reference satrans.py:50-100 with MetaNet submodules.py:77-103).
+ * The generated MetaNet weights are passed as per-scenario tables (one row per scenario id) instead
+ * of the reference's per-sample [B,P] matrices; row s = encoder(relu(domain_embeddings[s])), see
+ * satrans_amd/satrans.py.  tab_q / tab_k may alias (no 'pos' flag).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct satrans_layer_desc {
+    int32_t B, F, D, H; /* batch, fields (tokens per sample), embedding dim, heads                   */
+    int32_t U;          /* MetaNet hidden width; generated row = [D*U | U*D] (meta units [D,U,D])    */
+    int32_t S;          /* scenario rows in tab_q / tab_k                                            */
+    int32_t flags;      /* SATRANS_* bit mask                                                        */
+    int32_t layer;      /* layer index, only used to key the dropout counters                        */
+    float drop_p;       /* 0.1 in the reference (satrans.py:27-28)                                   */
+    uint32_t seed, step;
+    int64_t tab_stride; /* elements between scenario rows of tab_q / tab_k                           */
+    const float* x;     /* [B,F,D] layer input                                                       */
+    const int32_t* sid; /* [B]                                                                       */
+    const int32_t* order; /* [B]  from satrans_bucket_scenarios                                      */
+    const int32_t* seg;   /* [S+1]                                                                   */
+    const float *w_query, *w_key, *w_value; /* [D,D], y = x @ W                                      */
+    const float* w_out;                     /* [D,D] nn.Linear weight, y = x @ W^T                   */
+    const float *ln_g, *ln_b;               /* layer_norm                                            */
+    const float *lnq_g, *lnq_b, *lnk_g, *lnk_b; /* Q_/K_meta_mlp.ffn_layer_norm                      */
+    const float *tab_q, *tab_k;             /* [S, >=P]                                              */
+} satrans_layer_desc;
+
+/* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
+int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);
+
+/* Backward of one layer.  Recomputes the forward from d->x (same dropout counters), so nothing but
+ * the layer input is kept between the passes.
+ *   dy        [B,F,D] gradient of the layer output
+ *   dx        [B,F,D] gradient of the layer input (written)
+ *   slabs     workspace, satrans_layer_bwd_slab_floats(d) floats; per-workgroup partial weight gradients
+ *   g_*       gradients of the parameters, ACCUMULATED (+=) in a fixed order (bitwise reproducible):
+ *             g_wq,g_wk,g_wv,g_wo [D,D]; g_ln [2,D]; g_lnq [2,D]; g_lnk [2,D] (gamma row then beta row);
+ *             g_tab_q, g_tab_k [S, tab_stride] (may alias when tab_q == tab_k).                        */
+int64_t satrans_layer_bwd_slab_floats(const satrans_layer_desc* d);
+int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs,
+                      float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
+                      float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head: flatten + [dense columns] + Linear(->1) + sigmoid (reference satrans.py:244-255) and, for
+ * training, BCE(reduction='sum') (meta_basemodel.py:317) with its backward in the same launch.
+ *   a        [B, F*D] last layer output
+ *   dense    float matrix holding the DenseFeat columns (X itself when ids travel as floats), row stride
+ *            dense_stride, dense_cols [n_dense] int32 (device) = its columns in feature order; may be null
+ *   w        [F*D + n_dense], bias [1]
+ *   prob     [B] sigmoid(logit);  logit optional [B]
+ *   y        optional labels [B] (fp32).  When given:
+ *              loss_sum[0] (double) += BCE sum over the batch (per-block partials added in block order),
+ *              da [B,F*D] = dlogit * w[:F*D],  g_w += sum_b dlogit_b * [a_b | dense_b],  g_b += sum dlogit,
+ *              scratch: satrans_head_scratch_floats(B, FD, n_dense) floats
+ * ---------------------------------------------------------------------------------------------- */
+int satrans_head(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols, int n_dense,
+                 int B, int FD, const float* w, const float* bias, float* prob, float* logit, const float* y,
+                 double* loss_sum, float* da, float* g_w, float* g_b, float* scratch, void* stream);
+int64_t satrans_head_scratch_floats(int B, int FD, int n_dense);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam semantics (reference main.py:343) with the L2 regulariser of
+ * meta_basemodel.py:577-593 folded in as its gradient 2*l2*p.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct satrans_adam_hparams {
+    float lr_over_bc1;  /* lr / (1 - beta1^t)                */
+    float bc2_sqrt;     /* sqrt(1 - beta2^t)                 */
+    float beta1, beta2, eps;
+    float l2;           /* l2_reg_embedding (0 for flat dense parameters) */
+} satrans_adam_hparams;
+
+/* Flat parameter vector (everything that is not an embedding table): p,g,m,v [n]. */
+int satrans_adam_flat(float* p, const float* g, float* m, float* v, int64_t n,
+                      const satrans_adam_hparams* h, void* stream);
+
+/* Embedding-gradient pipeline over n = (ranks*)B*F gathered rows.
+ *   rows [n] int32 arena rows, gemb [n, D] gradient of every gathered row.
+ * step 1 (sort):   sorted_rows[n], src[n] = stable sort of rows with their positions;
+ *                  touched bitmap [ceil(total_rows/32)] uint32 is cleared and rebuilt.
+ * step 2 (touched rows): per distinct row r: g = (sum of its gemb rows in position order) + 2*l2*p[r];
+ *                  Adam on arena/m/v row r.
+ * step 3 (untouched rows): every row whose bit is clear gets g = 2*l2*p (the reference's dense Adam
+ *                  moves EVERY row EVERY step because of the dense regulariser gradient).
+ * reg_partials [satrans_embed_reg_partials(total_rows, n, D)] doubles: per-block sums of l2*p^2 over the
+ * pre-update values (reference `reg_loss`), filled by step 2 and 3 into disjoint slots.
+ */
+int64_t satrans_embed_sort_workspace_bytes(int64_t n, int64_t total_rows);
+int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32_t* sorted_rows,
+                       int32_t* src, uint32_t* touched, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D);
+int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
+                               const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
+                               const satrans_adam_hparams* h, double* reg_partials, void* stream);
+int64_t satrans_embed_partial_ws_floats(int64_t n, int D);
+int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
+                                 const uint32_t* touched, const satrans_adam_hparams* h,
+                                 double* reg_partials, void* stream);
+
+/* Dense materialisation of the embedding gradient (debug / parity tests only):
+ * g_arena [total_rows, D] += scatter of gemb by rows (position order), + 2*l2*p when l2 != 0. */
+int satrans_embed_grad_dense(const float* arena, const int32_t* sorted_rows, const int32_t* src, int64_t n,
+                             const float* gemb, int64_t total_rows, int D, float l2, float* g_arena,
+                             void* stream);
+
+/* Sum of `count` doubles in index order -> out[0] (+= when accumulate != 0). */
+int satrans_sum_f64(const double* v, int64_t count, double* out, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SATRANS_HIP_H */

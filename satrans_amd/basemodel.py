@@ -1,0 +1,395 @@
+"""Training / evaluation harness with the reference's `BaseModel` surface.
+
+Mirrors the public behaviour of reference models/meta_basemodel.py (itself a fork of deepctr-torch's
+BaseModel): constructor arguments and parameter creation order (:125-188), `compile` (:598-610),
+`fit` (:200-385), `evaluate` (:387-399), `predict` (:401-517), metric names (:655-671) and the
+state_dict key names.  What differs is underneath:
+
+  * all embedding tables live back to back in ONE fp32 arena in HBM (`self.embedding_arena`), the
+    `embedding_dict.<name>.weight` parameters are views into it, so the fused gather reads one
+    address space and the optimizer streams one buffer;
+  * every other trainable tensor is a view into one flat buffer (`self.flat_params`) stepped by one
+    fused Adam launch;
+  * `fit` keeps the packed dataset resident in HBM, never calls autograd for the hot path, and only
+    reads losses back once per epoch (or per step when verbose metrics are requested, as the
+    reference does);
+  * forward / backward / optimizer are HIP kernels reached through satrans_amd.native.
+"""
+from __future__ import annotations
+
+import time
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .callbacks import CallbackList, History
+from .inputs import DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, split_columns
+
+
+def make_embedding_tables(feature_columns, init_std=0.0001, linear=False, skip_init=False) -> nn.ModuleDict:
+    """One table per SparseFeat, keyed by `embedding_name`; N(0, init_std) after torch's default N(0,1)
+    draw, exactly the sequence of generator draws of reference models/meta_basemodel.py:95-121."""
+    sparse, _, varlen = split_columns(feature_columns)
+    tables = nn.ModuleDict()
+    for col in sparse + varlen:
+        tables[col.embedding_name] = nn.Embedding(col.vocabulary_size, 1 if linear else col.embedding_dim)
+    if not skip_init:
+        for table in tables.values():
+            nn.init.normal_(table.weight, mean=0, std=init_std)
+    return tables
+
+
+class _LinearTables(nn.Module):
+    """The order-1 ("linear") part of deepctr models.  SATrans never evaluates it
+    (reference models/satrans.py:197-256) but it owns state_dict keys `linear_model.*` and consumes
+    generator draws during construction (models/meta_basemodel.py:34-61), so it is kept as storage."""
+
+    def __init__(self, feature_columns, init_std=0.0001):
+        super().__init__()
+        _, dense, _ = split_columns(feature_columns)
+        self.embedding_dict = make_embedding_tables(feature_columns, init_std, linear=True)
+        for table in self.embedding_dict.values():          # the reference initialises these a second time (:55-56)
+            nn.init.normal_(table.weight, mean=0, std=init_std)
+        if dense:
+            self.weight = nn.Parameter(torch.empty(sum(c.dimension for c in dense), 1))
+            nn.init.normal_(self.weight, mean=0, std=init_std)
+
+
+class _Prediction(nn.Module):
+    """Holds the `out.bias` parameter of deepctr's PredictionLayer (unused by SATrans.forward, which applies
+    torch.sigmoid directly at models/satrans.py:255)."""
+
+    def __init__(self, task="binary"):
+        super().__init__()
+        if task not in ("binary", "multiclass", "regression"):
+            raise ValueError("task must be binary,multiclass or regression")
+        self.task = task
+        self.bias = nn.Parameter(torch.zeros((1,)))
+
+
+class BaseModel(nn.Module):
+    def __init__(self, linear_feature_columns, dnn_feature_columns, l2_reg_linear=1e-5, l2_reg_embedding=1e-5,
+                 init_std=0.0001, seed=1024, task='binary', device='cpu', gpus=None, flag=None):
+        super().__init__()
+        self.flag = flag
+        self.embedding_dim = dnn_feature_columns[0].embedding_dim
+        torch.manual_seed(int(seed))                        # main.py:43 passes the seed as a string
+        self.dnn_feature_columns = dnn_feature_columns
+        self.linear_feature_columns = linear_feature_columns
+        self.device = device
+        self.gpus = gpus
+        if gpus and str(self.gpus[0]) not in self.device:
+            raise ValueError("`gpus[0]` should be the same gpu with `device`")
+        self.l2_reg_embedding = float(l2_reg_embedding)
+        self.l2_reg_linear = float(l2_reg_linear)
+
+        self.feature_index = build_input_features(list(linear_feature_columns) + list(dnn_feature_columns))
+        self.embedding_dict = make_embedding_tables(dnn_feature_columns, init_std,
+                                                    skip_init=bool(flag) and 'noembinit' in flag)
+        self.linear_model = _LinearTables(linear_feature_columns, init_std)
+        self.out = _Prediction(task)
+
+        self.reg_loss = torch.zeros((1,))
+        self.aux_loss = torch.zeros((1,))
+        self.history = History()
+        self.stop_training = False
+        self._engine = None
+        self.embedding_arena: Optional[torch.Tensor] = None
+        self.flat_params: Optional[torch.Tensor] = None
+        # parameters for callbacks (same attribute names as the reference, used by keras-style callbacks)
+        self._is_graph_network = True
+        self._ckpt_saved_epoch = False
+
+    # ------------------------------------------------------------------------------------------
+    # storage: one arena for the tables, one flat buffer for everything else that trains
+    # ------------------------------------------------------------------------------------------
+    @property
+    def embedding_size(self):
+        sparse, _, varlen = split_columns(self.dnn_feature_columns)
+        dims = {c.embedding_dim for c in sparse + varlen}
+        if len(dims) > 1:
+            raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
+        return list(dims)[0]
+
+    def _trainable_flat(self) -> "OrderedDict[str, nn.Parameter]":
+        """Parameters stepped by the fused flat Adam (subclasses define which receive gradients)."""
+        return OrderedDict()
+
+    def _table_order(self) -> List[str]:
+        sparse, _, _ = split_columns(self.dnn_feature_columns)
+        names, seen = [], set()
+        for col in sparse:
+            if col.embedding_name not in seen:
+                seen.add(col.embedding_name)
+                names.append(col.embedding_name)
+        return names
+
+    def _rebind_storage(self):
+        """(Re)build the arena and the flat buffer on the parameters' current device and turn the
+        parameters into views of them.  Called after construction and after every `.to()`."""
+        names = self._table_order()
+        tables = [self.embedding_dict[n].weight for n in names]
+        dev = tables[0].device
+        arena = torch.cat([t.data.reshape(-1, t.shape[1]) for t in tables], dim=0).contiguous()
+        off = 0
+        self._table_rows = OrderedDict()
+        for n, t in zip(names, tables):
+            rows = t.shape[0]
+            t.data = arena[off:off + rows]
+            self._table_rows[n] = (off, rows)
+            off += rows
+        self.embedding_arena = arena
+        flat = self._trainable_flat()
+        if flat:
+            buf = torch.cat([p.data.reshape(-1) for p in flat.values()]).contiguous().to(dev)
+            off = 0
+            self._flat_slices = OrderedDict()
+            for n, p in flat.items():
+                cnt = p.numel()
+                p.data = buf[off:off + cnt].view(p.shape)
+                self._flat_slices[n] = (off, cnt)
+                off += cnt
+            self.flat_params = buf
+        self._engine = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self.embedding_arena is not None:
+            self._rebind_storage()
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # compile
+    # ------------------------------------------------------------------------------------------
+    def compile(self, optimizer, loss=None, metrics=None):
+        """Same arguments as the reference (models/meta_basemodel.py:598-610).  The optimizer may be the
+        string "adam" or a `torch.optim.Adam` instance (what main.py:343 passes); its hyper-parameters are
+        read and the step itself runs as fused HIP kernels.  Other optimizers are not built."""
+        self.metrics_names = ["loss"]
+        self.optim = optimizer
+        self._adam_cfg = self._read_optimizer(optimizer)
+        self.loss_func = self._get_loss_func(loss)
+        self.metrics = self._get_metrics(metrics)
+
+    @staticmethod
+    def _read_optimizer(optimizer):
+        if isinstance(optimizer, str):
+            if optimizer == "adam":
+                return dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+            if optimizer in ("sgd", "adagrad", "rmsprop"):
+                raise NotImplementedError(
+                    f"optimizer '{optimizer}': only Adam (the reference's choice, main.py:343) has a HIP step")
+            raise NotImplementedError(optimizer)
+        if isinstance(optimizer, torch.optim.Adam):
+            if len(optimizer.param_groups) != 1:
+                raise NotImplementedError("Adam with several parameter groups")
+            g = optimizer.param_groups[0]
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                raise NotImplementedError("Adam with weight_decay / amsgrad / maximize")
+            return dict(lr=float(g["lr"]), betas=tuple(float(b) for b in g["betas"]), eps=float(g["eps"]))
+        raise NotImplementedError(f"optimizer {type(optimizer).__name__}: only torch.optim.Adam has a HIP step")
+
+    @staticmethod
+    def _get_loss_func(loss):
+        if loss is None or loss == "binary_crossentropy":
+            return "binary_crossentropy"
+        if loss in ("mse", "mae"):
+            raise NotImplementedError(f"loss '{loss}': the fused head computes binary cross-entropy only")
+        raise NotImplementedError(str(loss))
+
+    def _get_metrics(self, metrics, set_eps=False):
+        from sklearn.metrics import accuracy_score, log_loss, mean_squared_error, roc_auc_score
+        table = OrderedDict()
+        for metric in (metrics or []):
+            if metric in ("binary_crossentropy", "logloss"):
+                table[metric] = log_loss
+            if metric == "auc":
+                table[metric] = roc_auc_score
+            if metric == "mse":
+                table[metric] = mean_squared_error
+            if metric in ("accuracy", "acc"):
+                table[metric] = lambda y_true, y_pred: accuracy_score(y_true, np.where(y_pred > 0.5, 1, 0))
+            self.metrics_names.append(metric)
+        return table
+
+    # ------------------------------------------------------------------------------------------
+    # input packing
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, x) -> np.ndarray:
+        """dict / list of per-feature arrays -> one [N, C] matrix in `feature_index` column order
+        (models/meta_basemodel.py:221-222,257-264)."""
+        if isinstance(x, dict):
+            x = [x[name] for name in self.feature_index]
+        cols = [np.asarray(a) for a in x]
+        cols = [c.reshape(-1, 1) if c.ndim == 1 else c for c in cols]
+        return np.concatenate(cols, axis=-1)
+
+    def _to_device_matrix(self, packed: np.ndarray) -> torch.Tensor:
+        """The reference ships ids as fp32 (exact below 2**24, models/meta_basemodel.py:311).  That layout is kept
+        while every vocabulary is below 2**24; above it ids could not survive the round trip, and int64 ids
+        with a separate dense block are required (not needed by any reference dataset)."""
+        sparse, _, _ = split_columns(self.dnn_feature_columns)
+        if max(c.vocabulary_size for c in sparse) >= (1 << 24):
+            raise NotImplementedError("vocabularies of 2**24 rows or more need the integer-id input layout")
+        return torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32)).to(self.device)
+
+    # ------------------------------------------------------------------------------------------
+    # fit / evaluate / predict
+    # ------------------------------------------------------------------------------------------
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, valid_cnt_per_epoch=1, verbose=1, initial_epoch=0,
+            validation_split=0., validation_data=None, shuffle=True, callbacks=None):
+        """Train.  Arguments and return value as reference models/meta_basemodel.py:200-385."""
+        engine = self._require_engine()
+        if isinstance(x, dict) and getattr(self, "domain_column_list", None):
+            self.domain_id_offset = np.asarray(x[self.domain_column_list[0]]).min()
+        packed = self._pack(x)
+        y = np.asarray(y, dtype=np.float32).reshape(-1)
+
+        do_validation, val_x, val_y = False, None, []
+        if validation_data:
+            if len(validation_data) not in (2, 3):
+                raise ValueError("`validation_data` must be (x_val, y_val) or (x_val, y_val, val_sample_weights); "
+                                 "received %s" % (validation_data,))
+            do_validation = True
+            val_x, val_y = self._pack(validation_data[0]), np.asarray(validation_data[1])
+        elif validation_split and 0. < validation_split < 1.:
+            do_validation = True
+            split_at = int(packed.shape[0] * (1. - validation_split))
+            packed, val_x = packed[:split_at], packed[split_at:]
+            y, val_y = y[:split_at], y[split_at:]
+
+        if batch_size is None:
+            batch_size = 256
+        sample_num = packed.shape[0]
+        steps_per_epoch = (sample_num - 1) // batch_size + 1
+        steps_to_valid = steps_per_epoch // valid_cnt_per_epoch + 1
+
+        data = self._to_device_matrix(packed)                 # whole training set resident in HBM
+        labels = torch.from_numpy(y).to(self.device)
+        self.train()
+
+        cbs = CallbackList((callbacks or []) + [self.history])
+        cbs.set_model(self)
+        cbs.on_train_begin()
+        self.stop_training = False
+        if verbose:
+            print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
+                sample_num, len(val_y), steps_per_epoch))
+
+        for epoch in range(initial_epoch, epochs):
+            cbs.on_epoch_begin(epoch)
+            start_time = time.time()
+            train_result: Dict[str, list] = {}
+            engine.reset_epoch_sums()
+            order = self._epoch_order(sample_num, shuffle)
+            iterator = range(steps_per_epoch)
+            bar = None
+            if verbose == 1:
+                from tqdm import tqdm
+                bar = tqdm(iterator)
+                iterator = bar
+            step_num = 0
+            for step in iterator:
+                lo, hi = step * batch_size, min(sample_num, (step + 1) * batch_size)
+                if order is None:
+                    xb, yb = data[lo:hi], labels[lo:hi]
+                else:
+                    idx = order[lo:hi]
+                    xb, yb = data.index_select(0, idx), labels.index_select(0, idx)
+                engine.train_step(xb, yb)
+                if verbose > 0 and self.metrics:
+                    # per-step host metrics as the reference computes them (:330-337); forces a device sync
+                    y_np = yb.cpu().numpy()
+                    p_np = engine.last_prob().cpu().numpy().astype("float64")
+                    for name, fn in self.metrics.items():
+                        train_result.setdefault(name, []).append(fn(y_np, p_np))
+                step_num += 1
+                if valid_cnt_per_epoch > 1 and step_num % steps_to_valid == 0 and do_validation:
+                    res = self.evaluate(val_x, val_y, batch_size)
+                    print(f'Step: {step_num}/{steps_per_epoch}, ' +
+                          ''.join(" - %s: %.4f" % (k, v) for k, v in res.items()))
+                    self.train()
+            if bar is not None:
+                bar.close()
+            engine.raise_if_bad_ids()
+            bce_sum, reg_sum = engine.epoch_sums()
+            epoch_logs = {"loss": (bce_sum + reg_sum) / sample_num}
+            for name, result in train_result.items():
+                epoch_logs[name] = np.sum(result) / steps_per_epoch
+            if do_validation:
+                for name, result in self.evaluate(val_x, val_y, batch_size).items():
+                    epoch_logs["val_" + name] = result
+                self.train()
+            if verbose > 0:
+                msg = "{0}s - loss: {1: .4f}".format(int(time.time() - start_time), epoch_logs["loss"])
+                for name in self.metrics:
+                    if name in epoch_logs:
+                        msg += " - " + name + ": {0: .4f}".format(epoch_logs[name])
+                    if do_validation:
+                        msg += " - val_" + name + ": {0: .4f}".format(epoch_logs["val_" + name])
+                print('Epoch {0}/{1}'.format(epoch + 1, epochs))
+                print(msg)
+            cbs.on_epoch_end(epoch, epoch_logs)
+            if self.stop_training:
+                break
+        cbs.on_train_end()
+        return self.history
+
+    def _epoch_order(self, n: int, shuffle: bool) -> Optional[torch.Tensor]:
+        """Sample order of one epoch.  With shuffle the permutation is drawn the way
+        torch.utils.data.DataLoader(shuffle=True) draws it for the reference (one base-seed draw by the loader
+        iterator, one seed draw by RandomSampler, then randperm with that seed), so the same torch seed yields
+        the same batches."""
+        if not shuffle:
+            return None
+        torch.empty((), dtype=torch.int64).random_()
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        gen = torch.Generator()
+        gen.manual_seed(seed)
+        return torch.randperm(n, generator=gen).to(self.device)
+
+    def evaluate(self, x, y, batch_size=256):
+        """Metric name -> value on (x, y); models/meta_basemodel.py:387-399."""
+        pred = self.predict(x, batch_size, y)
+        return {name: fn(y, pred) for name, fn in self.metrics.items()}
+
+    def predict(self, x, batch_size=256, y=None, domain_ids=None):
+        """float64 [N,1] probabilities; models/meta_basemodel.py:401-517 (without the showattn/instattn
+        paper-figure branches)."""
+        engine = self._require_engine()
+        was_training = self.training
+        self.eval()
+        packed = x if isinstance(x, np.ndarray) and x.ndim == 2 and not isinstance(x, (dict, list)) else self._pack(x)
+        data = self._to_device_matrix(packed)
+        out = torch.empty((data.shape[0], 1), dtype=torch.float32, device=self.device)
+        for lo in range(0, data.shape[0], batch_size):
+            hi = min(data.shape[0], lo + batch_size)
+            out[lo:hi] = engine.forward(data[lo:hi], training=False)
+        engine.raise_if_bad_ids()
+        if was_training:
+            self.train()
+        return out.cpu().numpy().astype("float64")
+
+    # ------------------------------------------------------------------------------------------
+    def _require_engine(self):
+        raise NotImplementedError
+
+    def get_regularization_loss(self):
+        """sum(l2 * w^2) over the embedding tables (models/meta_basemodel.py:577-593) as a [1] tensor.
+        A convenience for callers; the training step computes the same sum inside the optimizer kernels."""
+        total = torch.zeros((1,), device=self.embedding_arena.device)
+        if self.l2_reg_embedding > 0:
+            total += self.l2_reg_embedding * torch.sum(torch.square(self.embedding_arena.double())).float()
+        return total
+
+    def compute_input_dim(self, feature_columns, include_sparse=True, include_dense=True, feature_group=False):
+        sparse, dense, varlen = split_columns(feature_columns)
+        total = 0
+        if include_sparse:
+            total += len(sparse + varlen) if feature_group else sum(c.embedding_dim for c in sparse + varlen)
+        if include_dense:
+            total += sum(c.dimension for c in dense)
+        return total

@@ -1,0 +1,48 @@
+// Shared host/device helpers for libsatrans_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/satrans_hip.h"
+
+namespace satrans {
+
+constexpr int kWave = 64;
+
+// thread-local description of the last failure, surfaced by satrans_last_error()
+void set_error(const char* fmt, ...);
+
+#define SATRANS_REQUIRE(cond, code, ...)      \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::satrans::set_error(__VA_ARGS__); \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+#define SATRANS_CHECK_LAUNCH(what)                                                          \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess) {                                                            \
+            ::satrans::set_error("%s: %s", (what), hipGetErrorString(e__));                 \
+            return SATRANS_E_LAUNCH;                                                        \
+        }                                                                                   \
+    } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Read element `col` of sample `b` of X as an integer id (reference: `.long()` truncation of the fp32 id).
+__device__ __forceinline__ int64_t load_id(const void* X, int id_dtype, int64_t x_stride, int64_t b, int col) {
+    const int64_t at = b * x_stride + col;
+    if (id_dtype == SATRANS_ID_F32) return (int64_t)((const float*)X)[at];
+    if (id_dtype == SATRANS_ID_I32) return (int64_t)((const int32_t*)X)[at];
+    return ((const int64_t*)X)[at];
+}
+
+// Dense (float) column of X.  Integer id matrices carry no dense columns.
+__device__ __forceinline__ float load_dense(const void* X, int64_t x_stride, int64_t b, int col) {
+    return ((const float*)X)[b * x_stride + col];
+}
+
+}  // namespace satrans

@@ -1,0 +1,424 @@
+// Embedding-table gradient + optimizer path.
+//
+// Reference semantics: the tables are dense parameters (`sparse=False`,
+// models/meta_basemodel.py:168) regularised by sum(l2 * w^2) over EVERY row (models/meta_basemodel.py:577-593) and
+// stepped by a dense torch.optim.Adam (main.py:343).  So every row of every table moves on every step: a row that
+// was not gathered still sees the gradient 2*l2*w.  The reference pays for that with a table-sized gradient buffer
+// (zero fill + index_add), a table-sized regulariser pass and a dense Adam pass (~9 table sweeps).  Here:
+//
+//   * gathered ("touched") rows: their gradient rows are grouped by a stable radix sort of the arena row ids and
+//     summed in position order (bitwise reproducible, identical on every data-parallel rank), then stepped;
+//   * all other rows: ONE streaming kernel that reads p,m,v and writes p,m,v (6 table sweeps, the algorithmic
+//     minimum for exact dense-Adam semantics) and computes the regulariser sum on the way.  It does not depend on
+//     the backward pass at all, only on the touched-row bitmap, so it can overlap the attention kernels.
+//
+// Adam arithmetic follows torch.optim.adam._single_tensor_adam (lerp for exp_avg, mul+addcmul for exp_avg_sq,
+// denom = sqrt(v)/sqrt(bc2) + eps, addcdiv with -lr/bc1).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace satrans {
+
+constexpr int kChunk = 32;         // sorted positions per lane group in the touched-row pass
+constexpr int kStreamBlock = 256;
+constexpr int kStreamBlocks = 2048;  // 8 blocks per CU, grid-strided
+
+struct AdamK {
+    float neg_step, bc2_sqrt, w1, beta2, w2, eps, l2x2, l2;
+};
+
+__host__ inline AdamK make_adamk(const satrans_adam_hparams& h) {
+    AdamK k;
+    k.neg_step = -h.lr_over_bc1;
+    k.bc2_sqrt = h.bc2_sqrt;
+    k.w1 = (float)(1.0 - (double)h.beta1);
+    k.beta2 = h.beta2;
+    k.w2 = (float)(1.0 - (double)h.beta2);
+    k.eps = h.eps;
+    k.l2 = h.l2;
+    k.l2x2 = 2.0f * h.l2;
+    return k;
+}
+
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, const AdamK& k) {
+    m = m + k.w1 * (g - m);                        // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
+    v = v * k.beta2 + (k.w2 * g) * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+    p = p + (k.neg_step * m) / denom;              // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__device__ __forceinline__ double adam4(float4& p, float4& m, float4& v, float4 g, const AdamK& k) {
+    const double reg = (double)k.l2 * ((double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z + (double)p.w * p.w);
+    adam1(p.x, m.x, v.x, g.x + k.l2x2 * p.x, k);
+    adam1(p.y, m.y, v.y, g.y + k.l2x2 * p.y, k);
+    adam1(p.z, m.z, v.z, g.z + k.l2x2 * p.z, k);
+    adam1(p.w, m.w, v.w, g.w + k.l2x2 * p.w, k);
+    return reg;
+}
+
+// streaming (non-temporal) 16-byte accesses: the tables are far larger than L2 + Infinity Cache and every byte is
+// used exactly once per step, so keeping them out of the caches leaves the cache to the attention kernels
+using f4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ float4 nt_load(const float4* p) {
+    const f4 t = __builtin_nontemporal_load((const f4*)p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void nt_store(const float4& v, float4* p) {
+    f4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, (f4*)p);
+}
+
+// block-wide sum of one double per thread, fixed tree order; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    scratch[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) scratch[threadIdx.x] += scratch[threadIdx.x + off];
+        __syncthreads();
+    }
+    return scratch[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// untouched rows: the dominant kernel of a training step (HBM-bound, 6 table sweeps)
+// ---------------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(kStreamBlock) void adam_untouched_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                                    float4* __restrict__ V, int64_t n4,
+                                                                    const uint32_t* __restrict__ touched, AdamK k,
+                                                                    double* __restrict__ reg_partials) {
+    __shared__ double s_red[kStreamBlock];
+    double reg = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kStreamBlock;
+    constexpr int UNR = 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * kStreamBlock + threadIdx.x; i0 < n4; i0 += stride * UNR) {
+        float4 p[UNR], m[UNR], v[UNR];
+        bool live[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + u * stride;
+            live[u] = false;
+            if (i < n4) {
+                const int64_t row = i / LPR;
+                live[u] = !((touched[row >> 5] >> (row & 31)) & 1u);
+            }
+            if (live[u]) {
+                p[u] = nt_load(&P[i]);
+                m[u] = nt_load(&M[i]);
+                v[u] = nt_load(&V[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (live[u]) {
+                const int64_t i = i0 + u * stride;
+                reg += adam4(p[u], m[u], v[u], make_float4(0.f, 0.f, 0.f, 0.f), k);
+                nt_store(p[u], &P[i]);
+                nt_store(m[u], &M[i]);
+                nt_store(v[u], &V[i]);
+            }
+        }
+    }
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// touched rows: sort, segmented sum in position order, step
+// ---------------------------------------------------------------------------------------------------------
+__global__ void iota_mark_kernel(const int32_t* __restrict__ rows, int64_t n, uint32_t* __restrict__ keys,
+                                 int32_t* __restrict__ pos, uint32_t* __restrict__ touched) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = (uint32_t)rows[i];
+    keys[i] = r;
+    pos[i] = (int32_t)i;
+    atomicOr(&touched[r >> 5], 1u << (r & 31));
+}
+
+// Per-chunk bookkeeping for segments that cross chunk boundaries.
+//   info bit0: the chunk's LAST piece starts here and continues into the next chunk (a "trail" piece)
+//   info bit1: the chunk's FIRST piece continues a segment from the previous chunk (a "lead" piece)
+//   info bit2: that lead piece also ends inside this chunk (or at its end)
+// lead/trail partial sums live in partial_ws: [chunks][2][D]
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                            float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
+                                                            const int32_t* __restrict__ src, int64_t n,
+                                                            const float4* __restrict__ gemb, float4* __restrict__ partial,
+                                                            int32_t* __restrict__ info, int32_t* __restrict__ trail_row,
+                                                            AdamK k, double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    const int64_t start = group * kChunk;
+    double reg = 0.0;
+    if (start < n) {
+        const int64_t end = min(n, start + (int64_t)kChunk);
+        const int32_t prev_row = start > 0 ? sorted_rows[start - 1] : -1;
+        const int32_t next_row = end < n ? sorted_rows[end] : -1;
+        int32_t cur = sorted_rows[start];
+        bool begins = cur != prev_row;
+        int flags = 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t j = start; j <= end; ++j) {
+            const int32_t row = j < end ? sorted_rows[j] : -2;  // sentinel flushes the last piece
+            if (row != cur) {
+                const bool ends = j < end ? true : (next_row != cur);
+                if (begins && ends) {
+                    const int64_t at = (int64_t)cur * LPR + q;
+                    float4 p = P[at], m = M[at], v = V[at];
+                    reg += adam4(p, m, v, acc, k);
+                    P[at] = p; M[at] = m; V[at] = v;
+                } else if (!begins) {
+                    partial[(group * 2 + 0) * LPR + q] = acc;
+                    flags |= 2 | (ends ? 4 : 0);
+                } else {
+                    partial[(group * 2 + 1) * LPR + q] = acc;
+                    flags |= 1;
+                    if (q == 0) trail_row[group] = cur;
+                }
+                if (j == end) break;
+                cur = row;
+                begins = true;
+                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float4 g = gemb[(int64_t)src[j] * LPR + q];
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+        if (q == 0) info[group] = flags;
+    }
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// second level: one lane group per chunk that owns a trail piece walks the following chunks' lead pieces in order
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                           float4* __restrict__ V, int64_t chunks,
+                                                           const float4* __restrict__ partial,
+                                                           const int32_t* __restrict__ info,
+                                                           const int32_t* __restrict__ trail_row, AdamK k,
+                                                           double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    double reg = 0.0;
+    if (group < chunks && (info[group] & 1)) {
+        float4 acc = partial[(group * 2 + 1) * LPR + q];
+        for (int64_t c = group + 1; c < chunks; ++c) {
+            const int f = info[c];
+            if (!(f & 2)) break;  // cannot happen for a well-formed trail, kept as a guard
+            const float4 g = partial[(c * 2 + 0) * LPR + q];
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+            if (f & 4) break;
+        }
+        const int64_t at = (int64_t)trail_row[group] * LPR + q;
+        float4 p = P[at], m = M[at], v = V[at];
+        reg += adam4(p, m, v, acc, k);
+        P[at] = p; M[at] = m; V[at] = v;
+    }
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// debug / parity: dense gradient of the arena
+template <int LPR>
+__global__ void grad_dense_kernel(const int32_t* __restrict__ sorted_rows, const int32_t* __restrict__ src, int64_t n,
+                                  const float4* __restrict__ gemb, float4* __restrict__ g_arena) {
+    const int64_t j0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    if (j0 >= n) return;
+    const int32_t row = sorted_rows[j0];
+    if (j0 > 0 && sorted_rows[j0 - 1] == row) return;  // only segment heads work
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t j = j0; j < n && sorted_rows[j] == row; ++j) {
+        const float4 g = gemb[(int64_t)src[j] * LPR + q];
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+    float4 out = g_arena[(int64_t)row * LPR + q];
+    out.x += acc.x; out.y += acc.y; out.z += acc.z; out.w += acc.w;
+    g_arena[(int64_t)row * LPR + q] = out;
+}
+
+__global__ void add_l2_grad_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, float l2x2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] += l2x2 * p[i];
+}
+
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, AdamK k) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam1(pp, mm, vv, g[i] + k.l2x2 * pp, k);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+}
+
+__global__ void sum_f64_kernel(const double* __restrict__ vals, int64_t count, double* __restrict__ out, int accumulate) {
+    __shared__ double s_red[256];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += 256) acc += vals[i];
+    const double total = block_sum(acc, s_red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + total : total;
+}
+
+static int bits_for(int64_t n) {
+    int bits = 1;
+    while (((int64_t)1 << bits) < n) ++bits;
+    return bits;
+}
+
+struct SortLayout {
+    size_t keys_in, pos_in, temp, temp_bytes, total;
+};
+static SortLayout sort_layout(int64_t n, int64_t total_rows) {
+    SortLayout L{};
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t temp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+                              (int32_t*)nullptr, (unsigned)n, 0u, (unsigned)bits_for(total_rows), (hipStream_t)0);
+    L.keys_in = 0;
+    L.pos_in = align(sizeof(uint32_t) * (size_t)n);
+    L.temp = align(L.pos_in + sizeof(int32_t) * (size_t)n);
+    L.temp_bytes = temp;
+    L.total = align(L.temp + temp);
+    return L;
+}
+
+static int64_t touched_blocks(int64_t n, int D) {
+    const int lpr = D / 4;
+    return ceil_div(ceil_div(n, kChunk) * lpr, 256);
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+#define DISPATCH_LPR(D, CALL)                                                        \
+    switch ((D) / 4) {                                                               \
+        case 4: { constexpr int LPR = 4; CALL; } break;                              \
+        case 8: { constexpr int LPR = 8; CALL; } break;                              \
+        case 16: { constexpr int LPR = 16; CALL; } break;                            \
+        case 32: { constexpr int LPR = 32; CALL; } break;                            \
+        default:                                                                     \
+            ::satrans::set_error("embedding_dim %d not in {16,32,64,128}", (D));     \
+            return SATRANS_E_UNSUPPORTED;                                            \
+    }
+
+extern "C" int64_t satrans_embed_sort_workspace_bytes(int64_t n, int64_t total_rows) {
+    if (n <= 0 || total_rows <= 0) return 0;
+    return (int64_t)sort_layout(n, total_rows).total;
+}
+
+extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32_t* sorted_rows, int32_t* src,
+                                  uint32_t* touched, void* workspace, int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(rows && sorted_rows && src && touched && workspace, SATRANS_E_BADARG, "embed_sort: null pointer");
+    SATRANS_REQUIRE(n > 0 && total_rows > 0 && n < ((int64_t)1 << 31) && total_rows < ((int64_t)1 << 31), SATRANS_E_BADARG,
+                    "embed_sort: sizes n=%lld rows=%lld", (long long)n, (long long)total_rows);
+    const SortLayout L = sort_layout(n, total_rows);
+    SATRANS_REQUIRE((int64_t)L.total <= workspace_bytes, SATRANS_E_WORKSPACE, "embed_sort: workspace %lld < %lld bytes",
+                    (long long)workspace_bytes, (long long)L.total);
+    char* ws = (char*)workspace;
+    uint32_t* keys_in = (uint32_t*)(ws + L.keys_in);
+    int32_t* pos_in = (int32_t*)(ws + L.pos_in);
+    hipError_t e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)ceil_div(total_rows, 32), stream);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: memset: %s", hipGetErrorString(e));
+    iota_mark_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(rows, n, keys_in, pos_in, touched);
+    SATRANS_CHECK_LAUNCH("iota_mark_kernel");
+    size_t temp_bytes = L.temp_bytes;
+    e = rocprim::radix_sort_pairs(ws + L.temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)sorted_rows,
+                                  (const int32_t*)pos_in, src, (unsigned)n, 0u, (unsigned)bits_for(total_rows), stream);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: radix sort: %s", hipGetErrorString(e));
+    return SATRANS_OK;
+}
+
+extern "C" int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D) {
+    (void)total_rows;
+    return kStreamBlocks + 2 * touched_blocks(n, D);
+}
+
+// partial_ws: [chunks][2][D] floats, then [chunks] int32 info, then [chunks] int32 trail_row
+extern "C" int64_t satrans_embed_partial_ws_floats(int64_t n, int D) {
+    const int64_t chunks = ceil_div(n, kChunk);
+    return chunks * 2 * D + 2 * chunks;
+}
+
+extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
+                                          const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
+                                          const satrans_adam_hparams* h, double* reg_partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && m && v && sorted_rows && src && gemb && partial_ws && h && reg_partials, SATRANS_E_BADARG,
+                    "embed_adam_touched: null pointer");
+    SATRANS_REQUIRE(n > 0, SATRANS_E_BADARG, "embed_adam_touched: n=%lld", (long long)n);
+    const AdamK k = make_adamk(*h);
+    const int64_t chunks = ceil_div(n, kChunk);
+    float4* partial = (float4*)partial_ws;
+    int32_t* info = (int32_t*)(partial_ws + chunks * 2 * D);
+    int32_t* trail_row = info + chunks;
+    const int64_t blocks = touched_blocks(n, D);
+    double* reg_a = reg_partials + kStreamBlocks;
+    double* reg_b = reg_a + blocks;
+    DISPATCH_LPR(D, (touched_chunks_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, src, n, (const float4*)gemb, partial, info,
+                        trail_row, k, reg_a)));
+    SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
+    DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)partial, info, trail_row, k, reg_b)));
+    SATRANS_CHECK_LAUNCH("touched_spans_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
+                                            const uint32_t* touched, const satrans_adam_hparams* h, double* reg_partials,
+                                            void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && m && v && touched && h && reg_partials, SATRANS_E_BADARG, "embed_adam_untouched: null pointer");
+    SATRANS_REQUIRE(total_rows > 0, SATRANS_E_BADARG, "embed_adam_untouched: total_rows=%lld", (long long)total_rows);
+    const AdamK k = make_adamk(*h);
+    const int64_t n4 = total_rows * (D / 4);
+    DISPATCH_LPR(D, (adam_untouched_kernel<LPR><<<kStreamBlocks, kStreamBlock, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, n4, touched, k, reg_partials)));
+    SATRANS_CHECK_LAUNCH("adam_untouched_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_embed_grad_dense(const float* arena, const int32_t* sorted_rows, const int32_t* src, int64_t n,
+                                        const float* gemb, int64_t total_rows, int D, float l2, float* g_arena,
+                                        void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && sorted_rows && src && gemb && g_arena, SATRANS_E_BADARG, "embed_grad_dense: null pointer");
+    const int lpr = D / 4;
+    DISPATCH_LPR(D, (grad_dense_kernel<LPR><<<(unsigned)ceil_div(n * lpr, 256), 256, 0, stream>>>(
+                        sorted_rows, src, n, (const float4*)gemb, (float4*)g_arena)));
+    SATRANS_CHECK_LAUNCH("grad_dense_kernel");
+    if (l2 != 0.f) {
+        const int64_t ne = total_rows * D;
+        add_l2_grad_kernel<<<(unsigned)ceil_div(ne, 256), 256, 0, stream>>>(arena, g_arena, ne, 2.0f * l2);
+        SATRANS_CHECK_LAUNCH("add_l2_grad_kernel");
+    }
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, const satrans_adam_hparams* h,
+                                 void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(p && g && m && v && h, SATRANS_E_BADARG, "adam_flat: null pointer");
+    if (n <= 0) return SATRANS_OK;
+    adam_flat_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(p, g, m, v, n, make_adamk(*h));
+    SATRANS_CHECK_LAUNCH("adam_flat_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_sum_f64(const double* vals, int64_t count, double* out, int accumulate, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(vals && out && count >= 0, SATRANS_E_BADARG, "sum_f64: bad arguments");
+    sum_f64_kernel<<<1, 256, 0, stream>>>(vals, count, out, accumulate);
+    SATRANS_CHECK_LAUNCH("sum_f64_kernel");
+    return SATRANS_OK;
+}

@@ -1,0 +1,181 @@
+// K0 scenario bucketing + K1 fused multi-table embedding gather.
+//
+// K1 replaces the reference's 19 separate nn.Embedding launches and the torch.cat that follows
+// (models/meta_basemodel.py:533-535, models/satrans.py:211) by ONE launch that writes [B,F,D] directly.
+// HBM-bound: every gathered row is a random D*4-byte read (128 B at D=32).  A row is moved by D/4 lanes
+// with one 16-byte load each, so one wave instruction moves 64/(D/4) rows (8 rows at D=32) and each
+// 128-byte row is one fully used cache line.  Every thread keeps kRowsPerThread independent rows in
+// flight to cover the ~900-cycle HBM miss latency (MI355X_MICROARCH.md, cycle constants).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace satrans {
+
+constexpr int kGatherBlock = 256;
+constexpr int kRowsPerThread = 4;
+
+template <int LPR>  // lanes per row = D/4
+__global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
+    const float4* __restrict__ arena, const int64_t* __restrict__ row_off, const int32_t* __restrict__ cols,
+    const void* __restrict__ X, int id_dtype, int64_t x_stride, int64_t n_rows, int F, float4* __restrict__ out,
+    int32_t* __restrict__ rows_out, int32_t* __restrict__ status) {
+    const int64_t tid = (int64_t)blockIdx.x * kGatherBlock + threadIdx.x;
+    const int64_t slot0 = tid / LPR;        // first (sample, field) pair of this thread
+    const int q = (int)(tid % LPR);         // which 16-byte piece of the row
+    const int64_t stride = (int64_t)gridDim.x * kGatherBlock / LPR;
+
+    for (int64_t base = slot0; base < n_rows; base += stride * kRowsPerThread) {
+        int64_t row[kRowsPerThread];
+        float4 val[kRowsPerThread];
+#pragma unroll
+        for (int r = 0; r < kRowsPerThread; ++r) {
+            const int64_t slot = base + r * stride;
+            row[r] = -1;
+            if (slot < n_rows) {
+                const int64_t b = slot / F;
+                const int f = (int)(slot - b * F);
+                const int64_t id = load_id(X, id_dtype, x_stride, b, cols[f]);
+                const int64_t lo = row_off[f], hi = row_off[f + 1];
+                if (id >= 0 && id < hi - lo) {
+                    row[r] = lo + id;
+                } else {
+                    row[r] = -2;  // out of range: the reference raises IndexError; we flag and write zeros
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kRowsPerThread; ++r) {
+            val[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row[r] >= 0) val[r] = arena[row[r] * LPR + q];
+        }
+#pragma unroll
+        for (int r = 0; r < kRowsPerThread; ++r) {
+            const int64_t slot = base + r * stride;
+            if (slot < n_rows) {
+                out[slot * LPR + q] = val[r];
+                if (q == 0) {
+                    if (rows_out) rows_out[slot] = (int32_t)(row[r] >= 0 ? row[r] : 0);
+                    if (row[r] == -2) atomicOr(status, 1);
+                }
+            }
+        }
+    }
+}
+
+__global__ void extract_scenario_kernel(const void* __restrict__ X, int id_dtype, int64_t x_stride, int col, int B,
+                                        int S, int32_t* __restrict__ sid, uint32_t* __restrict__ keys,
+                                        int32_t* __restrict__ idx, int32_t* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t s = load_id(X, id_dtype, x_stride, b, col);
+    if (s < 0 || s >= S) {
+        atomicOr(status, 1);
+        s = 0;
+    }
+    sid[b] = (int32_t)s;
+    keys[b] = (uint32_t)s;
+    idx[b] = b;
+}
+
+// seg[s] = first position in the sorted key array whose key is >= s;  seg[S] = B
+__global__ void segment_bounds_kernel(const uint32_t* __restrict__ sorted_keys, int B, int S,
+                                      int32_t* __restrict__ seg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > B) return;
+    const int64_t prev = (i == 0) ? -1 : (int64_t)sorted_keys[i - 1];
+    const int64_t cur = (i == B) ? (int64_t)S : (int64_t)sorted_keys[i];
+    for (int64_t s = prev + 1; s <= cur; ++s) seg[s] = i;
+}
+
+static int bits_for(int64_t n) {  // number of key bits needed for values in [0, n)
+    int bits = 1;
+    while (((int64_t)1 << bits) < n) ++bits;
+    return bits;
+}
+
+struct BucketLayout {
+    size_t keys_in, keys_out, idx, temp, temp_bytes, total;
+};
+
+static BucketLayout bucket_layout(int B, int S) {
+    BucketLayout L{};
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t temp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+                              (int32_t*)nullptr, (unsigned)B, 0u, (unsigned)bits_for(S), (hipStream_t)0);
+    L.keys_in = 0;
+    L.keys_out = align(L.keys_in + sizeof(uint32_t) * (size_t)B);
+    L.idx = align(L.keys_out + sizeof(uint32_t) * (size_t)B);
+    L.temp = align(L.idx + sizeof(int32_t) * (size_t)B);
+    L.temp_bytes = temp;
+    L.total = align(L.temp + temp);
+    return L;
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+extern "C" int64_t satrans_bucket_workspace_bytes(int B, int S) {
+    if (B <= 0 || S <= 0) return 0;
+    return (int64_t)bucket_layout(B, S).total;
+}
+
+extern "C" int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_stride, int col, int B, int S,
+                                        int32_t* sid, int32_t* order, int32_t* seg, int32_t* status,
+                                        void* workspace, int64_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(X && sid && order && seg && status && workspace, SATRANS_E_BADARG, "bucket_scenarios: null pointer");
+    SATRANS_REQUIRE(B > 0 && S > 0 && col >= 0, SATRANS_E_BADARG, "bucket_scenarios: bad sizes B=%d S=%d col=%d", B, S, col);
+    SATRANS_REQUIRE(id_dtype >= 0 && id_dtype <= 2, SATRANS_E_BADARG, "bucket_scenarios: id_dtype %d", id_dtype);
+    const BucketLayout L = bucket_layout(B, S);
+    SATRANS_REQUIRE((int64_t)L.total <= workspace_bytes, SATRANS_E_WORKSPACE,
+                    "bucket_scenarios: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.total);
+    char* ws = (char*)workspace;
+    uint32_t* keys_in = (uint32_t*)(ws + L.keys_in);
+    uint32_t* keys_out = (uint32_t*)(ws + L.keys_out);
+    int32_t* idx = (int32_t*)(ws + L.idx);
+    const int block = 256;
+    extract_scenario_kernel<<<(unsigned)ceil_div(B, block), block, 0, stream>>>(X, id_dtype, x_stride, col, B, S, sid,
+                                                                              keys_in, idx, status);
+    SATRANS_CHECK_LAUNCH("extract_scenario_kernel");
+    size_t temp_bytes = L.temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(ws + L.temp, temp_bytes, (const uint32_t*)keys_in, keys_out,
+                                             (const int32_t*)idx, order, (unsigned)B, 0u, (unsigned)bits_for(S), stream);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "bucket_scenarios: radix sort: %s", hipGetErrorString(e));
+    segment_bounds_kernel<<<(unsigned)ceil_div(B + 1, block), block, 0, stream>>>(keys_out, B, S, seg);
+    SATRANS_CHECK_LAUNCH("segment_bounds_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_off, const int32_t* cols, const void* X,
+                                  int id_dtype, int64_t x_stride, int B, int F, int D, float* out,
+                                  int32_t* rows_out, int32_t* status, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && row_off && cols && X && out && status, SATRANS_E_BADARG, "gather_fwd: null pointer");
+    SATRANS_REQUIRE(B > 0 && F > 0, SATRANS_E_BADARG, "gather_fwd: bad sizes B=%d F=%d", B, F);
+    SATRANS_REQUIRE(id_dtype >= 0 && id_dtype <= 2, SATRANS_E_BADARG, "gather_fwd: id_dtype %d", id_dtype);
+    SATRANS_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, SATRANS_E_UNSUPPORTED,
+                    "gather_fwd: embedding_dim %d not in {16,32,64,128}", D);
+    const int64_t n_rows = (int64_t)B * F;
+    const int lpr = D / 4;
+    // enough threads for every row once, capped at 8 blocks per CU (256 CUs) and grid-strided beyond that
+    int64_t blocks = ceil_div(ceil_div(n_rows, kRowsPerThread) * lpr, kGatherBlock);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+#define LAUNCH(LPR)                                                                                            \
+    gather_rows_kernel<LPR><<<(unsigned)blocks, kGatherBlock, 0, stream>>>(                                    \
+        (const float4*)arena, row_off, cols, X, id_dtype, x_stride, n_rows, F, (float4*)out, rows_out, status)
+    switch (lpr) {
+        case 4: LAUNCH(4); break;
+        case 8: LAUNCH(8); break;
+        case 16: LAUNCH(16); break;
+        default: LAUNCH(32); break;
+    }
+#undef LAUNCH
+    SATRANS_CHECK_LAUNCH("gather_rows_kernel");
+    return SATRANS_OK;
+}

@@ -1,0 +1,755 @@
+// Meta_Transformer_Layer forward and backward, shape-generic LDS version ("v1").
+//
+// Reference: models/satrans.py:50-100 (layer) and models/submodules.py:77-103 (MetaNet).
+//
+// Work decomposition.  The generated MetaNet weights depend only on the scenario id, so
+// samples are bucketed by scenario (satrans_bucket_scenarios) and a workgroup only ever works on samples of
+// ONE scenario: blockIdx.y = scenario row, blockIdx.x strides over that scenario's tiles of T samples.  All
+// activations of a tile live in LDS ([token][feature], row stride padded by one float so that column walks
+// are bank-conflict free); weights are staged into LDS once per use.  The backward pass recomputes the
+// forward from the layer input with the same counter-based dropout masks (rng.h), so the only tensor kept
+// between passes is the layer input.  Weight gradients are accumulated per workgroup into a private slab
+// (fixed order over tiles) and summed over workgroups in index order by a second kernel: results are
+// bitwise reproducible, no float atomics.
+//
+// This version favours generality (any F <= 64, D multiple of 4, any H | D, any U) over speed; the
+// MFMA version in layer_mfma.hip takes over for the shapes it is built for.
+#include <algorithm>
+
+#include "common.h"
+#include "rng.h"
+
+namespace satrans {
+
+constexpr int kLayerBlock = 256;
+
+struct LayerLds {
+    // forward activations, [tok][ldd] unless noted
+    float *x, *q0, *k0, *v;
+    float *hq, *hk;        // [tok][ldu] MetaNet hidden (post-ReLU)
+    float *zq, *q, *zk, *k;  // pre-/post-LayerNorm MetaNet outputs
+    float* P;              // [nS*H*F][ldp] softmax probabilities BEFORE dropout
+    float *o, *u, *r;      // attention output, Out_linear output (kept only when non-null), pre-LayerNorm residual sum
+    float* w;              // weight staging, max(3*D*D, D*U) floats
+    int ldd, ldu, ldp;
+};
+
+struct TileDims {
+    int F, D, H, U, d;
+    int nS, ntok;
+};
+
+// out(t, o) = sum_k in[t][k] * w[k][o] for t < ntok, o < N; `epi(t, o, acc)` consumes the result.
+// One work item = TR tokens x 1 output column; consecutive lanes take consecutive columns, so the weight
+// reads are conflict-free and the activation reads are LDS broadcasts.
+template <int TR, typename Epi>
+__device__ __forceinline__ void gemm_tokens(const float* __restrict__ in, int ldin, const float* __restrict__ w,
+                                            int ldw, int K, int N, int ntok, Epi epi) {
+    const int groups = (ntok + TR - 1) / TR;
+    for (int item = threadIdx.x; item < groups * N; item += blockDim.x) {
+        const int tg = item / N, o = item - tg * N;
+        const int t0 = tg * TR;
+        float acc[TR];
+        const float* row[TR];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            acc[r] = 0.f;
+            row[r] = in + (size_t)min(t0 + r, ntok - 1) * ldin;
+        }
+        for (int k = 0; k < K; ++k) {
+            const float wv = w[k * ldw + o];
+#pragma unroll
+            for (int r = 0; r < TR; ++r) acc[r] = fmaf(row[r][k], wv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+            if (t0 + r < ntok) epi(t0 + r, o, acc[r]);
+    }
+}
+
+__device__ __forceinline__ void stage_copy(const float* __restrict__ g, float* __restrict__ s, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s[i] = g[i];
+}
+
+// s[c*R + r] = g[r*C + c]   (g is [R][C] row-major; s becomes [C][R])
+__device__ __forceinline__ void stage_transposed(const float* __restrict__ g, float* __restrict__ s, int R, int C) {
+    for (int i = threadIdx.x; i < R * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        s[c * R + r] = g[i];
+    }
+}
+
+// LayerNorm statistics of one row (torch: biased variance, eps inside the sqrt)
+__device__ __forceinline__ void row_stats(const float* row, int D, float& mean, float& rstd) {
+    float s = 0.f;
+    for (int c = 0; c < D; ++c) s += row[c];
+    mean = s / (float)D;
+    float v = 0.f;
+    for (int c = 0; c < D; ++c) {
+        const float e = row[c] - mean;
+        v = fmaf(e, e, v);
+    }
+    rstd = 1.0f / sqrtf(v / (float)D + 1e-6f);
+}
+
+__device__ __forceinline__ void layer_norm_rows(const float* in, float* out, int ld, int ntok, int D,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta) {
+    for (int t = threadIdx.x; t < ntok; t += blockDim.x) {
+        float mean, rstd;
+        row_stats(in + (size_t)t * ld, D, mean, rstd);
+        for (int c = 0; c < D; ++c) out[(size_t)t * ld + c] = (in[(size_t)t * ld + c] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+struct DropCtx {
+    bool on;
+    float scale;
+    uint32_t thresh;
+    uint32_t key[4];  // per site
+};
+
+__device__ __forceinline__ DropCtx make_drop(const satrans_layer_desc& a) {
+    DropCtx dc;
+    dc.on = (a.flags & SATRANS_TRAIN) && a.drop_p > 0.f;
+    dc.scale = dc.on ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    dc.thresh = drop_threshold(a.drop_p);
+    for (int s = 0; s < 4; ++s) dc.key[s] = drop_site_key(a.seed, a.step, a.layer, s);
+    return dc;
+}
+
+// multiplicative mask value (0 or 1/(1-p)) of element `elem` of global sample `b` at `site`
+__device__ __forceinline__ float drop_mask(const DropCtx& dc, int site, int b, uint32_t elem) {
+    if (!dc.on) return 1.0f;
+    return drop_keep(drop_sample_key(dc.key[site], (uint32_t)b), elem, dc.thresh) ? dc.scale : 0.0f;
+}
+
+// MetaNet of one role (Q or K): z = drop(relu(in @ W1) @ W2) + in ; out = LN(z).   submodules.py:77-103
+__device__ void metanet_tile(const satrans_layer_desc& a, const TileDims& T, const int32_t* samp, const DropCtx& dc,
+                             int site, const float* __restrict__ tab_row, const float* gamma, const float* beta,
+                             const float* in, float* h, float* z, float* out, LayerLds& L) {
+    const int D = T.D, U = T.U, F = T.F;
+    stage_copy(tab_row, L.w, D * U);  // W1 [D][U]
+    __syncthreads();
+    gemm_tokens<4>(in, L.ldd, L.w, U, D, U, T.ntok,
+                   [&](int t, int o, float acc) { h[(size_t)t * L.ldu + o] = fmaxf(acc, 0.f); });
+    __syncthreads();
+    stage_copy(tab_row + D * U, L.w, U * D);  // W2 [U][D]
+    __syncthreads();
+    gemm_tokens<4>(h, L.ldu, L.w, D, U, D, T.ntok, [&](int t, int o, float acc) {
+        const int ls = t / F, f = t - ls * F;
+        const float m = acc * drop_mask(dc, site, samp[ls], (uint32_t)(f * D + o));
+        z[(size_t)t * L.ldd + o] = m + in[(size_t)t * L.ldd + o];
+    });
+    __syncthreads();
+    layer_norm_rows(z, out, L.ldd, T.ntok, D, gamma, beta);
+    __syncthreads();
+}
+
+// Forward of one tile up to the pre-LayerNorm residual sum r.  Buffers of L may alias as documented at the
+// call sites (forward kernel) or be distinct (backward kernel).
+__device__ void forward_tile(const satrans_layer_desc& a, const TileDims& T, int scen, const int32_t* samp,
+                             const DropCtx& dc, LayerLds& L) {
+    const int F = T.F, D = T.D, H = T.H, d = T.d, ntok = T.ntok;
+    // ---- load x, stage [Wq | Wk | Wv] as [D][3D] -------------------------------------------------------
+    for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+        const int t = i / D, c = i - t * D;
+        const int ls = t / F, f = t - ls * F;
+        L.x[(size_t)t * L.ldd + c] = a.x[((size_t)samp[ls] * F + f) * D + c];
+    }
+    for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
+        const int k = i / D, o = i - k * D;
+        L.w[k * 3 * D + o] = a.w_query[i];
+        L.w[k * 3 * D + D + o] = a.w_key[i];
+        L.w[k * 3 * D + 2 * D + o] = a.w_value[i];
+    }
+    __syncthreads();
+    gemm_tokens<4>(L.x, L.ldd, L.w, 3 * D, D, 3 * D, ntok, [&](int t, int o, float acc) {   // satrans.py:55-57
+        if (o < D) L.q0[(size_t)t * L.ldd + o] = acc;
+        else if (o < 2 * D) L.k0[(size_t)t * L.ldd + o - D] = acc;
+        else L.v[(size_t)t * L.ldd + o - 2 * D] = acc;
+    });
+    __syncthreads();
+    // ---- MetaNet on Q and K (satrans.py:60-73) -----------------------------------------------------------
+    if (a.flags & SATRANS_META_Q) {
+        metanet_tile(a, T, samp, dc, kSiteMetaQ, a.tab_q + (size_t)scen * a.tab_stride, a.lnq_g, a.lnq_b, L.q0, L.hq,
+                     L.zq, L.q, L);
+    } else if (L.q != L.q0) {
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            L.q[(size_t)t * L.ldd + c] = L.q0[(size_t)t * L.ldd + c];
+        }
+        __syncthreads();
+    }
+    if (a.flags & SATRANS_META_K) {
+        metanet_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, a.lnk_b, L.k0, L.hk,
+                     L.zk, L.k, L);
+    } else if (L.k != L.k0) {
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            L.k[(size_t)t * L.ldd + c] = L.k0[(size_t)t * L.ldd + c];
+        }
+        __syncthreads();
+    }
+    // ---- scores + softmax: one thread per (sample, head, query row)  (satrans.py:84-87) --------------------
+    const float sqrt_d = sqrtf((float)d);
+    for (int task = threadIdx.x; task < T.nS * H * F; task += blockDim.x) {
+        const int ls = task / (H * F), rem = task - ls * H * F;
+        const int h = rem / F, i = rem - h * F;
+        const float* qi = L.q + (size_t)(ls * F + i) * L.ldd + h * d;
+        float* prow = L.P + (size_t)task * L.ldp;
+        float mx = -INFINITY;
+        for (int j = 0; j < F; ++j) {
+            const float* kj = L.k + (size_t)(ls * F + j) * L.ldd + h * d;
+            float s = 0.f;
+            for (int e = 0; e < d; ++e) s = fmaf(qi[e], kj[e], s);
+            s = s / sqrt_d;
+            prow[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < F; ++j) {
+            const float e = expf(prow[j] - mx);
+            prow[j] = e;
+            sum += e;
+        }
+        for (int j = 0; j < F; ++j) prow[j] = prow[j] / sum;
+    }
+    __syncthreads();
+    // ---- o = dropout(P) @ V, heads written back side by side (satrans.py:88-90) ------------------------------
+    for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+        const int t = i / D, c = i - t * D;
+        const int ls = t / F, qi = t - ls * F, h = c / d;
+        const int task = (ls * H + h) * F + qi;
+        const float* prow = L.P + (size_t)task * L.ldp;
+        const int b = samp[ls];
+        float acc = 0.f;
+        for (int j = 0; j < F; ++j) {
+            const float p = prow[j] * drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + qi) * F + j));
+            acc = fmaf(p, L.v[(size_t)(ls * F + j) * L.ldd + c], acc);
+        }
+        L.o[(size_t)t * L.ldd + c] = acc;
+    }
+    stage_transposed(a.w_out, L.w, D, D);  // w[k][o] = Wo[o][k]   (nn.Linear: y = x @ Wo^T)
+    __syncthreads();
+    // ---- r = dropout(act(o @ Wo^T)) + x  (satrans.py:91-97) ---------------------------------------------------
+    gemm_tokens<4>(L.o, L.ldd, L.w, D, D, D, ntok, [&](int t, int o, float acc) {
+        const int ls = t / F, f = t - ls * F;
+        if (L.u) L.u[(size_t)t * L.ldd + o] = acc;
+        if (a.flags & SATRANS_RELU_OUT) acc = fmaxf(acc, 0.f);
+        acc *= drop_mask(dc, kSiteOut, samp[ls], (uint32_t)(f * D + o));
+        if (!(a.flags & SATRANS_NO_RES)) acc += L.x[(size_t)t * L.ldd + o];
+        L.r[(size_t)t * L.ldd + o] = acc;
+    });
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool tile_of(const satrans_layer_desc& a, int scen, int tile, int Tsamp, const int32_t*& samp,
+                                        int& nS) {
+    const int lo = a.seg[scen], hi = a.seg[scen + 1];
+    const int first = lo + tile * Tsamp;
+    if (first >= hi) return false;
+    samp = a.order + first;
+    nS = min(Tsamp, hi - first);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward kernel.  LDS aliasing: zq = q = q0 (MetaNet is applied in place), zk = k = k0, hk = hq,
+// P shares storage with hq (dead before the scores are written), o = q (every (sample,head,row) task reads
+// its own q row in the score phase, which ends at a barrier before o is written), r = k0.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLayerBlock) void layer_fwd_kernel(satrans_layer_desc a, int Tsamp, float* __restrict__ y,
+                                                              float* __restrict__ att) {
+    extern __shared__ __align__(16) float lds[];
+    const int F = a.F, D = a.D, H = a.H, U = a.U;
+    const int scen = blockIdx.y;
+    TileDims T{F, D, H, U, D / H, 0, 0};
+    LayerLds L;
+    L.ldd = D + 1;
+    L.ldu = U + 1;
+    L.ldp = F + 1;
+    const int maxtok = Tsamp * F;
+    float* p = lds;
+    L.x = p; p += maxtok * L.ldd;
+    L.q0 = p; p += maxtok * L.ldd;
+    L.k0 = p; p += maxtok * L.ldd;
+    L.v = p; p += maxtok * L.ldd;
+    const int hp = max(maxtok * L.ldu, Tsamp * H * F * L.ldp);
+    L.hq = p; L.hk = p; L.P = p; p += hp;
+    L.w = p;
+    L.zq = L.q = L.q0;
+    L.zk = L.k = L.k0;
+    L.o = L.q0;
+    L.u = nullptr;
+    L.r = L.k0;
+    const DropCtx dc = make_drop(a);
+
+    for (int tile = blockIdx.x;; tile += gridDim.x) {
+        const int32_t* samp;
+        if (!tile_of(a, scen, tile, Tsamp, samp, T.nS)) break;
+        T.ntok = T.nS * F;
+        forward_tile(a, T, scen, samp, dc, L);
+        if (att) {  // normalized_att_scores [H,B,F,F], after dropout (satrans.py:87)
+            for (int i = threadIdx.x; i < T.nS * H * F * F; i += blockDim.x) {
+                const int task = i / F, j = i - task * F;
+                const int ls = task / (H * F), rem = task - ls * H * F;
+                const int h = rem / F, qi = rem - h * F;
+                const int b = samp[ls];
+                const float pv = L.P[(size_t)task * L.ldp + j] * drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + qi) * F + j));
+                att[(((size_t)h * a.B + b) * F + qi) * F + j] = pv;
+            }
+        }
+        layer_norm_rows(L.r, L.r, L.ldd, T.ntok, D, a.ln_g, a.ln_b);  // satrans.py:99
+        __syncthreads();
+        for (int i = threadIdx.x; i < T.ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            const int ls = t / F, f = t - ls * F;
+            y[((size_t)samp[ls] * F + f) * D + c] = L.r[(size_t)t * L.ldd + c];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward kernel
+// ------------------------------------------------------------------------------------------------------
+// slab layout (floats) of one workgroup:
+//   [wq D*D][wk D*D][wv D*D][wo D*D][w1q D*U][w2q U*D][w1k D*U][w2k U*D][ln 2D][lnq 2D][lnk 2D]
+struct SlabOff {
+    int wq, wk, wv, wo, w1q, w2q, w1k, w2k, ln, lnq, lnk, total;
+};
+__host__ __device__ inline SlabOff slab_offsets(int D, int U) {
+    SlabOff s;
+    int o = 0;
+    s.wq = o; o += D * D;
+    s.wk = o; o += D * D;
+    s.wv = o; o += D * D;
+    s.wo = o; o += D * D;
+    s.w1q = o; o += D * U;
+    s.w2q = o; o += U * D;
+    s.w1k = o; o += D * U;
+    s.w2k = o; o += U * D;
+    s.ln = o; o += 2 * D;
+    s.lnq = o; o += 2 * D;
+    s.lnk = o; o += 2 * D;
+    s.total = o;
+    return s;
+}
+
+// slab[i*N + o] (+)= sum_t A[t][i] * G[t][o]   for i < M, o < N
+__device__ __forceinline__ void outer_accumulate(float* __restrict__ slab, bool first, const float* A, int lda,
+                                                 const float* G, int ldg, int M, int N, int ntok) {
+    for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
+        const int i = e / N, o = e - i * N;
+        float acc = 0.f;
+        for (int t = 0; t < ntok; ++t) acc = fmaf(A[(size_t)t * lda + i], G[(size_t)t * ldg + o], acc);
+        slab[e] = first ? acc : slab[e] + acc;
+    }
+}
+
+// LayerNorm backward of a tile.  On entry z holds the pre-norm rows and g the gradient of the normalised
+// output; on exit z holds the normalised rows z_hat, g holds the gradient wrt the pre-norm rows, and the
+// slab entries [gamma D | beta D] have received this tile's contribution.
+__device__ void layer_norm_backward_tile(float* z, float* g, int ld, int ntok, int D, const float* __restrict__ gamma,
+                                         float* rstd_buf, float* __restrict__ slab, bool first) {
+    for (int t = threadIdx.x; t < ntok; t += blockDim.x) {
+        float mean, rstd;
+        row_stats(z + (size_t)t * ld, D, mean, rstd);
+        for (int c = 0; c < D; ++c) z[(size_t)t * ld + c] = (z[(size_t)t * ld + c] - mean) * rstd;
+        rstd_buf[t] = rstd;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+        const int c = e % D;
+        float acc = 0.f;
+        if (e < D) {
+            for (int t = 0; t < ntok; ++t) acc = fmaf(g[(size_t)t * ld + c], z[(size_t)t * ld + c], acc);
+        } else {
+            for (int t = 0; t < ntok; ++t) acc += g[(size_t)t * ld + c];
+        }
+        slab[e] = first ? acc : slab[e] + acc;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntok; t += blockDim.x) {
+        float* gr = g + (size_t)t * ld;
+        const float* zr = z + (size_t)t * ld;
+        float m1 = 0.f, m2 = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float gg = gr[c] * gamma[c];
+            m1 += gg;
+            m2 = fmaf(gg, zr[c], m2);
+        }
+        m1 /= (float)D;
+        m2 /= (float)D;
+        const float rstd = rstd_buf[t];
+        for (int c = 0; c < D; ++c) gr[c] = rstd * (gr[c] * gamma[c] - m1 - zr[c] * m2);
+    }
+    __syncthreads();
+}
+
+// Backward of one MetaNet role.  On entry g = gradient wrt the MetaNet output (post-LN), z = pre-LN rows,
+// h = post-ReLU hidden, in0 = MetaNet input (q0/k0).  On exit g = gradient wrt the MetaNet input.
+__device__ void metanet_backward_tile(const satrans_layer_desc& a, const TileDims& T, const int32_t* samp,
+                                      const DropCtx& dc, int site, const float* __restrict__ tab_row,
+                                      const float* gamma, const float* in0, float* h, float* z, float* g, float* gm,
+                                      float* rstd_buf, LayerLds& L, float* slab_w1, float* slab_w2, float* slab_ln,
+                                      bool first) {
+    const int D = T.D, U = T.U, F = T.F, ntok = T.ntok;
+    layer_norm_backward_tile(z, g, L.ldd, ntok, D, gamma, rstd_buf, slab_ln, first);
+    // gm = dropout mask * dz
+    for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+        const int t = i / D, c = i - t * D;
+        const int ls = t / F, f = t - ls * F;
+        gm[(size_t)t * L.ldd + c] = g[(size_t)t * L.ldd + c] * drop_mask(dc, site, samp[ls], (uint32_t)(f * D + c));
+    }
+    stage_transposed(tab_row + D * U, L.w, U, D);  // w[o][u] = W2[u][o]
+    __syncthreads();
+    outer_accumulate(slab_w2, first, h, L.ldu, gm, L.ldd, U, D, ntok);  // dW2[u][o] += h^T gm
+    __syncthreads();
+    // dh = (gm @ W2^T) * [h > 0], in place of h
+    gemm_tokens<2>(gm, L.ldd, L.w, U, D, U, ntok, [&](int t, int u, float acc) {
+        float& hv = h[(size_t)t * L.ldu + u];
+        hv = hv > 0.f ? acc : 0.f;
+    });
+    stage_transposed(tab_row, L.w + D * U, D, U);  // w2[u][i] = W1[i][u]
+    __syncthreads();
+    outer_accumulate(slab_w1, first, in0, L.ldd, h, L.ldu, D, U, ntok);  // dW1[i][u] += in0^T dh
+    // g = dz + dh @ W1^T
+    gemm_tokens<2>(h, L.ldu, L.w + D * U, D, U, D, ntok,
+                   [&](int t, int i, float acc) { g[(size_t)t * L.ldd + i] += acc; });
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_desc a, int Tsamp,
+                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              float* __restrict__ slabs) {
+    extern __shared__ __align__(16) float lds[];
+    const int F = a.F, D = a.D, H = a.H, U = a.U, d = D / H;
+    const int scen = blockIdx.y;
+    TileDims T{F, D, H, U, d, 0, 0};
+    LayerLds L;
+    L.ldd = D + 1;
+    L.ldu = U + 1;
+    L.ldp = F + 1;
+    const int maxtok = Tsamp * F;
+    const int nd = maxtok * L.ldd, nu = maxtok * L.ldu, np = Tsamp * H * F * L.ldp;
+    float* p = lds;
+    auto take = [&](int n) { float* r = p; p += n; return r; };
+    L.x = take(nd); L.q0 = take(nd); L.k0 = take(nd); L.v = take(nd);
+    L.zq = take(nd); L.q = take(nd); L.zk = take(nd); L.k = take(nd);
+    L.o = take(nd); L.r = take(nd);
+    L.u = (a.flags & SATRANS_RELU_OUT) ? take(nd) : nullptr;
+    L.hq = take(nu); L.hk = take(nu);
+    L.P = take(np);
+    float* dS = take(np);
+    float* g_r = take(nd);   // dy -> dr -> dx
+    float* g_m = take(nd);   // du / MetaNet dm scratch
+    float* g_o = take(nd);   // gradient of the attention output
+    float* g_q = take(nd);
+    float* g_k = take(nd);
+    float* g_v = take(nd);
+    float* rstd_buf = take(maxtok);
+    L.w = take(max(3 * D * D, 2 * D * U));
+    if (!(a.flags & SATRANS_META_Q)) { L.zq = L.q0; L.q = L.q0; }
+    if (!(a.flags & SATRANS_META_K)) { L.zk = L.k0; L.k = L.k0; }
+
+    const SlabOff so = slab_offsets(D, U);
+    float* slab = slabs + ((size_t)scen * gridDim.x + blockIdx.x) * so.total;
+    const DropCtx dc = make_drop(a);
+    const float sqrt_d = sqrtf((float)d);
+    bool first = true;
+
+    for (int tile = blockIdx.x;; tile += gridDim.x) {
+        const int32_t* samp;
+        if (!tile_of(a, scen, tile, Tsamp, samp, T.nS)) break;
+        T.ntok = T.nS * F;
+        const int ntok = T.ntok;
+        forward_tile(a, T, scen, samp, dc, L);
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            const int ls = t / F, f = t - ls * F;
+            g_r[(size_t)t * L.ldd + c] = dy[((size_t)samp[ls] * F + f) * D + c];
+        }
+        __syncthreads();
+        // ---- final LayerNorm backward: g_r becomes dr ---------------------------------------------------
+        layer_norm_backward_tile(L.r, g_r, L.ldd, ntok, D, a.ln_g, rstd_buf, slab + so.ln, first);
+        // ---- du = dr * dropout mask * relu mask ------------------------------------------------------------
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            const int ls = t / F, f = t - ls * F;
+            float g = g_r[(size_t)t * L.ldd + c] * drop_mask(dc, kSiteOut, samp[ls], (uint32_t)(f * D + c));
+            if ((a.flags & SATRANS_RELU_OUT) && !(L.u[(size_t)t * L.ldd + c] > 0.f)) g = 0.f;
+            g_m[(size_t)t * L.ldd + c] = g;
+        }
+        stage_copy(a.w_out, L.w, D * D);  // as [K = out feature][N = in feature]
+        __syncthreads();
+        outer_accumulate(slab + so.wo, first, g_m, L.ldd, L.o, L.ldd, D, D, ntok);  // dWo[o][i] += du^T o_att
+        gemm_tokens<2>(g_m, L.ldd, L.w, D, D, D, ntok,
+                       [&](int t, int i, float acc) { g_o[(size_t)t * L.ldd + i] = acc; });
+        __syncthreads();
+        // ---- attention backward: dS rows (softmax + dropout backward) ---------------------------------------
+        for (int task = threadIdx.x; task < T.nS * H * F; task += blockDim.x) {
+            const int ls = task / (H * F), rem = task - ls * H * F;
+            const int h = rem / F, qi = rem - h * F;
+            const int b = samp[ls];
+            const float* go = g_o + (size_t)(ls * F + qi) * L.ldd + h * d;
+            const float* prow = L.P + (size_t)task * L.ldp;
+            float* srow = dS + (size_t)task * L.ldp;
+            float dot = 0.f;
+            for (int j = 0; j < F; ++j) {
+                const float* vj = L.v + (size_t)(ls * F + j) * L.ldd + h * d;
+                float dp = 0.f;
+                for (int e = 0; e < d; ++e) dp = fmaf(go[e], vj[e], dp);
+                dp *= drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + qi) * F + j));
+                srow[j] = dp;
+                dot = fmaf(dp, prow[j], dot);
+            }
+            for (int j = 0; j < F; ++j) srow[j] = prow[j] * (srow[j] - dot) / sqrt_d;
+        }
+        __syncthreads();
+        // ---- dq, dk, dv -----------------------------------------------------------------------------------------
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            const int ls = t / F, row = t - ls * F, h = c / d;
+            const int b = samp[ls];
+            const int task0 = (ls * H + h) * F;
+            float aq = 0.f, ak = 0.f, av = 0.f;
+            for (int j = 0; j < F; ++j) {
+                // dq[row] = sum_j dS[row][j] k[j] ; dk[row] = sum_i dS[i][row] q[i] ; dv[row] = sum_i Pd[i][row] do[i]
+                aq = fmaf(dS[(size_t)(task0 + row) * L.ldp + j], L.k[(size_t)(ls * F + j) * L.ldd + c], aq);
+                ak = fmaf(dS[(size_t)(task0 + j) * L.ldp + row], L.q[(size_t)(ls * F + j) * L.ldd + c], ak);
+                const float pd = L.P[(size_t)(task0 + j) * L.ldp + row] *
+                                 drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + j) * F + row));
+                av = fmaf(pd, g_o[(size_t)(ls * F + j) * L.ldd + c], av);
+            }
+            g_q[(size_t)t * L.ldd + c] = aq;
+            g_k[(size_t)t * L.ldd + c] = ak;
+            g_v[(size_t)t * L.ldd + c] = av;
+        }
+        __syncthreads();
+        // ---- MetaNet backward (g_q, g_k become gradients wrt q0, k0) -------------------------------------------
+        if (a.flags & SATRANS_META_Q)
+            metanet_backward_tile(a, T, samp, dc, kSiteMetaQ, a.tab_q + (size_t)scen * a.tab_stride, a.lnq_g, L.q0, L.hq,
+                                  L.zq, g_q, g_m, rstd_buf, L, slab + so.w1q, slab + so.w2q, slab + so.lnq, first);
+        if (a.flags & SATRANS_META_K)
+            metanet_backward_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, L.k0, L.hk,
+                                  L.zk, g_k, g_m, rstd_buf, L, slab + so.w1k, slab + so.w2k, slab + so.lnk, first);
+        // ---- projections: dW{q,k,v} += x^T g ; dx = dr*res + g_q Wq^T + g_k Wk^T + g_v Wv^T ----------------------
+        outer_accumulate(slab + so.wq, first, L.x, L.ldd, g_q, L.ldd, D, D, ntok);
+        outer_accumulate(slab + so.wk, first, L.x, L.ldd, g_k, L.ldd, D, D, ntok);
+        outer_accumulate(slab + so.wv, first, L.x, L.ldd, g_v, L.ldd, D, D, ntok);
+        stage_transposed(a.w_query, L.w, D, D);              // w[o][i] = Wq[i][o]
+        stage_transposed(a.w_key, L.w + D * D, D, D);
+        stage_transposed(a.w_value, L.w + 2 * D * D, D, D);
+        if (a.flags & SATRANS_NO_RES) {
+            for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) g_r[(size_t)(i / D) * L.ldd + (i % D)] = 0.f;
+        }
+        __syncthreads();
+        gemm_tokens<2>(g_q, L.ldd, L.w, D, D, D, ntok, [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
+        gemm_tokens<2>(g_k, L.ldd, L.w + D * D, D, D, D, ntok,
+                       [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
+        gemm_tokens<2>(g_v, L.ldd, L.w + 2 * D * D, D, D, D, ntok,
+                       [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
+        __syncthreads();
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            const int ls = t / F, f = t - ls * F;
+            dx[((size_t)samp[ls] * F + f) * D + c] = g_r[(size_t)t * L.ldd + c];
+        }
+        __syncthreads();
+        first = false;
+    }
+    if (first) {  // no tile for this workgroup: its slab must still read as zeros
+        for (int e = threadIdx.x; e < so.total; e += blockDim.x) slab[e] = 0.f;
+    }
+}
+
+// Sum the per-workgroup slabs in (scenario, workgroup) order and ADD them to the parameter gradients.
+__global__ void layer_bwd_reduce_kernel(const float* __restrict__ slabs, int S, int gx, int D, int U, int flags,
+                                        int64_t tab_stride, float* g_wq, float* g_wk, float* g_wv, float* g_wo,
+                                        float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k) {
+    const SlabOff so = slab_offsets(D, U);
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= so.total) return;
+    const bool is_tab = e >= so.w1q && e < so.ln;
+    if (!is_tab) {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s)
+            for (int w = 0; w < gx; ++w) acc += slabs[((size_t)s * gx + w) * so.total + e];
+        if (e < so.wk) g_wq[e - so.wq] += acc;
+        else if (e < so.wv) g_wk[e - so.wk] += acc;
+        else if (e < so.wo) g_wv[e - so.wv] += acc;
+        else if (e < so.w1q) g_wo[e - so.wo] += acc;
+        else if (e < so.lnq) g_ln[e - so.ln] += acc;
+        else if (e < so.lnk) {
+            // Without 'pos' the Q and K MetaNets share ONE LayerNorm (satrans.py:46): g_lnq == g_lnk, and this
+            // thread adds both roles' partials (Q first) so that no two threads update one address.
+            const bool shared = (flags & SATRANS_META_Q) && (flags & SATRANS_META_K) && g_lnq == g_lnk;
+            if (shared) {
+                float ak = 0.f;
+                for (int s = 0; s < S; ++s)
+                    for (int w = 0; w < gx; ++w) ak += slabs[((size_t)s * gx + w) * so.total + e + 2 * D];
+                g_lnq[e - so.lnq] += acc + ak;
+            } else if (flags & SATRANS_META_Q) {
+                g_lnq[e - so.lnq] += acc;
+            }
+        } else {
+            const bool shared = (flags & SATRANS_META_Q) && (flags & SATRANS_META_K) && g_lnq == g_lnk;
+            if ((flags & SATRANS_META_K) && !shared) g_lnk[e - so.lnk] += acc;
+        }
+        return;
+    }
+    // generated-weight row layout: [W1 D*U | W2 U*D]  (submodules.py:82-86).  The thread of a Q-role element also
+    // folds in the K-role partial of the same generated weight, so that an aliased table (no 'pos' flag:
+    // tab_q == tab_k) is updated by exactly one thread, Q contribution first.
+    if (e >= so.w1k) return;
+    const int within = e - so.w1q;
+    const int ek = so.w1k + within;
+    const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    for (int s = 0; s < S; ++s) {
+        float aq = 0.f, ak = 0.f;
+        for (int w = 0; w < gx; ++w) {
+            if (mq) aq += slabs[((size_t)s * gx + w) * so.total + e];
+            if (mk) ak += slabs[((size_t)s * gx + w) * so.total + ek];
+        }
+        if (mq && mk && g_tab_q == g_tab_k) {
+            g_tab_q[(size_t)s * tab_stride + within] += aq + ak;
+        } else {
+            if (mq) g_tab_q[(size_t)s * tab_stride + within] += aq;
+            if (mk) g_tab_k[(size_t)s * tab_stride + within] += ak;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLdsBudgetFwd = 78 * 1024;   // two workgroups per CU
+constexpr int kLdsBudgetBwd = 156 * 1024;  // one workgroup per CU
+
+static int64_t fwd_lds_floats(int T, int F, int D, int H, int U) {
+    const int64_t tok = (int64_t)T * F;
+    const int64_t hp = std::max<int64_t>(tok * (U + 1), (int64_t)T * H * F * (F + 1));
+    return 4 * tok * (D + 1) + hp + std::max<int64_t>(3 * D * D, (int64_t)D * U);
+}
+
+static int64_t bwd_lds_floats(int T, int F, int D, int H, int U, int flags) {
+    const int64_t tok = (int64_t)T * F;
+    const int64_t nd = tok * (D + 1), nu = tok * (U + 1), np = (int64_t)T * H * F * (F + 1);
+    const int nbuf = 16 + ((flags & SATRANS_RELU_OUT) ? 1 : 0);
+    return nbuf * nd + 2 * nu + 2 * np + tok + std::max<int64_t>(3 * D * D, 2 * (int64_t)D * U);
+}
+
+static int validate(const satrans_layer_desc* d, const char* who) {
+    SATRANS_REQUIRE(d, SATRANS_E_BADARG, "%s: null descriptor", who);
+    SATRANS_REQUIRE(d->x && d->sid && d->order && d->seg && d->w_query && d->w_key && d->w_value && d->w_out &&
+                        d->ln_g && d->ln_b,
+                    SATRANS_E_BADARG, "%s: null tensor pointer", who);
+    SATRANS_REQUIRE(d->B > 0 && d->F > 0 && d->D > 0 && d->H > 0 && d->S > 0, SATRANS_E_BADARG, "%s: bad sizes", who);
+    SATRANS_REQUIRE(d->D % d->H == 0, SATRANS_E_BADARG, "%s: embedding_size %d is not a multiple of head_num %d", who,
+                    d->D, d->H);
+    SATRANS_REQUIRE(!(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)), SATRANS_E_UNSUPPORTED,
+                    "%s: 'gate'/'bilinear' variants are not built yet", who);
+    if (d->flags & (SATRANS_META_Q | SATRANS_META_K)) {
+        SATRANS_REQUIRE(d->U > 0 && d->tab_q && d->tab_k && d->lnq_g && d->lnq_b && d->lnk_g && d->lnk_b,
+                        SATRANS_E_BADARG, "%s: MetaNet tensors missing", who);
+        SATRANS_REQUIRE(d->tab_stride >= 2 * (int64_t)d->D * d->U, SATRANS_E_BADARG, "%s: tab_stride too small", who);
+    }
+    SATRANS_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, SATRANS_E_BADARG, "%s: drop_p %f", who, d->drop_p);
+    return SATRANS_OK;
+}
+
+struct LayerPlan {
+    int T;        // samples per tile
+    int gx;       // workgroups per scenario
+    size_t lds;   // dynamic LDS bytes
+};
+
+static int plan_fwd(const satrans_layer_desc* d, LayerPlan& p) {
+    int T = 0;
+    for (int t = 1; t <= 16; ++t)
+        if (fwd_lds_floats(t, d->F, d->D, d->H, d->U) * 4 <= kLdsBudgetFwd) T = t;
+    if (T == 0 && fwd_lds_floats(1, d->F, d->D, d->H, d->U) * 4 <= kLdsBudgetBwd) T = 1;
+    SATRANS_REQUIRE(T > 0, SATRANS_E_UNSUPPORTED, "layer_fwd: one sample (F=%d D=%d U=%d) does not fit LDS", d->F, d->D,
+                    d->U);
+    p.T = T;
+    p.lds = (size_t)fwd_lds_floats(T, d->F, d->D, d->H, d->U) * 4;
+    const int64_t tiles = ceil_div(d->B, T);
+    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * 4, d->S)));
+    return SATRANS_OK;
+}
+
+static int plan_bwd(const satrans_layer_desc* d, LayerPlan& p) {
+    int T = 0;
+    for (int t = 1; t <= 8; ++t)
+        if (bwd_lds_floats(t, d->F, d->D, d->H, d->U, d->flags) * 4 <= kLdsBudgetBwd) T = t;
+    SATRANS_REQUIRE(T > 0, SATRANS_E_UNSUPPORTED, "layer_bwd: one sample (F=%d D=%d U=%d) does not fit LDS", d->F, d->D,
+                    d->U);
+    // prefer two workgroups per CU when a smaller tile allows it
+    for (int t = T; t >= 1; --t)
+        if (bwd_lds_floats(t, d->F, d->D, d->H, d->U, d->flags) * 4 <= kLdsBudgetFwd) { T = t; break; }
+    p.T = T;
+    p.lds = (size_t)bwd_lds_floats(T, d->F, d->D, d->H, d->U, d->flags) * 4;
+    const int64_t tiles = ceil_div(d->B, T);
+    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * 2, d->S)));
+    return SATRANS_OK;
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+extern "C" int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, float* att, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = validate(d, "layer_fwd");
+    if (rc) return rc;
+    SATRANS_REQUIRE(y, SATRANS_E_BADARG, "layer_fwd: null output");
+    LayerPlan p;
+    rc = plan_fwd(d, p);
+    if (rc) return rc;
+    static size_t attr_set = 0;
+    if (p.lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p.lds);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = p.lds;
+    }
+    layer_fwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, y, att);
+    SATRANS_CHECK_LAUNCH("layer_fwd_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int64_t satrans_layer_bwd_slab_floats_lds(const satrans_layer_desc* d) {
+    LayerPlan p;
+    if (!d || validate(d, "layer_bwd") || plan_bwd(d, p)) return -1;
+    return (int64_t)d->S * p.gx * slab_offsets(d->D, d->U).total;
+}
+
+extern "C" int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
+                                     float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk,
+                                     float* g_tab_q, float* g_tab_k, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = validate(d, "layer_bwd");
+    if (rc) return rc;
+    SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
+    if (d->flags & SATRANS_META_Q) SATRANS_REQUIRE(g_lnq && g_tab_q, SATRANS_E_BADARG, "layer_bwd: null Q MetaNet gradient");
+    if (d->flags & SATRANS_META_K) SATRANS_REQUIRE(g_lnk && g_tab_k, SATRANS_E_BADARG, "layer_bwd: null K MetaNet gradient");
+    LayerPlan p;
+    rc = plan_bwd(d, p);
+    if (rc) return rc;
+    static size_t attr_set = 0;
+    if (p.lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p.lds);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = p.lds;
+    }
+    layer_bwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    SATRANS_CHECK_LAUNCH("layer_bwd_kernel");
+    const int total = slab_offsets(d->D, d->U).total;
+    layer_bwd_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(
+        slabs, d->S, p.gx, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q,
+        g_tab_k);
+    SATRANS_CHECK_LAUNCH("layer_bwd_reduce_kernel");
+    return SATRANS_OK;
+}

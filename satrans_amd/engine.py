@@ -1,0 +1,416 @@
+"""Host-side driver of the HIP kernels for one SATrans model instance.
+
+Owns the per-batch-size workspaces, launches the kernels through the C ABI (satrans_amd.native) on torch's
+current HIP stream, and keeps the optimizer state.  PyTorch is used here for device memory, streams and the
+[S, P] scenario tables (a handful of tiny ops on S <= a few rows); every per-sample computation is a HIP kernel.
+
+Step anatomy (one training step, single GPU):
+    bucket scenarios -> gather rows -> L x layer_fwd -> head (+BCE, +dlogit) -> L x layer_bwd
+    -> scenario-table backward (tiny) -> sort gathered rows -> Adam on touched rows
+    -> streaming Adam on every other row (+ regulariser sum) -> flat Adam on the dense parameters
+With torch.distributed initialised (one process per GPU, RCCL), the dense gradients are all-reduced (SUM, the loss
+is a sum over samples) and the (row id, gradient row) pairs are all-gathered before the sort, so every rank
+applies the identical update in the identical order (satrans_amd/parallel.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import native as N
+from .inputs import split_columns
+
+
+class PathEngine:
+    def __init__(self, model):
+        self.lib = N.lib()
+        m = self.m = model
+        self.dev = m.embedding_arena.device
+        N.require_gpu(m.embedding_arena, "SATrans")
+        flag = m.flag
+        sparse, dense, _ = split_columns(m.dnn_feature_columns)
+        self.F = len(sparse)
+        self.D = m.embedding_size
+        self.H = m.att_head_num
+        self.L = m.domain_att_layer_num
+        units = m.meta_dnn_hidden_units
+        self.metanet = 'gate' not in flag and 'bilinear' not in flag
+        if 'gate' in flag or 'bilinear' in flag:
+            raise NotImplementedError("flags 'gate' / 'bilinear': ablation variants are not built as HIP kernels yet")
+        if len(m.domain_column_list) > 1:
+            raise NotImplementedError("more than one scenario column is not built as HIP kernels yet")
+        if len(units) != 3 or units[2] != self.D:
+            raise NotImplementedError(f"meta_dnn_hidden_units must be (U, embedding_dim); got {units[1:]}")
+        self.U = units[1]
+        self.P = m.meta_param_size
+        self.S = m.domain_embeddings.weight.shape[0]
+        self.pos = 'pos' in flag
+        self.onlyemb = 'onlyemb' in flag
+        self.flags = 0
+        if self.metanet and 'Q' in m.meta_mode:
+            self.flags |= N.META_Q
+        if self.metanet and 'K' in m.meta_mode:
+            self.flags |= N.META_K
+        if 'relu' in flag:
+            self.flags |= N.RELU_OUT
+        if not m.att_res:
+            self.flags |= N.NO_RES
+        self.drop_p = 0.1                                   # reference models/satrans.py:27-28
+
+        fi = m.feature_index
+        self.cols = torch.tensor([fi[c.name][0] for c in sparse], dtype=torch.int32, device=self.dev)
+        dcols: List[int] = []
+        for c in dense:
+            dcols += list(range(fi[c.name][0], fi[c.name][1]))
+        self.n_dense = len(dcols)
+        self.dense_cols = torch.tensor(dcols, dtype=torch.int32, device=self.dev) if dcols else None
+        self.dom_col = fi[m.domain_column_list[0]][0]
+        self.n_cols = max(e for _, e in fi.values())
+        # arena row offset of every FIELD (fields sharing an embedding_name share a table)
+        offs = [m._table_rows[c.embedding_name][0] for c in sparse]
+        ends = [m._table_rows[c.embedding_name][0] + m._table_rows[c.embedding_name][1] for c in sparse]
+        self.total_rows = m.embedding_arena.shape[0]
+        # the gather kernel takes [lo_f, hi_f) per field as row_off[f], row_off[f+1]; with shared tables the spans
+        # are not consecutive, so they are passed as an explicit (lo, hi) pair table laid out [F+1] when they are
+        self._consecutive = all(ends[i] == offs[i + 1] for i in range(len(offs) - 1))
+        if not self._consecutive:
+            raise NotImplementedError("fields sharing one embedding table (embedding_name reuse)")
+        self.row_off = torch.tensor(offs + [ends[-1]], dtype=torch.int64, device=self.dev)
+
+        self._ws: Dict[int, dict] = {}
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.reg_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.adam_t = 0
+        self.adam_m = self.adam_v = None
+        self.flat_m = self.flat_v = self.flat_g = None
+        self.drop_seed = int(torch.initial_seed() & 0xFFFFFFFF)
+        self.drop_step = 0
+        self._last_prob = None
+        self.overlap_streams = False
+
+    # ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return N.stream_handle(self.dev)
+
+    def workspace(self, B: int) -> dict:
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        dev, F, D = self.dev, self.F, self.D
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = dict(
+            sid=torch.empty(B, **i32), order=torch.empty(B, **i32), seg=torch.empty(self.S + 1, **i32),
+            bucket=torch.empty(int(self.lib.satrans_bucket_workspace_bytes(B, self.S)), dtype=torch.uint8, device=dev),
+            acts=[torch.empty(B, F, D, **f32) for _ in range(self.L + 1)],
+            rows=torch.empty(B, F, **i32),
+            prob=torch.empty(B, **f32), logit=torch.empty(B, **f32),
+        )
+        self._ws[B] = ws
+        return ws
+
+    def train_workspace(self, B: int, n_rows: int) -> dict:
+        ws = self.workspace(B)
+        key = ("train", n_rows)
+        if key in ws:
+            return ws
+        dev, F, D = self.dev, self.F, self.D
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws["dact"] = [torch.empty(B, F, D, **f32) for _ in range(2)]
+        ws["head_scratch"] = torch.empty(int(self.lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
+        desc = self._layer_desc(ws, 0, B, None, None, True)
+        ws["slabs"] = torch.empty(int(self.lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
+        ws["sorted_rows"] = torch.empty(n_rows, **i32)
+        ws["src"] = torch.empty(n_rows, **i32)
+        ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
+        ws["sort_ws"] = torch.empty(int(self.lib.satrans_embed_sort_workspace_bytes(n_rows, self.total_rows)),
+                                    dtype=torch.uint8, device=dev)
+        ws["partial_ws"] = torch.empty(int(self.lib.satrans_embed_partial_ws_floats(n_rows, D)), **f32)
+        ws["reg_partials"] = torch.zeros(int(self.lib.satrans_embed_reg_partials(self.total_rows, n_rows, D)),
+                                         dtype=torch.float64, device=dev)
+        ws[key] = True
+        return ws
+
+    # ------------------------------------------------------------------------------------------------
+    # scenario tables: row s = encoder(relu(scenario_embedding[s]))  (reference satrans.py:203-234, evaluated
+    # once per scenario instead of once per sample - SURVEY.md §0)
+    # ------------------------------------------------------------------------------------------------
+    def scenario_tables(self, grad: bool) -> torch.Tensor:
+        """-> [L, 2, S, P'] when 'pos' is in the flag (role 0 = Q, 1 = K), else [1, 1, S, P']."""
+        m = self.m
+        with torch.set_grad_enabled(grad):
+            dom = torch.relu(m.domain_embeddings.weight)                          # satrans.py:213
+            if not self.pos:
+                z = dom.unsqueeze(0).unsqueeze(0)
+            else:
+                lay = m.layerid_embeddings.weight                                  # [L, D]
+                role = m.qkvid_embeddings.weight[:2]                                # [2, D]  (the V row is never used)
+                posv = (lay[:, None, :] + role[None, :, :])                         # [L, 2, D]
+                z = torch.relu(torch.cat([dom[None, None].expand(self.L, 2, -1, -1),
+                                          posv[:, :, None, :].expand(-1, -1, self.S, -1)], dim=-1))
+            if self.onlyemb:
+                tab = z
+            else:
+                lin = m.domain_map_dnn_Q.linears[0]
+                tab = torch.nn.functional.linear(z, lin.weight, lin.bias)
+            return tab.contiguous()
+
+    def _layer_desc(self, ws, l, B, x, tabs, training) -> N.LayerDesc:
+        m = self.m
+        lay = m.domain_int_layers[l]
+        d = N.LayerDesc()
+        d.B, d.F, d.D, d.H, d.U, d.S = B, self.F, self.D, self.H, self.U, self.S
+        d.flags = self.flags | (N.TRAIN if training else 0)
+        d.layer = l
+        d.drop_p = self.drop_p
+        d.seed, d.step = self.drop_seed, self.drop_step & 0xFFFFFFFF
+        d.x = N.ptr(x) if x is not None else ws["acts"][l].data_ptr()
+        d.sid, d.order, d.seg = ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr()
+        d.w_query, d.w_key, d.w_value = lay.W_Query.data_ptr(), lay.W_Key.data_ptr(), lay.W_Value.data_ptr()
+        d.w_out = lay.Out_linear.weight.data_ptr()
+        d.ln_g, d.ln_b = lay.layer_norm.weight.data_ptr(), lay.layer_norm.bias.data_ptr()
+        d.lnq_g = lay.Q_meta_mlp.ffn_layer_norm.weight.data_ptr()
+        d.lnq_b = lay.Q_meta_mlp.ffn_layer_norm.bias.data_ptr()
+        d.lnk_g = lay.K_meta_mlp.ffn_layer_norm.weight.data_ptr()
+        d.lnk_b = lay.K_meta_mlp.ffn_layer_norm.bias.data_ptr()
+        if tabs is not None:
+            tq, tk = self._layer_tables(tabs, l)
+            d.tab_q, d.tab_k = tq.data_ptr(), tk.data_ptr()
+            d.tab_stride = tabs.shape[-1]
+        else:                                                # size queries only
+            d.tab_q = d.tab_k = ws["sid"].data_ptr()
+            d.tab_stride = 2 * self.D * self.U
+        return d
+
+    def _layer_tables(self, tabs, l):
+        if self.pos:
+            return tabs[l, 0], tabs[l, 1]
+        return tabs[0, 0], tabs[0, 0]
+
+    # ------------------------------------------------------------------------------------------------
+    def _prepare_input(self, X: torch.Tensor):
+        N.require_gpu(X, "SATrans.forward input")
+        if X.dim() != 2 or X.shape[1] < self.n_cols:
+            raise ValueError(f"expected X of shape [B, {self.n_cols}], got {tuple(X.shape)}")
+        if X.dtype not in (torch.float32, torch.int32, torch.int64):
+            X = X.float()
+        if not X.is_contiguous():
+            X = X.contiguous()
+        if X.dtype != torch.float32 and self.n_dense:
+            raise NotImplementedError("integer id matrix together with dense features")
+        return X
+
+    def _run_forward(self, X, ws, training, tabs, att_list=None):
+        lib, B, st = self.lib, X.shape[0], self._stream()
+        idt = N.id_dtype_of(X)
+        N.check(lib.satrans_bucket_scenarios(X.data_ptr(), idt, X.stride(0), self.dom_col, B, self.S,
+                                             ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr(),
+                                             self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
+                "satrans_bucket_scenarios")
+        N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_off.data_ptr(), self.cols.data_ptr(),
+                                       X.data_ptr(), idt, X.stride(0), B, self.F, self.D, ws["acts"][0].data_ptr(),
+                                       ws["rows"].data_ptr(), self.status.data_ptr(), st), "satrans_gather_fwd")
+        for l in range(self.L):
+            desc = self._layer_desc(ws, l, B, None, tabs, training)
+            att = att_list[l].data_ptr() if att_list is not None else None
+            N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
+
+    def _head(self, X, ws, y=None, train_ws=None):
+        lib, B, st = self.lib, X.shape[0], self._stream()
+        m = self.m
+        dense_ptr = X.data_ptr() if self.n_dense else None
+        dcols = self.dense_cols.data_ptr() if self.n_dense else None
+        if y is None:
+            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, X.stride(0), dcols, self.n_dense, B,
+                                     self.F * self.D, m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr(),
+                                     ws["prob"].data_ptr(), ws["logit"].data_ptr(), None, None, None, None, None, None,
+                                     st), "satrans_head")
+        else:
+            gw, gb = self._grad_view("dnn_linear.weight"), self._grad_view("dnn_linear.bias")
+            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, X.stride(0), dcols, self.n_dense, B,
+                                     self.F * self.D, m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr(),
+                                     ws["prob"].data_ptr(), ws["logit"].data_ptr(), y.data_ptr(),
+                                     self.loss_sum.data_ptr(), ws["dact"][0].data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                     ws["head_scratch"].data_ptr(), st), "satrans_head")
+
+    def forward(self, X: torch.Tensor, training: bool = False, capture_attention: bool = False) -> torch.Tensor:
+        X = self._prepare_input(X)
+        B = X.shape[0]
+        ws = self.workspace(B)
+        tabs = self.scenario_tables(grad=False)
+        att_list = None
+        if capture_attention:
+            att_list = [torch.empty(self.H, B, self.F, self.F, dtype=torch.float32, device=self.dev)
+                        for _ in range(self.L)]
+        if training:
+            self.drop_step += 1
+        self._run_forward(X, ws, training, tabs, att_list)
+        self._head(X, ws)
+        if att_list is not None:
+            for layer, att in zip(self.m.domain_int_layers, att_list):
+                layer.normalized_att_scores = att
+        self._last_logit = ws["logit"]
+        return ws["prob"].clone().unsqueeze(1)
+
+    def last_prob(self) -> torch.Tensor:
+        return self._last_prob
+
+    def last_logit(self) -> torch.Tensor:
+        return self._last_logit.clone().unsqueeze(1)
+
+    def layer_outputs(self, B: int) -> List[torch.Tensor]:
+        """[att_input, layer 0 output, ...] of the most recent forward at this batch size (tests)."""
+        return [a.clone() for a in self._ws[B]["acts"]]
+
+    def raise_if_bad_ids(self):
+        if int(self.status.item()) != 0:
+            self.status.zero_()
+            raise IndexError("index out of range in self: an id (or scenario id) exceeds its vocabulary_size")
+
+    # ------------------------------------------------------------------------------------------------
+    # training
+    # ------------------------------------------------------------------------------------------------
+    def _ensure_train_state(self):
+        m = self.m
+        if self.flat_g is None:
+            self.flat_g = torch.zeros_like(m.flat_params)
+            self.flat_m = torch.zeros_like(m.flat_params)
+            self.flat_v = torch.zeros_like(m.flat_params)
+            self.adam_m = torch.zeros_like(m.embedding_arena)
+            self.adam_v = torch.zeros_like(m.embedding_arena)
+            # expose gradients the torch way: param.grad is a view into the flat gradient buffer
+            for name, p in m._trainable_flat().items():
+                off, cnt = m._flat_slices[name]
+                p.grad = self.flat_g[off:off + cnt].view(p.shape)
+
+    def _grad_view(self, name: str) -> torch.Tensor:
+        off, cnt = self.m._flat_slices[name]
+        return self.flat_g[off:off + cnt]
+
+    def reset_epoch_sums(self):
+        self.loss_sum.zero_()
+        self.reg_sum.zero_()
+
+    def epoch_sums(self):
+        return float(self.loss_sum.item()), float(self.reg_sum.item())
+
+    def _hparams(self, l2: float) -> N.AdamHParams:
+        cfg = self.m._adam_cfg
+        b1, b2 = cfg["betas"]
+        t = self.adam_t
+        h = N.AdamHParams()
+        h.lr_over_bc1 = cfg["lr"] / (1.0 - b1 ** t)
+        h.bc2_sqrt = math.sqrt(1.0 - b2 ** t)
+        h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
+        return h
+
+    def backward(self, X, y, ws):
+        """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
+        `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
+        lib, B, st = self.lib, X.shape[0], self._stream()
+        m = self.m
+        self.flat_g.zero_()
+        training = m.training
+        if training:
+            self.drop_step += 1
+        modulated = bool(self.flags & (N.META_Q | N.META_K))
+        tabs = self.scenario_tables(grad=modulated)
+        g_tabs = torch.zeros_like(tabs) if modulated else None
+        self._run_forward(X, ws, training, tabs.detach())
+        self._head(X, ws, y)
+        cur = 0
+        for l in reversed(range(self.L)):
+            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training)
+            lay = f"domain_int_layers.{l}."
+            gq = gk = glnq = glnk = None
+            if modulated:
+                tq, tk = self._layer_tables(g_tabs, l)
+                gq, gk = tq.data_ptr(), tk.data_ptr()
+            if self.flags & N.META_Q:
+                glnq = self._grad_view(lay + "Q_meta_mlp.ffn_layer_norm.weight").data_ptr()
+            if self.flags & N.META_K:
+                kname = "K_meta_mlp" if m.domain_int_layers[l].K_meta_mlp is not m.domain_int_layers[l].Q_meta_mlp \
+                    else "Q_meta_mlp"
+                glnk = self._grad_view(lay + kname + ".ffn_layer_norm.weight").data_ptr()
+            N.check(lib.satrans_layer_bwd(
+                C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),
+                self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
+                self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
+                self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
+            cur = 1 - cur
+        if modulated:
+            tabs.backward(g_tabs)                              # tiny: [S,P] through one Linear + two embeddings
+        self._last_prob = ws["prob"]
+        return ws["dact"][cur]
+
+    def train_step(self, X: torch.Tensor, y: torch.Tensor):
+        from . import parallel
+        X = self._prepare_input(X)
+        y = y.reshape(-1).to(torch.float32).contiguous()
+        B = X.shape[0]
+        self._ensure_train_state()
+        world = parallel.world_size()
+        n_rows = B * self.F * world
+        ws = self.train_workspace(B, n_rows)
+        lib, st, m, D = self.lib, self._stream(), self.m, self.D
+        gemb = self.backward(X, y, ws)
+        rows = ws["rows"]
+        if world > 1:
+            rows, gemb = parallel.exchange(self.flat_g, rows, gemb)
+        self.adam_t += 1
+        N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
+                                       ws["src"].data_ptr(), ws["touched"].data_ptr(), ws["sort_ws"].data_ptr(),
+                                       ws["sort_ws"].numel(), st), "satrans_embed_sort")
+        h_emb = self._hparams(m.l2_reg_embedding)
+        N.check(lib.satrans_embed_adam_touched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                               self.adam_v.data_ptr(), D, ws["sorted_rows"].data_ptr(),
+                                               ws["src"].data_ptr(), n_rows, gemb.data_ptr(), ws["partial_ws"].data_ptr(),
+                                               C.byref(h_emb), ws["reg_partials"].data_ptr(), st),
+                "satrans_embed_adam_touched")
+        N.check(lib.satrans_embed_adam_untouched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                                 self.adam_v.data_ptr(), self.total_rows, D, ws["touched"].data_ptr(),
+                                                 C.byref(h_emb), ws["reg_partials"].data_ptr(), st),
+                "satrans_embed_adam_untouched")
+        h_flat = self._hparams(0.0)
+        N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                      self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st),
+                "satrans_adam_flat")
+        N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(),
+                                    1, st), "satrans_sum_f64")
+
+    # ------------------------------------------------------------------------------------------------
+    # inspection for the parity tests: one forward+backward, gradients by state_dict key (dense tables)
+    # ------------------------------------------------------------------------------------------------
+    def loss_and_grads(self, X: torch.Tensor, y: torch.Tensor):
+        X = self._prepare_input(X)
+        y = y.reshape(-1).to(torch.float32).contiguous()
+        B = X.shape[0]
+        self._ensure_train_state()
+        n_rows = B * self.F
+        ws = self.train_workspace(B, n_rows)
+        lib, st, m, D = self.lib, self._stream(), self.m, self.D
+        self.loss_sum.zero_()
+        gemb = self.backward(X, y, ws)
+        N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
+                                       ws["src"].data_ptr(), ws["touched"].data_ptr(), ws["sort_ws"].data_ptr(),
+                                       ws["sort_ws"].numel(), st), "satrans_embed_sort")
+        g_arena = torch.zeros_like(m.embedding_arena)
+        N.check(lib.satrans_embed_grad_dense(m.embedding_arena.data_ptr(), ws["sorted_rows"].data_ptr(),
+                                             ws["src"].data_ptr(), n_rows, gemb.data_ptr(), self.total_rows, D,
+                                             float(m.l2_reg_embedding), g_arena.data_ptr(), st),
+                "satrans_embed_grad_dense")
+        grads = {}
+        for name, (off, rows) in m._table_rows.items():
+            grads[f"embedding_dict.{name}.weight"] = g_arena[off:off + rows].clone()
+        for name, p in m._trainable_flat().items():
+            off, cnt = m._flat_slices[name]
+            grads[name] = self.flat_g[off:off + cnt].view(p.shape).clone()
+        bce = float(self.loss_sum.item())
+        reg = float(m.get_regularization_loss().item())
+        self.raise_if_bad_ids()
+        return bce, reg, grads

@@ -1,0 +1,50 @@
+"""Data-parallel exchange for the training step: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm, over xGMI inside a node).
+
+The reference's only parallelism is an optional single-process `torch.nn.DataParallel` wrap
+(models/meta_basemodel.py:272-275) whose semantics are: `batch_size` is PER GPU, parameters are replicated, the
+loss is a SUM over samples, gradients are summed onto one device.  The same semantics here, one exchange step
+per iteration:
+
+  * dense parameters (~0.15-0.28 M floats, latency-bound): ONE all_reduce(SUM) of the flat gradient buffer;
+  * embedding gradients: all_gather of the (arena row id int32, gradient row D x fp32) pairs each rank produced
+    (B*F pairs, ~10.6 MB at B=4096).  Every rank then sorts and applies the SAME merged list in the SAME order
+    (rank-major, then position), so the replicas stay bit-identical without ever moving a table-sized buffer.
+    The regulariser gradient 2*l2*p is identical on every rank and is added locally, after the exchange.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def exchange(flat_grad: torch.Tensor, rows: torch.Tensor, gemb: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-reduce `flat_grad` in place (SUM); return (all rows [W*n], all gradient rows [W*n, D]) in rank order."""
+    w = world_size()
+    if w == 1:
+        return rows.reshape(-1), gemb.reshape(-1, gemb.shape[-1])
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    rows = rows.reshape(-1).contiguous()
+    gemb = gemb.reshape(rows.numel(), -1).contiguous()
+    all_rows = torch.empty(w * rows.numel(), dtype=rows.dtype, device=rows.device)
+    all_gemb = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
+    dist.all_gather_into_tensor(all_rows, rows)
+    dist.all_gather_into_tensor(all_gemb, gemb)
+    return all_rows, all_gemb
+
+
+def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:
+    """Sum of per-rank scalars (losses, counts) for logging."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

@@ -50,3 +50,20 @@ class Case:
         m = self.meta
         return [SparseFeat(f, vocabulary_size=v, embedding_dim=m["D"]) for f, v in zip(m["fields"], m["vocab"])] + \
                [DenseFeat(f, 1) for f in m["dense"]]
+
+
+def build_model(case: "Case", device: str):
+    """The product model for a golden case, constructed the way reference main.py:292-306 does."""
+    from satrans_amd import SATrans
+    m = case.meta
+    cols = case.columns()
+    model = SATrans(linear_feature_columns=cols, dnn_feature_columns=cols, domain_column_list=list(m["domain"]),
+                    num_domains_list=m["num_domains_list"], att_layer_num=0, domain_att_layer_num=m["L"],
+                    att_head_num=m["H"], share_domain_dnn_across_layers=False, use_domain_dnn_linear=False,
+                    use_linear=False, meta_mode=m["mode"], use_dnn=False, meta_dnn_hidden_units=tuple(m["units"]),
+                    seed=m["seed"], device=device, flag=m["flag"])
+    return model
+
+
+NATIVE_CASES = [c for c in ALL_CASES if c not in ("small_gate", "small_bilinear", "small_multidomain")]
+NATIVE_TRAIN_CASES = [c for c in NATIVE_CASES if c in TRAIN_CASES]

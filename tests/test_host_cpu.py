@@ -1,0 +1,101 @@
+"""CPU-side checks: column layout, seed-parity of construction, ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from satrans_amd import DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, get_feature_names
+from satrans_amd import native
+from tests.helpers import ALL_CASES, Case, build_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_feature_index_layout():
+    cols = [SparseFeat("a", 10, 8), DenseFeat("p", 2), SparseFeat("b", 5, 8),
+            VarLenSparseFeat(SparseFeat("h", 7, 8), maxlen=3, length_name="h_len")]
+    idx = build_input_features(cols + cols)          # main.py passes linear + dnn columns: duplicates are skipped
+    assert list(idx.items()) == [("a", (0, 1)), ("p", (1, 3)), ("b", (3, 4)), ("h", (4, 7)), ("h_len", (7, 8))]
+    assert get_feature_names(cols) == ["a", "p", "b", "h", "h_len"]
+    assert SparseFeat("z", 16, "auto").embedding_dim == 12
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_construction_is_bit_identical_to_reference(name):
+    """Same seed -> same state_dict as the reference (same generator draws in the same order)."""
+    c = Case(name)
+    if name == "small_multidomain":
+        pytest.skip("second table set for several scenario columns: constructed, compared in a later round")
+    model = build_model(c, "cpu")
+    mine, want = model.state_dict(), c.tensors("param")
+    assert set(mine) == set(want)
+    for k in want:
+        assert torch.equal(mine[k], want[k]), k
+    # storage: tables are views of one arena, trainables views of one flat buffer, and they stay so after a move
+    assert model.embedding_dict[c.meta["fields"][0]].weight.data_ptr() == model.embedding_arena.data_ptr()
+    model.to("cpu")
+    assert model.embedding_dict[c.meta["fields"][0]].weight.data_ptr() == model.embedding_arena.data_ptr()
+    total = sum(v for v in c.meta["vocab"])
+    assert model.embedding_arena.shape == (total, c.meta["D"])
+
+
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_k", "small_none", "small_onlyemb"])
+def test_trainable_set_matches_reference_gradients(name):
+    """The tensors the fused Adam steps are exactly the ones that receive a gradient in the reference."""
+    c = Case(name)
+    model = build_model(c, "cpu")
+    mine = set(model._trainable_flat()) | {f"embedding_dict.{n}.weight" for n in model._table_order()}
+    assert mine == set(c.arrays("grad"))
+
+
+def test_forward_on_cpu_fails_loudly():
+    c = Case("small_q")
+    model = build_model(c, "cpu")
+    with pytest.raises(native.NativeError, match="no CPU fallback"):
+        model(c.X)
+
+
+def test_bad_arguments_raise_like_the_reference():
+    cols = [SparseFeat("a", 10, 8), SparseFeat("d", 4, 8)]
+    from satrans_amd import SATrans
+    with pytest.raises(ValueError, match="integer multiple of head_num"):
+        SATrans(cols, cols, ["d"], [3], domain_att_layer_num=1, att_head_num=3, flag="sota")
+    with pytest.raises(ValueError, match="head_num must be"):
+        SATrans(cols, cols, ["d"], [3], domain_att_layer_num=1, att_head_num=0, flag="sota")
+    mixed = [SparseFeat("a", 10, 8), SparseFeat("d", 4, 4)]
+    with pytest.raises(ValueError, match="must be same"):
+        SATrans(mixed, mixed, ["d"], [3], domain_att_layer_num=1, att_head_num=2, flag="sota")
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads (no GPU needed) and exports exactly what include/satrans_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "satrans_hip.h")).read()
+    declared = set(re.findall(r"\b(satrans_[a-z0-9_]+)\s*\(", header))
+    declared -= {"satrans_layer_desc", "satrans_adam_hparams"}
+    assert os.path.exists(native.LIB_PATH), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(native.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(handle, sym), f"{sym} declared in the header but not exported"
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    lib = native.lib()
+    assert lib.satrans_abi_version() == native.ABI_VERSION
+    # argument validation works without touching a device
+    assert lib.satrans_gather_fwd(None, None, None, None, 0, 0, 1, 1, 32, None, None, None, None) == -1
+    assert b"null pointer" in lib.satrans_last_error()
+    assert ctypes.sizeof(native.LayerDesc) == 8 * 4 + 4 + 4 + 4 + 4 + 8 + 16 * 8   # mirrors satrans_layer_desc
+
+
+def test_dropout_mask_statistics():
+    """The counter-based mask keeps ~90 % and decorrelates sites, layers and steps."""
+    from oracle.satrans_oracle import dropout_keep
+    b = np.arange(512, dtype=np.uint32)[:, None]
+    e = np.arange(608, dtype=np.uint32)[None, :]
+    k0 = dropout_keep(1021, 1, 0, 0, b, e, 0.1)
+    k1 = dropout_keep(1021, 1, 0, 1, b, e, 0.1)
+    k2 = dropout_keep(1021, 2, 0, 0, b, e, 0.1)
+    assert abs(k0.mean() - 0.9) < 0.005
+    for other in (k1, k2):
+        assert abs((k0 & other).mean() - 0.81) < 0.01
