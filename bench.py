@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the SATrans training step on MI355X (BASELINE.json metric: training samples/sec, AliCCP-shaped
+input, embedding_dim 32, 3 layers, 4 heads, meta_mode QK).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step of the reference's `fit` loop (models/meta_basemodel.py:310-328) on one batch
+per GPU: gather -> 3 layers -> head -> BCE(sum) -> backward -> dense-semantics Adam + L2 over ALL 6.57 M embedding
+rows (what the reference's dense `torch.optim.Adam` + `get_regularization_loss` do every step) -> Adam on the
+other parameters.  Dropout is on (p = 0.1, four sites per layer).  Inputs are synthetic, AliCCP-shaped
+ and already resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALICCP_FIELDS = ['101', '121', '122', '124', '125', '126', '127', '128', '129', '205', '206', '207', '210', '216',
+                 '508', '509', '702', '853', '301']                                # reference main.py:99-101
+ALICCP_MAX = {'101': 444861, '121': 97, '122': 13, '124': 2, '125': 7, '126': 3, '127': 3, '128': 2, '129': 4,
+              '205': 4348615, '206': 8993, '207': 695124, '210': 99606, '216': 234880, '508': 8185, '509': 472354,
+              '702': 167813, '853': 91358, '301': 3}                               # reference main.py:124-127
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
+FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
+
+
+def synth_batches(n_rows, seed):
+    rng = np.random.RandomState(seed)
+    cols = []
+    for f in ALICCP_FIELDS:
+        lo = 1 if f == '301' else 0                                                # scenario ids start at 1 (main.py:112-114)
+        cols.append(rng.randint(lo, ALICCP_MAX[f] + 1, size=n_rows))
+    X = np.stack(cols, axis=1).astype(np.float32)                                  # ids travel as fp32 (meta_basemodel.py:311)
+    y = (rng.rand(n_rows) < 0.04).astype(np.float32)                               # assumed CTR level
+    return X, y
+
+
+def build_model(device, lr):
+    from satrans_amd import SATrans, SparseFeat
+    cols = [SparseFeat(f, vocabulary_size=ALICCP_MAX[f] + 2, embedding_dim=32) for f in ALICCP_FIELDS]
+    model = SATrans(cols, cols, ['301'], [3], att_layer_num=0, domain_att_layer_num=3, att_head_num=4,
+                    use_linear=False, use_dnn=False, meta_mode='QK', seed='1021', device=device, flag='sota')
+    model.compile(torch.optim.Adam(model.parameters(), lr=lr), "binary_crossentropy",
+                  metrics=["binary_crossentropy", "auc"])                          # main.py:343
+    return model
+
+
+def oracle_spec():
+    from oracle.satrans_oracle import PathSpec
+    return PathSpec(sparse=[(f, i) for i, f in enumerate(ALICCP_FIELDS)], dense=[], domain_cols=[18],
+                    embedding_dim=32, head_num=4, layer_num=3, flag='sota', meta_mode='QK', meta_units=[32, 64, 32])
+
+
+def cpu_baseline(state, X, y, batch, lr, steps):
+    """The reference's training step restated op for op (oracle/satrans_oracle.py: per-sample generated weights,
+    torch CPU dropout, dense L2 over all rows, dense torch.optim.Adam), timed on this box's host cores."""
+    from oracle import satrans_oracle as O
+    torch.set_num_threads(min(os.cpu_count(), 32))  # more threads only add contention (256-core box: 70 s/step)
+    tr = O.OracleTrainer(state, oracle_spec(), lr=lr)
+    drop = O.Dropper("torch", 0.1)
+    times = []
+    for s in range(steps + 1):
+        xb = torch.from_numpy(X[s * batch:(s + 1) * batch])
+        yb = torch.from_numpy(y[s * batch:(s + 1) * batch])
+        t0 = time.perf_counter()
+        tr.step(xb, yb, drop)
+        times.append(time.perf_counter() - t0)
+    timed = times[1:]                                                              # first step allocates Adam state
+    return batch / (sum(timed) / len(timed)), len(timed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8192, help="samples per GPU per step (reference main.py:80)")
+    ap.add_argument("--lr", type=float, default=0.005)
+    ap.add_argument("--cpu-steps", type=int, default=1, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--no-phase-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    B, K, W = args.batch, args.steps, args.warmup
+    t_build = time.time()
+    model = build_model("cpu", args.lr)                                            # seeded init on CPU, as the reference
+    do_cpu = world == 1 and args.cpu_steps > 0
+    state_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if do_cpu else None
+    if do_cpu:                                                                     # keep the reference's aliasing
+        sd = model.state_dict()
+        by_ptr = {}
+        for k, v in sd.items():
+            state_cpu[k] = by_ptr.setdefault(v.data_ptr(), state_cpu[k])
+    model.to(device)
+    model.device = device
+    eng = model._require_engine()
+    eng.drop_seed = (eng.drop_seed ^ (rank * 0x9E3779B1)) & 0xFFFFFFFF           # different masks on every rank
+    if rank == 0:
+        print(f"[bench] model built in {time.time() - t_build:.1f}s; tables {model.embedding_arena.numel() * 4 / 1e6:.0f} MB",
+              file=sys.stderr)
+
+    X, y = synth_batches((K + W) * B, seed=100 + rank)
+    Xd, yd = torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)
+    model.train()
+
+    def step(i):
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+
+    for i in range(W):
+        step(i)
+    if not args.no_phase_timing:
+        eng.timers = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.raise_if_bad_ids()
+    phases = eng.phase_ms() if eng.timers is not None else {}
+    eng.timers = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel ----------------------------------------------------------------
+    F, D, L = 19, 32, 3
+    total_rows = model.embedding_arena.shape[0]
+    uniq = int(torch.unique(eng._ws[B]["rows"]).numel()) if B in eng._ws else 0
+    fwd_flops = 2.0 * (12 * F * D * D + 2 * F * F * D) * B                         # per layer launch
+    per_launch = {
+        "adam_untouched": dict(kernel="adam_untouched_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+                               work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
+        "layer_bwd": dict(kernel="layer_bwd_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
+                          work=2.0 * fwd_flops / 1e12),
+        "layer_fwd": dict(kernel="layer_fwd_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
+                          work=fwd_flops / 1e12),
+        "gather_fwd": dict(kernel="gather_rows_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
+                           work=B * F * (2 * D * 4 + 4) / 1e9),
+    }
+    count = {"layer_fwd": L, "layer_bwd": L}
+    kernels, dominant, dom_time = {}, None, -1.0
+    for name, ms in phases.items():
+        per_step = ms * count.get(name, 1)
+        entry = {"ms_per_launch": round(ms, 4), "ms_per_step": round(per_step, 4)}
+        if name in per_launch:
+            spec = per_launch[name]
+            ach = spec["work"] / (ms / 1e3)
+            entry.update(bound=spec["bound"], achieved=round(ach, 2), peak=spec["peak"], unit=spec["unit"],
+                         frac=round(ach / spec["peak"], 4))
+            if per_step > dom_time:
+                dominant, dom_time = name, per_step
+        kernels[name] = entry
+    roofline = None
+    if dominant:
+        e, spec = kernels[dominant], per_launch[dominant]
+        roofline = {"kernel": spec["kernel"], "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"],
+                    "unit": e["unit"], "frac": e["frac"], "traffic": None,
+                    "algorithmic_per_launch": spec["work"], "launch_ms": e["ms_per_launch"]}
+
+    # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
+    err = None
+    try:
+        from oracle import satrans_oracle as O
+        model.eval()
+        nb = 2048
+        model(Xd[:nb])
+        gpu_logit = eng.last_logit().cpu()
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        _, ref_logit = O.forward(sd, torch.from_numpy(X[:nb]), oracle_spec())
+        err = float((gpu_logit - ref_logit).abs().max())
+        del sd
+    except Exception as ex:                                                        # the number is informative only
+        print(f"[bench] logit parity check skipped: {ex}", file=sys.stderr)
+
+    cpu = None
+    if do_cpu:
+        t_cpu = time.time()
+        Xc, yc = synth_batches((args.cpu_steps + 1) * B, seed=7)
+        v, n = cpu_baseline(state_cpu, Xc, yc, B, args.lr, args.cpu_steps)
+        cpu = {"value": round(v, 1), "unit": "samples/s", "cores": min(os.cpu_count(), 32), "kind": "port",
+               "sample": f"{n} timed training steps of B={B} after 1 untimed step (dropout on, dense L2 + dense Adam, "
+                         f"no per-step sklearn metrics), {time.time() - t_cpu:.0f}s wall"}
+
+    value = world * B * K / elapsed
+    out = {
+        "metric": "training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)",
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: AliCCP-shaped SATrans training step, 19 fields, 6,571,961 table rows "
+                               "(841 MB fp32), uniform ids, dropout on, dense-Adam+L2 semantics over all rows",
+                   "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": 32, "layers": 3, "heads": 4,
+                   "parallelism": f"dp{world}"},
+        "fwd_logit_max_abs_err_vs_cpu_oracle": err,
+        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,11 +90,35 @@ class PathEngine:
         self.drop_seed = int(torch.initial_seed() & 0xFFFFFFFF)
         self.drop_step = 0
         self._last_prob = None
-        self.overlap_streams = False
+        # optional per-phase timing with HIP events recorded on the launch stream (bench.py): name -> [(start, end)]
+        self.timers: Optional[Dict[str, list]] = None
 
     # ------------------------------------------------------------------------------------------------
     def _stream(self):
         return N.stream_handle(self.dev)
+
+    class _Phase:
+        def __init__(self, eng, name):
+            self.eng, self.name = eng, name
+
+        def __enter__(self):
+            if self.eng.timers is not None:
+                self.t0 = torch.cuda.Event(enable_timing=True)
+                self.t0.record(torch.cuda.current_stream(self.eng.dev))
+
+        def __exit__(self, *exc):
+            if self.eng.timers is not None:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(torch.cuda.current_stream(self.eng.dev))
+                self.eng.timers.setdefault(self.name, []).append((self.t0, t1))
+
+    def phase(self, name):
+        return PathEngine._Phase(self, name)
+
+    def phase_ms(self) -> Dict[str, float]:
+        """Mean milliseconds per occurrence of every timed phase (synchronises)."""
+        torch.cuda.synchronize(self.dev)
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in (self.timers or {}).items()}
 
     def workspace(self, B: int) -> dict:
         ws = self._ws.get(B)
@@ -212,13 +236,16 @@ class PathEngine:
                                              ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr(),
                                              self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
                 "satrans_bucket_scenarios")
-        N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_off.data_ptr(), self.cols.data_ptr(),
-                                       X.data_ptr(), idt, X.stride(0), B, self.F, self.D, ws["acts"][0].data_ptr(),
-                                       ws["rows"].data_ptr(), self.status.data_ptr(), st), "satrans_gather_fwd")
+        with self.phase("gather_fwd"):
+            N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_off.data_ptr(),
+                                           self.cols.data_ptr(), X.data_ptr(), idt, X.stride(0), B, self.F, self.D,
+                                           ws["acts"][0].data_ptr(), ws["rows"].data_ptr(), self.status.data_ptr(), st),
+                    "satrans_gather_fwd")
         for l in range(self.L):
             desc = self._layer_desc(ws, l, B, None, tabs, training)
             att = att_list[l].data_ptr() if att_list is not None else None
-            N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
+            with self.phase("layer_fwd"):
+                N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
 
     def _head(self, X, ws, y=None, train_ws=None):
         lib, B, st = self.lib, X.shape[0], self._stream()
@@ -337,11 +364,12 @@ class PathEngine:
                 kname = "K_meta_mlp" if m.domain_int_layers[l].K_meta_mlp is not m.domain_int_layers[l].Q_meta_mlp \
                     else "Q_meta_mlp"
                 glnk = self._grad_view(lay + kname + ".ffn_layer_norm.weight").data_ptr()
-            N.check(lib.satrans_layer_bwd(
-                C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),
-                self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
-                self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
-                self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
+            with self.phase("layer_bwd"):
+                N.check(lib.satrans_layer_bwd(
+                    C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),
+                    self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
+                    self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
+                    self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
             cur = 1 - cur
         if modulated:
             tabs.backward(g_tabs)                              # tiny: [S,P] through one Linear + two embeddings
@@ -363,19 +391,22 @@ class PathEngine:
         if world > 1:
             rows, gemb = parallel.exchange(self.flat_g, rows, gemb)
         self.adam_t += 1
-        N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
-                                       ws["src"].data_ptr(), ws["touched"].data_ptr(), ws["sort_ws"].data_ptr(),
-                                       ws["sort_ws"].numel(), st), "satrans_embed_sort")
+        with self.phase("embed_sort"):
+            N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
+                                           ws["src"].data_ptr(), ws["touched"].data_ptr(), ws["sort_ws"].data_ptr(),
+                                           ws["sort_ws"].numel(), st), "satrans_embed_sort")
         h_emb = self._hparams(m.l2_reg_embedding)
-        N.check(lib.satrans_embed_adam_touched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                               self.adam_v.data_ptr(), D, ws["sorted_rows"].data_ptr(),
-                                               ws["src"].data_ptr(), n_rows, gemb.data_ptr(), ws["partial_ws"].data_ptr(),
-                                               C.byref(h_emb), ws["reg_partials"].data_ptr(), st),
-                "satrans_embed_adam_touched")
-        N.check(lib.satrans_embed_adam_untouched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                                 self.adam_v.data_ptr(), self.total_rows, D, ws["touched"].data_ptr(),
-                                                 C.byref(h_emb), ws["reg_partials"].data_ptr(), st),
-                "satrans_embed_adam_untouched")
+        with self.phase("adam_touched"):
+            N.check(lib.satrans_embed_adam_touched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                                   self.adam_v.data_ptr(), D, ws["sorted_rows"].data_ptr(),
+                                                   ws["src"].data_ptr(), n_rows, gemb.data_ptr(),
+                                                   ws["partial_ws"].data_ptr(), C.byref(h_emb),
+                                                   ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_touched")
+        with self.phase("adam_untouched"):
+            N.check(lib.satrans_embed_adam_untouched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                                     self.adam_v.data_ptr(), self.total_rows, D,
+                                                     ws["touched"].data_ptr(), C.byref(h_emb),
+                                                     ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_untouched")
         h_flat = self._hparams(0.0)
         N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                       self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st),
