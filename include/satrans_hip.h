@@ -108,6 +108,10 @@ typedef struct satrans_layer_desc {
     const float *tab_q, *tab_k;             /* [S, >=P]                                              */
 } satrans_layer_desc;
 
+/* Which arm evaluates the dense products of the layer kernels: 0 = automatic (f32 MFMA when D and U are multiples
+ * of 16, scalar FMA loops otherwise), 1 = always the scalar arm (ablation, debugging).  Process-wide. */
+int satrans_set_layer_impl(int impl);
+
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);
 

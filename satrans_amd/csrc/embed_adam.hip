@@ -137,7 +137,9 @@ __global__ void iota_mark_kernel(const int32_t* __restrict__ rows, int64_t n, ui
     const uint32_t r = (uint32_t)rows[i];
     keys[i] = r;
     pos[i] = (int32_t)i;
-    atomicOr(&touched[r >> 5], 1u << (r & 31));
+    // small-vocabulary fields send thousands of ids to the same word: only the first setter pays for the atomic
+    const uint32_t bit = 1u << (r & 31);
+    if (!(__builtin_nontemporal_load(&touched[r >> 5]) & bit)) atomicOr(&touched[r >> 5], bit);
 }
 
 // Per-chunk bookkeeping for segments that cross chunk boundaries.

@@ -12,9 +12,15 @@
 // (fixed order over tiles) and summed over workgroups in index order by a second kernel: results are
 // bitwise reproducible, no float atomics.
 //
-// This version favours generality (any F <= 64, D multiple of 4, any H | D, any U) over speed; the
-// MFMA version in layer_mfma.hip takes over for the shapes it is built for.
+// Two flavours of the dense products share this control flow (LayerLds::mfma, chosen on the host):
+//   * MFMA: v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: bit-for-bit a k-ordered fmaf chain, so the fp32 parity
+//     bar is kept) with the TOKENS on the N side (lane & 15) and the output features on the M side, activations
+//     read from the [token][feature] LDS images as 16-byte B fragments, weights as conflict-free 4-byte A
+//     fragments (row stride padded by 4 floats).  Needs D % 16 == 0 and U % 16 == 0.
+//   * scalar FMA loops: any F, any D multiple of 4, any H | D, any U (the fallback and the ablation arm).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "rng.h"
@@ -30,21 +36,64 @@ struct LayerLds {
     float *zq, *q, *zk, *k;  // pre-/post-LayerNorm MetaNet outputs
     float* P;              // [nS*H*F][ldp] softmax probabilities BEFORE dropout
     float *o, *u, *r;      // attention output, Out_linear output (kept only when non-null), pre-LayerNorm residual sum
-    float* w;              // weight staging, max(3*D*D, D*U) floats
+    float* w;              // weight staging
     int ldd, ldu, ldp;
+    int mfma;              // 1: MFMA products, 0: scalar FMA loops
+    int wp;                // row padding (floats) of staged weight matrices: 4 with MFMA, else 0
 };
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct TileDims {
     int F, D, H, U, d;
     int nS, ntok;
 };
 
+// MFMA form of out(t, o) = sum_k in[t][k] * w[k][o].  One work item = 16 tokens x 16 output features, one item per
+// wave at a time.  v_mfma_f32_16x16x4_f32 operand maps (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D[row = 4*(lane>>4) + reg][col = lane&15].  Tokens sit on j, output features on i.
+// The contraction index of MFMA step (t, r) held by lane group g is feature 16t + 4g + r, so a lane's four B
+// values of one t are ONE 16-byte LDS read of its token row, and the accumulator comes out as four consecutive
+// output features of one token.  Rows >= ntok of `in` may hold anything (a B column only feeds its own D column).
+template <typename Epi>
+__device__ __forceinline__ void gemm_tokens_mfma(const float* __restrict__ in, int ldin, const float* __restrict__ w,
+                                                 int ldw, int K, int N, int ntok, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int ntt = (ntok + 15) >> 4, nob = N >> 4;
+    for (int item = wave; item < ntt * nob; item += nw) {
+        const int tt = item / nob, ot = item - tt * nob;
+        const float* brow = in + (size_t)(16 * tt + n) * ldin + 4 * g;
+        const float* acol = w + (size_t)(4 * g) * ldw + 16 * ot + n;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < (K >> 4); ++t) {
+            const float4 b = *reinterpret_cast<const float4*>(brow + 16 * t);
+            const float* ac = acol + (size_t)(16 * t) * ldw;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[ldw], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[2 * ldw], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[3 * ldw], b.w, acc, 0, 0, 0);
+        }
+        const int tok = 16 * tt + n, o0 = 16 * ot + 4 * g;
+        if (tok < ntok) {
+            epi(tok, o0, acc[0]);
+            epi(tok, o0 + 1, acc[1]);
+            epi(tok, o0 + 2, acc[2]);
+            epi(tok, o0 + 3, acc[3]);
+        }
+    }
+}
+
 // out(t, o) = sum_k in[t][k] * w[k][o] for t < ntok, o < N; `epi(t, o, acc)` consumes the result.
-// One work item = TR tokens x 1 output column; consecutive lanes take consecutive columns, so the weight
-// reads are conflict-free and the activation reads are LDS broadcasts.
+// Scalar form: one work item = TR tokens x 1 output column; consecutive lanes take consecutive columns, so the
+// weight reads are conflict-free and the activation reads are LDS broadcasts.
 template <int TR, typename Epi>
-__device__ __forceinline__ void gemm_tokens(const float* __restrict__ in, int ldin, const float* __restrict__ w,
-                                            int ldw, int K, int N, int ntok, Epi epi) {
+__device__ __forceinline__ void gemm_tokens(bool mfma, const float* __restrict__ in, int ldin,
+                                            const float* __restrict__ w, int ldw, int K, int N, int ntok, Epi epi) {
+    if (mfma) {
+        gemm_tokens_mfma(in, ldin, w, ldw, K, N, ntok, epi);
+        return;
+    }
     const int groups = (ntok + TR - 1) / TR;
     for (int item = threadIdx.x; item < groups * N; item += blockDim.x) {
         const int tg = item / N, o = item - tg * N;
@@ -67,15 +116,20 @@ __device__ __forceinline__ void gemm_tokens(const float* __restrict__ in, int ld
     }
 }
 
-__device__ __forceinline__ void stage_copy(const float* __restrict__ g, float* __restrict__ s, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s[i] = g[i];
-}
-
-// s[c*R + r] = g[r*C + c]   (g is [R][C] row-major; s becomes [C][R])
-__device__ __forceinline__ void stage_transposed(const float* __restrict__ g, float* __restrict__ s, int R, int C) {
+// s[r*ld + c] = g[r*C + c]   (g is [R][C] row-major)
+__device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* __restrict__ s, int R, int C, int ld) {
     for (int i = threadIdx.x; i < R * C; i += blockDim.x) {
         const int r = i / C, c = i - r * C;
-        s[c * R + r] = g[i];
+        s[r * ld + c] = g[i];
+    }
+}
+
+// s[c*ld + r] = g[r*C + c]   (g is [R][C] row-major; s becomes [C][R] with row stride ld)
+__device__ __forceinline__ void stage_transposed(const float* __restrict__ g, float* __restrict__ s, int R, int C,
+                                                 int ld) {
+    for (int i = threadIdx.x; i < R * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        s[c * ld + r] = g[i];
     }
 }
 
@@ -128,14 +182,14 @@ __device__ void metanet_tile(const satrans_layer_desc& a, const TileDims& T, con
                              int site, const float* __restrict__ tab_row, const float* gamma, const float* beta,
                              const float* in, float* h, float* z, float* out, LayerLds& L) {
     const int D = T.D, U = T.U, F = T.F;
-    stage_copy(tab_row, L.w, D * U);  // W1 [D][U]
+    stage_rows(tab_row, L.w, D, U, U + L.wp);  // W1 [D][U]
     __syncthreads();
-    gemm_tokens<4>(in, L.ldd, L.w, U, D, U, T.ntok,
+    gemm_tokens<4>(L.mfma, in, L.ldd, L.w, U + L.wp, D, U, T.ntok,
                    [&](int t, int o, float acc) { h[(size_t)t * L.ldu + o] = fmaxf(acc, 0.f); });
     __syncthreads();
-    stage_copy(tab_row + D * U, L.w, U * D);  // W2 [U][D]
+    stage_rows(tab_row + D * U, L.w, U, D, D + L.wp);  // W2 [U][D]
     __syncthreads();
-    gemm_tokens<4>(h, L.ldu, L.w, D, U, D, T.ntok, [&](int t, int o, float acc) {
+    gemm_tokens<4>(L.mfma, h, L.ldu, L.w, D + L.wp, U, D, T.ntok, [&](int t, int o, float acc) {
         const int ls = t / F, f = t - ls * F;
         const float m = acc * drop_mask(dc, site, samp[ls], (uint32_t)(f * D + o));
         z[(size_t)t * L.ldd + o] = m + in[(size_t)t * L.ldd + o];
@@ -156,14 +210,15 @@ __device__ void forward_tile(const satrans_layer_desc& a, const TileDims& T, int
         const int ls = t / F, f = t - ls * F;
         L.x[(size_t)t * L.ldd + c] = a.x[((size_t)samp[ls] * F + f) * D + c];
     }
+    const int ld3 = 3 * D + L.wp;
     for (int i = threadIdx.x; i < D * D; i += blockDim.x) {
         const int k = i / D, o = i - k * D;
-        L.w[k * 3 * D + o] = a.w_query[i];
-        L.w[k * 3 * D + D + o] = a.w_key[i];
-        L.w[k * 3 * D + 2 * D + o] = a.w_value[i];
+        L.w[k * ld3 + o] = a.w_query[i];
+        L.w[k * ld3 + D + o] = a.w_key[i];
+        L.w[k * ld3 + 2 * D + o] = a.w_value[i];
     }
     __syncthreads();
-    gemm_tokens<4>(L.x, L.ldd, L.w, 3 * D, D, 3 * D, ntok, [&](int t, int o, float acc) {   // satrans.py:55-57
+    gemm_tokens<4>(L.mfma, L.x, L.ldd, L.w, ld3, D, 3 * D, ntok, [&](int t, int o, float acc) {   // satrans.py:55-57
         if (o < D) L.q0[(size_t)t * L.ldd + o] = acc;
         else if (o < 2 * D) L.k0[(size_t)t * L.ldd + o - D] = acc;
         else L.v[(size_t)t * L.ldd + o - 2 * D] = acc;
@@ -229,10 +284,10 @@ __device__ void forward_tile(const satrans_layer_desc& a, const TileDims& T, int
         }
         L.o[(size_t)t * L.ldd + c] = acc;
     }
-    stage_transposed(a.w_out, L.w, D, D);  // w[k][o] = Wo[o][k]   (nn.Linear: y = x @ Wo^T)
+    stage_transposed(a.w_out, L.w, D, D, D + L.wp);  // w[k][o] = Wo[o][k]   (nn.Linear: y = x @ Wo^T)
     __syncthreads();
     // ---- r = dropout(act(o @ Wo^T)) + x  (satrans.py:91-97) ---------------------------------------------------
-    gemm_tokens<4>(L.o, L.ldd, L.w, D, D, D, ntok, [&](int t, int o, float acc) {
+    gemm_tokens<4>(L.mfma, L.o, L.ldd, L.w, D + L.wp, D, D, ntok, [&](int t, int o, float acc) {
         const int ls = t / F, f = t - ls * F;
         if (L.u) L.u[(size_t)t * L.ldd + o] = acc;
         if (a.flags & SATRANS_RELU_OUT) acc = fmaxf(acc, 0.f);
@@ -258,24 +313,26 @@ __device__ __forceinline__ bool tile_of(const satrans_layer_desc& a, int scen, i
 // P shares storage with hq (dead before the scores are written), o = q (every (sample,head,row) task reads
 // its own q row in the score phase, which ends at a barrier before o is written), r = k0.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLayerBlock) void layer_fwd_kernel(satrans_layer_desc a, int Tsamp, float* __restrict__ y,
-                                                              float* __restrict__ att) {
+__global__ __launch_bounds__(kLayerBlock) void layer_fwd_kernel(satrans_layer_desc a, int Tsamp, int use_mfma,
+                                                              float* __restrict__ y, float* __restrict__ att) {
     extern __shared__ __align__(16) float lds[];
     const int F = a.F, D = a.D, H = a.H, U = a.U;
     const int scen = blockIdx.y;
     TileDims T{F, D, H, U, D / H, 0, 0};
     LayerLds L;
-    L.ldd = D + 1;
-    L.ldu = U + 1;
+    L.mfma = use_mfma;
+    L.wp = use_mfma ? 4 : 0;
+    L.ldd = D + (use_mfma ? 4 : 1);
+    L.ldu = U + (use_mfma ? 4 : 1);
     L.ldp = F + 1;
     const int maxtok = Tsamp * F;
     float* p = lds;
-    L.x = p; p += maxtok * L.ldd;
-    L.q0 = p; p += maxtok * L.ldd;
-    L.k0 = p; p += maxtok * L.ldd;
-    L.v = p; p += maxtok * L.ldd;
-    const int hp = max(maxtok * L.ldu, Tsamp * H * F * L.ldp);
-    L.hq = p; L.hk = p; L.P = p; p += hp;
+    auto take = [&](int n) { float* r = p; p += (n + 3) & ~3; return r; };
+    L.x = take(maxtok * L.ldd);
+    L.q0 = take(maxtok * L.ldd);
+    L.k0 = take(maxtok * L.ldd);
+    L.v = take(maxtok * L.ldd);
+    L.hq = L.hk = L.P = take(max(maxtok * L.ldu, Tsamp * H * F * L.ldp));
     L.w = p;
     L.zq = L.q = L.q0;
     L.zk = L.k = L.k0;
@@ -337,8 +394,33 @@ __host__ __device__ inline SlabOff slab_offsets(int D, int U) {
 }
 
 // slab[i*N + o] (+)= sum_t A[t][i] * G[t][o]   for i < M, o < N
-__device__ __forceinline__ void outer_accumulate(float* __restrict__ slab, bool first, const float* A, int lda,
-                                                 const float* G, int ldg, int M, int N, int ntok) {
+// MFMA form: the contraction runs over TOKENS (4 per MFMA step), both operands are 4-byte reads of the
+// [token][feature] LDS images (A[i = lane&15][k = token 4*kt + (lane>>4)], B[k][j = lane&15]); one work item is a
+// 16 x 16 block of the weight gradient.  Rows >= ntok are masked to zero.
+__device__ __forceinline__ void outer_accumulate(bool mfma, float* __restrict__ slab, bool first, const float* A,
+                                                 int lda, const float* G, int ldg, int M, int N, int ntok) {
+    if (mfma) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const int n = lane & 15, g = lane >> 4;
+        const int nmb = M >> 4, nnb = N >> 4;
+        for (int item = wave; item < nmb * nnb; item += nw) {
+            const int mt = item / nnb, nt = item - mt * nnb;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; t0 < ntok; t0 += 4) {
+                const int tok = t0 + g;
+                const bool ok = tok < ntok;
+                const float av = ok ? A[(size_t)tok * lda + 16 * mt + n] : 0.f;
+                const float gv = ok ? G[(size_t)tok * ldg + 16 * nt + n] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (16 * mt + 4 * g + r) * N + 16 * nt + n;
+                slab[e] = first ? acc[r] : slab[e] + acc[r];
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < M * N; e += blockDim.x) {
         const int i = e / N, o = e - i * N;
         float acc = 0.f;
@@ -402,25 +484,31 @@ __device__ void metanet_backward_tile(const satrans_layer_desc& a, const TileDim
         const int ls = t / F, f = t - ls * F;
         gm[(size_t)t * L.ldd + c] = g[(size_t)t * L.ldd + c] * drop_mask(dc, site, samp[ls], (uint32_t)(f * D + c));
     }
-    stage_transposed(tab_row + D * U, L.w, U, D);  // w[o][u] = W2[u][o]
+    float* w2t = L.w;                        // [D][U + wp]: w2t[o][u] = W2[u][o]
+    float* w1t = L.w + D * (U + L.wp);       // [U][D + wp]: w1t[u][i] = W1[i][u]
+    stage_transposed(tab_row + D * U, w2t, U, D, U + L.wp);
     __syncthreads();
-    outer_accumulate(slab_w2, first, h, L.ldu, gm, L.ldd, U, D, ntok);  // dW2[u][o] += h^T gm
+    outer_accumulate(L.mfma, slab_w2, first, h, L.ldu, gm, L.ldd, U, D, ntok);  // dW2[u][o] += h^T gm
     __syncthreads();
     // dh = (gm @ W2^T) * [h > 0], in place of h
-    gemm_tokens<2>(gm, L.ldd, L.w, U, D, U, ntok, [&](int t, int u, float acc) {
+    gemm_tokens<2>(L.mfma, gm, L.ldd, w2t, U + L.wp, D, U, ntok, [&](int t, int u, float acc) {
         float& hv = h[(size_t)t * L.ldu + u];
         hv = hv > 0.f ? acc : 0.f;
     });
-    stage_transposed(tab_row, L.w + D * U, D, U);  // w2[u][i] = W1[i][u]
+    stage_transposed(tab_row, w1t, D, U, D + L.wp);
     __syncthreads();
-    outer_accumulate(slab_w1, first, in0, L.ldd, h, L.ldu, D, U, ntok);  // dW1[i][u] += in0^T dh
+    outer_accumulate(L.mfma, slab_w1, first, in0, L.ldd, h, L.ldu, D, U, ntok);  // dW1[i][u] += in0^T dh
     // g = dz + dh @ W1^T
-    gemm_tokens<2>(h, L.ldu, L.w + D * U, D, U, D, ntok,
+    gemm_tokens<2>(L.mfma, h, L.ldu, w1t, D + L.wp, U, D, ntok,
                    [&](int t, int i, float acc) { g[(size_t)t * L.ldd + i] += acc; });
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_desc a, int Tsamp,
+// LDS aliasing (each pair is separated by a barrier between the last read of the first and the first write of the
+// second): du / MetaNet dm scratch lives in r (dead once the final LayerNorm backward has consumed it), the
+// gradient of the attention output replaces the attention output o (dead after dWo), dv replaces v (last read by
+// the softmax-backward pass).
+__global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_desc a, int Tsamp, int use_mfma,
                                                               const float* __restrict__ dy, float* __restrict__ dx,
                                                               float* __restrict__ slabs) {
     extern __shared__ __align__(16) float lds[];
@@ -428,13 +516,15 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
     const int scen = blockIdx.y;
     TileDims T{F, D, H, U, d, 0, 0};
     LayerLds L;
-    L.ldd = D + 1;
-    L.ldu = U + 1;
+    L.mfma = use_mfma;
+    L.wp = use_mfma ? 4 : 0;
+    L.ldd = D + (use_mfma ? 4 : 1);
+    L.ldu = U + (use_mfma ? 4 : 1);
     L.ldp = F + 1;
     const int maxtok = Tsamp * F;
     const int nd = maxtok * L.ldd, nu = maxtok * L.ldu, np = Tsamp * H * F * L.ldp;
     float* p = lds;
-    auto take = [&](int n) { float* r = p; p += n; return r; };
+    auto take = [&](int n) { float* r = p; p += (n + 3) & ~3; return r; };
     L.x = take(nd); L.q0 = take(nd); L.k0 = take(nd); L.v = take(nd);
     L.zq = take(nd); L.q = take(nd); L.zk = take(nd); L.k = take(nd);
     L.o = take(nd); L.r = take(nd);
@@ -443,13 +533,13 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
     L.P = take(np);
     float* dS = take(np);
     float* g_r = take(nd);   // dy -> dr -> dx
-    float* g_m = take(nd);   // du / MetaNet dm scratch
-    float* g_o = take(nd);   // gradient of the attention output
     float* g_q = take(nd);
     float* g_k = take(nd);
-    float* g_v = take(nd);
     float* rstd_buf = take(maxtok);
-    L.w = take(max(3 * D * D, 2 * D * U));
+    L.w = take(max(3 * D * (D + L.wp), D * (U + L.wp) + U * (D + L.wp)));
+    float* g_m = L.r;        // du / MetaNet dm scratch
+    float* g_o = L.o;        // gradient of the attention output
+    float* g_v = L.v;
     if (!(a.flags & SATRANS_META_Q)) { L.zq = L.q0; L.q = L.q0; }
     if (!(a.flags & SATRANS_META_K)) { L.zk = L.k0; L.k = L.k0; }
 
@@ -481,10 +571,11 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
             if ((a.flags & SATRANS_RELU_OUT) && !(L.u[(size_t)t * L.ldd + c] > 0.f)) g = 0.f;
             g_m[(size_t)t * L.ldd + c] = g;
         }
-        stage_copy(a.w_out, L.w, D * D);  // as [K = out feature][N = in feature]
+        stage_rows(a.w_out, L.w, D, D, D + L.wp);  // as [K = out feature][N = in feature]
         __syncthreads();
-        outer_accumulate(slab + so.wo, first, g_m, L.ldd, L.o, L.ldd, D, D, ntok);  // dWo[o][i] += du^T o_att
-        gemm_tokens<2>(g_m, L.ldd, L.w, D, D, D, ntok,
+        outer_accumulate(L.mfma, slab + so.wo, first, g_m, L.ldd, L.o, L.ldd, D, D, ntok);  // dWo[o][i] += du^T o_att
+        __syncthreads();                                                                // o is dead: g_o takes its place
+        gemm_tokens<2>(L.mfma, g_m, L.ldd, L.w, D + L.wp, D, D, ntok,
                        [&](int t, int i, float acc) { g_o[(size_t)t * L.ldd + i] = acc; });
         __syncthreads();
         // ---- attention backward: dS rows (softmax + dropout backward) ---------------------------------------
@@ -535,20 +626,22 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
             metanet_backward_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, L.k0, L.hk,
                                   L.zk, g_k, g_m, rstd_buf, L, slab + so.w1k, slab + so.w2k, slab + so.lnk, first);
         // ---- projections: dW{q,k,v} += x^T g ; dx = dr*res + g_q Wq^T + g_k Wk^T + g_v Wv^T ----------------------
-        outer_accumulate(slab + so.wq, first, L.x, L.ldd, g_q, L.ldd, D, D, ntok);
-        outer_accumulate(slab + so.wk, first, L.x, L.ldd, g_k, L.ldd, D, D, ntok);
-        outer_accumulate(slab + so.wv, first, L.x, L.ldd, g_v, L.ldd, D, D, ntok);
-        stage_transposed(a.w_query, L.w, D, D);              // w[o][i] = Wq[i][o]
-        stage_transposed(a.w_key, L.w + D * D, D, D);
-        stage_transposed(a.w_value, L.w + 2 * D * D, D, D);
+        outer_accumulate(L.mfma, slab + so.wq, first, L.x, L.ldd, g_q, L.ldd, D, D, ntok);
+        outer_accumulate(L.mfma, slab + so.wk, first, L.x, L.ldd, g_k, L.ldd, D, D, ntok);
+        outer_accumulate(L.mfma, slab + so.wv, first, L.x, L.ldd, g_v, L.ldd, D, D, ntok);
+        const int ldt = D + L.wp, wsz = D * ldt;
+        stage_transposed(a.w_query, L.w, D, D, ldt);              // w[o][i] = Wq[i][o]
+        stage_transposed(a.w_key, L.w + wsz, D, D, ldt);
+        stage_transposed(a.w_value, L.w + 2 * wsz, D, D, ldt);
         if (a.flags & SATRANS_NO_RES) {
             for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) g_r[(size_t)(i / D) * L.ldd + (i % D)] = 0.f;
         }
         __syncthreads();
-        gemm_tokens<2>(g_q, L.ldd, L.w, D, D, D, ntok, [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
-        gemm_tokens<2>(g_k, L.ldd, L.w + D * D, D, D, D, ntok,
+        gemm_tokens<2>(L.mfma, g_q, L.ldd, L.w, ldt, D, D, ntok,
                        [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
-        gemm_tokens<2>(g_v, L.ldd, L.w + 2 * D * D, D, D, D, ntok,
+        gemm_tokens<2>(L.mfma, g_k, L.ldd, L.w + wsz, ldt, D, D, ntok,
+                       [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
+        gemm_tokens<2>(L.mfma, g_v, L.ldd, L.w + 2 * wsz, ldt, D, D, ntok,
                        [&](int t, int i, float acc) { g_r[(size_t)t * L.ldd + i] += acc; });
         __syncthreads();
         for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
@@ -562,6 +655,20 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
     if (first) {  // no tile for this workgroup: its slab must still read as zeros
         for (int e = threadIdx.x; e < so.total; e += blockDim.x) slab[e] = 0.f;
     }
+}
+
+// First level of the slab reduction: partial[(s*G + grp)][e] = sum of the slabs of scenario s whose workgroup index
+// falls in group grp (contiguous ranges, summed in index order).
+__global__ void slab_group_sum_kernel(const float* __restrict__ slabs, int gx, int G, int total,
+                                      float* __restrict__ partial) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int s = blockIdx.y / G, grp = blockIdx.y - s * G;
+    const int per = (gx + G - 1) / G;
+    const int lo = grp * per, hi = min(gx, lo + per);
+    float acc = 0.f;
+    for (int w = lo; w < hi; ++w) acc += slabs[((size_t)s * gx + w) * total + e];
+    partial[(size_t)blockIdx.y * total + e] = acc;
 }
 
 // Sum the per-workgroup slabs in (scenario, workgroup) order and ADD them to the parameter gradients.
@@ -626,18 +733,35 @@ __global__ void layer_bwd_reduce_kernel(const float* __restrict__ slabs, int S, 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kLdsBudgetFwd = 78 * 1024;   // two workgroups per CU
 constexpr int kLdsBudgetBwd = 156 * 1024;  // one workgroup per CU
+constexpr int kReduceSplit = 16;           // first-level groups of the slab reduction
 
-static int64_t fwd_lds_floats(int T, int F, int D, int H, int U) {
+static int64_t r4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+
+static int64_t fwd_lds_floats(int T, int F, int D, int H, int U, int mfma) {
     const int64_t tok = (int64_t)T * F;
-    const int64_t hp = std::max<int64_t>(tok * (U + 1), (int64_t)T * H * F * (F + 1));
-    return 4 * tok * (D + 1) + hp + std::max<int64_t>(3 * D * D, (int64_t)D * U);
+    const int pad = mfma ? 4 : 1, wp = mfma ? 4 : 0;
+    const int64_t hp = std::max<int64_t>(tok * (U + pad), (int64_t)T * H * F * (F + 1));
+    const int64_t w = std::max<int64_t>((int64_t)D * (3 * D + wp), std::max<int64_t>((int64_t)D * (U + wp), (int64_t)U * (D + wp)));
+    return 4 * r4(tok * (D + pad)) + r4(hp) + w + 64;
 }
 
-static int64_t bwd_lds_floats(int T, int F, int D, int H, int U, int flags) {
+static int64_t bwd_lds_floats(int T, int F, int D, int H, int U, int flags, int mfma) {
     const int64_t tok = (int64_t)T * F;
-    const int64_t nd = tok * (D + 1), nu = tok * (U + 1), np = (int64_t)T * H * F * (F + 1);
-    const int nbuf = 16 + ((flags & SATRANS_RELU_OUT) ? 1 : 0);
-    return nbuf * nd + 2 * nu + 2 * np + tok + std::max<int64_t>(3 * D * D, 2 * (int64_t)D * U);
+    const int pad = mfma ? 4 : 1, wp = mfma ? 4 : 0;
+    const int64_t nd = r4(tok * (D + pad)), nu = r4(tok * (U + pad)), np = r4((int64_t)T * H * F * (F + 1));
+    const int nbuf = 13 + ((flags & SATRANS_RELU_OUT) ? 1 : 0);
+    const int64_t w = std::max<int64_t>(3 * (int64_t)D * (D + wp), (int64_t)D * (U + wp) + (int64_t)U * (D + wp));
+    return nbuf * nd + 2 * nu + 2 * np + r4(tok) + w + 64;
+}
+
+// MFMA needs 16-aligned feature counts; SATRANS_LAYER_IMPL=lds forces the scalar arm (ablation / debugging)
+static int g_layer_impl = 0;  // 0 = auto, 1 = scalar FMA arm, set by satrans_set_layer_impl
+static int want_mfma(const satrans_layer_desc* d) {
+    static const char* env = getenv("SATRANS_LAYER_IMPL");
+    if (g_layer_impl == 1 || (env && strcmp(env, "lds") == 0)) return 0;
+    if (d->D % 16) return 0;
+    if ((d->flags & (SATRANS_META_Q | SATRANS_META_K)) && (d->U % 16)) return 0;
+    return 1;
 }
 
 static int validate(const satrans_layer_desc* d, const char* who) {
@@ -646,6 +770,7 @@ static int validate(const satrans_layer_desc* d, const char* who) {
                         d->ln_g && d->ln_b,
                     SATRANS_E_BADARG, "%s: null tensor pointer", who);
     SATRANS_REQUIRE(d->B > 0 && d->F > 0 && d->D > 0 && d->H > 0 && d->S > 0, SATRANS_E_BADARG, "%s: bad sizes", who);
+    SATRANS_REQUIRE(d->D % 4 == 0, SATRANS_E_UNSUPPORTED, "%s: embedding_size %d is not a multiple of 4", who, d->D);
     SATRANS_REQUIRE(d->D % d->H == 0, SATRANS_E_BADARG, "%s: embedding_size %d is not a multiple of head_num %d", who,
                     d->D, d->H);
     SATRANS_REQUIRE(!(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)), SATRANS_E_UNSUPPORTED,
@@ -662,42 +787,53 @@ static int validate(const satrans_layer_desc* d, const char* who) {
 struct LayerPlan {
     int T;        // samples per tile
     int gx;       // workgroups per scenario
+    int mfma;
     size_t lds;   // dynamic LDS bytes
 };
 
 static int plan_fwd(const satrans_layer_desc* d, LayerPlan& p) {
+    p.mfma = want_mfma(d);
     int T = 0;
     for (int t = 1; t <= 16; ++t)
-        if (fwd_lds_floats(t, d->F, d->D, d->H, d->U) * 4 <= kLdsBudgetFwd) T = t;
-    if (T == 0 && fwd_lds_floats(1, d->F, d->D, d->H, d->U) * 4 <= kLdsBudgetBwd) T = 1;
+        if (fwd_lds_floats(t, d->F, d->D, d->H, d->U, p.mfma) * 4 <= kLdsBudgetFwd) T = t;
+    if (T == 0 && fwd_lds_floats(1, d->F, d->D, d->H, d->U, p.mfma) * 4 <= kLdsBudgetBwd) T = 1;
     SATRANS_REQUIRE(T > 0, SATRANS_E_UNSUPPORTED, "layer_fwd: one sample (F=%d D=%d U=%d) does not fit LDS", d->F, d->D,
                     d->U);
     p.T = T;
-    p.lds = (size_t)fwd_lds_floats(T, d->F, d->D, d->H, d->U) * 4;
+    p.lds = (size_t)fwd_lds_floats(T, d->F, d->D, d->H, d->U, p.mfma) * 4;
     const int64_t tiles = ceil_div(d->B, T);
     p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * 4, d->S)));
     return SATRANS_OK;
 }
 
 static int plan_bwd(const satrans_layer_desc* d, LayerPlan& p) {
+    p.mfma = want_mfma(d);
     int T = 0;
     for (int t = 1; t <= 8; ++t)
-        if (bwd_lds_floats(t, d->F, d->D, d->H, d->U, d->flags) * 4 <= kLdsBudgetBwd) T = t;
+        if (bwd_lds_floats(t, d->F, d->D, d->H, d->U, d->flags, p.mfma) * 4 <= kLdsBudgetBwd) T = t;
     SATRANS_REQUIRE(T > 0, SATRANS_E_UNSUPPORTED, "layer_bwd: one sample (F=%d D=%d U=%d) does not fit LDS", d->F, d->D,
                     d->U);
-    // prefer two workgroups per CU when a smaller tile allows it
-    for (int t = T; t >= 1; --t)
-        if (bwd_lds_floats(t, d->F, d->D, d->H, d->U, d->flags) * 4 <= kLdsBudgetFwd) { T = t; break; }
+    if (!p.mfma) {  // scalar arm: prefer two workgroups per CU when a smaller tile allows it
+        for (int t = T; t >= 1; --t)
+            if (bwd_lds_floats(t, d->F, d->D, d->H, d->U, d->flags, 0) * 4 <= kLdsBudgetFwd) { T = t; break; }
+    }
     p.T = T;
-    p.lds = (size_t)bwd_lds_floats(T, d->F, d->D, d->H, d->U, d->flags) * 4;
+    p.lds = (size_t)bwd_lds_floats(T, d->F, d->D, d->H, d->U, d->flags, p.mfma) * 4;
     const int64_t tiles = ceil_div(d->B, T);
-    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * 2, d->S)));
+    const int per_cu = p.lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
+    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * per_cu, d->S)));
     return SATRANS_OK;
 }
 
 }  // namespace satrans
 
 using namespace satrans;
+
+extern "C" int satrans_set_layer_impl(int impl) {
+    SATRANS_REQUIRE(impl == 0 || impl == 1, SATRANS_E_BADARG, "set_layer_impl: %d is not 0 (auto) or 1 (scalar)", impl);
+    g_layer_impl = impl;
+    return SATRANS_OK;
+}
 
 extern "C" int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, float* att, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -714,7 +850,7 @@ extern "C" int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, floa
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd: LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_fwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, y, att);
+    layer_fwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, p.mfma, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_kernel");
     return SATRANS_OK;
 }
@@ -722,7 +858,7 @@ extern "C" int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, floa
 extern "C" int64_t satrans_layer_bwd_slab_floats_lds(const satrans_layer_desc* d) {
     LayerPlan p;
     if (!d || validate(d, "layer_bwd") || plan_bwd(d, p)) return -1;
-    return (int64_t)d->S * p.gx * slab_offsets(d->D, d->U).total;
+    return ((int64_t)d->S * p.gx + (int64_t)d->S * kReduceSplit) * slab_offsets(d->D, d->U).total;
 }
 
 extern "C" int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
@@ -744,12 +880,17 @@ extern "C" int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* d
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd: LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, p.mfma, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_kernel");
+    // two-level, fixed-order reduction of the per-workgroup slabs: kReduceSplit contiguous groups per scenario first
     const int total = slab_offsets(d->D, d->U).total;
+    float* partial = slabs + (size_t)d->S * p.gx * total;
+    slab_group_sum_kernel<<<dim3((unsigned)ceil_div(total, 256), d->S * kReduceSplit), 256, 0, stream>>>(
+        slabs, p.gx, kReduceSplit, total, partial);
+    SATRANS_CHECK_LAUNCH("slab_group_sum_kernel");
     layer_bwd_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(
-        slabs, d->S, p.gx, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q,
-        g_tab_k);
+        partial, d->S, kReduceSplit, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk,
+        g_tab_q, g_tab_k);
     SATRANS_CHECK_LAUNCH("layer_bwd_reduce_kernel");
     return SATRANS_OK;
 }

@@ -249,3 +249,25 @@ def test_single_sample_and_empty_scenarios():
         p = model(xb.to(DEV)).cpu()
         p_ref, _ = O.forward(c.tensors("param"), xb, c.spec())
         np.testing.assert_allclose(p.numpy(), p_ref.numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["aliccp_sota", "small_pos_dense", "small_d64"])
+def test_scalar_arm_matches_golden_too(name):
+    """The scalar-FMA arm of the layer kernels (fallback for feature counts that are not multiples of 16, and the
+    ablation arm) against the same golden vectors; everything else in this file runs the MFMA arm."""
+    from satrans_amd import native as N
+    c = Case(name)
+    N.check(N.lib().satrans_set_layer_impl(1), "set_layer_impl")
+    try:
+        model = build_model(c, DEV)
+        model.compile("adam", "binary_crossentropy")
+        model.eval()
+        model(c.X.to(DEV))
+        eng = model._engine
+        np.testing.assert_allclose(eng.last_logit().cpu().numpy(), c.arrays("out")["logit"], rtol=0, atol=LOGIT_ATOL)
+        bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+        for k, g in c.arrays("grad").items():
+            scale = max(1e-6, float(np.abs(g).max()))
+            np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
+    finally:
+        N.check(N.lib().satrans_set_layer_impl(0), "set_layer_impl")
