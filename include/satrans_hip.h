@@ -108,8 +108,12 @@ typedef struct satrans_layer_desc {
     const float *tab_q, *tab_k;             /* [S, >=P]                                              */
 } satrans_layer_desc;
 
-/* Which arm evaluates the dense products of the layer kernels: 0 = automatic (f32 MFMA when D and U are multiples
- * of 16, scalar FMA loops otherwise), 1 = always the scalar arm (ablation, debugging).  Process-wide. */
+/* Which implementation evaluates satrans_layer_fwd/_bwd (process-wide; initial value from SATRANS_LAYER_IMPL):
+ * 0 = automatic: register-chained f32-MFMA kernels for the shapes they are built for ((D,U,H) = (32,64,4), (16,32,2),
+ *     (64,16,4)), else the LDS-resident kernels with MFMA products (D, U multiples of 16), else the same kernels
+ *     with scalar FMA loops (any shape);
+ * 1 = LDS-resident kernels with scalar FMA loops (the "wavefront/VALU" ablation arm);
+ * 2 = LDS-resident kernels with MFMA products. */
 int satrans_set_layer_impl(int impl);
 
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */

@@ -1,5 +1,7 @@
-// Error reporting and the shape dispatch of the public layer entry points.
+// Error reporting and the dispatch of the public layer entry points over the three implementations.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -11,11 +13,20 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
 }
+static int g_layer_impl = -1;
 }  // namespace satrans
 
 extern "C" {
 
+int satrans_layer_validate(const satrans_layer_desc* d, const char* who);
+int satrans_layer_fused_supported(const satrans_layer_desc* d);
+int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, float* att, void* stream);
 int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, float* att, void* stream);
+int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d);
+int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d);
+int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq, float* g_wk,
+                            float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
+                            float* g_tab_k, void* stream);
 int64_t satrans_layer_bwd_slab_floats_lds(const satrans_layer_desc* d);
 int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq, float* g_wk,
                           float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
@@ -24,15 +35,50 @@ int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* dy, float* d
 const char* satrans_last_error(void) { return satrans::g_error; }
 int satrans_abi_version(void) { return SATRANS_ABI_VERSION; }
 
+// 0 = automatic: register-chained MFMA kernels (layer_fused.hip) for the shapes they are built for, else the LDS
+//     kernels with MFMA products, else the LDS kernels with scalar FMA loops;
+// 1 = LDS kernels, scalar FMA loops;  2 = LDS kernels, MFMA products.     Initial value from SATRANS_LAYER_IMPL.
+int satrans_layer_impl(void) {
+    if (satrans::g_layer_impl < 0) {
+        const char* env = getenv("SATRANS_LAYER_IMPL");
+        satrans::g_layer_impl = env ? atoi(env) : 0;
+        if (satrans::g_layer_impl < 0 || satrans::g_layer_impl > 2) satrans::g_layer_impl = 0;
+    }
+    return satrans::g_layer_impl;
+}
+
+int satrans_set_layer_impl(int impl) {
+    SATRANS_REQUIRE(impl >= 0 && impl <= 2, SATRANS_E_BADARG, "set_layer_impl: %d is not 0, 1 or 2", impl);
+    satrans::g_layer_impl = impl;
+    return SATRANS_OK;
+}
+
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream) {
+    int rc = satrans_layer_validate(d, "layer_fwd");
+    if (rc) return rc;
+    if (satrans_layer_impl() == 0 && satrans_layer_fused_supported(d)) return satrans_layer_fwd_fused(d, y, att, stream);
     return satrans_layer_fwd_lds(d, y, att, stream);
 }
 
-int64_t satrans_layer_bwd_slab_floats(const satrans_layer_desc* d) { return satrans_layer_bwd_slab_floats_lds(d); }
+// large enough for whichever implementation satrans_layer_bwd may pick (the choice can change between calls through
+// satrans_set_layer_impl)
+int64_t satrans_layer_bwd_slab_floats(const satrans_layer_desc* d) {
+    if (satrans_layer_validate(d, "layer_bwd")) return -1;
+    int64_t n = satrans_layer_bwd_slab_floats_lds(d);
+    if (satrans_layer_bwd_fused_supported(d)) {
+        const int64_t f = satrans_layer_bwd_slab_floats_fused(d);
+        if (f > n) n = f;
+    }
+    return n;
+}
 
 int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq, float* g_wk,
                       float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k,
                       void* stream) {
+    int rc = satrans_layer_validate(d, "layer_bwd");
+    if (rc) return rc;
+    if (satrans_layer_impl() == 0 && satrans_layer_bwd_fused_supported(d))
+        return satrans_layer_bwd_fused(d, dy, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
     return satrans_layer_bwd_lds(d, dy, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
 }
 

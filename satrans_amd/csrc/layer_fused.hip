@@ -1,0 +1,1224 @@
+// Meta_Transformer_Layer forward and backward, register-chained MFMA version for compile-time shapes.
+//
+// Reference: models/satrans.py:50-100 (layer), models/submodules.py:77-103 (MetaNet).  Same decomposition as
+// layer_lds.hip (workgroup = one scenario, persistent over that scenario's tiles of T samples; backward recomputes
+// the forward; weight gradients in per-workgroup slabs reduced in a fixed order), but built for speed:
+//
+//   * every weight matrix is staged into LDS ONCE per workgroup (the generated MetaNet weights of the workgroup's
+//     scenario included) and stays there for all its tiles;
+//   * the token-wise chain  x -> {q0,k0,v} -> relu(q0 W1) -> (.) W2 -> +q0 -> LayerNorm  runs per 16-token tile in
+//     one wave entirely in registers: with tokens on the N side of v_mfma_f32_16x16x4_f32 the accumulator of one
+//     product (lane: token = lane&15, features 16t + 4*(lane>>4) + r) IS the B operand of the next one, so no data
+//     moves between the products.  f32-in/f32-accumulate MFMA is bit-for-bit an fmaf chain: fp32 parity is kept;
+//   * LayerNorm statistics are a 8-register sum plus two cross-lane shuffles (lanes n, n+16, n+32, n+48 hold one
+//     token);
+//   * only q, k, v cross LDS (the feature x feature attention needs whole samples): one lane per
+//     (sample, head, query row), keys/values read as LDS broadcasts, two passes (max, then exp / sum / PV), nothing
+//     of size F x F is stored;
+//   * shapes are template parameters (D, U, H): no runtime division in any inner loop.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "common.h"
+#include "rng.h"
+
+extern "C" int satrans_layer_slab_reduce(float* slabs, int S, int gx, int D, int U, int flags, int64_t tab_stride,
+                                         float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
+                                         float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream);
+extern "C" int64_t satrans_layer_slab_reduce_extra_floats(int S, int D, int U);
+
+namespace satrans {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kFusedBlock = 256;
+constexpr int kFusedWaves = kFusedBlock / 64;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// out[mt] (16 output features x 16 tokens, D-layout) = sum over KT_*16 input features.
+// w: LDS image [K][LDW], w[k*LDW + o] = weight from input feature k to output feature o.
+// `wl` = w + 4*g*LDW + n (per-lane base), so every A fragment is one ds_read_b32 at a compile-time offset.
+template <int KT_, int MT_, int LDW>
+__device__ __forceinline__ void chain(const float* __restrict__ wl, const float (&in)[KT_][4], float (&out)[MT_][4]) {
+    f32x4 acc[MT_];
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mt = 0; mt < MT_; ++mt) acc[mt] = mfma4(wl[(16 * t + r) * LDW + 16 * mt], in[t][r], acc[mt]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) {
+        out[mt][0] = acc[mt][0]; out[mt][1] = acc[mt][1]; out[mt][2] = acc[mt][2]; out[mt][3] = acc[mt][3];
+    }
+}
+
+// sum over the D features of each token: registers, then the four lane groups
+__device__ __forceinline__ float token_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// LayerNorm over features of a D-layout fragment (torch: biased variance, eps = 1e-6 inside the sqrt).
+// gam/bet: LDS vectors [D]; g4 = 4*(lane>>4).  Returns mean / rstd through references when asked for.
+template <int KT_>
+__device__ __forceinline__ void layer_norm_frag(float (&v)[KT_][4], const float* gam, const float* bet, int g4,
+                                                float& mean, float& rstd) {
+    constexpr float invD = 1.0f / (16 * KT_);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    mean = token_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = v[t][r] - mean;
+            q = fmaf(e, e, q);
+        }
+    rstd = 1.0f / sqrtf(token_sum(q) * invD + 1e-6f);
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) {
+        const float4 gg = *reinterpret_cast<const float4*>(gam + 16 * t + g4);
+        const float4 bb = *reinterpret_cast<const float4*>(bet + 16 * t + g4);
+        v[t][0] = (v[t][0] - mean) * rstd * gg.x + bb.x;
+        v[t][1] = (v[t][1] - mean) * rstd * gg.y + bb.y;
+        v[t][2] = (v[t][2] - mean) * rstd * gg.z + bb.z;
+        v[t][3] = (v[t][3] - mean) * rstd * gg.w + bb.w;
+    }
+}
+
+struct FusedDrop {
+    bool on;
+    float scale;
+    uint32_t thresh;
+    uint32_t key[4];
+};
+
+__device__ __forceinline__ FusedDrop fused_drop(const satrans_layer_desc& a) {
+    FusedDrop dc;
+    dc.on = (a.flags & SATRANS_TRAIN) && a.drop_p > 0.f;
+    dc.scale = dc.on ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    dc.thresh = drop_threshold(a.drop_p);
+    for (int s = 0; s < 4; ++s) dc.key[s] = drop_site_key(a.seed, a.step, a.layer, s);
+    return dc;
+}
+
+// weight images resident in LDS for the whole kernel
+template <int D, int U>
+struct FwdImages {
+    static constexpr int LD = D + 4, LU = U + 4;
+    float *wq, *wk, *wv, *woT;   // [D][LD]
+    float *w1q, *w1k;            // [D][LU]
+    float *w2q, *w2k;            // [U][LD]
+    float *lnq_g, *lnq_b, *lnk_g, *lnk_b, *ln_g, *ln_b;  // [D]
+};
+
+__device__ __forceinline__ void stage_image(const float* __restrict__ g, float* __restrict__ s, int R, int C, int ld,
+                                            bool transpose) {
+    for (int i = threadIdx.x; i < R * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        if (transpose) s[c * ld + r] = g[i];
+        else s[r * ld + c] = g[i];
+    }
+}
+
+// MetaNet of one role on a D-layout fragment: out = LN(drop(relu(in W1) W2) + in)     submodules.py:77-103
+// Also hands back the hidden activations, the pre-norm rows and the statistics for the backward pass.
+template <int D, int U>
+__device__ __forceinline__ void metanet_frag(const float* w1l, const float* w2l, const float* gam, const float* bet,
+                                             int g4, const FusedDrop& dc, int site, uint32_t sample_key, int f,
+                                             const float (&in)[D / 16][4], float (&h)[U / 16][4],
+                                             float (&out)[D / 16][4], float& mean, float& rstd) {
+    constexpr int KT = D / 16, UT = U / 16;
+    chain<KT, UT, U + 4>(w1l, in, h);
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
+    chain<UT, KT, D + 4>(w2l, h, out);
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = out[t][r];
+            if (dc.on) m = drop_keep(sample_key, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? m * dc.scale : 0.f;
+            out[t][r] = m + in[t][r];
+        }
+    layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
+}
+
+template <int D, int U, int H>
+__global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
+                                                                      float* __restrict__ y, float* __restrict__ att) {
+    constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
+    extern __shared__ __align__(16) float lds[];
+    const int F = a.F, scen = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
+    const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
+    const bool same_tab = a.tab_q == a.tab_k;
+
+    // ---- carve LDS, stage every weight once -------------------------------------------------------------
+    float* p = lds;
+    auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
+    FwdImages<D, U> W;
+    W.wq = take(D * LD); W.wk = take(D * LD); W.wv = take(D * LD); W.woT = take(D * LD);
+    W.w1q = take(D * LU); W.w2q = take(U * LD);
+    W.w1k = same_tab ? W.w1q : take(D * LU);
+    W.w2k = same_tab ? W.w2q : take(U * LD);
+    W.lnq_g = take(D); W.lnq_b = take(D); W.lnk_g = take(D); W.lnk_b = take(D); W.ln_g = take(D); W.ln_b = take(D);
+    const int rows = ((Tsamp * F + 15) >> 4) << 4;
+    float* sq = take(rows * LD);
+    float* sk = take(rows * LD);
+    float* sv = take(rows * LD);
+
+    stage_image(a.w_query, W.wq, D, D, LD, false);
+    stage_image(a.w_key, W.wk, D, D, LD, false);
+    stage_image(a.w_value, W.wv, D, D, LD, false);
+    stage_image(a.w_out, W.woT, D, D, LD, true);      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
+    if (meta_q) {
+        const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+        stage_image(row, W.w1q, D, U, LU, false);
+        stage_image(row + D * U, W.w2q, U, D, LD, false);
+    }
+    if (meta_k && (!same_tab || !meta_q)) {
+        const float* row = a.tab_k + (size_t)scen * a.tab_stride;
+        stage_image(row, W.w1k, D, U, LU, false);
+        stage_image(row + D * U, W.w2k, U, D, LD, false);
+    }
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        W.ln_g[i] = a.ln_g[i]; W.ln_b[i] = a.ln_b[i];
+        if (meta_q) { W.lnq_g[i] = a.lnq_g[i]; W.lnq_b[i] = a.lnq_b[i]; }
+        if (meta_k) { W.lnk_g[i] = a.lnk_g[i]; W.lnk_b[i] = a.lnk_b[i]; }
+    }
+    __syncthreads();
+
+    const int wl = g4 * 0 + n;  // per-lane offset inside an image: row 4g, column n
+    const float* wq_l = W.wq + g4 * LD + wl;
+    const float* wk_l = W.wk + g4 * LD + wl;
+    const float* wv_l = W.wv + g4 * LD + wl;
+    const float* wo_l = W.woT + g4 * LD + wl;
+    const float* w1q_l = W.w1q + g4 * LU + wl;
+    const float* w2q_l = W.w2q + g4 * LD + wl;
+    const float* w1k_l = W.w1k + g4 * LU + wl;
+    const float* w2k_l = W.w2k + g4 * LD + wl;
+    const FusedDrop dc = fused_drop(a);
+    const float sqrt_d = sqrtf((float)d);
+    const int lo = a.seg[scen], hi = a.seg[scen + 1];
+
+    for (int first = lo + blockIdx.x * Tsamp; first < hi; first += gridDim.x * Tsamp) {
+        const int32_t* samp = a.order + first;
+        const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
+
+        // ---- phase 1: projections + MetaNet per 16-token tile, all in registers --------------------------
+        for (int tt = wave; tt < ntt; tt += kFusedWaves) {
+            const int tok = 16 * tt + n;
+            const bool valid = tok < ntok;
+            const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
+            const int b = samp[ls];
+            const float* xrow = a.x + ((size_t)b * F + f) * D + g4;
+            float x[KT][4], q[KT][4], k[KT][4], v[KT][4];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const float4 xv = *reinterpret_cast<const float4*>(xrow + 16 * t);
+                x[t][0] = xv.x; x[t][1] = xv.y; x[t][2] = xv.z; x[t][3] = xv.w;
+            }
+            chain<KT, KT, LD>(wq_l, x, q);                                               // satrans.py:55-57
+            chain<KT, KT, LD>(wk_l, x, k);
+            chain<KT, KT, LD>(wv_l, x, v);
+            float mean, rstd;
+            if (meta_q) {                                                                  // satrans.py:60-66
+                float h[UT][4], o[KT][4];
+                metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
+                                   drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[t][r] = o[t][r];
+            }
+            if (meta_k) {                                                                  // satrans.py:67-73
+                float h[UT][4], o[KT][4];
+                metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
+                                   drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) k[t][r] = o[t][r];
+            }
+            float* qd = sq + (size_t)tok * LD + g4;
+            float* kd = sk + (size_t)tok * LD + g4;
+            float* vd = sv + (size_t)tok * LD + g4;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                *reinterpret_cast<float4*>(qd + 16 * t) = make_float4(q[t][0], q[t][1], q[t][2], q[t][3]);
+                *reinterpret_cast<float4*>(kd + 16 * t) = make_float4(k[t][0], k[t][1], k[t][2], k[t][3]);
+                *reinterpret_cast<float4*>(vd + 16 * t) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: attention, one lane per (sample, head, query row)  (satrans.py:75-90) -------------------
+        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
+            const int ls = task / (H * F), rem = task - ls * H * F;
+            const int h = rem / F, i = rem - h * F;
+            const int b = samp[ls];
+            float qi[d];
+            float* qrow = sq + (size_t)(ls * F + i) * LD + h * d;
+#pragma unroll
+            for (int e = 0; e < d; e += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
+                qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
+            }
+            const float* kbase = sk + (size_t)(ls * F) * LD + h * d;
+            const float* vbase = sv + (size_t)(ls * F) * LD + h * d;
+            float mx = -INFINITY;
+            for (int j = 0; j < F; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                }
+                mx = fmaxf(mx, s / sqrt_d);
+            }
+            float oacc[d];
+#pragma unroll
+            for (int e = 0; e < d; ++e) oacc[e] = 0.f;
+            float sum = 0.f;
+            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)b);
+            for (int j = 0; j < F; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                }
+                const float ex = expf(s / sqrt_d - mx);
+                sum += ex;
+                float pe = ex;
+                if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
+                    oacc[e] = fmaf(pe, v4.x, oacc[e]); oacc[e + 1] = fmaf(pe, v4.y, oacc[e + 1]);
+                    oacc[e + 2] = fmaf(pe, v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe, v4.w, oacc[e + 3]);
+                }
+            }
+            const float inv = 1.0f / sum;
+            if (att) {   // normalized_att_scores [H,B,F,F], after dropout (satrans.py:87); rarely requested
+                float* arow = att + (((size_t)h * a.B + b) * F + i) * F;
+                for (int j = 0; j < F; ++j) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < d; e += 4) {
+                        const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                        s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                        s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                    }
+                    float pj = expf(s / sqrt_d - mx) / sum;
+                    if (dc.on) pj = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? pj * dc.scale : 0.f;
+                    arow[j] = pj;
+                }
+            }
+            // the attention output takes the place of this task's own q row (nobody else reads it)
+#pragma unroll
+            for (int e = 0; e < d; e += 4)
+                *reinterpret_cast<float4*>(qrow + e) =
+                    make_float4(oacc[e] * inv, oacc[e + 1] * inv, oacc[e + 2] * inv, oacc[e + 3] * inv);
+        }
+        __syncthreads();
+
+        // ---- phase 3: Out_linear, dropout, residual, LayerNorm per 16-token tile (satrans.py:91-99) ------------
+        for (int tt = wave; tt < ntt; tt += kFusedWaves) {
+            const int tok = 16 * tt + n;
+            const bool valid = tok < ntok;
+            const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
+            const int b = samp[ls];
+            float o[KT][4], u[KT][4];
+            const float* orow = sq + (size_t)tok * LD + g4;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * t);
+                o[t][0] = ov.x; o[t][1] = ov.y; o[t][2] = ov.z; o[t][3] = ov.w;
+            }
+            chain<KT, KT, LD>(wo_l, o, u);
+            const float* xrow = a.x + ((size_t)b * F + f) * D + g4;
+            const uint32_t skey = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const float4 xv = *reinterpret_cast<const float4*>(xrow + 16 * t);
+                const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = u[t][r];
+                    if (a.flags & SATRANS_RELU_OUT) val = fmaxf(val, 0.f);
+                    if (dc.on) val = drop_keep(skey, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? val * dc.scale : 0.f;
+                    if (!(a.flags & SATRANS_NO_RES)) val += xr[r];
+                    u[t][r] = val;
+                }
+            }
+            float mean, rstd;
+            layer_norm_frag<KT>(u, W.ln_g, W.ln_b, g4, mean, rstd);
+            if (valid) {
+                float* yrow = y + ((size_t)b * F + f) * D + g4;
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+                    *reinterpret_cast<float4*>(yrow + 16 * t) = make_float4(u[t][0], u[t][1], u[t][2], u[t][3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// Backward.  One workgroup tile = T samples with T*F <= 64 tokens, i.e. at most ONE 16-token tile per wave, so all
+// token-wise state of a tile (x, q0, k0, MetaNet hidden, normalised rows, statistics, dr) stays in the owning wave's
+// registers across the attention barriers: nothing is recomputed twice, nothing is stashed.  Phases per tile:
+//   A  (wave/tile)  forward chain, q k v -> LDS
+//   B  (lane/task)  attention forward -> o, softmax statistics (max, 1/sum) per (sample, head, row)
+//   C  (wave/tile)  Out_linear + residual + LayerNorm forward and backward, dWo, go = du Wo (replaces o)
+//   D  (lane/task)  softmax backward by rows: dot_i, dq_i
+//   E  (lane/task)  by columns: dk_j, dv_j (replace k_j, v_j)
+//   F  (wave/tile)  MetaNet backward for Q and K, projection backward, all weight gradients, dx
+// Weight gradients are MFMA products contracted over the tile's 16 tokens; their operands are written row-wise
+// into the wave's OWN rows of the q / o / dq buffers (dead by then), so phase F needs no workgroup barrier.  The
+// accumulators live in registers for the whole persistent loop and are combined over the four waves at the end.
+// -------------------------------------------------------------------------------------------------------------------
+struct SlabOffF {
+    int wq, wk, wv, wo, w1q, w2q, w1k, w2k, ln, lnq, lnk, total;
+};
+__host__ __device__ inline SlabOffF slab_offsets_f(int D, int U) {   // same layout as layer_lds.hip
+    SlabOffF s;
+    int o = 0;
+    s.wq = o; o += D * D;
+    s.wk = o; o += D * D;
+    s.wv = o; o += D * D;
+    s.wo = o; o += D * D;
+    s.w1q = o; o += D * U;
+    s.w2q = o; o += U * D;
+    s.w1k = o; o += D * U;
+    s.w2k = o; o += U * D;
+    s.ln = o; o += 2 * D;
+    s.lnq = o; o += 2 * D;
+    s.lnk = o; o += 2 * D;
+    s.total = o;
+    return s;
+}
+
+template <int KT_>
+__device__ __forceinline__ void load_frag(const float* row, float (&v)[KT_][4], bool ok = true) {
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(row + 16 * t);
+        v[t][0] = ok ? q.x : 0.f; v[t][1] = ok ? q.y : 0.f; v[t][2] = ok ? q.z : 0.f; v[t][3] = ok ? q.w : 0.f;
+    }
+}
+template <int KT_>
+__device__ __forceinline__ void store_frag(float* row, const float (&v)[KT_][4], bool ok = true) {
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+        *reinterpret_cast<float4*>(row + 16 * t) = ok ? make_float4(v[t][0], v[t][1], v[t][2], v[t][3])
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// acc[MOFF+mt][NOFF+nt] += sum over the wave's 16 token rows of A[tok][16mt + .] * G[tok][16nt + .]   (mt < MT_, nt < NT_)
+// al / gl: per-lane bases  buffer + (tile_row0 + g)*ld + n ; step ks adds 4 rows
+template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
+__device__ __forceinline__ void wgrad(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float av[MT_], gv[NT_];
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) av[mt] = al[4 * ks * LDA + 16 * mt];
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt) gv[nt] = gl[4 * ks * LDG + 16 * nt];
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT_; ++nt)
+                acc[MOFF + mt][NOFF + nt] = mfma4(av[mt], gv[nt], acc[MOFF + mt][NOFF + nt]);
+    }
+}
+
+// LayerNorm forward that keeps the normalised rows and 1/std for the backward pass
+template <int KT_>
+__device__ __forceinline__ void layer_norm_keep(const float (&z)[KT_][4], float (&zh)[KT_][4], float& rstd) {
+    constexpr float invD = 1.0f / (16 * KT_);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) s += (z[t][0] + z[t][1]) + (z[t][2] + z[t][3]);
+    const float mean = token_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = z[t][r] - mean;
+            q = fmaf(e, e, q);
+        }
+    rstd = 1.0f / sqrtf(token_sum(q) * invD + 1e-6f);
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zh[t][r] = (z[t][r] - mean) * rstd;
+}
+
+// LayerNorm backward on a D-layout fragment: g (gradient of the normalised-and-scaled output) becomes the gradient
+// of the pre-norm rows; gamma / beta gradients accumulate per lane (reduced over lanes and waves at kernel end).
+template <int KT_>
+__device__ __forceinline__ void layer_norm_bwd(float (&g)[KT_][4], const float (&zh)[KT_][4], float rstd,
+                                               const float* gam, int g4, float (&acc_g)[KT_][4],
+                                               float (&acc_b)[KT_][4]) {
+    constexpr float invD = 1.0f / (16 * KT_);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) {
+        const float4 gm4 = *reinterpret_cast<const float4*>(gam + 16 * t + g4);
+        const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc_g[t][r] = fmaf(g[t][r], zh[t][r], acc_g[t][r]);
+            acc_b[t][r] += g[t][r];
+            g[t][r] *= gm[r];
+            m1 += g[t][r];
+            m2 = fmaf(g[t][r], zh[t][r], m2);
+        }
+    }
+    m1 = token_sum(m1) * invD;
+    m2 = token_sum(m2) * invD;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[t][r] = rstd * (g[t][r] - m1 - zh[t][r] * m2);
+}
+
+template <int D, int U, int H, bool SAME>   // SAME: Q and K roles share one generated-weight table (no 'pos' flag)
+__global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
+                                                                         const float* __restrict__ dy,
+                                                                         float* __restrict__ dx,
+                                                                         float* __restrict__ slabs) {
+    constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
+    constexpr int HB = (UT + KT - 1) / KT;          // row buffers needed to hold one U-wide operand (<= 2)
+    constexpr int NB = (UT < KT) ? UT : KT;          // 16-feature tiles of such an operand held by one row buffer
+    static_assert(HB <= 2 && UT == HB * NB, "MetaNet hidden width must be D/.. or 2*D for the fused backward");
+    extern __shared__ __align__(16) float lds[];
+    const int F = a.F, scen = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
+    const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
+    constexpr bool same_tab = SAME;
+    const bool relu_out = a.flags & SATRANS_RELU_OUT, use_res = !(a.flags & SATRANS_NO_RES);
+
+    // ---- LDS: forward images, transposed images, LN vectors, 5 row buffers, softmax statistics ------------------
+    float* p = lds;
+    auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
+    float* wq = take(D * LD); float* wk = take(D * LD); float* wv = take(D * LD); float* woT = take(D * LD);
+    float* w1q = take(D * LU); float* w2q = take(U * LD);
+    float* w1k = same_tab ? w1q : take(D * LU);
+    float* w2k = same_tab ? w2q : take(U * LD);
+    float* wqT = take(D * LD); float* wkT = take(D * LD); float* wvT = take(D * LD); float* wo = take(D * LD);
+    float* w1qT = take(U * LD); float* w2qT = take(D * LU);     // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]
+    float* w1kT = same_tab ? w1qT : take(U * LD);
+    float* w2kT = same_tab ? w2qT : take(D * LU);
+    float* lnq_g = take(D); float* lnk_g = take(D); float* ln_g = take(D);
+    float* lnq_b = take(D); float* lnk_b = take(D); float* ln_b = take(D);
+    constexpr int ROWS = 64;
+    float* sq = take(ROWS * LD);     // q      | phase F scratch
+    float* sk = take(ROWS * LD);     // k      -> dk
+    float* sv = take(ROWS * LD);     // v      -> dv
+    float* so = take(ROWS * LD);     // o      -> go | phase F scratch
+    float* sg = take(ROWS * LD);     // du (phase C scratch) -> dq | phase F scratch
+    const int ntask_max = Tsamp * H * F;
+    float* st_mx = take(ntask_max); float* st_inv = take(ntask_max); float* st_dot = take(ntask_max);
+
+    const int lo = a.seg[scen], hi = a.seg[scen + 1];
+    const bool idle = lo + (int)blockIdx.x * Tsamp >= hi;      // no tile for this workgroup: only its zero slab is due
+    if (!idle) {
+    stage_image(a.w_query, wq, D, D, LD, false);   stage_image(a.w_query, wqT, D, D, LD, true);
+    stage_image(a.w_key, wk, D, D, LD, false);     stage_image(a.w_key, wkT, D, D, LD, true);
+    stage_image(a.w_value, wv, D, D, LD, false);   stage_image(a.w_value, wvT, D, D, LD, true);
+    stage_image(a.w_out, woT, D, D, LD, true);     stage_image(a.w_out, wo, D, D, LD, false);
+    if (meta_q) {
+        const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+        stage_image(row, w1q, D, U, LU, false);          stage_image(row, w1qT, D, U, LD, true);
+        stage_image(row + D * U, w2q, U, D, LD, false);  stage_image(row + D * U, w2qT, U, D, LU, true);
+    }
+    if (meta_k && (!same_tab || !meta_q)) {
+        const float* row = a.tab_k + (size_t)scen * a.tab_stride;
+        stage_image(row, w1k, D, U, LU, false);          stage_image(row, w1kT, D, U, LD, true);
+        stage_image(row + D * U, w2k, U, D, LD, false);  stage_image(row + D * U, w2kT, U, D, LU, true);
+    }
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        ln_g[i] = a.ln_g[i]; ln_b[i] = a.ln_b[i];
+        if (meta_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
+        if (meta_k) { lnk_g[i] = a.lnk_g[i]; lnk_b[i] = a.lnk_b[i]; }
+    }
+    // rows of padding tokens are multiplied by exact zeros in the token-contraction products: they must hold
+    // finite numbers from the start (0 * NaN would poison an accumulator)
+    for (int i = threadIdx.x; i < 5 * ROWS * LD; i += blockDim.x) sq[i] = 0.f;
+    }
+    __syncthreads();
+
+    const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
+    const FusedDrop dc = fused_drop(a);
+    const float sqrt_d = sqrtf((float)d);
+
+    // ---- register accumulators of the weight gradients (whole kernel) ----------------------------------------------
+    f32x4 acc_wq[KT][KT], acc_wk[KT][KT], acc_wv[KT][KT], acc_wo[KT][KT];
+    f32x4 acc_w1q[KT][UT], acc_w2q[UT][KT], acc_w1k[KT][UT], acc_w2k[UT][KT];
+    float agq[KT][4], abq[KT][4], agk[KT][4], abk[KT][4], agl[KT][4], abl[KT][4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) { acc_wq[i][j] = zero4; acc_wk[i][j] = zero4; acc_wv[i][j] = zero4; acc_wo[i][j] = zero4; }
+#pragma unroll
+        for (int j = 0; j < UT; ++j) { acc_w1q[i][j] = zero4; acc_w2q[j][i] = zero4; acc_w1k[i][j] = zero4; acc_w2k[j][i] = zero4; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { agq[i][r] = abq[i][r] = agk[i][r] = abk[i][r] = agl[i][r] = abl[i][r] = 0.f; }
+    }
+
+    // this wave's 16 rows of every row buffer
+    const int row0 = 16 * wave;
+    float* my_q = sq + (size_t)(row0 + n) * LD + g4;   // D-layout row access (float4 per t)
+    float* my_k = sk + (size_t)(row0 + n) * LD + g4;
+    float* my_v = sv + (size_t)(row0 + n) * LD + g4;
+    float* my_o = so + (size_t)(row0 + n) * LD + g4;
+    float* my_g = sg + (size_t)(row0 + n) * LD + g4;
+    const float* wg_q = sq + (size_t)(row0 + g) * LD + n;   // token-contraction access (one float per step)
+    const float* wg_v = sv + (size_t)(row0 + g) * LD + n;
+    const float* wg_o = so + (size_t)(row0 + g) * LD + n;
+    const float* wg_g = sg + (size_t)(row0 + g) * LD + n;
+
+    for (int first = lo + blockIdx.x * Tsamp; first < hi; first += gridDim.x * Tsamp) {
+        const int32_t* samp = a.order + first;
+        const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
+        const bool has_tile = wave < ntt;
+        const int tok = row0 + n;
+        const bool valid = has_tile && tok < ntok;
+        const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
+        const int b = samp[ls];
+        const uint32_t key_q = drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b);
+        const uint32_t key_k = drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b);
+        const uint32_t key_o = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
+
+        // token-wise state that lives from phase A to phase F
+        float x[KT][4], q0[KT][4], k0[KT][4], hq[UT][4], hk[UT][4], zhq[KT][4], zhk[KT][4], dr[KT][4];
+        float rstd_q = 0.f, rstd_k = 0.f;
+
+        // ================= phase A: forward chain ====================================================================
+        if (has_tile) {
+            load_frag<KT>(a.x + ((size_t)b * F + f) * D + g4, x);
+            float v[KT][4], q[KT][4], k[KT][4];
+            chain<KT, KT, LD>(wq + lo_d, x, q0);
+            chain<KT, KT, LD>(wk + lo_d, x, k0);
+            chain<KT, KT, LD>(wv + lo_d, x, v);
+            if (meta_q) {
+                float m[KT][4];
+                chain<KT, UT, LU>(w1q + lo_u, q0, hq);
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hq[t][r] = fmaxf(hq[t][r], 0.f);
+                chain<UT, KT, LD>(w2q + lo_d, hq, m);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mm = m[t][r];
+                        if (dc.on) mm = drop_keep(key_q, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? mm * dc.scale : 0.f;
+                        m[t][r] = mm + q0[t][r];
+                    }
+                layer_norm_keep<KT>(m, zhq, rstd_q);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 gg = *reinterpret_cast<const float4*>(lnq_g + 16 * t + g4);
+                    const float4 bb = *reinterpret_cast<const float4*>(lnq_b + 16 * t + g4);
+                    q[t][0] = zhq[t][0] * gg.x + bb.x; q[t][1] = zhq[t][1] * gg.y + bb.y;
+                    q[t][2] = zhq[t][2] * gg.z + bb.z; q[t][3] = zhq[t][3] * gg.w + bb.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[t][r] = q0[t][r];
+            }
+            if (meta_k) {
+                float m[KT][4];
+                chain<KT, UT, LU>(w1k + lo_u, k0, hk);
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hk[t][r] = fmaxf(hk[t][r], 0.f);
+                chain<UT, KT, LD>(w2k + lo_d, hk, m);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mm = m[t][r];
+                        if (dc.on) mm = drop_keep(key_k, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? mm * dc.scale : 0.f;
+                        m[t][r] = mm + k0[t][r];
+                    }
+                layer_norm_keep<KT>(m, zhk, rstd_k);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 gg = *reinterpret_cast<const float4*>(lnk_g + 16 * t + g4);
+                    const float4 bb = *reinterpret_cast<const float4*>(lnk_b + 16 * t + g4);
+                    k[t][0] = zhk[t][0] * gg.x + bb.x; k[t][1] = zhk[t][1] * gg.y + bb.y;
+                    k[t][2] = zhk[t][2] * gg.z + bb.z; k[t][3] = zhk[t][3] * gg.w + bb.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) k[t][r] = k0[t][r];
+            }
+            store_frag<KT>(my_q, q);
+            store_frag<KT>(my_k, k);
+            store_frag<KT>(my_v, v);
+        }
+        __syncthreads();
+
+        // ================= phase B: attention forward, statistics ======================================================
+        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
+            const int tls = task / (H * F), rem = task - tls * H * F;
+            const int h = rem / F, i = rem - h * F;
+            const int tb = samp[tls];
+            float qi[d];
+            const float* qrow = sq + (size_t)(tls * F + i) * LD + h * d;
+#pragma unroll
+            for (int e = 0; e < d; e += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
+                qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
+            }
+            const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
+            const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
+            float mx = -INFINITY;
+            for (int j = 0; j < F; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                }
+                mx = fmaxf(mx, s / sqrt_d);
+            }
+            float oacc[d];
+#pragma unroll
+            for (int e = 0; e < d; ++e) oacc[e] = 0.f;
+            float sum = 0.f;
+            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            for (int j = 0; j < F; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                }
+                const float ex = expf(s / sqrt_d - mx);
+                sum += ex;
+                float pe = ex;
+                if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
+                    oacc[e] = fmaf(pe, v4.x, oacc[e]); oacc[e + 1] = fmaf(pe, v4.y, oacc[e + 1]);
+                    oacc[e + 2] = fmaf(pe, v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe, v4.w, oacc[e + 3]);
+                }
+            }
+            const float inv = 1.0f / sum;
+            st_mx[task] = mx;
+            st_inv[task] = inv;
+            float* orow = so + (size_t)(tls * F + i) * LD + h * d;
+#pragma unroll
+            for (int e = 0; e < d; e += 4)
+                *reinterpret_cast<float4*>(orow + e) =
+                    make_float4(oacc[e] * inv, oacc[e + 1] * inv, oacc[e + 2] * inv, oacc[e + 3] * inv);
+        }
+        __syncthreads();
+
+        // ================= phase C: output block forward + backward ======================================================
+        if (has_tile) {
+            float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4];
+            load_frag<KT>(my_o, o);
+            chain<KT, KT, LD>(woT + lo_d, o, u);
+            float keep[KT][4];      // multiplicative factor of du: dropout mask times ReLU mask
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = u[t][r], kf = 1.0f;
+                    if (relu_out) { kf = val > 0.f ? 1.0f : 0.f; val = fmaxf(val, 0.f); }
+                    if (dc.on) {
+                        const float mk = drop_keep(key_o, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? dc.scale : 0.f;
+                        val *= mk; kf *= mk;
+                    }
+                    keep[t][r] = kf;
+                    u[t][r] = use_res ? val + x[t][r] : val;
+                }
+            float rstd_o;
+            layer_norm_keep<KT>(u, zh, rstd_o);
+            load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy, valid);
+            layer_norm_bwd<KT>(gy, zh, rstd_o, ln_g, g4, agl, abl);          // gy is now dr
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dr[t][r] = use_res ? gy[t][r] : 0.f;
+                    gy[t][r] *= keep[t][r];                                     // du
+                }
+            store_frag<KT>(my_g, gy);                                           // du rows (zero for padding tokens)
+            wgrad<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
+            float go[KT][4];
+            chain<KT, KT, LD>(wo + lo_d, gy, go);                               // go = du Wo
+            store_frag<KT>(my_o, go);
+        }
+        __syncthreads();
+
+        // ================= phase D: softmax backward by rows: dot_i and dq_i ==============================================
+        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
+            const int tls = task / (H * F), rem = task - tls * H * F;
+            const int h = rem / F, i = rem - h * F;
+            const int tb = samp[tls];
+            float qi[d], gi[d], dq[d];
+            const float* qrow = sq + (size_t)(tls * F + i) * LD + h * d;
+            const float* grow = so + (size_t)(tls * F + i) * LD + h * d;
+#pragma unroll
+            for (int e = 0; e < d; e += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
+                const float4 g4v = *reinterpret_cast<const float4*>(grow + e);
+                qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
+                gi[e] = g4v.x; gi[e + 1] = g4v.y; gi[e + 2] = g4v.z; gi[e + 3] = g4v.w;
+            }
+            const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
+            const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
+            const float mx = st_mx[task], inv = st_inv[task];
+            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            float dot = 0.f;
+            for (int j = 0; j < F; ++j) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
+                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                    dp = fmaf(gi[e], v4.x, dp); dp = fmaf(gi[e + 1], v4.y, dp);
+                    dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
+                }
+                const float pj = expf(s / sqrt_d - mx) * inv;
+                if (dc.on) dp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? dp * dc.scale : 0.f;
+                dot = fmaf(dp, pj, dot);
+            }
+            st_dot[task] = dot;
+#pragma unroll
+            for (int e = 0; e < d; ++e) dq[e] = 0.f;
+            for (int j = 0; j < F; ++j) {
+                float s = 0.f, dp = 0.f;
+                float kj[d];
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
+                    kj[e] = k4.x; kj[e + 1] = k4.y; kj[e + 2] = k4.z; kj[e + 3] = k4.w;
+                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                    dp = fmaf(gi[e], v4.x, dp); dp = fmaf(gi[e + 1], v4.y, dp);
+                    dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
+                }
+                const float pj = expf(s / sqrt_d - mx) * inv;
+                if (dc.on) dp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? dp * dc.scale : 0.f;
+                const float ds = pj * (dp - dot) / sqrt_d;
+#pragma unroll
+                for (int e = 0; e < d; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
+            }
+            float* dqrow = sg + (size_t)(tls * F + i) * LD + h * d;
+#pragma unroll
+            for (int e = 0; e < d; e += 4)
+                *reinterpret_cast<float4*>(dqrow + e) = make_float4(dq[e], dq[e + 1], dq[e + 2], dq[e + 3]);
+        }
+        __syncthreads();
+
+        // ================= phase E: by columns: dk_j, dv_j (in place of k_j, v_j) ===========================================
+        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
+            const int tls = task / (H * F), rem = task - tls * H * F;
+            const int h = rem / F, j = rem - h * F;
+            const int tb = samp[tls];
+            float kj[d], vj[d], dk[d], dv[d];
+            float* krow = sk + (size_t)(tls * F + j) * LD + h * d;
+            float* vrow = sv + (size_t)(tls * F + j) * LD + h * d;
+#pragma unroll
+            for (int e = 0; e < d; e += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(krow + e);
+                const float4 v4 = *reinterpret_cast<const float4*>(vrow + e);
+                kj[e] = k4.x; kj[e + 1] = k4.y; kj[e + 2] = k4.z; kj[e + 3] = k4.w;
+                vj[e] = v4.x; vj[e + 1] = v4.y; vj[e + 2] = v4.z; vj[e + 3] = v4.w;
+                dk[e] = dk[e + 1] = dk[e + 2] = dk[e + 3] = 0.f;
+                dv[e] = dv[e + 1] = dv[e + 2] = dv[e + 3] = 0.f;
+            }
+            const float* qbase = sq + (size_t)(tls * F) * LD + h * d;
+            const float* gbase = so + (size_t)(tls * F) * LD + h * d;
+            const int st0 = (tls * H + h) * F;
+            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            for (int i = 0; i < F; ++i) {
+                float qi[d], gi[d];
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int e = 0; e < d; e += 4) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(qbase + (size_t)i * LD + e);
+                    const float4 g4v = *reinterpret_cast<const float4*>(gbase + (size_t)i * LD + e);
+                    qi[e] = q4.x; qi[e + 1] = q4.y; qi[e + 2] = q4.z; qi[e + 3] = q4.w;
+                    gi[e] = g4v.x; gi[e + 1] = g4v.y; gi[e + 2] = g4v.z; gi[e + 3] = g4v.w;
+                    s = fmaf(q4.x, kj[e], s); s = fmaf(q4.y, kj[e + 1], s);
+                    s = fmaf(q4.z, kj[e + 2], s); s = fmaf(q4.w, kj[e + 3], s);
+                    dp = fmaf(g4v.x, vj[e], dp); dp = fmaf(g4v.y, vj[e + 1], dp);
+                    dp = fmaf(g4v.z, vj[e + 2], dp); dp = fmaf(g4v.w, vj[e + 3], dp);
+                }
+                const float pij = expf(s / sqrt_d - st_mx[st0 + i]) * st_inv[st0 + i];
+                float mk = 1.0f;
+                if (dc.on) mk = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? dc.scale : 0.f;
+                const float ds = pij * (dp * mk - st_dot[st0 + i]) / sqrt_d;
+                const float pd = pij * mk;
+#pragma unroll
+                for (int e = 0; e < d; ++e) {
+                    dk[e] = fmaf(ds, qi[e], dk[e]);
+                    dv[e] = fmaf(pd, gi[e], dv[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < d; e += 4) {
+                *reinterpret_cast<float4*>(krow + e) = make_float4(dk[e], dk[e + 1], dk[e + 2], dk[e + 3]);
+                *reinterpret_cast<float4*>(vrow + e) = make_float4(dv[e], dv[e + 1], dv[e + 2], dv[e + 3]);
+            }
+        }
+        __syncthreads();
+
+        // ================= phase F: MetaNet and projection backward, weight gradients, dx ==================================
+        if (has_tile) {
+            float gq[KT][4], gk[KT][4];
+            load_frag<KT>(my_g, gq, valid);      // gradient of the (post-MetaNet) queries
+            load_frag<KT>(my_k, gk, valid);      // ... keys; the value gradients stay in sv for dWv and are read below
+            // rows >= ntok of sv still hold forward values: they are neutralised by x = 0 in the dWv product and
+            // masked when read as a fragment
+
+            auto metanet_bwd = [&](float (&gout)[KT][4], const float (&zh)[KT][4], float rstd, const float* gam,
+                                   float (&ag)[KT][4], float (&ab)[KT][4], uint32_t key, float (&h)[UT][4],
+                                   const float (&in0)[KT][4], const float* w2T, const float* w1T,
+                                   f32x4 (&acc_w1)[KT][UT], f32x4 (&acc_w2)[UT][KT]) {
+                layer_norm_bwd<KT>(gout, zh, rstd, gam, g4, ag, ab);            // gout = dz
+                float dm[KT][4];
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mk = 1.0f;
+                        if (dc.on) mk = drop_keep(key, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? dc.scale : 0.f;
+                        dm[t][r] = gout[t][r] * mk;
+                    }
+                // dW2[u][o] += h^T dm : h goes to the q (and o) rows of this tile, dm to the dq rows
+                {
+                    float part[KT][4];
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[t][r] = (t < NB) ? h[t % UT][r] : 0.f;
+                    store_frag<KT>(my_q, part);
+                    if constexpr (HB == 2) {
+#pragma unroll
+                        for (int t = 0; t < KT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) part[t][r] = (t < NB) ? h[(NB + t) % UT][r] : 0.f;
+                        store_frag<KT>(my_o, part);
+                    }
+                    store_frag<KT>(my_g, dm);
+                    wgrad<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
+                    if constexpr (HB == 2) wgrad<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
+                }
+                // dh = (dm W2^T) * [h > 0]
+                float dh[UT][4];
+                chain<KT, UT, LU>(w2T + lo_u, dm, dh);
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dh[t][r] = h[t][r] > 0.f ? dh[t][r] : 0.f;
+                // dW1[i][u] += in0^T dh : in0 to the dq rows, dh to the q (and o) rows
+                {
+                    float part[KT][4];
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[t][r] = (t < NB) ? dh[t % UT][r] : 0.f;
+                    store_frag<KT>(my_q, part);
+                    if constexpr (HB == 2) {
+#pragma unroll
+                        for (int t = 0; t < KT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) part[t][r] = (t < NB) ? dh[(NB + t) % UT][r] : 0.f;
+                        store_frag<KT>(my_o, part);
+                    }
+                    store_frag<KT>(my_g, in0, valid);
+                    wgrad<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
+                    if constexpr (HB == 2) wgrad<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
+                }
+                // gradient of the MetaNet input: dz + dh W1^T
+                float back[KT][4];
+                chain<UT, KT, LD>(w1T + lo_d, dh, back);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gout[t][r] += back[t][r];
+            };
+
+            if (meta_q)
+                metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, key_q, hq, q0, w2qT, w1qT, acc_w1q, acc_w2q);
+            if (meta_k) {
+                if constexpr (SAME)   // one table: both roles add into the same accumulators
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, key_k, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
+                else
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, key_k, hk, k0, w2kT, w1kT, acc_w1k, acc_w2k);
+            }
+
+            // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
+            store_frag<KT>(my_q, x, valid);
+            store_frag<KT>(my_o, gq);
+            wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
+            store_frag<KT>(my_o, gk);
+            wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
+            wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
+            float gv[KT][4], back[KT][4];
+            load_frag<KT>(my_v, gv, valid);
+            chain<KT, KT, LD>(wqT + lo_d, gq, back);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            chain<KT, KT, LD>(wkT + lo_d, gk, back);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            chain<KT, KT, LD>(wvT + lo_d, gv, back);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
+        }
+        __syncthreads();
+    }
+
+    // ---- combine the four waves' accumulators through LDS (fixed order) and write this workgroup's slab ----------------
+    const SlabOffF so_ = slab_offsets_f(D, U);
+    float* slab = slabs + ((size_t)scen * gridDim.x + blockIdx.x) * so_.total;
+    float* stage = sq;   // the five row buffers are contiguous: 5 * 64 * LD floats of staging space
+    auto flush = [&](auto& acc, auto mtc, auto ntc, int off, bool live) {
+        constexpr int MT_ = decltype(mtc)::value, NT_ = decltype(ntc)::value;
+        constexpr int ncols = 16 * NT_, sz = MT_ * 16 * ncols;
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT_; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[wave * sz + (16 * mt + g4 + r) * ncols + 16 * nt + n] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < sz; e += kFusedBlock)
+            slab[off + e] = live ? ((stage[e] + stage[sz + e]) + stage[2 * sz + e]) + stage[3 * sz + e] : 0.f;
+        __syncthreads();
+    };
+    using KTc = std::integral_constant<int, KT>;
+    using UTc = std::integral_constant<int, UT>;
+    flush(acc_wq, KTc{}, KTc{}, so_.wq, true);
+    flush(acc_wk, KTc{}, KTc{}, so_.wk, true);
+    flush(acc_wv, KTc{}, KTc{}, so_.wv, true);
+    flush(acc_wo, KTc{}, KTc{}, so_.wo, true);
+    // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the region of a role only
+    // when that role is active, so the sums go to the Q region when Q is modulated, else to the K region
+    const bool to_k = SAME && !meta_q;
+    flush(acc_w1q, KTc{}, UTc{}, to_k ? so_.w1k : so_.w1q, true);
+    flush(acc_w2q, UTc{}, KTc{}, to_k ? so_.w2k : so_.w2q, true);
+    flush(acc_w1k, KTc{}, UTc{}, to_k ? so_.w1q : so_.w1k, !SAME);
+    flush(acc_w2k, UTc{}, KTc{}, to_k ? so_.w2q : so_.w2k, !SAME);
+    auto flush_ln = [&](float (&ag)[KT][4], float (&ab)[KT][4], int off) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sg_ = ag[t][r], sb_ = ab[t][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    sg_ += __shfl_xor(sg_, m, 64);
+                    sb_ += __shfl_xor(sb_, m, 64);
+                }
+                if (n == 0) {
+                    stage[wave * 2 * D + 16 * t + g4 + r] = sg_;
+                    stage[wave * 2 * D + D + 16 * t + g4 + r] = sb_;
+                }
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * D; e += kFusedBlock)
+            slab[off + e] = ((stage[e] + stage[2 * D + e]) + stage[4 * D + e]) + stage[6 * D + e];
+        __syncthreads();
+    };
+    flush_ln(agl, abl, so_.ln);
+    flush_ln(agq, abq, so_.lnq);
+    flush_ln(agk, abk, so_.lnk);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------------------------
+static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
+    const int LD = D + 4, LU = U + 4;
+    const int64_t rows = (((int64_t)T * F + 15) / 16) * 16;
+    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 3 * rows * LD + 64;
+}
+
+template <int D, int U, int H>
+static int launch_fwd(const satrans_layer_desc* d, float* y, float* att, hipStream_t stream) {
+    const bool same_tab = d->tab_q == d->tab_k;
+    // samples per tile: as many as keep two workgroups per CU, preferring tiles that fill their 16-token MFMA rows
+    int best = 0;
+    double best_eff = 0.0;
+    for (int budget : {78 * 1024, 156 * 1024}) {   // two workgroups per CU if any tile fits, else one
+        for (int t = 1; t <= 16; ++t) {
+            if (fused_fwd_lds_floats(t, d->F, D, U, same_tab) * 4 > budget) break;
+            const int tok = t * d->F, ntt = (tok + 15) / 16;
+            const double eff =
+                (double)tok / (16.0 * ntt) * (double)ntt / (double)(ceil_div(ntt, kFusedWaves) * kFusedWaves);
+            if (eff >= best_eff) { best_eff = eff; best = t; }
+        }
+        if (best) break;
+    }
+    SATRANS_REQUIRE(best > 0, SATRANS_E_UNSUPPORTED, "layer_fwd(fused): F=%d does not fit LDS", d->F);
+    const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab) * 4;
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
+        attr_set = lds;
+    }
+    const int64_t tiles = ceil_div(d->B, best);
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * 2, d->S)));
+    layer_fwd_fused_kernel<D, U, H><<<dim3(gx, d->S), kFusedBlock, lds, stream>>>(*d, best, y, att);
+    SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
+    return SATRANS_OK;
+}
+
+}  // namespace satrans
+
+extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d);
+
+namespace satrans {
+
+static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab) {
+    const int LD = D + 4, LU = U + 4;
+    auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
+    return 8 * (int64_t)D * LD + (same_tab ? 1 : 2) * 2 * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 5 * 64 * LD +
+           3 * r4((int64_t)T * H * F) + 64;
+}
+
+struct FusedBwdPlan {
+    int T, gx;
+    size_t lds;
+};
+
+static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
+    if (!satrans_layer_fused_supported(d) || d->D > 32 || d->F > 64) return false;
+    const bool same_tab = d->tab_q == d->tab_k;
+    p.T = 64 / d->F;
+    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab) * 4;
+    if (p.lds > 160 * 1024) return false;
+    // one workgroup per CU; scenario rows without samples cost nothing (their workgroups exit at once), so the grid is
+    // sized as if one row were empty (AliCCP: ids 1..3 of 4 rows)
+    const int64_t tiles = ceil_div(d->B, p.T);
+    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256, std::max(1, d->S - 1))));
+    return true;
+}
+
+template <int D, int U, int H, bool SAME>
+static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
+                      hipStream_t stream) {
+    static size_t attr_set = 0;
+    if (p.lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
+        attr_set = p.lds;
+    }
+    layer_bwd_fused_kernel<D, U, H, SAME><<<dim3(p.gx, d->S), kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
+    return SATRANS_OK;
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+// 1 when the fused kernels are built for this shape
+extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d) {
+    if (!d) return 0;
+    if (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) return 0;
+    if (d->F > 64) return 0;
+    const int D = d->D, U = d->U, H = d->H;
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
+    if (D == 32 && H == 4 && (!meta || U == 64)) return 1;
+    if (D == 16 && H == 2 && (!meta || U == 32)) return 1;
+    if (D == 64 && H == 4 && (!meta || U == 16)) return 1;
+    return 0;
+}
+
+extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, float* att, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(satrans_layer_fused_supported(d), SATRANS_E_UNSUPPORTED, "layer_fwd(fused): shape not built");
+    if (d->D == 32) return launch_fwd<32, 64, 4>(d, y, att, stream);
+    if (d->D == 16) return launch_fwd<16, 32, 2>(d, y, att, stream);
+    return launch_fwd<64, 16, 4>(d, y, att, stream);
+}
+
+extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
+    FusedBwdPlan p;
+    return d && fused_bwd_plan(d, p) ? 1 : 0;
+}
+
+extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d) {
+    FusedBwdPlan p;
+    if (!d || !fused_bwd_plan(d, p)) return -1;
+    return (int64_t)d->S * p.gx * slab_offsets_f(d->D, d->U).total + satrans_layer_slab_reduce_extra_floats(d->S, d->D, d->U);
+}
+
+extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
+                                       float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk,
+                                       float* g_tab_q, float* g_tab_k, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FusedBwdPlan p;
+    SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");
+    const bool same = d->tab_q == d->tab_k;
+    int rc;
+    if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true>(d, p, dy, dx, slabs, stream)
+                              : launch_bwd<32, 64, 4, false>(d, p, dy, dx, slabs, stream);
+    else rc = same ? launch_bwd<16, 32, 2, true>(d, p, dy, dx, slabs, stream)
+                   : launch_bwd<16, 32, 2, false>(d, p, dy, dx, slabs, stream);
+    if (rc) return rc;
+    return satrans_layer_slab_reduce(slabs, d->S, p.gx, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln,
+                                     g_lnq, g_lnk, g_tab_q, g_tab_k, stream_);
+}

@@ -25,6 +25,8 @@
 #include "common.h"
 #include "rng.h"
 
+extern "C" int satrans_layer_impl(void);
+
 namespace satrans {
 
 constexpr int kLayerBlock = 256;
@@ -755,10 +757,8 @@ static int64_t bwd_lds_floats(int T, int F, int D, int H, int U, int flags, int 
 }
 
 // MFMA needs 16-aligned feature counts; SATRANS_LAYER_IMPL=lds forces the scalar arm (ablation / debugging)
-static int g_layer_impl = 0;  // 0 = auto, 1 = scalar FMA arm, set by satrans_set_layer_impl
 static int want_mfma(const satrans_layer_desc* d) {
-    static const char* env = getenv("SATRANS_LAYER_IMPL");
-    if (g_layer_impl == 1 || (env && strcmp(env, "lds") == 0)) return 0;
+    if (satrans_layer_impl() == 1) return 0;
     if (d->D % 16) return 0;
     if ((d->flags & (SATRANS_META_Q | SATRANS_META_K)) && (d->U % 16)) return 0;
     return 1;
@@ -829,11 +829,28 @@ static int plan_bwd(const satrans_layer_desc* d, LayerPlan& p) {
 
 using namespace satrans;
 
-extern "C" int satrans_set_layer_impl(int impl) {
-    SATRANS_REQUIRE(impl == 0 || impl == 1, SATRANS_E_BADARG, "set_layer_impl: %d is not 0 (auto) or 1 (scalar)", impl);
-    g_layer_impl = impl;
+// two-level, fixed-order reduction of S*gx per-workgroup slabs (kReduceSplit contiguous groups per scenario first);
+// the first-level partials live behind the slabs in the same workspace
+extern "C" int64_t satrans_layer_slab_reduce_extra_floats(int S, int D, int U) {
+    return (int64_t)S * kReduceSplit * slab_offsets(D, U).total;
+}
+
+extern "C" int satrans_layer_slab_reduce(float* slabs, int S, int gx, int D, int U, int flags, int64_t tab_stride,
+                                         float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
+                                         float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int total = slab_offsets(D, U).total;
+    float* partial = slabs + (size_t)S * gx * total;
+    slab_group_sum_kernel<<<dim3((unsigned)ceil_div(total, 256), S * kReduceSplit), 256, 0, stream>>>(
+        slabs, gx, kReduceSplit, total, partial);
+    SATRANS_CHECK_LAUNCH("slab_group_sum_kernel");
+    layer_bwd_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(
+        partial, S, kReduceSplit, D, U, flags, tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
+    SATRANS_CHECK_LAUNCH("layer_bwd_reduce_kernel");
     return SATRANS_OK;
 }
+
+extern "C" int satrans_layer_validate(const satrans_layer_desc* d, const char* who) { return validate(d, who); }
 
 extern "C" int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, float* att, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -882,15 +899,6 @@ extern "C" int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* d
     }
     layer_bwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, p.mfma, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_kernel");
-    // two-level, fixed-order reduction of the per-workgroup slabs: kReduceSplit contiguous groups per scenario first
-    const int total = slab_offsets(d->D, d->U).total;
-    float* partial = slabs + (size_t)d->S * p.gx * total;
-    slab_group_sum_kernel<<<dim3((unsigned)ceil_div(total, 256), d->S * kReduceSplit), 256, 0, stream>>>(
-        slabs, p.gx, kReduceSplit, total, partial);
-    SATRANS_CHECK_LAUNCH("slab_group_sum_kernel");
-    layer_bwd_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(
-        partial, d->S, kReduceSplit, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk,
-        g_tab_q, g_tab_k);
-    SATRANS_CHECK_LAUNCH("layer_bwd_reduce_kernel");
-    return SATRANS_OK;
+    return satrans_layer_slab_reduce(slabs, d->S, p.gx, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln,
+                                     g_lnq, g_lnk, g_tab_q, g_tab_k, stream_);
 }

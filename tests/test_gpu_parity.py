@@ -251,13 +251,14 @@ def test_single_sample_and_empty_scenarios():
         np.testing.assert_allclose(p.numpy(), p_ref.numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("impl", [1, 2])
 @pytest.mark.parametrize("name", ["aliccp_sota", "small_pos_dense", "small_d64"])
-def test_scalar_arm_matches_golden_too(name):
-    """The scalar-FMA arm of the layer kernels (fallback for feature counts that are not multiples of 16, and the
-    ablation arm) against the same golden vectors; everything else in this file runs the MFMA arm."""
+def test_other_layer_implementations_match_golden_too(name, impl):
+    """The LDS-resident layer kernels - scalar-FMA arm (1: fallback for any shape, the ablation arm) and MFMA arm (2) -
+    against the same golden vectors; everything else in this file runs the automatic choice (fused kernels)."""
     from satrans_amd import native as N
     c = Case(name)
-    N.check(N.lib().satrans_set_layer_impl(1), "set_layer_impl")
+    N.check(N.lib().satrans_set_layer_impl(impl), "set_layer_impl")
     try:
         model = build_model(c, DEV)
         model.compile("adam", "binary_crossentropy")
