@@ -130,16 +130,22 @@ __global__ __launch_bounds__(kStreamBlock) void adam_untouched_kernel(float4* __
 // ---------------------------------------------------------------------------------------------------------
 // touched rows: sort, segmented sum in position order, step
 // ---------------------------------------------------------------------------------------------------------
-__global__ void iota_mark_kernel(const int32_t* __restrict__ rows, int64_t n, uint32_t* __restrict__ keys,
-                                 int32_t* __restrict__ pos, uint32_t* __restrict__ touched) {
+__global__ void iota_kernel(const int32_t* __restrict__ rows, int64_t n, uint32_t* __restrict__ keys,
+                            int32_t* __restrict__ pos) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t r = (uint32_t)rows[i];
-    keys[i] = r;
+    keys[i] = (uint32_t)rows[i];
     pos[i] = (int32_t)i;
-    // small-vocabulary fields send thousands of ids to the same word: only the first setter pays for the atomic
-    const uint32_t bit = 1u << (r & 31);
-    if (!(__builtin_nontemporal_load(&touched[r >> 5]) & bit)) atomicOr(&touched[r >> 5], bit);
+}
+
+// Touched-row bitmap from the SORTED ids: only the first position of every run sets its bit, so a row gathered
+// thousands of times (small-vocabulary fields) costs one atomic instead of thousands on one address.
+__global__ void mark_heads_kernel(const int32_t* __restrict__ sorted_rows, int64_t n, uint32_t* __restrict__ touched) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = (uint32_t)sorted_rows[i];
+    if (i > 0 && (uint32_t)sorted_rows[i - 1] == r) return;
+    atomicOr(&touched[r >> 5], 1u << (r & 31));
 }
 
 // Per-chunk bookkeeping for segments that cross chunk boundaries.
@@ -331,12 +337,14 @@ extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_
     int32_t* pos_in = (int32_t*)(ws + L.pos_in);
     hipError_t e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)ceil_div(total_rows, 32), stream);
     SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: memset: %s", hipGetErrorString(e));
-    iota_mark_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(rows, n, keys_in, pos_in, touched);
-    SATRANS_CHECK_LAUNCH("iota_mark_kernel");
+    iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(rows, n, keys_in, pos_in);
+    SATRANS_CHECK_LAUNCH("iota_kernel");
     size_t temp_bytes = L.temp_bytes;
     e = rocprim::radix_sort_pairs(ws + L.temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)sorted_rows,
                                   (const int32_t*)pos_in, src, (unsigned)n, 0u, (unsigned)bits_for(total_rows), stream);
     SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: radix sort: %s", hipGetErrorString(e));
+    mark_heads_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(sorted_rows, n, touched);
+    SATRANS_CHECK_LAUNCH("mark_heads_kernel");
     return SATRANS_OK;
 }
 

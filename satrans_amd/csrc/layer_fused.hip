@@ -98,6 +98,26 @@ __device__ __forceinline__ void layer_norm_frag(float (&v)[KT_][4], const float*
     }
 }
 
+// Work distribution.  The (scenario, tile) pairs of a batch form one global list (scenario-major); a flat grid of
+// G workgroups - sized to the number of CUs, so that exactly one round is resident - splits it into G contiguous,
+// equally long ranges.  A workgroup whose range crosses a scenario boundary re-stages the generated MetaNet weights
+// there.  Scenario rows without samples cost nothing and skewed scenario sizes (real traffic is skewed) balance.
+__device__ __forceinline__ int tiles_of(const int32_t* __restrict__ seg, int s, int T) {
+    return (seg[s + 1] - seg[s] + T - 1) / T;
+}
+struct WorkRange {
+    int g0, g1, per, total;
+};
+__device__ __forceinline__ WorkRange work_range(const int32_t* __restrict__ seg, int S, int T, int G, int w) {
+    WorkRange r;
+    r.total = 0;
+    for (int s = 0; s < S; ++s) r.total += tiles_of(seg, s, T);
+    r.per = (r.total + G - 1) / G;
+    r.g0 = min(r.total, w * r.per);
+    r.g1 = min(r.total, r.g0 + r.per);
+    return r;
+}
+
 struct FusedDrop {
     bool on;
     float scale;
@@ -163,13 +183,13 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                                                                       float* __restrict__ y, float* __restrict__ att) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
     extern __shared__ __align__(16) float lds[];
-    const int F = a.F, scen = blockIdx.y;
+    const int F = a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
     const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
     const bool same_tab = a.tab_q == a.tab_k;
 
-    // ---- carve LDS, stage every weight once -------------------------------------------------------------
+    // ---- carve LDS, stage the scenario-independent weights once --------------------------------------------
     float* p = lds;
     auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
     FwdImages<D, U> W;
@@ -187,24 +207,13 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
     stage_image(a.w_key, W.wk, D, D, LD, false);
     stage_image(a.w_value, W.wv, D, D, LD, false);
     stage_image(a.w_out, W.woT, D, D, LD, true);      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
-    if (meta_q) {
-        const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-        stage_image(row, W.w1q, D, U, LU, false);
-        stage_image(row + D * U, W.w2q, U, D, LD, false);
-    }
-    if (meta_k && (!same_tab || !meta_q)) {
-        const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-        stage_image(row, W.w1k, D, U, LU, false);
-        stage_image(row + D * U, W.w2k, U, D, LD, false);
-    }
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         W.ln_g[i] = a.ln_g[i]; W.ln_b[i] = a.ln_b[i];
         if (meta_q) { W.lnq_g[i] = a.lnq_g[i]; W.lnq_b[i] = a.lnq_b[i]; }
         if (meta_k) { W.lnk_g[i] = a.lnk_g[i]; W.lnk_b[i] = a.lnk_b[i]; }
     }
-    __syncthreads();
 
-    const int wl = g4 * 0 + n;  // per-lane offset inside an image: row 4g, column n
+    const int wl = n;  // per-lane offset inside an image: row 4g, column n
     const float* wq_l = W.wq + g4 * LD + wl;
     const float* wk_l = W.wk + g4 * LD + wl;
     const float* wv_l = W.wv + g4 * LD + wl;
@@ -214,10 +223,30 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
     const float* w1k_l = W.w1k + g4 * LU + wl;
     const float* w2k_l = W.w2k + g4 * LD + wl;
     const FusedDrop dc = fused_drop(a);
-    const float sqrt_d = sqrtf((float)d);
-    const int lo = a.seg[scen], hi = a.seg[scen + 1];
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d);   // scores * (1/sqrt d): within 1 ulp of the reference's true division
+    const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
 
-    for (int first = lo + blockIdx.x * Tsamp; first < hi; first += gridDim.x * Tsamp) {
+    int pre = 0;
+    for (int scen = 0; scen < a.S && pre < wr.g1; ++scen) {
+      const int nt_s = tiles_of(a.seg, scen, Tsamp);
+      const int t0 = max(wr.g0, pre) - pre, t1 = min(wr.g1, pre + nt_s) - pre;
+      pre += nt_s;
+      if (t0 >= t1) continue;
+      // ---- this scenario's generated MetaNet weights (the previous tile loop ended on a barrier) ------------------
+      if (meta_q) {
+          const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+          stage_image(row, W.w1q, D, U, LU, false);
+          stage_image(row + D * U, W.w2q, U, D, LD, false);
+      }
+      if (meta_k && (!same_tab || !meta_q)) {
+          const float* row = a.tab_k + (size_t)scen * a.tab_stride;
+          stage_image(row, W.w1k, D, U, LU, false);
+          stage_image(row + D * U, W.w2k, U, D, LD, false);
+      }
+      __syncthreads();
+      const int lo = a.seg[scen], hi = a.seg[scen + 1];
+      for (int tile = t0; tile < t1; ++tile) {
+        const int first = lo + tile * Tsamp;
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
 
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                     s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
                     s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                 }
-                mx = fmaxf(mx, s / sqrt_d);
+                mx = fmaxf(mx, s * inv_sqrt_d);
             }
             float oacc[d];
 #pragma unroll
@@ -306,7 +335,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                     s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
                     s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                 }
-                const float ex = expf(s / sqrt_d - mx);
+                const float ex = __expf(s * inv_sqrt_d - mx);
                 sum += ex;
                 float pe = ex;
                 if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                         s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
                         s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                     }
-                    float pj = expf(s / sqrt_d - mx) / sum;
+                    float pj = __expf(s * inv_sqrt_d - mx) / sum;
                     if (dc.on) pj = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? pj * dc.scale : 0.f;
                     arow[j] = pj;
                 }
@@ -380,9 +409,9 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
             }
         }
         __syncthreads();
+      }
     }
 }
-
 
 // -------------------------------------------------------------------------------------------------------------------
 // Backward.  One workgroup tile = T samples with T*F <= 64 tokens, i.e. at most ONE 16-token tile per wave, so all
@@ -516,14 +545,14 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     constexpr int NB = (UT < KT) ? UT : KT;          // 16-feature tiles of such an operand held by one row buffer
     static_assert(HB <= 2 && UT == HB * NB, "MetaNet hidden width must be D/.. or 2*D for the fused backward");
     extern __shared__ __align__(16) float lds[];
-    const int F = a.F, scen = blockIdx.y;
+    const int F = a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
     const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
     constexpr bool same_tab = SAME;
     const bool relu_out = a.flags & SATRANS_RELU_OUT, use_res = !(a.flags & SATRANS_NO_RES);
 
-    // ---- LDS: forward images, transposed images, LN vectors, 5 row buffers, softmax statistics ------------------
+    // ---- LDS: forward images, transposed images, LN vectors, 5 row buffers, softmax cache ------------------------
     float* p = lds;
     auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
     float* wq = take(D * LD); float* wk = take(D * LD); float* wv = take(D * LD); float* woT = take(D * LD);
@@ -543,39 +572,32 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     float* so = take(ROWS * LD);     // o      -> go | phase F scratch
     float* sg = take(ROWS * LD);     // du (phase C scratch) -> dq | phase F scratch
     const int ntask_max = Tsamp * H * F;
-    float* st_mx = take(ntask_max); float* st_inv = take(ntask_max); float* st_dot = take(ntask_max);
+    float* st_inv = take(ntask_max);                  // 1 / sum_j exp(s_ij - max_i)
+    float* st_dot = take(ntask_max);                  // sum_j dP_ij P_ij
+    uint32_t* st_keep = (uint32_t*)take(ntask_max);   // bit j: attention-dropout keep flag of (i, j)   (F <= 32)
+    float* sP = take(ntask_max * F);                  // exp(s_ij - max_i), the un-normalised softmax numerators
 
-    const int lo = a.seg[scen], hi = a.seg[scen + 1];
-    const bool idle = lo + (int)blockIdx.x * Tsamp >= hi;      // no tile for this workgroup: only its zero slab is due
+    const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
+    const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
     if (!idle) {
-    stage_image(a.w_query, wq, D, D, LD, false);   stage_image(a.w_query, wqT, D, D, LD, true);
-    stage_image(a.w_key, wk, D, D, LD, false);     stage_image(a.w_key, wkT, D, D, LD, true);
-    stage_image(a.w_value, wv, D, D, LD, false);   stage_image(a.w_value, wvT, D, D, LD, true);
-    stage_image(a.w_out, woT, D, D, LD, true);     stage_image(a.w_out, wo, D, D, LD, false);
-    if (meta_q) {
-        const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-        stage_image(row, w1q, D, U, LU, false);          stage_image(row, w1qT, D, U, LD, true);
-        stage_image(row + D * U, w2q, U, D, LD, false);  stage_image(row + D * U, w2qT, U, D, LU, true);
-    }
-    if (meta_k && (!same_tab || !meta_q)) {
-        const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-        stage_image(row, w1k, D, U, LU, false);          stage_image(row, w1kT, D, U, LD, true);
-        stage_image(row + D * U, w2k, U, D, LD, false);  stage_image(row + D * U, w2kT, U, D, LU, true);
-    }
-    for (int i = threadIdx.x; i < D; i += blockDim.x) {
-        ln_g[i] = a.ln_g[i]; ln_b[i] = a.ln_b[i];
-        if (meta_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
-        if (meta_k) { lnk_g[i] = a.lnk_g[i]; lnk_b[i] = a.lnk_b[i]; }
-    }
-    // rows of padding tokens are multiplied by exact zeros in the token-contraction products: they must hold
-    // finite numbers from the start (0 * NaN would poison an accumulator)
-    for (int i = threadIdx.x; i < 5 * ROWS * LD; i += blockDim.x) sq[i] = 0.f;
+        stage_image(a.w_query, wq, D, D, LD, false);   stage_image(a.w_query, wqT, D, D, LD, true);
+        stage_image(a.w_key, wk, D, D, LD, false);     stage_image(a.w_key, wkT, D, D, LD, true);
+        stage_image(a.w_value, wv, D, D, LD, false);   stage_image(a.w_value, wvT, D, D, LD, true);
+        stage_image(a.w_out, woT, D, D, LD, true);     stage_image(a.w_out, wo, D, D, LD, false);
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+            ln_g[i] = a.ln_g[i]; ln_b[i] = a.ln_b[i];
+            if (meta_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
+            if (meta_k) { lnk_g[i] = a.lnk_g[i]; lnk_b[i] = a.lnk_b[i]; }
+        }
+        // rows of padding tokens are multiplied by exact zeros in the token-contraction products: they must hold
+        // finite numbers from the start (0 * NaN would poison an accumulator)
+        for (int i = threadIdx.x; i < 5 * ROWS * LD; i += blockDim.x) sq[i] = 0.f;
     }
     __syncthreads();
 
     const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
     const FusedDrop dc = fused_drop(a);
-    const float sqrt_d = sqrtf((float)d);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d);
 
     // ---- register accumulators of the weight gradients (whole kernel) ----------------------------------------------
     f32x4 acc_wq[KT][KT], acc_wk[KT][KT], acc_wv[KT][KT], acc_wo[KT][KT];
@@ -604,7 +626,56 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const float* wg_o = so + (size_t)(row0 + g) * LD + n;
     const float* wg_g = sg + (size_t)(row0 + g) * LD + n;
 
-    for (int first = lo + blockIdx.x * Tsamp; first < hi; first += gridDim.x * Tsamp) {
+    // output: [G][CSZ] scenario-independent part, then [G + S][TSZ] generated-weight records (record index =
+    // workgroup + scenario: strictly increasing along the global tile list, hence unique)
+    constexpr int CSZ = 4 * D * D + 6 * D, TSZ = 4 * D * U;
+    float* common = slabs + (size_t)blockIdx.x * CSZ;
+    float* records = slabs + (size_t)gridDim.x * CSZ;
+    float* stage = sq;   // the five row buffers are contiguous: 5 * 64 * LD floats of staging space
+    using KTc = std::integral_constant<int, KT>;
+    using UTc = std::integral_constant<int, UT>;
+    // combine the four waves' accumulators of one matrix through LDS in a fixed order, write it out, clear it
+    auto flush = [&](auto& acc, auto mtc, auto ntc, float* dst, bool live) {
+        constexpr int MT_ = decltype(mtc)::value, NT_ = decltype(ntc)::value;
+        constexpr int ncols = 16 * NT_, sz = MT_ * 16 * ncols;
+        if (live) {
+#pragma unroll
+            for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT_; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[wave * sz + (16 * mt + g4 + r) * ncols + 16 * nt + n] = acc[mt][nt][r];
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < sz; e += kFusedBlock)
+            dst[e] = live ? ((stage[e] + stage[sz + e]) + stage[2 * sz + e]) + stage[3 * sz + e] : 0.f;
+        __syncthreads();
+    };
+
+    int pre = 0;
+    for (int scen = 0; scen < a.S && pre < wr.g1; ++scen) {
+      const int nt_s = tiles_of(a.seg, scen, Tsamp);
+      const int t0 = max(wr.g0, pre) - pre, t1 = min(wr.g1, pre + nt_s) - pre;
+      pre += nt_s;
+      if (t0 >= t1) continue;
+      // ---- this scenario's generated MetaNet weights, both orientations (previous tile loop ended on a barrier) -----
+      if (meta_q) {
+          const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+          stage_image(row, w1q, D, U, LU, false);          stage_image(row, w1qT, D, U, LD, true);
+          stage_image(row + D * U, w2q, U, D, LD, false);  stage_image(row + D * U, w2qT, U, D, LU, true);
+      }
+      if (meta_k && (!same_tab || !meta_q)) {
+          const float* row = a.tab_k + (size_t)scen * a.tab_stride;
+          stage_image(row, w1k, D, U, LU, false);          stage_image(row, w1kT, D, U, LD, true);
+          stage_image(row + D * U, w2k, U, D, LD, false);  stage_image(row + D * U, w2kT, U, D, LU, true);
+      }
+      __syncthreads();
+      const int lo = a.seg[scen], hi = a.seg[scen + 1];
+      for (int tile = t0; tile < t1; ++tile) {
+        const int first = lo + tile * Tsamp;
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
         const bool has_tile = wave < ntt;
@@ -693,7 +764,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         __syncthreads();
 
-        // ================= phase B: attention forward, statistics ======================================================
+        // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
             const int h = rem / F, i = rem - h * F;
@@ -707,6 +778,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             }
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
+            float* prow = sP + (size_t)task * F;
             float mx = -INFINITY;
             for (int j = 0; j < F; ++j) {
                 float s = 0.f;
@@ -716,25 +788,26 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
                     s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                 }
-                mx = fmaxf(mx, s / sqrt_d);
+                s *= inv_sqrt_d;
+                prow[j] = s;
+                mx = fmaxf(mx, s);
             }
             float oacc[d];
 #pragma unroll
             for (int e = 0; e < d; ++e) oacc[e] = 0.f;
             float sum = 0.f;
+            uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
             for (int j = 0; j < F; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
-                }
-                const float ex = expf(s / sqrt_d - mx);
+                const float ex = __expf(prow[j] - mx);
+                prow[j] = ex;
                 sum += ex;
                 float pe = ex;
-                if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
+                if (dc.on) {
+                    const bool kp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh);
+                    pe = kp ? ex * dc.scale : 0.f;
+                    if (!kp) keep &= ~(1u << j);
+                }
 #pragma unroll
                 for (int e = 0; e < d; e += 4) {
                     const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
@@ -743,8 +816,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
             }
             const float inv = 1.0f / sum;
-            st_mx[task] = mx;
             st_inv[task] = inv;
+            st_keep[task] = keep;
             float* orow = so + (size_t)(tls * F + i) * LD + h * d;
 #pragma unroll
             for (int e = 0; e < d; e += 4)
@@ -795,56 +868,47 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
             const int h = rem / F, i = rem - h * F;
-            const int tb = samp[tls];
-            float qi[d], gi[d], dq[d];
-            const float* qrow = sq + (size_t)(tls * F + i) * LD + h * d;
+            float gi[d], dq[d];
             const float* grow = so + (size_t)(tls * F + i) * LD + h * d;
 #pragma unroll
             for (int e = 0; e < d; e += 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
                 const float4 g4v = *reinterpret_cast<const float4*>(grow + e);
-                qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
                 gi[e] = g4v.x; gi[e + 1] = g4v.y; gi[e + 2] = g4v.z; gi[e + 3] = g4v.w;
             }
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
-            const float mx = st_mx[task], inv = st_inv[task];
-            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            const float* prow = sP + (size_t)task * F;
+            const float inv = st_inv[task];
+            const uint32_t keep = st_keep[task];
+            const float scale = dc.scale;
             float dot = 0.f;
             for (int j = 0; j < F; ++j) {
-                float s = 0.f, dp = 0.f;
+                float dp = 0.f;
 #pragma unroll
                 for (int e = 0; e < d; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
                     const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
-                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                     dp = fmaf(gi[e], v4.x, dp); dp = fmaf(gi[e + 1], v4.y, dp);
                     dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
                 }
-                const float pj = expf(s / sqrt_d - mx) * inv;
-                if (dc.on) dp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? dp * dc.scale : 0.f;
-                dot = fmaf(dp, pj, dot);
+                dp = ((keep >> j) & 1u) ? dp * scale : 0.f;
+                dot = fmaf(dp, prow[j] * inv, dot);
             }
             st_dot[task] = dot;
 #pragma unroll
             for (int e = 0; e < d; ++e) dq[e] = 0.f;
             for (int j = 0; j < F; ++j) {
-                float s = 0.f, dp = 0.f;
+                float dp = 0.f;
                 float kj[d];
 #pragma unroll
                 for (int e = 0; e < d; e += 4) {
                     const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
                     const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
                     kj[e] = k4.x; kj[e + 1] = k4.y; kj[e + 2] = k4.z; kj[e + 3] = k4.w;
-                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                     dp = fmaf(gi[e], v4.x, dp); dp = fmaf(gi[e + 1], v4.y, dp);
                     dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
                 }
-                const float pj = expf(s / sqrt_d - mx) * inv;
-                if (dc.on) dp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? dp * dc.scale : 0.f;
-                const float ds = pj * (dp - dot) / sqrt_d;
+                dp = ((keep >> j) & 1u) ? dp * scale : 0.f;
+                const float ds = (prow[j] * inv) * (dp - dot) * inv_sqrt_d;
 #pragma unroll
                 for (int e = 0; e < d; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
             }
@@ -859,15 +923,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
             const int h = rem / F, j = rem - h * F;
-            const int tb = samp[tls];
-            float kj[d], vj[d], dk[d], dv[d];
+            float vj[d], dk[d], dv[d];
             float* krow = sk + (size_t)(tls * F + j) * LD + h * d;
             float* vrow = sv + (size_t)(tls * F + j) * LD + h * d;
 #pragma unroll
             for (int e = 0; e < d; e += 4) {
-                const float4 k4 = *reinterpret_cast<const float4*>(krow + e);
                 const float4 v4 = *reinterpret_cast<const float4*>(vrow + e);
-                kj[e] = k4.x; kj[e + 1] = k4.y; kj[e + 2] = k4.z; kj[e + 3] = k4.w;
                 vj[e] = v4.x; vj[e + 1] = v4.y; vj[e + 2] = v4.z; vj[e + 3] = v4.w;
                 dk[e] = dk[e + 1] = dk[e + 2] = dk[e + 3] = 0.f;
                 dv[e] = dv[e + 1] = dv[e + 2] = dv[e + 3] = 0.f;
@@ -875,25 +936,22 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* qbase = sq + (size_t)(tls * F) * LD + h * d;
             const float* gbase = so + (size_t)(tls * F) * LD + h * d;
             const int st0 = (tls * H + h) * F;
-            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            const float scale = dc.scale;
             for (int i = 0; i < F; ++i) {
                 float qi[d], gi[d];
-                float s = 0.f, dp = 0.f;
+                float dp = 0.f;
 #pragma unroll
                 for (int e = 0; e < d; e += 4) {
                     const float4 q4 = *reinterpret_cast<const float4*>(qbase + (size_t)i * LD + e);
                     const float4 g4v = *reinterpret_cast<const float4*>(gbase + (size_t)i * LD + e);
                     qi[e] = q4.x; qi[e + 1] = q4.y; qi[e + 2] = q4.z; qi[e + 3] = q4.w;
                     gi[e] = g4v.x; gi[e + 1] = g4v.y; gi[e + 2] = g4v.z; gi[e + 3] = g4v.w;
-                    s = fmaf(q4.x, kj[e], s); s = fmaf(q4.y, kj[e + 1], s);
-                    s = fmaf(q4.z, kj[e + 2], s); s = fmaf(q4.w, kj[e + 3], s);
                     dp = fmaf(g4v.x, vj[e], dp); dp = fmaf(g4v.y, vj[e + 1], dp);
                     dp = fmaf(g4v.z, vj[e + 2], dp); dp = fmaf(g4v.w, vj[e + 3], dp);
                 }
-                const float pij = expf(s / sqrt_d - st_mx[st0 + i]) * st_inv[st0 + i];
-                float mk = 1.0f;
-                if (dc.on) mk = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? dc.scale : 0.f;
-                const float ds = pij * (dp * mk - st_dot[st0 + i]) / sqrt_d;
+                const float pij = sP[(size_t)(st0 + i) * F + j] * st_inv[st0 + i];
+                const float mk = ((st_keep[st0 + i] >> j) & 1u) ? scale : 0.f;
+                const float ds = pij * (dp * mk - st_dot[st0 + i]) * inv_sqrt_d;
                 const float pd = pij * mk;
 #pragma unroll
                 for (int e = 0; e < d; ++e) {
@@ -1021,42 +1079,25 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
         __syncthreads();
+      }
+      // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
+      // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the part of a role only
+      // when that role is active, so the sums go to the Q part when Q is modulated, else to the K part
+      {
+          float* rec = records + (size_t)(blockIdx.x + scen) * TSZ;
+          const bool to_k = SAME && !meta_q;
+          flush(acc_w1q, KTc{}, UTc{}, rec + (to_k ? 2 * D * U : 0), true);
+          flush(acc_w2q, UTc{}, KTc{}, rec + (to_k ? 3 * D * U : D * U), true);
+          flush(acc_w1k, KTc{}, UTc{}, rec + (to_k ? 0 : 2 * D * U), !SAME);
+          flush(acc_w2k, UTc{}, KTc{}, rec + (to_k ? D * U : 3 * D * U), !SAME);
+      }
     }
 
-    // ---- combine the four waves' accumulators through LDS (fixed order) and write this workgroup's slab ----------------
-    const SlabOffF so_ = slab_offsets_f(D, U);
-    float* slab = slabs + ((size_t)scen * gridDim.x + blockIdx.x) * so_.total;
-    float* stage = sq;   // the five row buffers are contiguous: 5 * 64 * LD floats of staging space
-    auto flush = [&](auto& acc, auto mtc, auto ntc, int off, bool live) {
-        constexpr int MT_ = decltype(mtc)::value, NT_ = decltype(ntc)::value;
-        constexpr int ncols = 16 * NT_, sz = MT_ * 16 * ncols;
-        if (live) {
-#pragma unroll
-            for (int mt = 0; mt < MT_; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT_; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        stage[wave * sz + (16 * mt + g4 + r) * ncols + 16 * nt + n] = acc[mt][nt][r];
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < sz; e += kFusedBlock)
-            slab[off + e] = live ? ((stage[e] + stage[sz + e]) + stage[2 * sz + e]) + stage[3 * sz + e] : 0.f;
-        __syncthreads();
-    };
-    using KTc = std::integral_constant<int, KT>;
-    using UTc = std::integral_constant<int, UT>;
-    flush(acc_wq, KTc{}, KTc{}, so_.wq, true);
-    flush(acc_wk, KTc{}, KTc{}, so_.wk, true);
-    flush(acc_wv, KTc{}, KTc{}, so_.wv, true);
-    flush(acc_wo, KTc{}, KTc{}, so_.wo, true);
-    // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the region of a role only
-    // when that role is active, so the sums go to the Q region when Q is modulated, else to the K region
-    const bool to_k = SAME && !meta_q;
-    flush(acc_w1q, KTc{}, UTc{}, to_k ? so_.w1k : so_.w1q, true);
-    flush(acc_w2q, UTc{}, KTc{}, to_k ? so_.w2k : so_.w2q, true);
-    flush(acc_w1k, KTc{}, UTc{}, to_k ? so_.w1q : so_.w1k, !SAME);
-    flush(acc_w2k, UTc{}, KTc{}, to_k ? so_.w2q : so_.w2k, !SAME);
+    // ---- scenario-independent gradients of this workgroup ------------------------------------------------------------------
+    flush(acc_wq, KTc{}, KTc{}, common, true);
+    flush(acc_wk, KTc{}, KTc{}, common + D * D, true);
+    flush(acc_wv, KTc{}, KTc{}, common + 2 * D * D, true);
+    flush(acc_wo, KTc{}, KTc{}, common + 3 * D * D, true);
     auto flush_ln = [&](float (&ag)[KT][4], float (&ab)[KT][4], int off) {
 #pragma unroll
         for (int t = 0; t < KT; ++t)
@@ -1075,17 +1116,105 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             }
         __syncthreads();
         for (int e = threadIdx.x; e < 2 * D; e += kFusedBlock)
-            slab[off + e] = ((stage[e] + stage[2 * D + e]) + stage[4 * D + e]) + stage[6 * D + e];
+            common[off + e] = ((stage[e] + stage[2 * D + e]) + stage[4 * D + e]) + stage[6 * D + e];
         __syncthreads();
     };
-    flush_ln(agl, abl, so_.ln);
-    flush_ln(agq, abq, so_.lnq);
-    flush_ln(agk, abk, so_.lnk);
+    flush_ln(agl, abl, 4 * D * D);
+    flush_ln(agq, abq, 4 * D * D + 2 * D);
+    flush_ln(agk, abk, 4 * D * D + 4 * D);
+}
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// Reduction of the backward kernel's output, fixed order (bitwise reproducible):
+//   common  [G][CSZ]   CSZ = 4*D*D + 6*D : [wq|wk|wv|wo|ln g,b|lnq g,b|lnk g,b] per workgroup
+//   records [G+S][TSZ] TSZ = 4*D*U       : [w1q|w2q|w1k|w2k] of (workgroup w, scenario s) at index w + s
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kFusedSplit = 16;
+
+__global__ void fused_common_partial_kernel(const float* __restrict__ common, int G, int CSZ, float* __restrict__ partial) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= CSZ) return;
+    const int per = (G + kFusedSplit - 1) / kFusedSplit;
+    const int lo = blockIdx.y * per, hi = min(G, lo + per);
+    float acc = 0.f;
+    for (int w = lo; w < hi; ++w) acc += common[(size_t)w * CSZ + e];
+    partial[(size_t)blockIdx.y * CSZ + e] = acc;
+}
+
+__global__ void fused_common_final_kernel(const float* __restrict__ partial, int D, int flags, float* g_wq, float* g_wk,
+                                          float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk) {
+    const int CSZ = 4 * D * D + 6 * D;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= CSZ) return;
+    auto total = [&](int at) {
+        float acc = 0.f;
+        for (int k = 0; k < kFusedSplit; ++k) acc += partial[(size_t)k * CSZ + at];
+        return acc;
+    };
+    const int DD = D * D;
+    if (e < DD) { g_wq[e] += total(e); return; }
+    if (e < 2 * DD) { g_wk[e - DD] += total(e); return; }
+    if (e < 3 * DD) { g_wv[e - 2 * DD] += total(e); return; }
+    if (e < 4 * DD) { g_wo[e - 3 * DD] += total(e); return; }
+    const int r = e - 4 * DD;                                   // [ln 2D | lnq 2D | lnk 2D]
+    const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    if (r < 2 * D) { g_ln[r] += total(e); return; }
+    // without 'pos' the Q and K MetaNets share ONE LayerNorm (satrans.py:46): one thread adds both roles, Q first
+    const bool shared = mq && mk && g_lnq == g_lnk;
+    if (r < 4 * D) {
+        if (shared) g_lnq[r - 2 * D] += total(e) + total(e + 2 * D);
+        else if (mq) g_lnq[r - 2 * D] += total(e);
+        return;
+    }
+    if (mk && !shared) g_lnk[r - 4 * D] += total(e);
+}
+
+__global__ void fused_records_kernel(const float* __restrict__ records, const int32_t* __restrict__ seg, int S, int T,
+                                     int G, int D, int U, int flags, int64_t tab_stride, float* g_tab_q, float* g_tab_k) {
+    const int half = 2 * D * U;                                  // one role: [W1 D*U | W2 U*D] = the generated row layout
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (e >= half) return;
+    // the workgroups whose tile range intersects scenario s (same arithmetic as work_range in the kernel)
+    int total = 0, pre = 0;
+    for (int k = 0; k < S; ++k) {
+        if (k == s) pre = total;
+        total += tiles_of(seg, k, T);
+    }
+    const int nt = tiles_of(seg, s, T);
+    if (nt == 0) return;
+    const int per = (total + G - 1) / G;
+    const int w_lo = pre / per, w_hi = (pre + nt - 1) / per;
+    const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    float aq = 0.f, ak = 0.f;
+    for (int w = w_lo; w <= w_hi; ++w) {
+        const float* rec = records + (size_t)(w + s) * 2 * half;
+        if (mq) aq += rec[e];
+        if (mk) ak += rec[half + e];
+    }
+    if (mq && mk && g_tab_q == g_tab_k) {
+        g_tab_q[(size_t)s * tab_stride + e] += aq + ak;
+    } else {
+        if (mq) g_tab_q[(size_t)s * tab_stride + e] += aq;
+        if (mk) g_tab_k[(size_t)s * tab_stride + e] += ak;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------------------------
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
     const int64_t rows = (((int64_t)T * F + 15) / 16) * 16;
@@ -1117,9 +1246,10 @@ static int launch_fwd(const satrans_layer_desc* d, float* y, float* att, hipStre
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
     }
-    const int64_t tiles = ceil_div(d->B, best);
-    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256 * 2, d->S)));
-    layer_fwd_fused_kernel<D, U, H><<<dim3(gx, d->S), kFusedBlock, lds, stream>>>(*d, best, y, att);
+    const int64_t tiles = ceil_div(d->B, best) + d->S;                 // upper bound of the tile list
+    const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
+    layer_fwd_fused_kernel<D, U, H><<<gx, kFusedBlock, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1133,25 +1263,24 @@ namespace satrans {
 static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
+    const int64_t tasks = (int64_t)T * H * F;
     return 8 * (int64_t)D * LD + (same_tab ? 1 : 2) * 2 * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 5 * 64 * LD +
-           3 * r4((int64_t)T * H * F) + 64;
+           3 * r4(tasks) + r4(tasks * F) + 64;
 }
 
 struct FusedBwdPlan {
-    int T, gx;
+    int T, G;
     size_t lds;
 };
 
 static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
-    if (!satrans_layer_fused_supported(d) || d->D > 32 || d->F > 64) return false;
+    if (!satrans_layer_fused_supported(d) || d->D > 32 || d->F > 32) return false;   // keep bits: one 32-bit word per row
     const bool same_tab = d->tab_q == d->tab_k;
     p.T = 64 / d->F;
     p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab) * 4;
     if (p.lds > 160 * 1024) return false;
-    // one workgroup per CU; scenario rows without samples cost nothing (their workgroups exit at once), so the grid is
-    // sized as if one row were empty (AliCCP: ids 1..3 of 4 rows)
-    const int64_t tiles = ceil_div(d->B, p.T);
-    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, ceil_div(256, std::max(1, d->S - 1))));
+    const int64_t tiles = ceil_div(d->B, p.T) + d->S;
+    p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
     return true;
 }
 
@@ -1165,7 +1294,7 @@ static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const 
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME><<<dim3(p.gx, d->S), kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1203,7 +1332,8 @@ extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
 extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d) {
     FusedBwdPlan p;
     if (!d || !fused_bwd_plan(d, p)) return -1;
-    return (int64_t)d->S * p.gx * slab_offsets_f(d->D, d->U).total + satrans_layer_slab_reduce_extra_floats(d->S, d->D, d->U);
+    const int64_t CSZ = 4 * (int64_t)d->D * d->D + 6 * d->D, TSZ = 4 * (int64_t)d->D * d->U;
+    return (int64_t)p.G * CSZ + (int64_t)(p.G + d->S) * TSZ + (int64_t)kFusedSplit * CSZ;
 }
 
 extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
@@ -1212,6 +1342,7 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     hipStream_t stream = (hipStream_t)stream_;
     FusedBwdPlan p;
     SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");
+    SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
     const bool same = d->tab_q == d->tab_k;
     int rc;
     if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true>(d, p, dy, dx, slabs, stream)
@@ -1219,6 +1350,18 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     else rc = same ? launch_bwd<16, 32, 2, true>(d, p, dy, dx, slabs, stream)
                    : launch_bwd<16, 32, 2, false>(d, p, dy, dx, slabs, stream);
     if (rc) return rc;
-    return satrans_layer_slab_reduce(slabs, d->S, p.gx, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln,
-                                     g_lnq, g_lnk, g_tab_q, g_tab_k, stream_);
+    const int D = d->D, U = d->U, CSZ = 4 * D * D + 6 * D, TSZ = 4 * D * U;
+    float* records = slabs + (size_t)p.G * CSZ;
+    float* partial = records + (size_t)(p.G + d->S) * TSZ;
+    fused_common_partial_kernel<<<dim3((unsigned)ceil_div(CSZ, 256), kFusedSplit), 256, 0, stream>>>(slabs, p.G, CSZ, partial);
+    SATRANS_CHECK_LAUNCH("fused_common_partial_kernel");
+    fused_common_final_kernel<<<(unsigned)ceil_div(CSZ, 256), 256, 0, stream>>>(partial, D, d->flags, g_wq, g_wk, g_wv, g_wo,
+                                                                            g_ln, g_lnq, g_lnk);
+    SATRANS_CHECK_LAUNCH("fused_common_final_kernel");
+    if (d->flags & (SATRANS_META_Q | SATRANS_META_K)) {
+        fused_records_kernel<<<dim3((unsigned)ceil_div(2 * D * U, 256), d->S), 256, 0, stream>>>(
+            records, d->seg, d->S, p.T, p.G, D, U, d->flags, d->tab_stride, g_tab_q, g_tab_k);
+        SATRANS_CHECK_LAUNCH("fused_records_kernel");
+    }
+    return SATRANS_OK;
 }
