@@ -14,6 +14,7 @@
 //
 // Adam arithmetic follows torch.optim.adam._single_tensor_adam (lerp for exp_avg, mul+addcmul for exp_avg_sq,
 // denom = sqrt(v)/sqrt(bc2) + eps, addcdiv with -lr/bc1).
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -386,13 +387,21 @@ extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int 
 
 extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
                                             const uint32_t* touched, const satrans_adam_hparams* h, double* reg_partials,
-                                            void* stream_) {
+                                            int grid_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(arena && m && v && touched && h && reg_partials, SATRANS_E_BADARG, "embed_adam_untouched: null pointer");
     SATRANS_REQUIRE(total_rows > 0, SATRANS_E_BADARG, "embed_adam_untouched: total_rows=%lld", (long long)total_rows);
     const AdamK k = make_adamk(*h);
     const int64_t n4 = total_rows * (D / 4);
-    DISPATCH_LPR(D, (adam_untouched_kernel<LPR><<<kStreamBlocks, kStreamBlock, 0, stream>>>(
+    // Grid: kStreamBlocks (8 blocks per CU) saturates HBM when the kernel runs alone (grid_blocks = 0).  When it is
+    // overlapped with the compute-bound layer kernels a smaller persistent grid leaves wave slots to them (measured:
+    // 512 blocks is the best trade on MI355X); the partial-sum slots beyond the grid are cleared.
+    const int blocks = grid_blocks > 0 && grid_blocks < kStreamBlocks ? grid_blocks : kStreamBlocks;
+    if (blocks < kStreamBlocks) {
+        hipError_t e = hipMemsetAsync(reg_partials + blocks, 0, sizeof(double) * (kStreamBlocks - blocks), stream);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_adam_untouched: memset: %s", hipGetErrorString(e));
+    }
+    DISPATCH_LPR(D, (adam_untouched_kernel<LPR><<<blocks, kStreamBlock, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, n4, touched, k, reg_partials)));
     SATRANS_CHECK_LAUNCH("adam_untouched_kernel");
     return SATRANS_OK;

@@ -91,20 +91,38 @@ __global__ __launch_bounds__(kHeadBlock) void head_kernel(const float* __restric
     }
 }
 
-__global__ void head_reduce_kernel(const float* __restrict__ partial, int nblk, int ncol, float* __restrict__ g_w,
-                                   float* __restrict__ g_b, double* __restrict__ loss_sum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol + 2) return;
+// block = 32 columns x 8 groups of partial rows (contiguous shares, index order), group sums combined in group order
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ partial, int nblk, int ncol,
+                                                        float* __restrict__ g_w, float* __restrict__ g_b,
+                                                        double* __restrict__ loss_sum) {
+    __shared__ double s_acc[8][32];
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + lane;
+    const int share = (nblk + 7) / 8;
+    const int lo = grp * share, hi = min(nblk, lo + share);
+    double acc = 0.0;
+    if (c < ncol + 2) {
+        if (c == ncol + 1) {
+            for (int k = lo; k < hi; ++k) acc += (double)partial[(size_t)k * (ncol + 2) + c];
+        } else {
+            float a32 = 0.f;
+            for (int k = lo; k < hi; ++k) a32 += partial[(size_t)k * (ncol + 2) + c];
+            acc = (double)a32;
+        }
+    }
+    s_acc[grp][lane] = acc;
+    __syncthreads();
+    if (grp != 0 || c >= ncol + 2) return;
     if (c == ncol + 1) {
-        double acc = 0.0;
-        for (int k = 0; k < nblk; ++k) acc += (double)partial[(size_t)k * (ncol + 2) + c];
-        loss_sum[0] += acc;
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += s_acc[k][lane];
+        loss_sum[0] += t;
         return;
     }
-    float acc = 0.f;
-    for (int k = 0; k < nblk; ++k) acc += partial[(size_t)k * (ncol + 2) + c];
-    if (c < ncol) g_w[c] += acc;
-    else g_b[0] += acc;
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += (float)s_acc[k][lane];
+    if (c < ncol) g_w[c] += t;
+    else g_b[0] += t;
 }
 
 }  // namespace satrans
@@ -131,7 +149,7 @@ extern "C" int satrans_head(const float* a, const float* dense, int64_t dense_st
     SATRANS_CHECK_LAUNCH("head_kernel");
     if (y) {
         const int ncol = FD + n_dense;
-        head_reduce_kernel<<<(unsigned)ceil_div(ncol + 2, 256), 256, 0, stream>>>(scratch, nblk, ncol, g_w, g_b, loss_sum);
+        head_reduce_kernel<<<(unsigned)ceil_div(ncol + 2, 32), 256, 0, stream>>>(scratch, nblk, ncol, g_w, g_b, loss_sum);
         SATRANS_CHECK_LAUNCH("head_reduce_kernel");
     }
     return SATRANS_OK;

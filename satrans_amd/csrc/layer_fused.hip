@@ -1170,12 +1170,17 @@ __global__ void fused_common_final_kernel(const float* __restrict__ partial, int
     if (mk && !shared) g_lnk[r - 4 * D] += total(e);
 }
 
-__global__ void fused_records_kernel(const float* __restrict__ records, const int32_t* __restrict__ seg, int S, int T,
-                                     int G, int D, int U, int flags, int64_t tab_stride, float* g_tab_q, float* g_tab_k) {
+// block = 32 elements x 8 groups of workgroups; every group adds its contiguous share of the workgroup range in index
+// order, the 8 group sums are then combined in group order (fixed order => bitwise reproducible)
+__global__ __launch_bounds__(256) void fused_records_kernel(const float* __restrict__ records,
+                                                          const int32_t* __restrict__ seg, int S, int T, int G, int D,
+                                                          int U, int flags, int64_t tab_stride, float* g_tab_q,
+                                                          float* g_tab_k) {
+    __shared__ float s_q[8][32], s_k[8][32];
     const int half = 2 * D * U;                                  // one role: [W1 D*U | W2 U*D] = the generated row layout
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + lane;
     const int s = blockIdx.y;
-    if (e >= half) return;
     // the workgroups whose tile range intersects scenario s (same arithmetic as work_range in the kernel)
     int total = 0, pre = 0;
     for (int k = 0; k < S; ++k) {
@@ -1186,13 +1191,23 @@ __global__ void fused_records_kernel(const float* __restrict__ records, const in
     if (nt == 0) return;
     const int per = (total + G - 1) / G;
     const int w_lo = pre / per, w_hi = (pre + nt - 1) / per;
+    const int share = (w_hi - w_lo + 8) / 8;
+    const int a = w_lo + grp * share, b = min(w_hi + 1, a + share);
     const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
     float aq = 0.f, ak = 0.f;
-    for (int w = w_lo; w <= w_hi; ++w) {
-        const float* rec = records + (size_t)(w + s) * 2 * half;
-        if (mq) aq += rec[e];
-        if (mk) ak += rec[half + e];
+    if (e < half) {
+        for (int w = a; w < b; ++w) {
+            const float* rec = records + (size_t)(w + s) * 2 * half;
+            if (mq) aq += rec[e];
+            if (mk) ak += rec[half + e];
+        }
     }
+    s_q[grp][lane] = aq;
+    s_k[grp][lane] = ak;
+    __syncthreads();
+    if (grp != 0 || e >= half) return;
+    aq = 0.f; ak = 0.f;
+    for (int k = 0; k < 8; ++k) { aq += s_q[k][lane]; ak += s_k[k][lane]; }
     if (mq && mk && g_tab_q == g_tab_k) {
         g_tab_q[(size_t)s * tab_stride + e] += aq + ak;
     } else {
@@ -1359,7 +1374,7 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
                                                                             g_ln, g_lnq, g_lnk);
     SATRANS_CHECK_LAUNCH("fused_common_final_kernel");
     if (d->flags & (SATRANS_META_Q | SATRANS_META_K)) {
-        fused_records_kernel<<<dim3((unsigned)ceil_div(2 * D * U, 256), d->S), 256, 0, stream>>>(
+        fused_records_kernel<<<dim3((unsigned)ceil_div(2 * D * U, 32), d->S), 256, 0, stream>>>(
             records, d->seg, d->S, p.T, p.G, D, U, d->flags, d->tab_stride, g_tab_q, g_tab_k);
         SATRANS_CHECK_LAUNCH("fused_records_kernel");
     }

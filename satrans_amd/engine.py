@@ -92,6 +92,10 @@ class PathEngine:
         self._last_prob = None
         # optional per-phase timing with HIP events recorded on the launch stream (bench.py): name -> [(start, end)]
         self.timers: Optional[Dict[str, list]] = None
+        # run the streaming Adam of untouched rows on a side stream under the layer kernels (SATRANS_OVERLAP=0: serial)
+        import os
+        self.overlap = os.environ.get("SATRANS_OVERLAP", "1") != "0"
+        self._side = None
 
     # ------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -229,7 +233,7 @@ class PathEngine:
             raise NotImplementedError("integer id matrix together with dense features")
         return X
 
-    def _run_forward(self, X, ws, training, tabs, att_list=None):
+    def _run_forward(self, X, ws, training, tabs, att_list=None, after_gather=None):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         N.check(lib.satrans_bucket_scenarios(X.data_ptr(), idt, X.stride(0), self.dom_col, B, self.S,
@@ -241,6 +245,8 @@ class PathEngine:
                                            self.cols.data_ptr(), X.data_ptr(), idt, X.stride(0), B, self.F, self.D,
                                            ws["acts"][0].data_ptr(), ws["rows"].data_ptr(), self.status.data_ptr(), st),
                     "satrans_gather_fwd")
+        if after_gather is not None:
+            after_gather(ws)
         for l in range(self.L):
             desc = self._layer_desc(ws, l, B, None, tabs, training)
             att = att_list[l].data_ptr() if att_list is not None else None
@@ -336,7 +342,7 @@ class PathEngine:
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
         return h
 
-    def backward(self, X, y, ws):
+    def backward(self, X, y, ws, after_gather=None):
         """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
         `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
         lib, B, st = self.lib, X.shape[0], self._stream()
@@ -348,7 +354,7 @@ class PathEngine:
         modulated = bool(self.flags & (N.META_Q | N.META_K))
         tabs = self.scenario_tables(grad=modulated)
         g_tabs = torch.zeros_like(tabs) if modulated else None
-        self._run_forward(X, ws, training, tabs.detach())
+        self._run_forward(X, ws, training, tabs.detach(), after_gather=after_gather)
         self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
@@ -377,6 +383,10 @@ class PathEngine:
         return ws["dact"][cur]
 
     def train_step(self, X: torch.Tensor, y: torch.Tensor):
+        """One optimizer step.  Launch order on the main stream: bucket, gather, [sort of the gathered row ids],
+        forward, head, backward, touched-row Adam, flat Adam.  The streaming Adam of all OTHER rows needs only the
+        touched-row bitmap, so it is issued right after the sort on a side stream and runs (HBM-bound) underneath
+        the compute-bound layer kernels; the main stream joins it at the end of the step."""
         from . import parallel
         X = self._prepare_input(X)
         y = y.reshape(-1).to(torch.float32).contiguous()
@@ -385,34 +395,62 @@ class PathEngine:
         world = parallel.world_size()
         n_rows = B * self.F * world
         ws = self.train_workspace(B, n_rows)
-        lib, st, m, D = self.lib, self._stream(), self.m, self.D
-        gemb = self.backward(X, y, ws)
-        rows = ws["rows"]
+        lib, m, D = self.lib, self.m, self.D
+        main = torch.cuda.current_stream(self.dev)
+        side_done = None
+        h_emb = None
+
+        def early(ws_):
+            nonlocal side_done, h_emb
+            rows = parallel.gather_rows(ws_["rows"]) if world > 1 else ws_["rows"]
+            self.adam_t += 1
+            h_emb = self._hparams(m.l2_reg_embedding)
+            with self.phase("embed_sort"):
+                N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws_["sorted_rows"].data_ptr(),
+                                               ws_["src"].data_ptr(), ws_["touched"].data_ptr(),
+                                               ws_["sort_ws"].data_ptr(), ws_["sort_ws"].numel(), self._stream()),
+                        "satrans_embed_sort")
+            if self.overlap:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.dev)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                self._side.wait_event(ready)
+                with torch.cuda.stream(self._side):
+                    self._launch_untouched(ws_, h_emb)
+                    side_done = torch.cuda.Event()
+                    side_done.record(self._side)
+            else:
+                self._launch_untouched(ws_, h_emb)
+
+        gemb = self.backward(X, y, ws, after_gather=early)
         if world > 1:
-            rows, gemb = parallel.exchange(self.flat_g, rows, gemb)
-        self.adam_t += 1
-        with self.phase("embed_sort"):
-            N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
-                                           ws["src"].data_ptr(), ws["touched"].data_ptr(), ws["sort_ws"].data_ptr(),
-                                           ws["sort_ws"].numel(), st), "satrans_embed_sort")
-        h_emb = self._hparams(m.l2_reg_embedding)
+            gemb = parallel.exchange_grads(self.flat_g, gemb)
+        st = self._stream()
         with self.phase("adam_touched"):
             N.check(lib.satrans_embed_adam_touched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
                                                    self.adam_v.data_ptr(), D, ws["sorted_rows"].data_ptr(),
                                                    ws["src"].data_ptr(), n_rows, gemb.data_ptr(),
                                                    ws["partial_ws"].data_ptr(), C.byref(h_emb),
                                                    ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_touched")
-        with self.phase("adam_untouched"):
-            N.check(lib.satrans_embed_adam_untouched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                                     self.adam_v.data_ptr(), self.total_rows, D,
-                                                     ws["touched"].data_ptr(), C.byref(h_emb),
-                                                     ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_untouched")
         h_flat = self._hparams(0.0)
         N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                       self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st),
                 "satrans_adam_flat")
+        if side_done is not None:
+            main.wait_event(side_done)
         N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(),
                                     1, st), "satrans_sum_f64")
+
+    def _launch_untouched(self, ws, h_emb):
+        m = self.m
+        with self.phase("adam_untouched"):
+            N.check(self.lib.satrans_embed_adam_untouched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                                          self.adam_v.data_ptr(), self.total_rows, self.D,
+                                                          ws["touched"].data_ptr(), C.byref(h_emb),
+                                                          ws["reg_partials"].data_ptr(),
+                                                          512 if self.overlap else 0, self._stream()),
+                    "satrans_embed_adam_untouched")
 
     # ------------------------------------------------------------------------------------------------
     # inspection for the parity tests: one forward+backward, gradients by state_dict key (dense tables)

@@ -43,6 +43,32 @@ def exchange(flat_grad: torch.Tensor, rows: torch.Tensor, gemb: torch.Tensor) ->
     return all_rows, all_gemb
 
 
+def gather_rows(rows: torch.Tensor) -> torch.Tensor:
+    """All-gather of the arena row ids every rank gathered this step ([W*n] int32, rank-major).  Issued right after
+    the gather kernel so that the sort (and the streaming Adam that only needs the touched-row bitmap) can start
+    while the layers are still computing."""
+    w = world_size()
+    rows = rows.reshape(-1).contiguous()
+    if w == 1:
+        return rows
+    out = torch.empty(w * rows.numel(), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, rows)
+    return out
+
+
+def exchange_grads(flat_grad: torch.Tensor, gemb: torch.Tensor) -> torch.Tensor:
+    """All-reduce `flat_grad` in place (SUM) and all-gather the gradient rows ([W*n, D], rank-major: the same order
+    as `gather_rows`)."""
+    w = world_size()
+    gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
+    if w == 1:
+        return gemb
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
+    dist.all_gather_into_tensor(out, gemb)
+    return out
+
+
 def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:
     """Sum of per-rank scalars (losses, counts) for logging."""
     if world_size() > 1:

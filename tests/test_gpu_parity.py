@@ -154,7 +154,7 @@ def test_optimizer_kernels_exact():
                                            src.data_ptr(), nrow, gemb_d.data_ptr(), part.data_ptr(), C.byref(hp(l2)),
                                            regp.data_ptr(), st), "touched")
     N.check(lib.satrans_embed_adam_untouched(Pd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), R, D, touched.data_ptr(),
-                                             C.byref(hp(l2)), regp.data_ptr(), st), "untouched")
+                                             C.byref(hp(l2)), regp.data_ptr(), 0, st), "untouched")
     np.testing.assert_allclose(Md.cpu().numpy(), Mr.numpy(), rtol=1e-6, atol=2e-7 * float(Mr.abs().max()))
     np.testing.assert_allclose(Vd.cpu().numpy(), Vr.numpy(), rtol=1e-6, atol=2e-7 * float(Vr.abs().max()))
     # inputs are identical and exactly summed, so the only slack is ~1 ulp in m, v amplified by lr/(sqrt(v)+eps)
