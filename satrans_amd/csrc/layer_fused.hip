@@ -312,6 +312,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
             const float* kbase = sk + (size_t)(ls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(ls * F) * LD + h * d;
             float mx = -INFINITY;
+#pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 float s = 0.f;
 #pragma unroll
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
             for (int e = 0; e < d; ++e) oacc[e] = 0.f;
             float sum = 0.f;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)b);
+#pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 float s = 0.f;
 #pragma unroll
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
             const float inv = 1.0f / sum;
             if (att) {   // normalized_att_scores [H,B,F,F], after dropout (satrans.py:87); rarely requested
                 float* arow = att + (((size_t)h * a.B + b) * F + i) * F;
-                for (int j = 0; j < F; ++j) {
+    #pragma unroll 4
+            for (int j = 0; j < F; ++j) {
                     float s = 0.f;
 #pragma unroll
                     for (int e = 0; e < d; e += 4) {
@@ -780,6 +783,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
             float* prow = sP + (size_t)task * F;
             float mx = -INFINITY;
+#pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 float s = 0.f;
 #pragma unroll
@@ -798,6 +802,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             float sum = 0.f;
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+#pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 const float ex = __expf(prow[j] - mx);
                 prow[j] = ex;
@@ -882,6 +887,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
             float dot = 0.f;
+#pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 float dp = 0.f;
 #pragma unroll
@@ -896,6 +902,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             st_dot[task] = dot;
 #pragma unroll
             for (int e = 0; e < d; ++e) dq[e] = 0.f;
+#pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 float dp = 0.f;
                 float kj[d];
@@ -937,6 +944,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* gbase = so + (size_t)(tls * F) * LD + h * d;
             const int st0 = (tls * H + h) * F;
             const float scale = dc.scale;
+#pragma unroll 4
             for (int i = 0; i < F; ++i) {
                 float qi[d], gi[d];
                 float dp = 0.f;
