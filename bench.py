@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="samples per GPU per step (reference main.py:80)")
     ap.add_argument("--lr", type=float, default=0.005)
-    ap.add_argument("--cpu-steps", type=int, default=1, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (0 = skip)")
     ap.add_argument("--no-phase-timing", action="store_true")
     args = ap.parse_args()
 
@@ -117,7 +117,6 @@ def main():
     model.to(device)
     model.device = device
     eng = model._require_engine()
-    eng.drop_seed = (eng.drop_seed ^ (rank * 0x9E3779B1)) & 0xFFFFFFFF           # different masks on every rank
     if rank == 0:
         print(f"[bench] model built in {time.time() - t_build:.1f}s; tables {model.embedding_arena.numel() * 4 / 1e6:.0f} MB",
               file=sys.stderr)

@@ -87,7 +87,9 @@ class PathEngine:
         self.adam_t = 0
         self.adam_m = self.adam_v = None
         self.flat_m = self.flat_v = self.flat_g = None
-        self.drop_seed = int(torch.initial_seed() & 0xFFFFFFFF)
+        from . import parallel
+        # every data-parallel rank draws different dropout masks
+        self.drop_seed = int((torch.initial_seed() ^ (parallel.rank() * 0x9E3779B1)) & 0xFFFFFFFF)
         self.drop_step = 0
         self._last_prob = None
         # optional per-phase timing with HIP events recorded on the launch stream (bench.py): name -> [(start, end)]
