@@ -44,17 +44,25 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // `wl` = w + 4*g*LDW + n (per-lane base), so every A fragment is one ds_read_b32 at a compile-time offset.
 template <int KT_, int MT_, int LDW>
 __device__ __forceinline__ void chain(const float* __restrict__ wl, const float (&in)[KT_][4], float (&out)[MT_][4]) {
+    constexpr int NS = 4 * KT_;   // contraction steps of 4 input features
     f32x4 acc[MT_];
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Left alone, hipcc funnels every A fragment through one register pair: ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs,
+    // i.e. one full LDS round trip per MFMA pair, which at one or two waves per SIMD idles the matrix pipe half of
+    // the time.  All A fragments of the chain are therefore read first (NS*MT_ registers) and a scheduling barrier
+    // keeps the reads above the MFMAs: the LDS latency is paid once per chain, the MFMAs then issue back to back
+    // behind counted lgkmcnt waits.
+    float a[NS][MT_];
 #pragma unroll
-    for (int t = 0; t < KT_; ++t) {
+    for (int st = 0; st < NS; ++st)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int mt = 0; mt < MT_; ++mt) a[st][mt] = wl[(16 * (st >> 2) + (st & 3)) * LDW + 16 * mt];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MT_; ++mt) acc[mt] = mfma4(wl[(16 * t + r) * LDW + 16 * mt], in[t][r], acc[mt]);
-        }
-    }
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) acc[mt] = mfma4(a[st][mt], in[st >> 2][st & 3], acc[mt]);
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt) {
         out[mt][0] = acc[mt][0]; out[mt][1] = acc[mt][1]; out[mt][2] = acc[mt][2]; out[mt][3] = acc[mt][3];
@@ -471,19 +479,22 @@ __device__ __forceinline__ void store_frag(float* row, const float (&v)[KT_][4],
 // al / gl: per-lane bases  buffer + (tile_row0 + g)*ld + n ; step ks adds 4 rows
 template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
 __device__ __forceinline__ void wgrad(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
+    // all operands of the four token steps are read first (4*(MT_+NT_) registers), then the MFMAs run back to back
+    float av[4][MT_], gv[4][NT_];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        float av[MT_], gv[NT_];
 #pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) av[mt] = al[4 * ks * LDA + 16 * mt];
+        for (int mt = 0; mt < MT_; ++mt) av[ks][mt] = al[4 * ks * LDA + 16 * mt];
 #pragma unroll
-        for (int nt = 0; nt < NT_; ++nt) gv[nt] = gl[4 * ks * LDG + 16 * nt];
+        for (int nt = 0; nt < NT_; ++nt) gv[ks][nt] = gl[4 * ks * LDG + 16 * nt];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int mt = 0; mt < MT_; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT_; ++nt)
-                acc[MOFF + mt][NOFF + nt] = mfma4(av[mt], gv[nt], acc[MOFF + mt][NOFF + nt]);
-    }
+                acc[MOFF + mt][NOFF + nt] = mfma4(av[ks][mt], gv[ks][nt], acc[MOFF + mt][NOFF + nt]);
 }
 
 // LayerNorm forward that keeps the normalised rows and 1/std for the backward pass
