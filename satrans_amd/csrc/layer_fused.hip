@@ -24,11 +24,6 @@
 #include "common.h"
 #include "rng.h"
 
-extern "C" int satrans_layer_slab_reduce(float* slabs, int S, int gx, int D, int U, int flags, int64_t tab_stride,
-                                         float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
-                                         float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream);
-extern "C" int64_t satrans_layer_slab_reduce_extra_floats(int S, int D, int U);
-
 namespace satrans {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;

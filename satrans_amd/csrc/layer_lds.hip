@@ -226,26 +226,56 @@ __device__ void forward_tile(const satrans_layer_desc& a, const TileDims& T, int
         else L.v[(size_t)t * L.ldd + o - 2 * D] = acc;
     });
     __syncthreads();
-    // ---- MetaNet on Q and K (satrans.py:60-73) -----------------------------------------------------------
-    if (a.flags & SATRANS_META_Q) {
-        metanet_tile(a, T, samp, dc, kSiteMetaQ, a.tab_q + (size_t)scen * a.tab_stride, a.lnq_g, a.lnq_b, L.q0, L.hq,
-                     L.zq, L.q, L);
-    } else if (L.q != L.q0) {
+    // ---- scenario modulation of Q and K (satrans.py:60-81) ----------------------------------------------------
+    auto copy_rows = [&](const float* src, float* dst) {
         for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
             const int t = i / D, c = i - t * D;
-            L.q[(size_t)t * L.ldd + c] = L.q0[(size_t)t * L.ldd + c];
+            dst[(size_t)t * L.ldd + c] = src[(size_t)t * L.ldd + c];
         }
-        __syncthreads();
-    }
-    if (a.flags & SATRANS_META_K) {
-        metanet_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, a.lnk_b, L.k0, L.hk,
-                     L.zk, L.k, L);
-    } else if (L.k != L.k0) {
+    };
+    if (a.flags & SATRANS_GATE) {
+        // flag 'gate' (satrans.py:61-62,68-69): q = q * vec * 2 with the generated row of length D
+        const float* gq = a.tab_q + (size_t)scen * a.tab_stride;
+        const float* gk = a.tab_k + (size_t)scen * a.tab_stride;
         for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
             const int t = i / D, c = i - t * D;
-            L.k[(size_t)t * L.ldd + c] = L.k0[(size_t)t * L.ldd + c];
+            const size_t at = (size_t)t * L.ldd + c;
+            L.q[at] = (a.flags & SATRANS_META_Q) ? L.q0[at] * gq[c] * 2.0f : L.q0[at];
+            L.k[at] = (a.flags & SATRANS_META_K) ? L.k0[at] * gk[c] * 2.0f : L.k0[at];
         }
         __syncthreads();
+    } else if (a.flags & SATRANS_BILINEAR) {
+        // flag 'bilinear' (satrans.py:79-81): per head q_h <- q_h @ M[h], M = generated row viewed as [H][d][d].
+        // Not in place: the products go to the hidden buffer first.
+        const float* M = a.tab_q + (size_t)scen * a.tab_stride;
+        for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+            const int t = i / D, c = i - t * D;
+            const int h = c / d, e2 = c - h * d;
+            const float* qrow = L.q0 + (size_t)t * L.ldd + h * d;
+            float acc = 0.f;
+            for (int e = 0; e < d; ++e) acc = fmaf(qrow[e], M[(h * d + e) * d + e2], acc);
+            L.hq[(size_t)t * L.ldd + c] = acc;
+        }
+        __syncthreads();
+        copy_rows(L.hq, L.q);
+        if (L.k != L.k0) copy_rows(L.k0, L.k);
+        __syncthreads();
+    } else {
+        // MetaNet on Q and K (satrans.py:60-73)
+        if (a.flags & SATRANS_META_Q) {
+            metanet_tile(a, T, samp, dc, kSiteMetaQ, a.tab_q + (size_t)scen * a.tab_stride, a.lnq_g, a.lnq_b, L.q0,
+                         L.hq, L.zq, L.q, L);
+        } else if (L.q != L.q0) {
+            copy_rows(L.q0, L.q);
+            __syncthreads();
+        }
+        if (a.flags & SATRANS_META_K) {
+            metanet_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, a.lnk_b, L.k0,
+                         L.hk, L.zk, L.k, L);
+        } else if (L.k != L.k0) {
+            copy_rows(L.k0, L.k);
+            __syncthreads();
+        }
     }
     // ---- scores + softmax: one thread per (sample, head, query row)  (satrans.py:84-87) --------------------
     const float sqrt_d = sqrtf((float)d);
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(kLayerBlock) void layer_fwd_kernel(satrans_layer_de
     L.q0 = take(maxtok * L.ldd);
     L.k0 = take(maxtok * L.ldd);
     L.v = take(maxtok * L.ldd);
-    L.hq = L.hk = L.P = take(max(maxtok * L.ldu, Tsamp * H * F * L.ldp));
+    L.hq = L.hk = L.P = take(max(max(maxtok * L.ldu, maxtok * L.ldd), Tsamp * H * F * L.ldp));
     L.w = p;
     L.zq = L.q = L.q0;
     L.zk = L.k = L.k0;
@@ -524,7 +554,7 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
     L.ldu = U + (use_mfma ? 4 : 1);
     L.ldp = F + 1;
     const int maxtok = Tsamp * F;
-    const int nd = maxtok * L.ldd, nu = maxtok * L.ldu, np = Tsamp * H * F * L.ldp;
+    const int nd = maxtok * L.ldd, nu = max(maxtok * L.ldu, maxtok * L.ldd), np = Tsamp * H * F * L.ldp;
     float* p = lds;
     auto take = [&](int n) { float* r = p; p += (n + 3) & ~3; return r; };
     L.x = take(nd); L.q0 = take(nd); L.k0 = take(nd); L.v = take(nd);
@@ -542,8 +572,10 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
     float* g_m = L.r;        // du / MetaNet dm scratch
     float* g_o = L.o;        // gradient of the attention output
     float* g_v = L.v;
-    if (!(a.flags & SATRANS_META_Q)) { L.zq = L.q0; L.q = L.q0; }
-    if (!(a.flags & SATRANS_META_K)) { L.zk = L.k0; L.k = L.k0; }
+    const bool q_mod = (a.flags & SATRANS_BILINEAR) || (a.flags & SATRANS_META_Q);
+    const bool k_mod = !(a.flags & SATRANS_BILINEAR) && (a.flags & SATRANS_META_K);
+    if (!q_mod) { L.zq = L.q0; L.q = L.q0; }
+    if (!k_mod) { L.zk = L.k0; L.k = L.k0; }
 
     const SlabOff so = slab_offsets(D, U);
     float* slab = slabs + ((size_t)scen * gridDim.x + blockIdx.x) * so.total;
@@ -620,13 +652,64 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
             g_v[(size_t)t * L.ldd + c] = av;
         }
         __syncthreads();
-        // ---- MetaNet backward (g_q, g_k become gradients wrt q0, k0) -------------------------------------------
-        if (a.flags & SATRANS_META_Q)
-            metanet_backward_tile(a, T, samp, dc, kSiteMetaQ, a.tab_q + (size_t)scen * a.tab_stride, a.lnq_g, L.q0, L.hq,
-                                  L.zq, g_q, g_m, rstd_buf, L, slab + so.w1q, slab + so.w2q, slab + so.lnq, first);
-        if (a.flags & SATRANS_META_K)
-            metanet_backward_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, L.k0, L.hk,
-                                  L.zk, g_k, g_m, rstd_buf, L, slab + so.w1k, slab + so.w2k, slab + so.lnk, first);
+        // ---- modulation backward (g_q, g_k become gradients wrt q0, k0) ---------------------------------------------------
+        if (a.flags & SATRANS_GATE) {
+            // q = q0 * vec * 2 : d vec[c] += sum_t g[t][c] * 2 q0[t][c] (first D entries of the role's slab region), g *= 2 vec
+            const float* gq = a.tab_q + (size_t)scen * a.tab_stride;
+            const float* gk = a.tab_k + (size_t)scen * a.tab_stride;
+            for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+                const bool role_k = e >= D;
+                const int c = role_k ? e - D : e;
+                if (!(a.flags & (role_k ? SATRANS_META_K : SATRANS_META_Q))) continue;
+                const float* g = role_k ? g_k : g_q;
+                const float* in0 = role_k ? L.k0 : L.q0;
+                float acc = 0.f;
+                for (int t = 0; t < ntok; ++t) acc = fmaf(g[(size_t)t * L.ldd + c], 2.0f * in0[(size_t)t * L.ldd + c], acc);
+                float* dst = slab + (role_k ? so.w1k : so.w1q) + c;
+                *dst = first ? acc : *dst + acc;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+                const int t = i / D, c = i - t * D;
+                const size_t at = (size_t)t * L.ldd + c;
+                if (a.flags & SATRANS_META_Q) g_q[at] *= 2.0f * gq[c];
+                if (a.flags & SATRANS_META_K) g_k[at] *= 2.0f * gk[c];
+            }
+            __syncthreads();
+        } else if (a.flags & SATRANS_BILINEAR) {
+            // q_h = q0_h @ M[h] : dM[h][e][e2] += sum_t q0[t][hd+e] g[t][hd+e2] ; dq0[t][hd+e] = sum_e2 g[t][hd+e2] M[h][e][e2]
+            const float* M = a.tab_q + (size_t)scen * a.tab_stride;
+            for (int e_ = threadIdx.x; e_ < D * d; e_ += blockDim.x) {
+                const int h = e_ / (d * d), rem = e_ - h * d * d;
+                const int e = rem / d, e2 = rem - e * d;
+                float acc = 0.f;
+                for (int t = 0; t < ntok; ++t)
+                    acc = fmaf(L.q0[(size_t)t * L.ldd + h * d + e], g_q[(size_t)t * L.ldd + h * d + e2], acc);
+                float* dst = slab + so.w1q + e_;
+                *dst = first ? acc : *dst + acc;
+            }
+            for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+                const int t = i / D, c = i - t * D;
+                const int h = c / d, e = c - h * d;
+                const float* grow = g_q + (size_t)t * L.ldd + h * d;
+                float acc = 0.f;
+                for (int e2 = 0; e2 < d; ++e2) acc = fmaf(grow[e2], M[(h * d + e) * d + e2], acc);
+                g_m[(size_t)t * L.ldd + c] = acc;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
+                const int t = i / D, c = i - t * D;
+                g_q[(size_t)t * L.ldd + c] = g_m[(size_t)t * L.ldd + c];
+            }
+            __syncthreads();
+        } else {
+            if (a.flags & SATRANS_META_Q)
+                metanet_backward_tile(a, T, samp, dc, kSiteMetaQ, a.tab_q + (size_t)scen * a.tab_stride, a.lnq_g, L.q0,
+                                      L.hq, L.zq, g_q, g_m, rstd_buf, L, slab + so.w1q, slab + so.w2q, slab + so.lnq, first);
+            if (a.flags & SATRANS_META_K)
+                metanet_backward_tile(a, T, samp, dc, kSiteMetaK, a.tab_k + (size_t)scen * a.tab_stride, a.lnk_g, L.k0,
+                                      L.hk, L.zk, g_k, g_m, rstd_buf, L, slab + so.w1k, slab + so.w2k, slab + so.lnk, first);
+        }
         // ---- projections: dW{q,k,v} += x^T g ; dx = dr*res + g_q Wq^T + g_k Wk^T + g_v Wv^T ----------------------
         outer_accumulate(L.mfma, slab + so.wq, first, L.x, L.ldd, g_q, L.ldd, D, D, ntok);
         outer_accumulate(L.mfma, slab + so.wk, first, L.x, L.ldd, g_k, L.ldd, D, D, ntok);
@@ -674,7 +757,7 @@ __global__ void slab_group_sum_kernel(const float* __restrict__ slabs, int gx, i
 }
 
 // Sum the per-workgroup slabs in (scenario, workgroup) order and ADD them to the parameter gradients.
-__global__ void layer_bwd_reduce_kernel(const float* __restrict__ slabs, int S, int gx, int D, int U, int flags,
+__global__ void layer_bwd_reduce_kernel(const float* __restrict__ slabs, int S, int gx, int D, int U, int H, int flags,
                                         int64_t tab_stride, float* g_wq, float* g_wk, float* g_wv, float* g_wo,
                                         float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k) {
     const SlabOff so = slab_offsets(D, U);
@@ -690,6 +773,7 @@ __global__ void layer_bwd_reduce_kernel(const float* __restrict__ slabs, int S, 
         else if (e < so.wo) g_wv[e - so.wv] += acc;
         else if (e < so.w1q) g_wo[e - so.wo] += acc;
         else if (e < so.lnq) g_ln[e - so.ln] += acc;
+        else if (flags & (SATRANS_GATE | SATRANS_BILINEAR)) return;   // no MetaNet, no MetaNet LayerNorm
         else if (e < so.lnk) {
             // Without 'pos' the Q and K MetaNets share ONE LayerNorm (satrans.py:46): g_lnq == g_lnk, and this
             // thread adds both roles' partials (Q first) so that no two threads update one address.
@@ -714,7 +798,12 @@ __global__ void layer_bwd_reduce_kernel(const float* __restrict__ slabs, int S, 
     if (e >= so.w1k) return;
     const int within = e - so.w1q;
     const int ek = so.w1k + within;
-    const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    // length of the generated row that is actually used, and which roles read it
+    bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    int tab_len = 2 * D * U;
+    if (flags & SATRANS_GATE) tab_len = D;                               // satrans.py:162-163
+    if (flags & SATRANS_BILINEAR) { tab_len = D * (D / H); mq = true; mk = false; }   // satrans.py:159-161, applied to Q only
+    if (within >= tab_len) return;
     for (int s = 0; s < S; ++s) {
         float aq = 0.f, ak = 0.f;
         for (int w = 0; w < gx; ++w) {
@@ -742,7 +831,7 @@ static int64_t r4(int64_t n) { return (n + 3) & ~(int64_t)3; }
 static int64_t fwd_lds_floats(int T, int F, int D, int H, int U, int mfma) {
     const int64_t tok = (int64_t)T * F;
     const int pad = mfma ? 4 : 1, wp = mfma ? 4 : 0;
-    const int64_t hp = std::max<int64_t>(tok * (U + pad), (int64_t)T * H * F * (F + 1));
+    const int64_t hp = std::max<int64_t>(std::max<int64_t>(tok * (U + pad), tok * (D + pad)), (int64_t)T * H * F * (F + 1));
     const int64_t w = std::max<int64_t>((int64_t)D * (3 * D + wp), std::max<int64_t>((int64_t)D * (U + wp), (int64_t)U * (D + wp)));
     return 4 * r4(tok * (D + pad)) + r4(hp) + w + 64;
 }
@@ -750,7 +839,8 @@ static int64_t fwd_lds_floats(int T, int F, int D, int H, int U, int mfma) {
 static int64_t bwd_lds_floats(int T, int F, int D, int H, int U, int flags, int mfma) {
     const int64_t tok = (int64_t)T * F;
     const int pad = mfma ? 4 : 1, wp = mfma ? 4 : 0;
-    const int64_t nd = r4(tok * (D + pad)), nu = r4(tok * (U + pad)), np = r4((int64_t)T * H * F * (F + 1));
+    const int64_t nd = r4(tok * (D + pad)), nu = r4(std::max<int64_t>(tok * (U + pad), tok * (D + pad))),
+                  np = r4((int64_t)T * H * F * (F + 1));
     const int nbuf = 13 + ((flags & SATRANS_RELU_OUT) ? 1 : 0);
     const int64_t w = std::max<int64_t>(3 * (int64_t)D * (D + wp), (int64_t)D * (U + wp) + (int64_t)U * (D + wp));
     return nbuf * nd + 2 * nu + 2 * np + r4(tok) + w + 64;
@@ -760,7 +850,8 @@ static int64_t bwd_lds_floats(int T, int F, int D, int H, int U, int flags, int 
 static int want_mfma(const satrans_layer_desc* d) {
     if (satrans_layer_impl() == 1) return 0;
     if (d->D % 16) return 0;
-    if ((d->flags & (SATRANS_META_Q | SATRANS_META_K)) && (d->U % 16)) return 0;
+    if (!(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) && (d->flags & (SATRANS_META_Q | SATRANS_META_K)) && (d->U % 16))
+        return 0;
     return 1;
 }
 
@@ -773,9 +864,15 @@ static int validate(const satrans_layer_desc* d, const char* who) {
     SATRANS_REQUIRE(d->D % 4 == 0, SATRANS_E_UNSUPPORTED, "%s: embedding_size %d is not a multiple of 4", who, d->D);
     SATRANS_REQUIRE(d->D % d->H == 0, SATRANS_E_BADARG, "%s: embedding_size %d is not a multiple of head_num %d", who,
                     d->D, d->H);
-    SATRANS_REQUIRE(!(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)), SATRANS_E_UNSUPPORTED,
-                    "%s: 'gate'/'bilinear' variants are not built yet", who);
-    if (d->flags & (SATRANS_META_Q | SATRANS_META_K)) {
+    const bool gate = d->flags & SATRANS_GATE, bil = d->flags & SATRANS_BILINEAR;
+    SATRANS_REQUIRE(!(gate && bil), SATRANS_E_BADARG, "%s: 'gate' and 'bilinear' together", who);
+    if (gate || bil) {
+        SATRANS_REQUIRE(d->U > 0 && d->tab_q && d->tab_k, SATRANS_E_BADARG, "%s: generated-weight table missing", who);
+        const int64_t need = gate ? d->D : (int64_t)d->D * (d->D / d->H);
+        SATRANS_REQUIRE(d->tab_stride >= need, SATRANS_E_BADARG, "%s: tab_stride %lld < %lld", who,
+                        (long long)d->tab_stride, (long long)need);
+        SATRANS_REQUIRE(2 * (int64_t)d->D * d->U >= need, SATRANS_E_UNSUPPORTED, "%s: U too small for the gradient slab", who);
+    } else if (d->flags & (SATRANS_META_Q | SATRANS_META_K)) {
         SATRANS_REQUIRE(d->U > 0 && d->tab_q && d->tab_k && d->lnq_g && d->lnq_b && d->lnk_g && d->lnk_b,
                         SATRANS_E_BADARG, "%s: MetaNet tensors missing", who);
         SATRANS_REQUIRE(d->tab_stride >= 2 * (int64_t)d->D * d->U, SATRANS_E_BADARG, "%s: tab_stride too small", who);
@@ -835,7 +932,7 @@ extern "C" int64_t satrans_layer_slab_reduce_extra_floats(int S, int D, int U) {
     return (int64_t)S * kReduceSplit * slab_offsets(D, U).total;
 }
 
-extern "C" int satrans_layer_slab_reduce(float* slabs, int S, int gx, int D, int U, int flags, int64_t tab_stride,
+extern "C" int satrans_layer_slab_reduce(float* slabs, int S, int gx, int D, int U, int H, int flags, int64_t tab_stride,
                                          float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
                                          float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -845,7 +942,7 @@ extern "C" int satrans_layer_slab_reduce(float* slabs, int S, int gx, int D, int
         slabs, gx, kReduceSplit, total, partial);
     SATRANS_CHECK_LAUNCH("slab_group_sum_kernel");
     layer_bwd_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(
-        partial, S, kReduceSplit, D, U, flags, tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
+        partial, S, kReduceSplit, D, U, H, flags, tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
     SATRANS_CHECK_LAUNCH("layer_bwd_reduce_kernel");
     return SATRANS_OK;
 }
@@ -885,8 +982,10 @@ extern "C" int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* d
     int rc = validate(d, "layer_bwd");
     if (rc) return rc;
     SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
-    if (d->flags & SATRANS_META_Q) SATRANS_REQUIRE(g_lnq && g_tab_q, SATRANS_E_BADARG, "layer_bwd: null Q MetaNet gradient");
-    if (d->flags & SATRANS_META_K) SATRANS_REQUIRE(g_lnk && g_tab_k, SATRANS_E_BADARG, "layer_bwd: null K MetaNet gradient");
+    const bool plain_meta = !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR));
+    if (d->flags & SATRANS_META_Q) SATRANS_REQUIRE((g_lnq || !plain_meta) && g_tab_q, SATRANS_E_BADARG, "layer_bwd: null Q gradient");
+    if (d->flags & SATRANS_META_K) SATRANS_REQUIRE((g_lnk || !plain_meta) && g_tab_k, SATRANS_E_BADARG, "layer_bwd: null K gradient");
+    if (d->flags & SATRANS_BILINEAR) SATRANS_REQUIRE(g_tab_q, SATRANS_E_BADARG, "layer_bwd: null bilinear gradient");
     LayerPlan p;
     rc = plan_bwd(d, p);
     if (rc) return rc;
@@ -899,6 +998,6 @@ extern "C" int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* d
     }
     layer_bwd_kernel<<<dim3(p.gx, d->S), kLayerBlock, p.lds, stream>>>(*d, p.T, p.mfma, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_kernel");
-    return satrans_layer_slab_reduce(slabs, d->S, p.gx, d->D, d->U, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo, g_ln,
-                                     g_lnq, g_lnk, g_tab_q, g_tab_k, stream_);
+    return satrans_layer_slab_reduce(slabs, d->S, p.gx, d->D, d->U, d->H, d->flags, d->tab_stride, g_wq, g_wk, g_wv, g_wo,
+                                     g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream_);
 }

@@ -37,9 +37,13 @@ class PathEngine:
         self.H = m.att_head_num
         self.L = m.domain_att_layer_num
         units = m.meta_dnn_hidden_units
-        self.metanet = 'gate' not in flag and 'bilinear' not in flag
-        if 'gate' in flag or 'bilinear' in flag:
-            raise NotImplementedError("flags 'gate' / 'bilinear': ablation variants are not built as HIP kernels yet")
+        self.gate = 'gate' in flag                       # reference satrans.py:61-62 (tested before 'bilinear')
+        self.bilinear = 'bilinear' in flag and not self.gate
+        if 'bilinear' in flag and 'gate' in flag:
+            # the reference applies the gate on Q/K AND the per-head bilinear map with a length-D vector reshaped to
+            # [H,d,d], which only works when D == D*D/H; not a configuration anyone runs
+            raise NotImplementedError("flags 'gate' and 'bilinear' together")
+        self.metanet = not self.gate and not self.bilinear
         if len(m.domain_column_list) > 1:
             raise NotImplementedError("more than one scenario column is not built as HIP kernels yet")
         if len(units) != 3 or units[2] != self.D:
@@ -50,10 +54,14 @@ class PathEngine:
         self.pos = 'pos' in flag
         self.onlyemb = 'onlyemb' in flag
         self.flags = 0
-        if self.metanet and 'Q' in m.meta_mode:
+        if not self.bilinear and 'Q' in m.meta_mode:       # MetaNet or gate on the queries
             self.flags |= N.META_Q
-        if self.metanet and 'K' in m.meta_mode:
+        if not self.bilinear and 'K' in m.meta_mode:       # ... on the keys
             self.flags |= N.META_K
+        if self.gate:
+            self.flags |= N.GATE
+        if self.bilinear:
+            self.flags |= N.BILINEAR                        # per-head map of the queries, whatever meta_mode says
         if 'relu' in flag:
             self.flags |= N.RELU_OUT
         if not m.att_res:
@@ -353,7 +361,7 @@ class PathEngine:
         training = m.training
         if training:
             self.drop_step += 1
-        modulated = bool(self.flags & (N.META_Q | N.META_K))
+        modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
         tabs = self.scenario_tables(grad=modulated)
         g_tabs = torch.zeros_like(tabs) if modulated else None
         self._run_forward(X, ws, training, tabs.detach(), after_gather=after_gather)
@@ -366,9 +374,9 @@ class PathEngine:
             if modulated:
                 tq, tk = self._layer_tables(g_tabs, l)
                 gq, gk = tq.data_ptr(), tk.data_ptr()
-            if self.flags & N.META_Q:
+            if self.metanet and self.flags & N.META_Q:
                 glnq = self._grad_view(lay + "Q_meta_mlp.ffn_layer_norm.weight").data_ptr()
-            if self.flags & N.META_K:
+            if self.metanet and self.flags & N.META_K:
                 kname = "K_meta_mlp" if m.domain_int_layers[l].K_meta_mlp is not m.domain_int_layers[l].Q_meta_mlp \
                     else "Q_meta_mlp"
                 glnk = self._grad_view(lay + kname + ".ffn_layer_norm.weight").data_ptr()
