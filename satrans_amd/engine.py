@@ -44,13 +44,33 @@ class PathEngine:
             # [H,d,d], which only works when D == D*D/H; not a configuration anyone runs
             raise NotImplementedError("flags 'gate' and 'bilinear' together")
         self.metanet = not self.gate and not self.bilinear
-        if len(m.domain_column_list) > 1:
-            raise NotImplementedError("more than one scenario column is not built as HIP kernels yet")
+        self.multi = len(m.domain_column_list) > 1
         if len(units) != 3 or units[2] != self.D:
             raise NotImplementedError(f"meta_dnn_hidden_units must be (U, embedding_dim); got {units[1:]}")
         self.U = units[1]
         self.P = m.meta_param_size
         self.S = m.domain_embeddings.weight.shape[0]
+        if self.multi:
+            # several scenario columns (satrans.py:205-207): the scenario embedding is the mean of those columns' rows,
+            # so the "scenario" of a sample is the TUPLE of ids; it is indexed by a composite id over the product of the
+            # columns' vocabularies and the generated-weight table gets one row per tuple
+            if 'onlyemb' in flag:
+                raise NotImplementedError("'onlyemb' with several scenario columns")
+            tabs_ = [m.domain_embedding_dict[c.embedding_name] for c in m.domain_feature_columns]
+            sizes = [t.weight.shape[0] for t in tabs_]
+            self.S = 1
+            for v in sizes:
+                self.S *= v
+            if self.S > 4096:
+                raise NotImplementedError(f"{self.S} scenario tuples: composite scenario tables above 4096 rows")
+            strides, acc = [], 1
+            for v in reversed(sizes):
+                strides.insert(0, acc)
+                acc *= v
+            comp = torch.arange(self.S, device=self.dev)
+            self._multi_tables = tabs_
+            self._multi_index = [(comp // st) % v for st, v in zip(strides, sizes)]
+            self._multi_strides = torch.tensor(strides, dtype=torch.int64, device=self.dev)
         self.pos = 'pos' in flag
         self.onlyemb = 'onlyemb' in flag
         self.flags = 0
@@ -76,6 +96,9 @@ class PathEngine:
         self.n_dense = len(dcols)
         self.dense_cols = torch.tensor(dcols, dtype=torch.int32, device=self.dev) if dcols else None
         self.dom_col = fi[m.domain_column_list[0]][0]
+        if self.multi:
+            self._multi_cols = torch.tensor([fi[c.name][0] for c in m.domain_feature_columns], dtype=torch.int64,
+                                            device=self.dev)
         self.n_cols = max(e for _, e in fi.values())
         # arena row offset of every FIELD (fields sharing an embedding_name share a table)
         offs = [m._table_rows[c.embedding_name][0] for c in sparse]
@@ -182,7 +205,11 @@ class PathEngine:
         """-> [L, 2, S, P'] when 'pos' is in the flag (role 0 = Q, 1 = K), else [1, 1, S, P']."""
         m = self.m
         with torch.set_grad_enabled(grad):
-            dom = torch.relu(m.domain_embeddings.weight)                          # satrans.py:213
+            if self.multi:                                                          # satrans.py:205-207
+                emb = torch.stack([t.weight[i] for t, i in zip(self._multi_tables, self._multi_index)], dim=-1).mean(-1)
+            else:
+                emb = m.domain_embeddings.weight
+            dom = torch.relu(emb)                                                   # satrans.py:213
             if not self.pos:
                 z = dom.unsqueeze(0).unsqueeze(0)
             else:
@@ -246,7 +273,11 @@ class PathEngine:
     def _run_forward(self, X, ws, training, tabs, att_list=None, after_gather=None):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
-        N.check(lib.satrans_bucket_scenarios(X.data_ptr(), idt, X.stride(0), self.dom_col, B, self.S,
+        sx, sidt, sstride, scol = X, idt, X.stride(0), self.dom_col
+        if self.multi:   # composite scenario id of every sample (a few elementwise torch ops on [B, k] ids)
+            sx = (X.index_select(1, self._multi_cols).long() * self._multi_strides).sum(1).to(torch.int32).contiguous()
+            sidt, sstride, scol = N.ID_I32, 1, 0
+        N.check(lib.satrans_bucket_scenarios(sx.data_ptr(), sidt, sstride, scol, B, self.S,
                                              ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr(),
                                              self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
                 "satrans_bucket_scenarios")

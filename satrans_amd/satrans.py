@@ -134,7 +134,13 @@ class SATrans(BaseModel):
     def _trainable_flat(self):
         flat = OrderedDict()
         flag = self.flag
-        flat["domain_embeddings.weight"] = self.domain_embeddings.weight
+        # scenario embedding: one table, or (several scenario columns, satrans.py:205-207) the mean of those columns'
+        # rows in the second table set `domain_embedding_dict`; `domain_embeddings` then receives no gradient
+        multi = len(self.domain_column_list) > 1
+        scen_keys = [f"domain_embedding_dict.{c.embedding_name}.weight" for c in self.domain_feature_columns] \
+            if multi else ["domain_embeddings.weight"]
+        for key in scen_keys:
+            flat[key] = self.get_parameter(key)
         for l, layer in enumerate(self.domain_int_layers):
             pre = f"domain_int_layers.{l}."
             flat[pre + "W_Query"] = layer.W_Query
@@ -162,7 +168,8 @@ class SATrans(BaseModel):
             flat["domain_map_dnn_Q.linears.0.weight"] = self.domain_map_dnn_Q.linears[0].weight
             flat["domain_map_dnn_Q.linears.0.bias"] = self.domain_map_dnn_Q.linears[0].bias
         if not modulated:
-            del flat["domain_embeddings.weight"]
+            for key in scen_keys:
+                del flat[key]
         flat["dnn_linear.weight"] = self.dnn_linear.weight
         flat["dnn_linear.bias"] = self.dnn_linear.bias
         return flat

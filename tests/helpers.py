@@ -65,5 +65,5 @@ def build_model(case: "Case", device: str):
     return model
 
 
-NATIVE_CASES = [c for c in ALL_CASES if c not in ("small_multidomain",)]
+NATIVE_CASES = list(ALL_CASES)
 NATIVE_TRAIN_CASES = [c for c in NATIVE_CASES if c in TRAIN_CASES]

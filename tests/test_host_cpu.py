@@ -27,8 +27,6 @@ def test_feature_index_layout():
 def test_construction_is_bit_identical_to_reference(name):
     """Same seed -> same state_dict as the reference (same generator draws in the same order)."""
     c = Case(name)
-    if name == "small_multidomain":
-        pytest.skip("second table set for several scenario columns: constructed, compared in a later round")
     model = build_model(c, "cpu")
     mine, want = model.state_dict(), c.tensors("param")
     assert set(mine) == set(want)
@@ -42,7 +40,8 @@ def test_construction_is_bit_identical_to_reference(name):
     assert model.embedding_arena.shape == (total, c.meta["D"])
 
 
-@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_k", "small_none", "small_onlyemb"])
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_k", "small_none", "small_onlyemb", "small_gate",
+                                  "small_bilinear", "small_multidomain"])
 def test_trainable_set_matches_reference_gradients(name):
     """The tensors the fused Adam steps are exactly the ones that receive a gradient in the reference."""
     c = Case(name)
