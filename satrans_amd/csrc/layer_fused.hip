@@ -27,6 +27,23 @@
 namespace satrans {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Diagnostic build only (-DSATRANS_STAMPS): per-phase cycle totals of wave 0 of every workgroup, summed with atomics
+// into a module-level array that satrans_debug_read_stamps copies out.  Never compiled into the shipped library.
+#ifdef SATRANS_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(slot)                                                                  \
+    do {                                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+        if (threadIdx.x == 0) atomicAdd(&g_stamps[slot], now_ - st_prev);            \
+        st_prev = now_;                                                              \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(slot)
+#endif
+
 constexpr int kFusedBlock = 256;
 constexpr int kFusedWaves = kFusedBlock / 64;
 
@@ -664,6 +681,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         __syncthreads();
     };
 
+    STAMP_DECL
+    STAMP(8);
     int pre = 0;
     for (int scen = 0; scen < a.S && pre < wr.g1; ++scen) {
       const int nt_s = tiles_of(a.seg, scen, Tsamp);
@@ -700,6 +719,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         float x[KT][4], q0[KT][4], k0[KT][4], hq[UT][4], hk[UT][4], zhq[KT][4], zhk[KT][4], dr[KT][4];
         float rstd_q = 0.f, rstd_k = 0.f;
 
+        STAMP(0);
         // ================= phase A: forward chain ====================================================================
         if (has_tile) {
             load_frag<KT>(a.x + ((size_t)b * F + f) * D + g4, x);
@@ -773,6 +793,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         __syncthreads();
 
+        STAMP(1);
         // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
@@ -789,18 +810,25 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
             float* prow = sP + (size_t)task * F;
             float mx = -INFINITY;
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                float s = 0.f;
+            // keys in chunks of 4: all loads of a chunk are issued before its scores are stored (the stores to the
+            // score cache may alias the key rows as far as the compiler knows, which would serialise load->store->load)
+            for (int j0 = 0; j0 < F; j0 += 4) {
+                float sc[4];
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, F - 1);
+                    float s_ = 0.f;
+#pragma unroll
+                    for (int e = 0; e < d; e += 4) {
+                        const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                        s_ = fmaf(qi[e], k4.x, s_); s_ = fmaf(qi[e + 1], k4.y, s_);
+                        s_ = fmaf(qi[e + 2], k4.z, s_); s_ = fmaf(qi[e + 3], k4.w, s_);
+                    }
+                    sc[u] = s_ * inv_sqrt_d;
                 }
-                s *= inv_sqrt_d;
-                prow[j] = s;
-                mx = fmaxf(mx, s);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < F) { prow[j0 + u] = sc[u]; mx = fmaxf(mx, sc[u]); }
             }
             float oacc[d];
 #pragma unroll
@@ -808,22 +836,37 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             float sum = 0.f;
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                const float ex = __expf(prow[j] - mx);
-                prow[j] = ex;
-                sum += ex;
-                float pe = ex;
-                if (dc.on) {
-                    const bool kp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh);
-                    pe = kp ? ex * dc.scale : 0.f;
-                    if (!kp) keep &= ~(1u << j);
+            for (int j0 = 0; j0 < F; j0 += 4) {
+                float ex[4], pe[4];
+                float4 vv[4][d / 4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, F - 1);
+                    ex[u] = __expf(prow[j] - mx);
+#pragma unroll
+                    for (int e = 0; e < d; e += 4) vv[u][e / 4] = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
                 }
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
-                    oacc[e] = fmaf(pe, v4.x, oacc[e]); oacc[e + 1] = fmaf(pe, v4.y, oacc[e + 1]);
-                    oacc[e + 2] = fmaf(pe, v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe, v4.w, oacc[e + 3]);
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    if (j < F) {
+                        prow[j] = ex[u];
+                        sum += ex[u];
+                        pe[u] = ex[u];
+                        if (dc.on) {
+                            const bool kp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh);
+                            pe[u] = kp ? ex[u] * dc.scale : 0.f;
+                            if (!kp) keep &= ~(1u << j);
+                        }
+                    } else {
+                        pe[u] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < d; e += 4) {
+                        const float4 v4 = vv[u][e / 4];
+                        oacc[e] = fmaf(pe[u], v4.x, oacc[e]); oacc[e + 1] = fmaf(pe[u], v4.y, oacc[e + 1]);
+                        oacc[e + 2] = fmaf(pe[u], v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe[u], v4.w, oacc[e + 3]);
+                    }
                 }
             }
             const float inv = 1.0f / sum;
@@ -837,6 +880,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         __syncthreads();
 
+        STAMP(2);
         // ================= phase C: output block forward + backward ======================================================
         if (has_tile) {
             float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4];
@@ -875,6 +919,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         __syncthreads();
 
+        STAMP(3);
         // ================= phase D: softmax backward by rows: dot_i and dq_i ==============================================
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
@@ -892,22 +937,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float inv = st_inv[task];
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
-            float dot = 0.f;
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                float dp = 0.f;
+            // one pass: with p_j = P_ij, dp_j = dP_ij (dropout applied) and dot = sum_j p_j dp_j,
+            //   dq_i = sum_j p_j (dp_j - dot) k_j / sqrt(d) = (sum_j p_j dp_j k_j  -  dot * sum_j p_j k_j) / sqrt(d)
+            float dot = 0.f, center = 0.f;
+            float acc_a[d], acc_b[d];
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
-                    dp = fmaf(gi[e], v4.x, dp); dp = fmaf(gi[e + 1], v4.y, dp);
-                    dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
-                }
-                dp = ((keep >> j) & 1u) ? dp * scale : 0.f;
-                dot = fmaf(dp, prow[j] * inv, dot);
-            }
-            st_dot[task] = dot;
-#pragma unroll
-            for (int e = 0; e < d; ++e) dq[e] = 0.f;
+            for (int e = 0; e < d; ++e) acc_a[e] = acc_b[e] = 0.f;
 #pragma unroll 4
             for (int j = 0; j < F; ++j) {
                 float dp = 0.f;
@@ -921,10 +956,20 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
                 }
                 dp = ((keep >> j) & 1u) ? dp * scale : 0.f;
-                const float ds = (prow[j] * inv) * (dp - dot) * inv_sqrt_d;
+                if (j == 0) center = dp;          // dP centred on its first value: same result (sum_j p_j = 1), but the
+                dp -= center;                     // two sums below no longer cancel when dP is nearly constant over j
+                const float pj = prow[j] * inv;
+                const float pd = pj * dp;
+                dot += pd;
 #pragma unroll
-                for (int e = 0; e < d; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
+                for (int e = 0; e < d; ++e) {
+                    acc_a[e] = fmaf(pd, kj[e], acc_a[e]);
+                    acc_b[e] = fmaf(pj, kj[e], acc_b[e]);
+                }
             }
+            st_dot[task] = dot + center;
+#pragma unroll
+            for (int e = 0; e < d; ++e) dq[e] = (acc_a[e] - dot * acc_b[e]) * inv_sqrt_d;
             float* dqrow = sg + (size_t)(tls * F + i) * LD + h * d;
 #pragma unroll
             for (int e = 0; e < d; e += 4)
@@ -932,6 +977,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         __syncthreads();
 
+        STAMP(4);
         // ================= phase E: by columns: dk_j, dv_j (in place of k_j, v_j) ===========================================
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
@@ -981,6 +1027,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         __syncthreads();
 
+        STAMP(5);
         // ================= phase F: MetaNet and projection backward, weight gradients, dx ==================================
         if (has_tile) {
             float gq[KT][4], gk[KT][4];
@@ -1093,6 +1140,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
         __syncthreads();
+        STAMP(6);
       }
       // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
       // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the part of a role only
@@ -1107,6 +1155,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       }
     }
 
+    STAMP(7);
     // ---- scenario-independent gradients of this workgroup ------------------------------------------------------------------
     flush(acc_wq, KTc{}, KTc{}, common, true);
     flush(acc_wk, KTc{}, KTc{}, common + D * D, true);
@@ -1394,3 +1443,14 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     }
     return SATRANS_OK;
 }
+
+#ifdef SATRANS_STAMPS
+extern "C" int satrans_debug_read_stamps(unsigned long long* h_out, int reset) {
+    if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(satrans::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(satrans::g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
