@@ -185,8 +185,7 @@ int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const in
                                const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
                                const satrans_adam_hparams* h, double* reg_partials, void* stream);
 int64_t satrans_embed_partial_ws_floats(int64_t n, int D);
-/* grid_blocks: 0 = the HBM-saturating default (8 blocks per CU); a smaller persistent grid (e.g. 512) when the call
- * runs on a side stream underneath compute-bound kernels */
+/* grid_blocks: 0 = the measured optimum (512 persistent blocks of 256 threads); otherwise the grid size to use */
 int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
                                  const uint32_t* touched, const satrans_adam_hparams* h,
                                  double* reg_partials, int grid_blocks, void* stream);

@@ -14,6 +14,7 @@
 //
 // Adam arithmetic follows torch.optim.adam._single_tensor_adam (lerp for exp_avg, mul+addcmul for exp_avg_sq,
 // denom = sqrt(v)/sqrt(bc2) + eps, addcdiv with -lr/bc1).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -25,7 +26,7 @@ namespace satrans {
 
 constexpr int kChunk = 32;         // sorted positions per lane group in the touched-row pass
 constexpr int kStreamBlock = 256;
-constexpr int kStreamBlocks = 2048;  // 8 blocks per CU, grid-strided
+constexpr int kStreamBlocks = 2048;  // upper bound of the streaming grid = slots reserved for its partial sums
 
 struct AdamK {
     float neg_step, bc2_sqrt, w1, beta2, w2, eps, l2x2, l2;
@@ -87,30 +88,33 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // ---------------------------------------------------------------------------------------------------------
 // untouched rows: the dominant kernel of a training step (HBM-bound, 6 table sweeps)
 // ---------------------------------------------------------------------------------------------------------
-template <int LPR>
+template <int LPR, int UNR, bool NT, bool CHUNKED = false>
 __global__ __launch_bounds__(kStreamBlock) void adam_untouched_kernel(float4* __restrict__ P, float4* __restrict__ M,
                                                                     float4* __restrict__ V, int64_t n4,
                                                                     const uint32_t* __restrict__ touched, AdamK k,
                                                                     double* __restrict__ reg_partials) {
     __shared__ double s_red[kStreamBlock];
     double reg = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kStreamBlock;
-    constexpr int UNR = 4;
-    for (int64_t i0 = (int64_t)blockIdx.x * kStreamBlock + threadIdx.x; i0 < n4; i0 += stride * UNR) {
+    // CHUNKED: every block sweeps one contiguous slice of the arrays (DRAM-page friendly) instead of a grid-wide stride
+    const int64_t stride = CHUNKED ? (int64_t)kStreamBlock : (int64_t)gridDim.x * kStreamBlock;
+    const int64_t slice = (((n4 + gridDim.x - 1) / gridDim.x) + kStreamBlock * UNR - 1) / (kStreamBlock * UNR) * (kStreamBlock * UNR);
+    const int64_t begin = CHUNKED ? (int64_t)blockIdx.x * slice + threadIdx.x : (int64_t)blockIdx.x * kStreamBlock + threadIdx.x;
+    const int64_t limit = CHUNKED ? min(n4, ((int64_t)blockIdx.x + 1) * slice) : n4;
+    for (int64_t i0 = begin; i0 < limit; i0 += stride * UNR) {
         float4 p[UNR], m[UNR], v[UNR];
         bool live[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t i = i0 + u * stride;
             live[u] = false;
-            if (i < n4) {
+            if (i < limit) {
                 const int64_t row = i / LPR;
                 live[u] = !((touched[row >> 5] >> (row & 31)) & 1u);
             }
             if (live[u]) {
-                p[u] = nt_load(&P[i]);
-                m[u] = nt_load(&M[i]);
-                v[u] = nt_load(&V[i]);
+                p[u] = NT ? nt_load(&P[i]) : P[i];
+                m[u] = NT ? nt_load(&M[i]) : M[i];
+                v[u] = NT ? nt_load(&V[i]) : V[i];
             }
         }
 #pragma unroll
@@ -118,9 +122,8 @@ __global__ __launch_bounds__(kStreamBlock) void adam_untouched_kernel(float4* __
             if (live[u]) {
                 const int64_t i = i0 + u * stride;
                 reg += adam4(p[u], m[u], v[u], make_float4(0.f, 0.f, 0.f, 0.f), k);
-                nt_store(p[u], &P[i]);
-                nt_store(m[u], &M[i]);
-                nt_store(v[u], &V[i]);
+                if (NT) { nt_store(p[u], &P[i]); nt_store(m[u], &M[i]); nt_store(v[u], &V[i]); }
+                else { P[i] = p[u]; M[i] = m[u]; V[i] = v[u]; }
             }
         }
     }
@@ -393,16 +396,34 @@ extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, in
     SATRANS_REQUIRE(total_rows > 0, SATRANS_E_BADARG, "embed_adam_untouched: total_rows=%lld", (long long)total_rows);
     const AdamK k = make_adamk(*h);
     const int64_t n4 = total_rows * (D / 4);
-    // Grid: kStreamBlocks (8 blocks per CU) saturates HBM when the kernel runs alone (grid_blocks = 0).  When it is
-    // overlapped with the compute-bound layer kernels a smaller persistent grid leaves wave slots to them (measured:
-    // 512 blocks is the best trade on MI355X); the partial-sum slots beyond the grid are cleared.
-    const int blocks = grid_blocks > 0 && grid_blocks < kStreamBlocks ? grid_blocks : kStreamBlocks;
+    // Grid: measured on MI355X (tools/adam_sweep.sh, 841 MB x 3 arrays): 512-768 persistent blocks of 256 threads reach
+    // 5.3-5.4 TB/s, 2048 blocks 4.7 TB/s, 256 blocks 3.8 TB/s; the contiguous-slice-per-block form is 6 % slower than the
+    // grid-wide stride.  512 also leaves wave slots to the layer kernels when the call runs on a side stream.
+    // grid_blocks / SATRANS_ADAM_BLOCKS override; partial-sum slots beyond the grid are cleared.
+    static const int env_blocks = getenv("SATRANS_ADAM_BLOCKS") ? atoi(getenv("SATRANS_ADAM_BLOCKS")) : 0;
+    const int want_blocks = env_blocks > 0 ? env_blocks : grid_blocks;
+    const int blocks = want_blocks > 0 ? std::min(want_blocks, kStreamBlocks) : 512;
     if (blocks < kStreamBlocks) {
         hipError_t e = hipMemsetAsync(reg_partials + blocks, 0, sizeof(double) * (kStreamBlocks - blocks), stream);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_adam_untouched: memset: %s", hipGetErrorString(e));
     }
-    DISPATCH_LPR(D, (adam_untouched_kernel<LPR><<<blocks, kStreamBlock, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, n4, touched, k, reg_partials)));
+    // tuning knob for experiments: SATRANS_ADAM_VARIANT = 0 (UNR 4, non-temporal; default) | 1 (UNR 8, nt) | 2 (UNR 4,
+    // cached) | 3 (UNR 8, cached) | 4 (UNR 2, nt)
+    static const int variant = getenv("SATRANS_ADAM_VARIANT") ? atoi(getenv("SATRANS_ADAM_VARIANT")) : 0;
+#define LAUNCH_ADAM(UNR_, NT_, ...)                                                                              \
+    DISPATCH_LPR(D, (adam_untouched_kernel<LPR, UNR_, NT_, ##__VA_ARGS__><<<blocks, kStreamBlock, 0, stream>>>(  \
+                        (float4*)arena, (float4*)m, (float4*)v, n4, touched, k, reg_partials)))
+    switch (variant) {
+        case 1: LAUNCH_ADAM(8, true); break;
+        case 2: LAUNCH_ADAM(4, false); break;
+        case 3: LAUNCH_ADAM(8, false); break;
+        case 4: LAUNCH_ADAM(2, true); break;
+        case 5: LAUNCH_ADAM(4, true, true); break;
+        case 6: LAUNCH_ADAM(8, true, true); break;
+        case 7: LAUNCH_ADAM(2, true, true); break;
+        default: LAUNCH_ADAM(4, true); break;
+    }
+#undef LAUNCH_ADAM
     SATRANS_CHECK_LAUNCH("adam_untouched_kernel");
     return SATRANS_OK;
 }

@@ -490,7 +490,7 @@ class PathEngine:
                                                           self.adam_v.data_ptr(), self.total_rows, self.D,
                                                           ws["touched"].data_ptr(), C.byref(h_emb),
                                                           ws["reg_partials"].data_ptr(),
-                                                          512 if self.overlap else 0, self._stream()),
+                                                          0, self._stream()),
                     "satrans_embed_adam_untouched")
 
     # ------------------------------------------------------------------------------------------------

@@ -272,3 +272,37 @@ def test_other_layer_implementations_match_golden_too(name, impl):
             np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
     finally:
         N.check(N.lib().satrans_set_layer_impl(0), "set_layer_impl")
+
+
+def test_fit_predict_at_baseline_config_scale():
+    """BASELINE configs[1] through the public API: 50,000 AliCCP-shaped rows (tables capped at 20k rows per field to
+    keep the test light), batch 8192 with a partial last batch, shuffle on, verbose=2 (per-step sklearn metrics),
+    then predict at batch 32768.  Checks History, shapes/dtypes, that the loss goes down, and that predict() agrees
+    with the CPU oracle evaluated on the trained weights."""
+    from satrans_amd import SATrans, SparseFeat
+    import bench
+    rng = np.random.RandomState(0)
+    N = 50000
+    vocab = {f: min(bench.ALICCP_MAX[f], 20000) + 2 for f in bench.ALICCP_FIELDS}
+    cols = [SparseFeat(f, vocabulary_size=vocab[f], embedding_dim=32) for f in bench.ALICCP_FIELDS]
+    x = {f: rng.randint(1 if f == '301' else 0, vocab[f] - 1, size=N) for f in bench.ALICCP_FIELDS}
+    # labels depend on two fields so that there is something to learn
+    y = ((x['121'] % 2 == 0) & (rng.rand(N) < 0.5) | (rng.rand(N) < 0.05)).astype(np.float32)
+    model = SATrans(cols, cols, ['301'], [3], att_layer_num=0, domain_att_layer_num=3, att_head_num=4,
+                    use_linear=False, use_dnn=False, meta_mode='QK', seed='1021', device=DEV, flag='sota')
+    model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy",
+                  metrics=["binary_crossentropy", "auc"])
+    hist = model.fit(x=dict(x), y=y, batch_size=8192, epochs=3, verbose=2)
+    assert list(hist.history) == ["loss", "binary_crossentropy", "auc"] and len(hist.history["loss"]) == 3
+    assert hist.history["loss"][-1] < hist.history["loss"][0]
+    assert hist.history["auc"][-1] > 0.6
+    pred = model.predict(dict(x), 8192 * 4)
+    assert pred.shape == (N, 1) and pred.dtype == np.float64 and np.isfinite(pred).all()
+    # oracle on the trained weights, first 4096 rows
+    spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(bench.ALICCP_FIELDS)], dense=[], domain_cols=[18],
+                      embedding_dim=32, head_num=4, layer_num=3, flag='sota', meta_mode='QK', meta_units=[32, 64, 32])
+    X = np.stack([x[f] for f in bench.ALICCP_FIELDS], axis=1).astype(np.float32)[:4096]
+    p_ref, _ = O.forward(sd_to_cpu(model), torch.from_numpy(X), spec)
+    np.testing.assert_allclose(pred[:4096], p_ref.numpy().astype(np.float64), rtol=0, atol=5e-6)
+    ev = model.evaluate(dict(x), y, 8192 * 4)
+    assert set(ev) == {"binary_crossentropy", "auc"}
