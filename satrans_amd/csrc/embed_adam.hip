@@ -163,13 +163,12 @@ __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict_
                                                             const int32_t* __restrict__ src, int64_t n,
                                                             const float4* __restrict__ gemb, float4* __restrict__ partial,
                                                             int32_t* __restrict__ info, int32_t* __restrict__ trail_row,
-                                                            AdamK k, double* __restrict__ reg_partials) {
-    __shared__ double s_red[256];
+                                                            float4* __restrict__ rowsum, int32_t* __restrict__ head_of) {
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
     const int64_t start = group * kChunk;
-    double reg = 0.0;
     if (start < n) {
+        int64_t head = start;          // position where the current run started
         const int64_t end = min(n, start + (int64_t)kChunk);
         const int32_t prev_row = start > 0 ? sorted_rows[start - 1] : -1;
         const int32_t next_row = end < n ? sorted_rows[end] : -1;
@@ -177,32 +176,73 @@ __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict_
         bool begins = cur != prev_row;
         int flags = 0;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t j = start; j <= end; ++j) {
-            const int32_t row = j < end ? sorted_rows[j] : -2;  // sentinel flushes the last piece
-            if (row != cur) {
-                const bool ends = j < end ? true : (next_row != cur);
-                if (begins && ends) {
-                    const int64_t at = (int64_t)cur * LPR + q;
-                    float4 p = P[at], m = M[at], v = V[at];
-                    reg += adam4(p, m, v, acc, k);
-                    P[at] = p; M[at] = m; V[at] = v;
-                } else if (!begins) {
-                    partial[(group * 2 + 0) * LPR + q] = acc;
-                    flags |= 2 | (ends ? 4 : 0);
-                } else {
-                    partial[(group * 2 + 1) * LPR + q] = acc;
-                    flags |= 1;
-                    if (q == 0) trail_row[group] = cur;
-                }
-                if (j == end) break;
-                cur = row;
-                begins = true;
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // a run that lies inside this chunk is complete: its sum goes to rowsum[head] and head_of[head] = 1; the
+        // optimizer step itself is a separate, fully parallel launch (one dependent load->store chain per row here
+        // would serialise ~25 HBM round trips per chunk)
+        auto flush = [&](bool ends) {
+            const bool complete = begins && ends;
+            if (q == 0) head_of[head] = complete ? 1 : 0;
+            if (complete) {
+                rowsum[head * LPR + q] = acc;
+            } else if (!begins) {
+                partial[(group * 2 + 0) * LPR + q] = acc;
+                flags |= 2 | (ends ? 4 : 0);
+            } else {
+                partial[(group * 2 + 1) * LPR + q] = acc;
+                flags |= 1;
+                if (q == 0) trail_row[group] = cur;
             }
-            const float4 g = gemb[(int64_t)src[j] * LPR + q];
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        };
+        // positions in batches of 8: the ids, source positions and the 8 gradient rows of a batch are loaded together
+        // (8 independent 16-byte loads in flight per lane), then consumed in position order
+        constexpr int kBatch = 8;
+        for (int64_t jb = start; jb < end; jb += kBatch) {
+            int32_t r[kBatch];
+            float4 g[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int64_t j = jb + u;
+                const bool ok = j < end;
+                r[u] = ok ? sorted_rows[j] : -2;
+                const int32_t sidx = ok ? src[j] : 0;
+                g[u] = ok ? gemb[(int64_t)sidx * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (jb + u < end) {
+                    if (r[u] != cur) {
+                        flush(true);
+                        cur = r[u];
+                        begins = true;
+                        head = jb + u;
+                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    if (q == 0 && jb + u != head) head_of[jb + u] = 0;
+                    acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w;
+                }
+            }
         }
+        flush(next_row != cur);
         if (q == 0) info[group] = flags;
+    }
+}
+
+// Adam on every row whose run was complete inside one chunk: one lane group per sorted position
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                           float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
+                                                           int64_t n, const float4* __restrict__ rowsum,
+                                                           const int32_t* __restrict__ head_of, AdamK k,
+                                                           double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    double reg = 0.0;
+    if (j < n && head_of[j] == 1) {
+        const int64_t at = (int64_t)sorted_rows[j] * LPR + q;
+        float4 p = P[at], m = M[at], v = V[at];
+        reg += adam4(p, m, v, rowsum[j * LPR + q], k);
+        P[at] = p; M[at] = m; V[at] = v;
     }
     const double total = block_sum(reg, s_red);
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
@@ -302,7 +342,11 @@ static SortLayout sort_layout(int64_t n, int64_t total_rows) {
     return L;
 }
 
-static int64_t touched_blocks(int64_t n, int D) {
+static int64_t touched_blocks(int64_t n, int D) {   // blocks of the per-position apply kernel (the larger of the two)
+    const int lpr = D / 4;
+    return ceil_div(n * lpr, 256);
+}
+static int64_t chunk_blocks(int64_t n, int D) {
     const int lpr = D / 4;
     return ceil_div(ceil_div(n, kChunk) * lpr, 256);
 }
@@ -357,10 +401,10 @@ extern "C" int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int
     return kStreamBlocks + 2 * touched_blocks(n, D);
 }
 
-// partial_ws: [chunks][2][D] floats, then [chunks] int32 info, then [chunks] int32 trail_row
+// partial_ws: [chunks][2][D] floats, [chunks] int32 info, [chunks] int32 trail_row, [n][D] run sums, [n] int32 head flags
 extern "C" int64_t satrans_embed_partial_ws_floats(int64_t n, int D) {
     const int64_t chunks = ceil_div(n, kChunk);
-    return chunks * 2 * D + 2 * chunks;
+    return chunks * 2 * D + 2 * chunks + 4 + n * D + n;
 }
 
 extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
@@ -375,14 +419,21 @@ extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int 
     float4* partial = (float4*)partial_ws;
     int32_t* info = (int32_t*)(partial_ws + chunks * 2 * D);
     int32_t* trail_row = info + chunks;
-    const int64_t blocks = touched_blocks(n, D);
+    const int64_t blocks = touched_blocks(n, D), cblocks = chunk_blocks(n, D);
     double* reg_a = reg_partials + kStreamBlocks;
     double* reg_b = reg_a + blocks;
-    DISPATCH_LPR(D, (touched_chunks_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
+    int64_t off = chunks * 2 * D + 2 * chunks;
+    off = (off + 3) & ~(int64_t)3;                     // keep the run sums 16-byte aligned
+    float4* rowsum = (float4*)(partial_ws + off);
+    int32_t* head_of = (int32_t*)(partial_ws + off + n * D);
+    DISPATCH_LPR(D, (touched_chunks_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, sorted_rows, src, n, (const float4*)gemb, partial, info,
-                        trail_row, k, reg_a)));
+                        trail_row, rowsum, head_of)));
     SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
-    DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
+    DISPATCH_LPR(D, (touched_apply_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, n, (const float4*)rowsum, head_of, k, reg_a)));
+    SATRANS_CHECK_LAUNCH("touched_apply_kernel");
+    DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)partial, info, trail_row, k, reg_b)));
     SATRANS_CHECK_LAUNCH("touched_spans_kernel");
     return SATRANS_OK;
