@@ -74,6 +74,7 @@ int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_stride, int 
  *   row_off    [F+1] int64 (device)
  *   cols       [F] int32 (device): X column of field f
  *   out        [B, F, D]
+ *   out        may be NULL: rows-only mode (ids -> arena rows, nothing is moved)
  *   rows_out   optional [B, F] int32: arena row of every gathered id (kept for the backward pass)
  *   status     [1] int32: set to 1 when an id falls outside its table
  * Bit-exact: every output element is a copy.
@@ -189,6 +190,25 @@ int64_t satrans_embed_partial_ws_floats(int64_t n, int D);
 int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
                                  const uint32_t* touched, const satrans_adam_hparams* h,
                                  double* reg_partials, int grid_blocks, void* stream);
+
+/* Lazy-exact form of the dense step (same tables bit for bit, HBM traffic only for touched rows): instead of
+ * satrans_embed_adam_untouched every step, the regulariser-only Adam steps of a row are postponed and replayed with
+ * identical arithmetic when the row is next gathered (replay, over the distinct rows of the sorted ids, BEFORE the
+ * gather of that step) or for all rows (flush: epoch end, before predict / state_dict).
+ *   last   [total_rows] int32: last step applied to each row (0 initially)
+ *   table  [>= target+1][2] fp32: table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s)), filled by the host
+ *   h      beta1, beta2, eps, l2 (lr_over_bc1 / bc2_sqrt are ignored)
+ *   reg_partials [satrans_embed_lazy_reg_partials(n, D)] doubles (zero-initialised by the caller): per-block sums of
+ *          l2*p^2 over the replayed steps; replay writes the first ceil(n*D/256) slots, flush the 4096 after them.
+ * satrans_embed_lazy_mark sets last[r] = t for the distinct rows of a step after their Adam update. */
+int64_t satrans_embed_lazy_reg_partials(int64_t n, int D);
+int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32_t* last, int D, const int32_t* sorted_rows,
+                              int64_t n, int target, const float* table, const satrans_adam_hparams* h,
+                              double* reg_partials, void* stream);
+int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_t* last, int64_t total_rows, int D, int target,
+                             const float* table, const satrans_adam_hparams* h, int64_t n, double* reg_partials,
+                             void* stream);
+int satrans_embed_lazy_mark(const int32_t* sorted_rows, int64_t n, int32_t* last, int t, void* stream);
 
 /* Dense materialisation of the embedding gradient (debug / parity tests only):
  * g_arena [total_rows, D] += scatter of gemb by rows (position order), + 2*l2*p when l2 != 0. */

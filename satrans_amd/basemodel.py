@@ -156,6 +156,9 @@ class BaseModel(nn.Module):
         self._engine = None
 
     def _apply(self, fn, *args, **kwargs):
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.flush_lazy()          # postponed optimizer steps must land before the storage is rebuilt
         out = super()._apply(fn, *args, **kwargs)
         if self.embedding_arena is not None:
             self._rebind_storage()
@@ -377,9 +380,20 @@ class BaseModel(nn.Module):
     def _require_engine(self):
         raise NotImplementedError
 
+    def _flush_engine(self):
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.flush_lazy()
+
+    def state_dict(self, *args, **kwargs):
+        """The tables are brought up to date first (postponed regulariser-only Adam steps, see engine.flush_lazy)."""
+        self._flush_engine()
+        return super().state_dict(*args, **kwargs)
+
     def get_regularization_loss(self):
         """sum(l2 * w^2) over the embedding tables (models/meta_basemodel.py:577-593) as a [1] tensor.
         A convenience for callers; the training step computes the same sum inside the optimizer kernels."""
+        self._flush_engine()
         total = torch.zeros((1,), device=self.embedding_arena.device)
         if self.l2_reg_embedding > 0:
             total += self.l2_reg_embedding * torch.sum(torch.square(self.embedding_arena.double())).float()

@@ -45,19 +45,27 @@ __host__ inline AdamK make_adamk(const satrans_adam_hparams& h) {
     return k;
 }
 
+// One Adam update of one element.  Every product / sum is spelled out (fmaf, __fmul_rn, ...) so that hipcc cannot
+// contract the expression differently in different kernels: the streaming kernel, the touched-row kernels and the
+// lazy replay must produce bit-identical tables.
+__device__ __forceinline__ void adam_core(float& p, float& m, float& v, float g, float neg_step, float bc2_sqrt, float w1,
+                                          float beta2, float w2, float eps) {
+    m = fmaf(w1, __fsub_rn(g, m), m);                               // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
+    v = fmaf(__fmul_rn(w2, g), g, __fmul_rn(v, beta2));             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step, m), denom));     // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, const AdamK& k) {
-    m = m + k.w1 * (g - m);                        // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
-    v = v * k.beta2 + (k.w2 * g) * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
-    p = p + (k.neg_step * m) / denom;              // param.addcdiv_(exp_avg, denom, value=-step_size)
+    adam_core(p, m, v, g, k.neg_step, k.bc2_sqrt, k.w1, k.beta2, k.w2, k.eps);
 }
 
 __device__ __forceinline__ double adam4(float4& p, float4& m, float4& v, float4 g, const AdamK& k) {
     const double reg = (double)k.l2 * ((double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z + (double)p.w * p.w);
-    adam1(p.x, m.x, v.x, g.x + k.l2x2 * p.x, k);
-    adam1(p.y, m.y, v.y, g.y + k.l2x2 * p.y, k);
-    adam1(p.z, m.z, v.z, g.z + k.l2x2 * p.z, k);
-    adam1(p.w, m.w, v.w, g.w + k.l2x2 * p.w, k);
+    adam1(p.x, m.x, v.x, __fadd_rn(g.x, __fmul_rn(k.l2x2, p.x)), k);
+    adam1(p.y, m.y, v.y, __fadd_rn(g.y, __fmul_rn(k.l2x2, p.y)), k);
+    adam1(p.z, m.z, v.z, __fadd_rn(g.z, __fmul_rn(k.l2x2, p.z)), k);
+    adam1(p.w, m.w, v.w, __fadd_rn(g.w, __fmul_rn(k.l2x2, p.w)), k);
     return reg;
 }
 
@@ -278,6 +286,111 @@ __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Lazy-exact form of the dense step.  A row that is not gathered at step s still takes the Adam step of the reference
+// (gradient 2*l2*p from the regulariser).  That update depends on nothing but the row's own (p, m, v) and on s (bias
+// corrections), so it can be postponed: `last[r]` is the last step applied to row r, and the pending steps
+// last[r]+1 .. target are replayed - the same adam1 arithmetic, the per-step constants read from a table the host
+// fills exactly as it would fill satrans_adam_hparams - right before the row is next gathered (replay kernel, over
+// the run heads of the sorted ids) or for all rows at once (flush kernel: epoch end, before predict / state_dict).
+// Bitwise the same tables as the every-step streaming kernel, with HBM traffic only for rows that are touched.
+// Each replayed step also contributes l2*|p|^2 (its pre-update value) to the regulariser sum of the epoch.
+// ---------------------------------------------------------------------------------------------------------
+struct LazyK {
+    float w1, beta2, w2, eps, l2x2, l2;
+};
+__host__ inline LazyK make_lazyk(const satrans_adam_hparams& h) {
+    LazyK k;
+    k.w1 = (float)(1.0 - (double)h.beta1);
+    k.beta2 = h.beta2;
+    k.w2 = (float)(1.0 - (double)h.beta2);
+    k.eps = h.eps;
+    k.l2 = h.l2;
+    k.l2x2 = 2.0f * h.l2;
+    return k;
+}
+
+// one element per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s))
+__device__ __forceinline__ double replay_element(float& p, float& m, float& v, int from, int to,
+                                                 const float2* __restrict__ table, const LazyK& k) {
+    double reg = 0.0;
+    for (int s = from + 1; s <= to; ++s) {
+        const float2 hp = table[s];
+        reg += (double)k.l2 * ((double)p * p);
+        // gradient of a row that was not gathered: 0 + 2*l2*p, the same expression the streaming kernel evaluates
+        const float g = __fadd_rn(0.f, __fmul_rn(k.l2x2, p));
+        adam_core(p, m, v, g, -hp.x, hp.y, k.w1, k.beta2, k.w2, k.eps);
+    }
+    return reg;
+}
+
+// replay for the rows of one batch: one group of D lanes per sorted position, run heads only
+template <int D>
+__global__ __launch_bounds__(256) void lazy_replay_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+                                                         int32_t* __restrict__ last, const int32_t* __restrict__ sorted_rows,
+                                                         int64_t n, int target, const float2* __restrict__ table, LazyK k,
+                                                         double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D;
+    const int c = threadIdx.x % D;
+    double reg = 0.0;
+    if (j < n) {
+        const int32_t row = sorted_rows[j];
+        const bool head = j == 0 || sorted_rows[j - 1] != row;
+        if (head) {
+            const int from = last[row];
+            if (from < target) {
+                const int64_t at = (int64_t)row * D + c;
+                float p = P[at], m = M[at], v = V[at];
+                reg = replay_element(p, m, v, from, target, table, k);
+                P[at] = p; M[at] = m; V[at] = v;
+            }
+        }
+    }
+    // every lane of a row has read last[row] before any lane overwrites it
+    __syncthreads();
+    if (j < n && c == 0) {
+        const int32_t row = sorted_rows[j];
+        if ((j == 0 || sorted_rows[j - 1] != row) && last[row] < target) last[row] = target;
+    }
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// replay for every row of the arena
+template <int D>
+__global__ __launch_bounds__(256) void lazy_flush_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+                                                        int32_t* __restrict__ last, int64_t total_rows, int target,
+                                                        const float2* __restrict__ table, LazyK k,
+                                                        double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    double reg = 0.0;
+    const int64_t groups_per_pass = (int64_t)gridDim.x * 256 / D;
+    const int c = threadIdx.x % D;
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D; row < total_rows; row += groups_per_pass) {
+        const int from = last[row];
+        if (from < target) {
+            const int64_t at = row * D + c;
+            float p = P[at], m = M[at], v = V[at];
+            reg += replay_element(p, m, v, from, target, table, k);
+            P[at] = p; M[at] = m; V[at] = v;
+        }
+    }
+    __syncthreads();    // all reads of last[] in this block are done; blocks own disjoint rows
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D; row < total_rows; row += groups_per_pass)
+        if (c == 0 && last[row] < target) last[row] = target;
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+__global__ void mark_last_kernel(const int32_t* __restrict__ sorted_rows, int64_t n, int32_t* __restrict__ last, int t) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t row = sorted_rows[j];
+    if (j == 0 || sorted_rows[j - 1] != row) last[row] = t;
+}
+
 // debug / parity: dense gradient of the arena
 template <int LPR>
 __global__ void grad_dense_kernel(const int32_t* __restrict__ sorted_rows, const int32_t* __restrict__ src, int64_t n,
@@ -307,7 +420,7 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float pp = p[i], mm = m[i], vv = v[i];
-    adam1(pp, mm, vv, g[i] + k.l2x2 * pp, k);
+    adam1(pp, mm, vv, __fadd_rn(g[i], __fmul_rn(k.l2x2, pp)), k);
     p[i] = pp; m[i] = mm; v[i] = vv;
 }
 
@@ -511,5 +624,63 @@ extern "C" int satrans_sum_f64(const double* vals, int64_t count, double* out, i
     SATRANS_REQUIRE(vals && out && count >= 0, SATRANS_E_BADARG, "sum_f64: bad arguments");
     sum_f64_kernel<<<1, 256, 0, stream>>>(vals, count, out, accumulate);
     SATRANS_CHECK_LAUNCH("sum_f64_kernel");
+    return SATRANS_OK;
+}
+
+// ---- lazy-exact path ---------------------------------------------------------------------------------------------
+constexpr int kFlushBlocks = 4096;
+
+extern "C" int64_t satrans_embed_lazy_reg_partials(int64_t n, int D) { return ceil_div(n * D, 256) + kFlushBlocks; }
+
+#define DISPATCH_D(D, CALL)                                                          \
+    switch (D) {                                                                     \
+        case 16: { constexpr int DD = 16; CALL; } break;                             \
+        case 32: { constexpr int DD = 32; CALL; } break;                             \
+        case 64: { constexpr int DD = 64; CALL; } break;                             \
+        case 128: { constexpr int DD = 128; CALL; } break;                           \
+        default:                                                                     \
+            ::satrans::set_error("embedding_dim %d not in {16,32,64,128}", (D));     \
+            return SATRANS_E_UNSUPPORTED;                                            \
+    }
+
+// Replays the pending regulariser-only steps (last[r], target] of every distinct row in sorted_rows.
+// table [>= target + 1] float2: table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s)); h supplies beta1, beta2, eps, l2.
+// reg_partials: satrans_embed_lazy_reg_partials(n, D) doubles; this call writes the first ceil(n*D/256).
+extern "C" int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32_t* last, int D,
+                                         const int32_t* sorted_rows, int64_t n, int target, const float* table,
+                                         const satrans_adam_hparams* h, double* reg_partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && m && v && last && sorted_rows && table && h && reg_partials, SATRANS_E_BADARG,
+                    "embed_lazy_replay: null pointer");
+    SATRANS_REQUIRE(n > 0 && target >= 0, SATRANS_E_BADARG, "embed_lazy_replay: n=%lld target=%d", (long long)n, target);
+    const LazyK k = make_lazyk(*h);
+    const int64_t blocks = ceil_div(n * D, 256);
+    DISPATCH_D(D, (lazy_replay_kernel<DD><<<(unsigned)blocks, 256, 0, stream>>>(arena, m, v, last, sorted_rows, n, target,
+                                                                                (const float2*)table, k, reg_partials)));
+    SATRANS_CHECK_LAUNCH("lazy_replay_kernel");
+    return SATRANS_OK;
+}
+
+// Brings EVERY row to step `target`.  Writes reg_partials[ceil(n*D/256) ...+kFlushBlocks) where n is the batch row count
+// the workspace was sized for (pass the same n).
+extern "C" int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_t* last, int64_t total_rows, int D,
+                                        int target, const float* table, const satrans_adam_hparams* h, int64_t n,
+                                        double* reg_partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && m && v && last && table && h && reg_partials, SATRANS_E_BADARG, "embed_lazy_flush: null pointer");
+    const LazyK k = make_lazyk(*h);
+    double* reg = reg_partials + ceil_div(n * D, 256);
+    DISPATCH_D(D, (lazy_flush_kernel<DD><<<kFlushBlocks, 256, 0, stream>>>(arena, m, v, last, total_rows, target,
+                                                                          (const float2*)table, k, reg)));
+    SATRANS_CHECK_LAUNCH("lazy_flush_kernel");
+    return SATRANS_OK;
+}
+
+// last[r] = t for every distinct row of sorted_rows (after the touched-row Adam of step t)
+extern "C" int satrans_embed_lazy_mark(const int32_t* sorted_rows, int64_t n, int32_t* last, int t, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(sorted_rows && last && n > 0, SATRANS_E_BADARG, "embed_lazy_mark: bad arguments");
+    mark_last_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(sorted_rows, n, last, t);
+    SATRANS_CHECK_LAUNCH("mark_last_kernel");
     return SATRANS_OK;
 }

@@ -49,13 +49,13 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
             val[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row[r] >= 0) val[r] = arena[row[r] * LPR + q];
+            if (row[r] >= 0 && out) val[r] = arena[row[r] * LPR + q];
         }
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
             const int64_t slot = base + r * stride;
             if (slot < n_rows) {
-                out[slot * LPR + q] = val[r];
+                if (out) out[slot * LPR + q] = val[r];
                 if (q == 0) {
                     if (rows_out) rows_out[slot] = (int32_t)(row[r] >= 0 ? row[r] : 0);
                     if (row[r] == -2) atomicOr(status, 1);
@@ -155,7 +155,7 @@ extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_off, co
                                   int id_dtype, int64_t x_stride, int B, int F, int D, float* out,
                                   int32_t* rows_out, int32_t* status, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SATRANS_REQUIRE(arena && row_off && cols && X && out && status, SATRANS_E_BADARG, "gather_fwd: null pointer");
+    SATRANS_REQUIRE(arena && row_off && cols && X && status && (out || rows_out), SATRANS_E_BADARG, "gather_fwd: null pointer");
     SATRANS_REQUIRE(B > 0 && F > 0, SATRANS_E_BADARG, "gather_fwd: bad sizes B=%d F=%d", B, F);
     SATRANS_REQUIRE(id_dtype >= 0 && id_dtype <= 2, SATRANS_E_BADARG, "gather_fwd: id_dtype %d", id_dtype);
     SATRANS_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, SATRANS_E_UNSUPPORTED,

@@ -129,6 +129,14 @@ class PathEngine:
         import os
         self.overlap = os.environ.get("SATRANS_OVERLAP", "1") != "0"
         self._side = None
+        # Lazy-exact dense Adam (default): the regulariser-only steps of rows that are not gathered are postponed and
+        # replayed - same arithmetic, same result bit for bit - when a row is next gathered, or for all rows by
+        # flush_lazy() (epoch end, before predict / state_dict).  SATRANS_LAZY_ADAM=0: streaming kernel every step.
+        self.lazy = os.environ.get("SATRANS_LAZY_ADAM", "1") != "0"
+        self.last_step = None            # [R] int32: last Adam step applied to every table row
+        self._hp_table = None            # [cap, 2] fp32: (lr / (1 - beta1^s), sqrt(1 - beta2^s)) for step s
+        self._hp_cfg = None
+        self._lazy_pending = False
 
     # ------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -194,6 +202,7 @@ class PathEngine:
         ws["partial_ws"] = torch.empty(int(self.lib.satrans_embed_partial_ws_floats(n_rows, D)), **f32)
         ws["reg_partials"] = torch.zeros(int(self.lib.satrans_embed_reg_partials(self.total_rows, n_rows, D)),
                                          dtype=torch.float64, device=dev)
+        ws["replay_reg"] = torch.zeros((n_rows * D + 255) // 256, dtype=torch.float64, device=dev)
         ws[key] = True
         return ws
 
@@ -313,6 +322,7 @@ class PathEngine:
                                      ws["head_scratch"].data_ptr(), st), "satrans_head")
 
     def forward(self, X: torch.Tensor, training: bool = False, capture_attention: bool = False) -> torch.Tensor:
+        self.flush_lazy()
         X = self._prepare_input(X)
         B = X.shape[0]
         ws = self.workspace(B)
@@ -357,6 +367,8 @@ class PathEngine:
             self.flat_v = torch.zeros_like(m.flat_params)
             self.adam_m = torch.zeros_like(m.embedding_arena)
             self.adam_v = torch.zeros_like(m.embedding_arena)
+            self.last_step = torch.zeros(self.total_rows, dtype=torch.int32, device=self.dev)
+            self._flush_reg = torch.zeros(4096, dtype=torch.float64, device=self.dev)
             # expose gradients the torch way: param.grad is a view into the flat gradient buffer
             for name, p in m._trainable_flat().items():
                 off, cnt = m._flat_slices[name]
@@ -371,6 +383,7 @@ class PathEngine:
         self.reg_sum.zero_()
 
     def epoch_sums(self):
+        self.flush_lazy()          # the regulariser sums of postponed steps belong to this epoch
         return float(self.loss_sum.item()), float(self.reg_sum.item())
 
     def _hparams(self, l2: float) -> N.AdamHParams:
@@ -441,16 +454,19 @@ class PathEngine:
         side_done = None
         h_emb = None
 
-        def early(ws_):
-            nonlocal side_done, h_emb
-            rows = parallel.gather_rows(ws_["rows"]) if world > 1 else ws_["rows"]
-            self.adam_t += 1
-            h_emb = self._hparams(m.l2_reg_embedding)
+        def sort_rows(ws_, rows):
             with self.phase("embed_sort"):
                 N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws_["sorted_rows"].data_ptr(),
                                                ws_["src"].data_ptr(), ws_["touched"].data_ptr(),
                                                ws_["sort_ws"].data_ptr(), ws_["sort_ws"].numel(), self._stream()),
                         "satrans_embed_sort")
+
+        def early(ws_):
+            nonlocal side_done, h_emb
+            rows = parallel.gather_rows(ws_["rows"]) if world > 1 else ws_["rows"]
+            self.adam_t += 1
+            h_emb = self._hparams(m.l2_reg_embedding)
+            sort_rows(ws_, rows)
             if self.overlap:
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.dev)
@@ -464,6 +480,31 @@ class PathEngine:
             else:
                 self._launch_untouched(ws_, h_emb)
 
+        if self.lazy:
+            # rows of this batch first (ids -> arena rows, nothing moved), sort them, and replay the postponed
+            # regulariser-only steps of exactly those rows up to step t-1, so that the gather below reads current values
+            idt = N.id_dtype_of(X)
+            st0 = self._stream()
+            N.check(lib.satrans_gather_fwd(m.embedding_arena.data_ptr(), self.row_off.data_ptr(), self.cols.data_ptr(),
+                                           X.data_ptr(), idt, X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
+                                           self.status.data_ptr(), st0), "satrans_gather_fwd(rows)")
+            rows = parallel.gather_rows(ws["rows"]) if world > 1 else ws["rows"]
+            sort_rows(ws, rows)
+            h_emb = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
+            self.adam_t += 1
+            if self.adam_t > 1:
+                table = self._table(self.adam_t)
+                with self.phase("lazy_replay"):
+                    N.check(lib.satrans_embed_lazy_replay(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                                          self.adam_v.data_ptr(), self.last_step.data_ptr(), D,
+                                                          ws["sorted_rows"].data_ptr(), n_rows, self.adam_t - 1,
+                                                          table.data_ptr(), C.byref(h_emb), ws["replay_reg"].data_ptr(),
+                                                          st0), "satrans_embed_lazy_replay")
+                N.check(lib.satrans_sum_f64(ws["replay_reg"].data_ptr(), ws["replay_reg"].numel(),
+                                            self.reg_sum.data_ptr(), 1, st0), "satrans_sum_f64")
+            h_emb = self._hparams(m.l2_reg_embedding)
+            early = None
+
         gemb = self.backward(X, y, ws, after_gather=early)
         if world > 1:
             gemb = parallel.exchange_grads(self.flat_g, gemb)
@@ -474,6 +515,10 @@ class PathEngine:
                                                    ws["src"].data_ptr(), n_rows, gemb.data_ptr(),
                                                    ws["partial_ws"].data_ptr(), C.byref(h_emb),
                                                    ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_touched")
+        if self.lazy:
+            N.check(lib.satrans_embed_lazy_mark(ws["sorted_rows"].data_ptr(), n_rows, self.last_step.data_ptr(),
+                                                self.adam_t, st), "satrans_embed_lazy_mark")
+            self._lazy_pending = True
         h_flat = self._hparams(0.0)
         N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                       self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st),
@@ -482,6 +527,34 @@ class PathEngine:
             main.wait_event(side_done)
         N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(),
                                     1, st), "satrans_sum_f64")
+
+    def _table(self, upto: int) -> torch.Tensor:
+        """Per-step Adam constants for the replay kernels, computed on the host exactly like `_hparams`."""
+        cfg = self.m._adam_cfg
+        key = (cfg["lr"], cfg["betas"])
+        if self._hp_table is None or self._hp_cfg != key or self._hp_table.shape[0] <= upto:
+            cap = max(4096, 2 * (upto + 1))
+            b1, b2 = cfg["betas"]
+            rows = [(0.0, 1.0)] + [(cfg["lr"] / (1.0 - b1 ** s), math.sqrt(1.0 - b2 ** s)) for s in range(1, cap)]
+            self._hp_table = torch.tensor(rows, dtype=torch.float32, device=self.dev).contiguous()
+            self._hp_cfg = key
+        return self._hp_table
+
+    def flush_lazy(self):
+        """Bring every table row to the current step (no-op when nothing is pending)."""
+        if not (self.lazy and self._lazy_pending):
+            return
+        m = self.m
+        h = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
+        st = self._stream()
+        table = self._table(self.adam_t)
+        N.check(self.lib.satrans_embed_lazy_flush(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
+                                                  self.adam_v.data_ptr(), self.last_step.data_ptr(), self.total_rows,
+                                                  self.D, self.adam_t, table.data_ptr(), C.byref(h), 0,
+                                                  self._flush_reg.data_ptr(), st), "satrans_embed_lazy_flush")
+        N.check(self.lib.satrans_sum_f64(self._flush_reg.data_ptr(), self._flush_reg.numel(), self.reg_sum.data_ptr(),
+                                         1, st), "satrans_sum_f64")
+        self._lazy_pending = False
 
     def _launch_untouched(self, ws, h_emb):
         m = self.m
@@ -497,6 +570,7 @@ class PathEngine:
     # inspection for the parity tests: one forward+backward, gradients by state_dict key (dense tables)
     # ------------------------------------------------------------------------------------------------
     def loss_and_grads(self, X: torch.Tensor, y: torch.Tensor):
+        self.flush_lazy()
         X = self._prepare_input(X)
         y = y.reshape(-1).to(torch.float32).contiguous()
         B = X.shape[0]

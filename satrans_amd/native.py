@@ -72,6 +72,12 @@ SIGNATURES = {
                                              C.POINTER(AdamHParams), _vp, _vp]),
     "satrans_embed_adam_untouched": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams), _vp,
                                                C.c_int, _vp]),
+    "satrans_embed_lazy_reg_partials": (C.c_int64, [C.c_int64, C.c_int]),
+    "satrans_embed_lazy_replay": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp,
+                                            C.POINTER(AdamHParams), _vp, _vp]),
+    "satrans_embed_lazy_flush": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, C.POINTER(AdamHParams),
+                                           C.c_int64, _vp, _vp]),
+    "satrans_embed_lazy_mark": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp]),
     "satrans_embed_grad_dense": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_float, _vp, _vp]),
     "satrans_sum_f64": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp]),
 }

@@ -306,3 +306,34 @@ def test_fit_predict_at_baseline_config_scale():
     np.testing.assert_allclose(pred[:4096], p_ref.numpy().astype(np.float64), rtol=0, atol=5e-6)
     ev = model.evaluate(dict(x), y, 8192 * 4)
     assert set(ev) == {"binary_crossentropy", "auc"}
+
+
+def test_lazy_adam_is_bitwise_the_streaming_adam():
+    """The lazy-exact optimizer path (postponed regulariser-only steps, replayed before a row is gathered and by the
+    flush) must leave EXACTLY the tables, moments and epoch sums of the every-step streaming kernel."""
+    c = Case("aliccp_sota")
+    rng = np.random.RandomState(11)
+    B, steps = 64, 9
+    Xs = [np.stack([rng.randint(1 if f == "301" else 0, v - 1, size=B) for f, v in zip(c.meta["fields"], c.meta["vocab"])],
+                   axis=1).astype(np.float32) for _ in range(steps)]
+    ys = [(rng.rand(B) < 0.3).astype(np.float32) for _ in range(steps)]
+    results = []
+    for lazy in (True, False):
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy")
+        model.train()
+        eng = model._require_engine()
+        eng.lazy, eng.overlap = lazy, False
+        eng.reset_epoch_sums()
+        for i, (xb, yb) in enumerate(zip(Xs, ys)):
+            eng.train_step(torch.from_numpy(xb).to(DEV), torch.from_numpy(yb).to(DEV))
+            if i == 4:      # a mid-run evaluation forces a flush in lazy mode and must not change anything
+                model.eval(); model(torch.from_numpy(xb).to(DEV)); model.train()
+        bce, reg = eng.epoch_sums()
+        results.append((sd_to_cpu(model), eng.adam_m.cpu(), eng.adam_v.cpu(), bce, reg))
+    (sd_l, m_l, v_l, bce_l, reg_l), (sd_d, m_d, v_d, bce_d, reg_d) = results
+    for k in sd_d:
+        assert torch.equal(sd_l[k], sd_d[k]), k
+    assert torch.equal(m_l, m_d) and torch.equal(v_l, v_d)
+    assert bce_l == bce_d
+    assert reg_l == pytest.approx(reg_d, rel=1e-12)
