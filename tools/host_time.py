@@ -1,0 +1,30 @@
+"""How long does the host need to ENQUEUE one training step (no synchronisation) vs the GPU to execute it?"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+
+model = bench.build_model("cpu", 0.005)
+model.to("cuda:0"); model.device = "cuda:0"
+eng = model._require_engine()
+B = 8192
+X, y = bench.synth_batches(60 * B, 5)
+Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+model.train()
+for i in range(5):
+    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(5, 55):
+    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"host enqueue {1e3 * (t1 - t0) / 50:.3f} ms/step ; wall incl. GPU drain {1e3 * (t2 - t0) / 50:.3f} ms/step")
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for i in range(5, 25):
+    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
