@@ -169,7 +169,8 @@ int satrans_adam_flat(float* p, const float* g, float* m, float* v, int64_t n,
 /* Embedding-gradient pipeline over n = (ranks*)B*F gathered rows.
  *   rows [n] int32 arena rows, gemb [n, D] gradient of every gathered row.
  * step 1 (sort):   sorted_rows[n], src[n] = stable sort of rows with their positions;
- *                  touched bitmap [ceil(total_rows/32)] uint32 is cleared and rebuilt.
+ *                  touched bitmap [ceil(total_rows/32)] uint32 is cleared and rebuilt (pass NULL to skip it: only
+ *                  step 3 reads it).
  * step 2 (touched rows): per distinct row r: g = (sum of its gemb rows in position order) + 2*l2*p[r];
  *                  Adam on arena/m/v row r.
  * step 3 (untouched rows): every row whose bit is clear gets g = 2*l2*p (the reference's dense Adam

@@ -314,15 +314,18 @@ __host__ inline LazyK make_lazyk(const satrans_adam_hparams& h) {
 // one element per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s))
 __device__ __forceinline__ double replay_element(float& p, float& m, float& v, int from, int to,
                                                  const float2* __restrict__ table, const LazyK& k) {
-    double reg = 0.0;
+    // sum of p^2 over the replayed steps in fp32 (<= a few thousand terms of one element: relative error ~1e-7 x steps,
+    // far inside the fp32 reduction the reference itself uses), converted to double once; the sums over elements,
+    // blocks and steps stay in double
+    float sq = 0.f;
     for (int s = from + 1; s <= to; ++s) {
         const float2 hp = table[s];
-        reg += (double)k.l2 * ((double)p * p);
+        sq = fmaf(p, p, sq);
         // gradient of a row that was not gathered: 0 + 2*l2*p, the same expression the streaming kernel evaluates
         const float g = __fadd_rn(0.f, __fmul_rn(k.l2x2, p));
         adam_core(p, m, v, g, -hp.x, hp.y, k.w1, k.beta2, k.w2, k.eps);
     }
-    return reg;
+    return (double)k.l2 * (double)sq;
 }
 
 // replay for the rows of one batch: one group of D lanes per sorted position, run heads only
@@ -424,10 +427,11 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
     p[i] = pp; m[i] = mm; v[i] = vv;
 }
 
-__global__ void sum_f64_kernel(const double* __restrict__ vals, int64_t count, double* __restrict__ out, int accumulate) {
-    __shared__ double s_red[256];
+__global__ __launch_bounds__(1024) void sum_f64_kernel(const double* __restrict__ vals, int64_t count,
+                                                      double* __restrict__ out, int accumulate) {
+    __shared__ double s_red[1024];
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += 256) acc += vals[i];
+    for (int64_t i = threadIdx.x; i < count; i += 1024) acc += vals[i];
     const double total = block_sum(acc, s_red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + total : total;
 }
@@ -487,7 +491,7 @@ extern "C" int64_t satrans_embed_sort_workspace_bytes(int64_t n, int64_t total_r
 extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32_t* sorted_rows, int32_t* src,
                                   uint32_t* touched, void* workspace, int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SATRANS_REQUIRE(rows && sorted_rows && src && touched && workspace, SATRANS_E_BADARG, "embed_sort: null pointer");
+    SATRANS_REQUIRE(rows && sorted_rows && src && workspace, SATRANS_E_BADARG, "embed_sort: null pointer");
     SATRANS_REQUIRE(n > 0 && total_rows > 0 && n < ((int64_t)1 << 31) && total_rows < ((int64_t)1 << 31), SATRANS_E_BADARG,
                     "embed_sort: sizes n=%lld rows=%lld", (long long)n, (long long)total_rows);
     const SortLayout L = sort_layout(n, total_rows);
@@ -496,7 +500,8 @@ extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_
     char* ws = (char*)workspace;
     uint32_t* keys_in = (uint32_t*)(ws + L.keys_in);
     int32_t* pos_in = (int32_t*)(ws + L.pos_in);
-    hipError_t e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)ceil_div(total_rows, 32), stream);
+    hipError_t e = hipSuccess;
+    if (touched) e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)ceil_div(total_rows, 32), stream);
     SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: memset: %s", hipGetErrorString(e));
     iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(rows, n, keys_in, pos_in);
     SATRANS_CHECK_LAUNCH("iota_kernel");
@@ -504,8 +509,10 @@ extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_
     e = rocprim::radix_sort_pairs(ws + L.temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)sorted_rows,
                                   (const int32_t*)pos_in, src, (unsigned)n, 0u, (unsigned)bits_for(total_rows), stream);
     SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: radix sort: %s", hipGetErrorString(e));
-    mark_heads_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(sorted_rows, n, touched);
-    SATRANS_CHECK_LAUNCH("mark_heads_kernel");
+    if (touched) {   // only the every-step streaming Adam needs the bitmap
+        mark_heads_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(sorted_rows, n, touched);
+        SATRANS_CHECK_LAUNCH("mark_heads_kernel");
+    }
     return SATRANS_OK;
 }
 
@@ -622,7 +629,7 @@ extern "C" int satrans_adam_flat(float* p, const float* g, float* m, float* v, i
 extern "C" int satrans_sum_f64(const double* vals, int64_t count, double* out, int accumulate, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(vals && out && count >= 0, SATRANS_E_BADARG, "sum_f64: bad arguments");
-    sum_f64_kernel<<<1, 256, 0, stream>>>(vals, count, out, accumulate);
+    sum_f64_kernel<<<1, 1024, 0, stream>>>(vals, count, out, accumulate);
     SATRANS_CHECK_LAUNCH("sum_f64_kernel");
     return SATRANS_OK;
 }

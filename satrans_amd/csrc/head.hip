@@ -10,7 +10,7 @@
 namespace satrans {
 
 constexpr int kHeadBlock = 256;
-constexpr int kSamplesPerBlock = 32;
+constexpr int kSamplesPerBlock = 8;   // 1024 blocks at B = 8192: the kernel is latency-bound, not bandwidth-bound
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -457,7 +457,7 @@ class PathEngine:
         def sort_rows(ws_, rows):
             with self.phase("embed_sort"):
                 N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws_["sorted_rows"].data_ptr(),
-                                               ws_["src"].data_ptr(), ws_["touched"].data_ptr(),
+                                               ws_["src"].data_ptr(), None if self.lazy else ws_["touched"].data_ptr(),
                                                ws_["sort_ws"].data_ptr(), ws_["sort_ws"].numel(), self._stream()),
                         "satrans_embed_sort")
 
