@@ -51,6 +51,41 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- head-dimension rows as packed pairs: one v_pk_fma_f32 does two of the d multiply-adds of a row ---------------
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+template <int d>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, f32x2 (&r)[d / 2]) {
+#pragma unroll
+    for (int e = 0; e < d; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + e);
+        r[e / 2] = f32x2{t.x, t.y};
+        r[e / 2 + 1] = f32x2{t.z, t.w};
+    }
+}
+template <int d>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const f32x2 (&r)[d / 2], float s) {
+#pragma unroll
+    for (int e = 0; e < d; e += 4)
+        *reinterpret_cast<float4*>(p + e) =
+            make_float4(r[e / 2].x * s, r[e / 2].y * s, r[e / 2 + 1].x * s, r[e / 2 + 1].y * s);
+}
+template <int d>
+__device__ __forceinline__ float dot_row(const f32x2 (&a)[d / 2], const f32x2 (&b)[d / 2]) {
+    f32x2 t = a[0] * b[0];
+#pragma unroll
+    for (int e = 1; e < d / 2; ++e) t = __builtin_elementwise_fma(a[e], b[e], t);
+    return t.x + t.y;
+}
+template <int d>
+__device__ __forceinline__ void axpy_row(float s, const f32x2 (&x)[d / 2], f32x2 (&acc)[d / 2]) {
+    const f32x2 ss = {s, s};
+#pragma unroll
+    for (int e = 0; e < d / 2; ++e) acc[e] = __builtin_elementwise_fma(ss, x[e], acc[e]);
+}
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kRowChunks = 8;   // the register-resident score row holds 4 * kRowChunks = 32 keys
+
 // out[mt] (16 output features x 16 tokens, D-layout) = sum over KT_*16 input features.
 // w: LDS image [K][LDW], w[k*LDW + o] = weight from input feature k to output feature o.
 // `wl` = w + 4*g*LDW + n (per-lane base), so every A fragment is one ds_read_b32 at a compile-time offset.
@@ -318,78 +353,144 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
         __syncthreads();
 
         // ---- phase 2: attention, one lane per (sample, head, query row)  (satrans.py:75-90) -------------------
-        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
+        if (F <= 4 * kRowChunks) {
+          // One pass over the keys: the score row stays in registers (chunks of four keys, guarded by the uniform F),
+          // so k is read once; exp2 of pre-scaled scores; padding keys of the last chunk read the last real row and
+          // carry a score of -inf, i.e. a weight of exactly 0.
+          const float sc_scale = inv_sqrt_d * kLog2e;
+          for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int ls = task / (H * F), rem = task - ls * H * F;
             const int h = rem / F, i = rem - h * F;
             const int b = samp[ls];
-            float qi[d];
             float* qrow = sq + (size_t)(ls * F + i) * LD + h * d;
-#pragma unroll
-            for (int e = 0; e < d; e += 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
-                qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
-            }
             const float* kbase = sk + (size_t)(ls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(ls * F) * LD + h * d;
+            f32x2 qi[d / 2];
+            load_row<d>(qrow, qi);
+            float sc[4 * kRowChunks];
             float mx = -INFINITY;
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+            for (int c = 0; c < kRowChunks; ++c) {
+                if (4 * c < F) {
+                    f32x2 kr[4][d / 2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) load_row<d>(kbase + (size_t)min(4 * c + u, F - 1) * LD, kr[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float s_ = 4 * c + u < F ? dot_row<d>(qi, kr[u]) * sc_scale : -INFINITY;
+                        sc[4 * c + u] = s_;
+                        mx = fmaxf(mx, s_);
+                    }
                 }
-                mx = fmaxf(mx, s * inv_sqrt_d);
             }
-            float oacc[d];
+            f32x2 oacc[d / 2];
 #pragma unroll
-            for (int e = 0; e < d; ++e) oacc[e] = 0.f;
+            for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
             float sum = 0.f;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)b);
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                float s = 0.f;
+            const uint32_t elem0 = (uint32_t)((h * F + i) * F);
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                    s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                    s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
-                }
-                const float ex = __expf(s * inv_sqrt_d - mx);
-                sum += ex;
-                float pe = ex;
-                if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
+            for (int c = 0; c < kRowChunks; ++c) {
+                if (4 * c < F) {
+                    f32x2 vr[4][d / 2];
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
-                    oacc[e] = fmaf(pe, v4.x, oacc[e]); oacc[e + 1] = fmaf(pe, v4.y, oacc[e + 1]);
-                    oacc[e + 2] = fmaf(pe, v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe, v4.w, oacc[e + 3]);
+                    for (int u = 0; u < 4; ++u) load_row<d>(vbase + (size_t)min(4 * c + u, F - 1) * LD, vr[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float ex = __builtin_amdgcn_exp2f(sc[4 * c + u] - mx);
+                        sum += ex;
+                        float pe = ex;
+                        if (dc.on) pe = drop_keep(skey, elem0 + (uint32_t)(4 * c + u), dc.thresh) ? ex * dc.scale : 0.f;
+                        sc[4 * c + u] = pe;
+                        axpy_row<d>(pe, vr[u], oacc);
+                    }
                 }
             }
-            const float inv = 1.0f / sum;
             if (att) {   // normalized_att_scores [H,B,F,F], after dropout (satrans.py:87); rarely requested
                 float* arow = att + (((size_t)h * a.B + b) * F + i) * F;
-    #pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                    float s = 0.f;
 #pragma unroll
-                    for (int e = 0; e < d; e += 4) {
-                        const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                        s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
-                        s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
-                    }
-                    float pj = __expf(s * inv_sqrt_d - mx) / sum;
-                    if (dc.on) pj = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? pj * dc.scale : 0.f;
-                    arow[j] = pj;
-                }
+                for (int c = 0; c < kRowChunks; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * c + u < F) arow[4 * c + u] = sc[4 * c + u] / sum;
             }
             // the attention output takes the place of this task's own q row (nobody else reads it)
-#pragma unroll
-            for (int e = 0; e < d; e += 4)
-                *reinterpret_cast<float4*>(qrow + e) =
-                    make_float4(oacc[e] * inv, oacc[e + 1] * inv, oacc[e + 2] * inv, oacc[e + 3] * inv);
+            store_row<d>(qrow, oacc, 1.0f / sum);
+          }
+        } else {
+          for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
+              const int ls = task / (H * F), rem = task - ls * H * F;
+              const int h = rem / F, i = rem - h * F;
+              const int b = samp[ls];
+              float qi[d];
+              float* qrow = sq + (size_t)(ls * F + i) * LD + h * d;
+  #pragma unroll
+              for (int e = 0; e < d; e += 4) {
+                  const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
+                  qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
+              }
+              const float* kbase = sk + (size_t)(ls * F) * LD + h * d;
+              const float* vbase = sv + (size_t)(ls * F) * LD + h * d;
+              float mx = -INFINITY;
+  #pragma unroll 4
+              for (int j = 0; j < F; ++j) {
+                  float s = 0.f;
+  #pragma unroll
+                  for (int e = 0; e < d; e += 4) {
+                      const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                      s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                      s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                  }
+                  mx = fmaxf(mx, s * inv_sqrt_d);
+              }
+              float oacc[d];
+  #pragma unroll
+              for (int e = 0; e < d; ++e) oacc[e] = 0.f;
+              float sum = 0.f;
+              const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)b);
+  #pragma unroll 4
+              for (int j = 0; j < F; ++j) {
+                  float s = 0.f;
+  #pragma unroll
+                  for (int e = 0; e < d; e += 4) {
+                      const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                      s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                      s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                  }
+                  const float ex = __expf(s * inv_sqrt_d - mx);
+                  sum += ex;
+                  float pe = ex;
+                  if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
+  #pragma unroll
+                  for (int e = 0; e < d; e += 4) {
+                      const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
+                      oacc[e] = fmaf(pe, v4.x, oacc[e]); oacc[e + 1] = fmaf(pe, v4.y, oacc[e + 1]);
+                      oacc[e + 2] = fmaf(pe, v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe, v4.w, oacc[e + 3]);
+                  }
+              }
+              const float inv = 1.0f / sum;
+              if (att) {   // normalized_att_scores [H,B,F,F], after dropout (satrans.py:87); rarely requested
+                  float* arow = att + (((size_t)h * a.B + b) * F + i) * F;
+      #pragma unroll 4
+              for (int j = 0; j < F; ++j) {
+                      float s = 0.f;
+  #pragma unroll
+                      for (int e = 0; e < d; e += 4) {
+                          const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
+                          s = fmaf(qi[e], k4.x, s); s = fmaf(qi[e + 1], k4.y, s);
+                          s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
+                      }
+                      float pj = __expf(s * inv_sqrt_d - mx) / sum;
+                      if (dc.on) pj = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? pj * dc.scale : 0.f;
+                      arow[j] = pj;
+                  }
+              }
+              // the attention output takes the place of this task's own q row (nobody else reads it)
+  #pragma unroll
+              for (int e = 0; e < d; e += 4)
+                  *reinterpret_cast<float4*>(qrow + e) =
+                      make_float4(oacc[e] * inv, oacc[e + 1] * inv, oacc[e + 2] * inv, oacc[e + 3] * inv);
+          }
         }
         __syncthreads();
 
@@ -443,8 +544,8 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
 //   A  (wave/tile)  forward chain, q k v -> LDS
 //   B  (lane/task)  attention forward -> o, softmax statistics (max, 1/sum) per (sample, head, row)
 //   C  (wave/tile)  Out_linear + residual + LayerNorm forward and backward, dWo, go = du Wo (replaces o)
-//   D  (lane/task)  softmax backward by rows: dot_i, dq_i
-//   E  (lane/task)  by columns: dk_j, dv_j (replace k_j, v_j)
+//   D  (lane/task)  softmax backward by rows: dS_ij (cached), dq_i
+//   E  (lane/task)  by columns from the cached dS and P: dk_j, dv_j (replace k_j, v_j)
 //   F  (wave/tile)  MetaNet backward for Q and K, projection backward, all weight gradients, dx
 // Weight gradients are MFMA products contracted over the tile's 16 tokens; their operands are written row-wise
 // into the wave's OWN rows of the q / o / dq buffers (dead by then), so phase F needs no workgroup barrier.  The
@@ -599,9 +700,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     float* sg = take(ROWS * LD);     // du (phase C scratch) -> dq | phase F scratch
     const int ntask_max = Tsamp * H * F;
     float* st_inv = take(ntask_max);                  // 1 / sum_j exp(s_ij - max_i)
-    float* st_dot = take(ntask_max);                  // sum_j dP_ij P_ij
     uint32_t* st_keep = (uint32_t*)take(ntask_max);   // bit j: attention-dropout keep flag of (i, j)   (F <= 32)
     float* sP = take(ntask_max * F);                  // exp(s_ij - max_i), the un-normalised softmax numerators
+    float* sDS = take(ntask_max * F);                 // dP_ij, then dS_ij (phases D, E)
 
     const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
@@ -795,88 +896,71 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
         STAMP(1);
         // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
+        // Scores are staged in the task's row of the numerator cache (pre-scaled by log2(e)/sqrt(d)), keys in chunks of
+        // four with all loads of a chunk issued before its results are stored; padding keys of the last chunk read the
+        // last real row and are masked arithmetically.
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
             const int h = rem / F, i = rem - h * F;
             const int tb = samp[tls];
-            float qi[d];
-            const float* qrow = sq + (size_t)(tls * F + i) * LD + h * d;
-#pragma unroll
-            for (int e = 0; e < d; e += 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(qrow + e);
-                qi[e] = t4.x; qi[e + 1] = t4.y; qi[e + 2] = t4.z; qi[e + 3] = t4.w;
-            }
+            f32x2 qi[d / 2];
+            load_row<d>(sq + (size_t)(tls * F + i) * LD + h * d, qi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
             float* prow = sP + (size_t)task * F;
+            const float sc_scale = inv_sqrt_d * kLog2e;
             float mx = -INFINITY;
-            // keys in chunks of 4: all loads of a chunk are issued before its scores are stored (the stores to the
-            // score cache may alias the key rows as far as the compiler knows, which would serialise load->store->load)
             for (int j0 = 0; j0 < F; j0 += 4) {
+                f32x2 kr[4][d / 2];
                 float sc[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = min(j0 + u, F - 1);
-                    float s_ = 0.f;
+                for (int u = 0; u < 4; ++u) load_row<d>(kbase + (size_t)min(j0 + u, F - 1) * LD, kr[u]);
 #pragma unroll
-                    for (int e = 0; e < d; e += 4) {
-                        const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                        s_ = fmaf(qi[e], k4.x, s_); s_ = fmaf(qi[e + 1], k4.y, s_);
-                        s_ = fmaf(qi[e + 2], k4.z, s_); s_ = fmaf(qi[e + 3], k4.w, s_);
-                    }
-                    sc[u] = s_ * inv_sqrt_d;
+                for (int u = 0; u < 4; ++u) {
+                    sc[u] = dot_row<d>(qi, kr[u]) * sc_scale;
+                    mx = fmaxf(mx, sc[u]);          // a padding key repeats the last real score: the maximum is unchanged
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) { prow[j0 + u] = sc[u]; mx = fmaxf(mx, sc[u]); }
+                    if (j0 + u < F) prow[j0 + u] = sc[u];
             }
-            float oacc[d];
+            f32x2 oacc[d / 2];
 #pragma unroll
-            for (int e = 0; e < d; ++e) oacc[e] = 0.f;
+            for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
             float sum = 0.f;
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            const uint32_t elem0 = (uint32_t)((h * F + i) * F);
             for (int j0 = 0; j0 < F; j0 += 4) {
-                float ex[4], pe[4];
-                float4 vv[4][d / 4];
+                f32x2 vr[4][d / 2];
+                float ex[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
-                    ex[u] = __expf(prow[j] - mx);
-#pragma unroll
-                    for (int e = 0; e < d; e += 4) vv[u][e / 4] = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
+                    ex[u] = prow[j];
+                    load_row<d>(vbase + (size_t)j * LD, vr[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + u;
-                    if (j < F) {
-                        prow[j] = ex[u];
-                        sum += ex[u];
-                        pe[u] = ex[u];
-                        if (dc.on) {
-                            const bool kp = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh);
-                            pe[u] = kp ? ex[u] * dc.scale : 0.f;
-                            if (!kp) keep &= ~(1u << j);
-                        }
-                    } else {
-                        pe[u] = 0.f;
+                    ex[u] = j < F ? __builtin_amdgcn_exp2f(ex[u] - mx) : 0.f;
+                    sum += ex[u];
+                    float pe = ex[u];
+                    if (dc.on) {
+                        const bool kp = drop_keep(skey, elem0 + (uint32_t)j, dc.thresh);
+                        pe = kp ? ex[u] * dc.scale : 0.f;
+                        keep = kp ? keep : keep & ~(1u << (j & 31));
                     }
-#pragma unroll
-                    for (int e = 0; e < d; e += 4) {
-                        const float4 v4 = vv[u][e / 4];
-                        oacc[e] = fmaf(pe[u], v4.x, oacc[e]); oacc[e + 1] = fmaf(pe[u], v4.y, oacc[e + 1]);
-                        oacc[e + 2] = fmaf(pe[u], v4.z, oacc[e + 2]); oacc[e + 3] = fmaf(pe[u], v4.w, oacc[e + 3]);
-                    }
+                    axpy_row<d>(pe, vr[u], oacc);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < F) prow[j0 + u] = ex[u];
             }
             const float inv = 1.0f / sum;
             st_inv[task] = inv;
             st_keep[task] = keep;
-            float* orow = so + (size_t)(tls * F + i) * LD + h * d;
-#pragma unroll
-            for (int e = 0; e < d; e += 4)
-                *reinterpret_cast<float4*>(orow + e) =
-                    make_float4(oacc[e] * inv, oacc[e + 1] * inv, oacc[e + 2] * inv, oacc[e + 3] * inv);
+            store_row<d>(so + (size_t)(tls * F + i) * LD + h * d, oacc, inv);
         }
         __syncthreads();
 
@@ -920,110 +1004,105 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         __syncthreads();
 
         STAMP(3);
-        // ================= phase D: softmax backward by rows: dot_i and dq_i ==============================================
+        // ================= phase D: softmax backward by rows: dS_ij (cached for phase E) and dq_i =========================
+        // pass 1: dP_ij = (go_i . v_j) * mask_ij staged in the task's row of the dS cache, dot_i = sum_j P_ij dP_ij;
+        // pass 2: dS_ij = P_ij (dP_ij - dot_i) / sqrt(d) replaces it, the numerator cache row becomes P_ij * mask_ij
+        //         (the coefficient of dv_j), dq_i = sum_j dS_ij k_j.
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
             const int h = rem / F, i = rem - h * F;
-            float gi[d], dq[d];
-            const float* grow = so + (size_t)(tls * F + i) * LD + h * d;
-#pragma unroll
-            for (int e = 0; e < d; e += 4) {
-                const float4 g4v = *reinterpret_cast<const float4*>(grow + e);
-                gi[e] = g4v.x; gi[e + 1] = g4v.y; gi[e + 2] = g4v.z; gi[e + 3] = g4v.w;
-            }
+            f32x2 gi[d / 2];
+            load_row<d>(so + (size_t)(tls * F + i) * LD + h * d, gi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
-            const float* prow = sP + (size_t)task * F;
+            float* prow = sP + (size_t)task * F;
+            float* drow = sDS + (size_t)task * F;
             const float inv = st_inv[task];
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
-            // one pass: with p_j = P_ij, dp_j = dP_ij (dropout applied) and dot = sum_j p_j dp_j,
-            //   dq_i = sum_j p_j (dp_j - dot) k_j / sqrt(d) = (sum_j p_j dp_j k_j  -  dot * sum_j p_j k_j) / sqrt(d)
-            float dot = 0.f, center = 0.f;
-            float acc_a[d], acc_b[d];
+            float dot = 0.f;
+            for (int j0 = 0; j0 < F; j0 += 4) {
+                f32x2 vr[4][d / 2];
+                float pj[4], dp[4];
 #pragma unroll
-            for (int e = 0; e < d; ++e) acc_a[e] = acc_b[e] = 0.f;
-#pragma unroll 4
-            for (int j = 0; j < F; ++j) {
-                float dp = 0.f;
-                float kj[d];
-#pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(kbase + (size_t)j * LD + e);
-                    const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
-                    kj[e] = k4.x; kj[e + 1] = k4.y; kj[e + 2] = k4.z; kj[e + 3] = k4.w;
-                    dp = fmaf(gi[e], v4.x, dp); dp = fmaf(gi[e + 1], v4.y, dp);
-                    dp = fmaf(gi[e + 2], v4.z, dp); dp = fmaf(gi[e + 3], v4.w, dp);
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, F - 1);
+                    pj[u] = prow[j];
+                    load_row<d>(vbase + (size_t)j * LD, vr[u]);
                 }
-                dp = ((keep >> j) & 1u) ? dp * scale : 0.f;
-                if (j == 0) center = dp;          // dP centred on its first value: same result (sum_j p_j = 1), but the
-                dp -= center;                     // two sums below no longer cancel when dP is nearly constant over j
-                const float pj = prow[j] * inv;
-                const float pd = pj * dp;
-                dot += pd;
 #pragma unroll
-                for (int e = 0; e < d; ++e) {
-                    acc_a[e] = fmaf(pd, kj[e], acc_a[e]);
-                    acc_b[e] = fmaf(pj, kj[e], acc_b[e]);
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    dp[u] = dot_row<d>(gi, vr[u]);
+                    dp[u] = ((keep >> (j & 31)) & 1u) ? dp[u] * scale : 0.f;
+                    pj[u] = j < F ? pj[u] * inv : 0.f;
+                    dot = fmaf(pj[u], dp[u], dot);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < F) drow[j0 + u] = dp[u];
             }
-            st_dot[task] = dot + center;
+            f32x2 dq[d / 2];
 #pragma unroll
-            for (int e = 0; e < d; ++e) dq[e] = (acc_a[e] - dot * acc_b[e]) * inv_sqrt_d;
-            float* dqrow = sg + (size_t)(tls * F + i) * LD + h * d;
+            for (int e = 0; e < d / 2; ++e) dq[e] = f32x2{0.f, 0.f};
+            for (int j0 = 0; j0 < F; j0 += 4) {
+                f32x2 kr[4][d / 2];
+                float pj[4], ds[4];
 #pragma unroll
-            for (int e = 0; e < d; e += 4)
-                *reinterpret_cast<float4*>(dqrow + e) = make_float4(dq[e], dq[e + 1], dq[e + 2], dq[e + 3]);
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, F - 1);
+                    pj[u] = prow[j];
+                    ds[u] = drow[j];
+                    load_row<d>(kbase + (size_t)j * LD, kr[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    pj[u] = j < F ? pj[u] * inv : 0.f;
+                    ds[u] = pj[u] * (ds[u] - dot) * inv_sqrt_d;
+                    pj[u] = ((keep >> (j & 31)) & 1u) ? pj[u] * scale : 0.f;
+                    axpy_row<d>(ds[u], kr[u], dq);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < F) { drow[j0 + u] = ds[u]; prow[j0 + u] = pj[u]; }
+            }
+            store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
         }
         __syncthreads();
 
         STAMP(4);
-        // ================= phase E: by columns: dk_j, dv_j (in place of k_j, v_j) ===========================================
+        // ================= phase E: by columns: dk_j = sum_i dS_ij q_i, dv_j = sum_i P_ij mask_ij go_i (in place of k_j, v_j)
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
             const int tls = task / (H * F), rem = task - tls * H * F;
             const int h = rem / F, j = rem - h * F;
-            float vj[d], dk[d], dv[d];
-            float* krow = sk + (size_t)(tls * F + j) * LD + h * d;
-            float* vrow = sv + (size_t)(tls * F + j) * LD + h * d;
+            f32x2 dk[d / 2], dv[d / 2];
 #pragma unroll
-            for (int e = 0; e < d; e += 4) {
-                const float4 v4 = *reinterpret_cast<const float4*>(vrow + e);
-                vj[e] = v4.x; vj[e + 1] = v4.y; vj[e + 2] = v4.z; vj[e + 3] = v4.w;
-                dk[e] = dk[e + 1] = dk[e + 2] = dk[e + 3] = 0.f;
-                dv[e] = dv[e + 1] = dv[e + 2] = dv[e + 3] = 0.f;
-            }
+            for (int e = 0; e < d / 2; ++e) { dk[e] = f32x2{0.f, 0.f}; dv[e] = f32x2{0.f, 0.f}; }
             const float* qbase = sq + (size_t)(tls * F) * LD + h * d;
             const float* gbase = so + (size_t)(tls * F) * LD + h * d;
-            const int st0 = (tls * H + h) * F;
-            const float scale = dc.scale;
-#pragma unroll 4
-            for (int i = 0; i < F; ++i) {
-                float qi[d], gi[d];
-                float dp = 0.f;
+            const float* dcol = sDS + (size_t)((tls * H + h) * F) * F + j;
+            const float* pcol = sP + (size_t)((tls * H + h) * F) * F + j;
+            for (int i0 = 0; i0 < F; i0 += 4) {
+                f32x2 qr[4][d / 2], gr[4][d / 2];
+                float ds[4], pm[4];
 #pragma unroll
-                for (int e = 0; e < d; e += 4) {
-                    const float4 q4 = *reinterpret_cast<const float4*>(qbase + (size_t)i * LD + e);
-                    const float4 g4v = *reinterpret_cast<const float4*>(gbase + (size_t)i * LD + e);
-                    qi[e] = q4.x; qi[e + 1] = q4.y; qi[e + 2] = q4.z; qi[e + 3] = q4.w;
-                    gi[e] = g4v.x; gi[e + 1] = g4v.y; gi[e + 2] = g4v.z; gi[e + 3] = g4v.w;
-                    dp = fmaf(g4v.x, vj[e], dp); dp = fmaf(g4v.y, vj[e + 1], dp);
-                    dp = fmaf(g4v.z, vj[e + 2], dp); dp = fmaf(g4v.w, vj[e + 3], dp);
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u, F - 1);
+                    ds[u] = dcol[(size_t)i * F];
+                    pm[u] = pcol[(size_t)i * F];
+                    load_row<d>(qbase + (size_t)i * LD, qr[u]);
+                    load_row<d>(gbase + (size_t)i * LD, gr[u]);
                 }
-                const float pij = sP[(size_t)(st0 + i) * F + j] * st_inv[st0 + i];
-                const float mk = ((st_keep[st0 + i] >> j) & 1u) ? scale : 0.f;
-                const float ds = pij * (dp * mk - st_dot[st0 + i]) * inv_sqrt_d;
-                const float pd = pij * mk;
 #pragma unroll
-                for (int e = 0; e < d; ++e) {
-                    dk[e] = fmaf(ds, qi[e], dk[e]);
-                    dv[e] = fmaf(pd, gi[e], dv[e]);
+                for (int u = 0; u < 4; ++u) {
+                    const bool real = i0 + u < F;
+                    axpy_row<d>(real ? ds[u] : 0.f, qr[u], dk);
+                    axpy_row<d>(real ? pm[u] : 0.f, gr[u], dv);
                 }
             }
-#pragma unroll
-            for (int e = 0; e < d; e += 4) {
-                *reinterpret_cast<float4*>(krow + e) = make_float4(dk[e], dk[e + 1], dk[e + 2], dk[e + 3]);
-                *reinterpret_cast<float4*>(vrow + e) = make_float4(dv[e], dv[e + 1], dv[e + 2], dv[e + 3]);
-            }
+            store_row<d>(sk + (size_t)(tls * F + j) * LD + h * d, dk, 1.0f);
+            store_row<d>(sv + (size_t)(tls * F + j) * LD + h * d, dv, 1.0f);
         }
         __syncthreads();
 
@@ -1343,7 +1422,7 @@ static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
     const int64_t tasks = (int64_t)T * H * F;
     return 8 * (int64_t)D * LD + (same_tab ? 1 : 2) * 2 * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 5 * 64 * LD +
-           3 * r4(tasks) + r4(tasks * F) + 64;
+           2 * r4(tasks) + 2 * r4(tasks * F) + 64;
 }
 
 struct FusedBwdPlan {
