@@ -97,8 +97,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # SATRANS_BENCH_SHARE_GPU=1 (diagnostic): all ranks on cuda:0 over gloo, to exercise the multi-rank step on a
+        # one-GPU box; its numbers are not a scaling measurement
+        if os.environ.get("SATRANS_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     device = f"cuda:{local_rank}"
@@ -147,7 +153,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng.raise_if_bad_ids()

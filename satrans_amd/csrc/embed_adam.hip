@@ -256,7 +256,79 @@ __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
 }
 
-// second level: one lane group per chunk that owns a trail piece walks the following chunks' lead pieces in order
+// Second level: a run that crosses chunk boundaries is the ordered sum  trail(c0) + lead(c0+1) + ... + lead(c1).
+// One lane group per SUPERCHUNK of kSuper chunks walks its chunks once: runs that end inside the superchunk take their
+// optimizer step here; what crosses a superchunk boundary leaves a record of the same shape one level up (lead/trail
+// partial sums, flags as for chunks), which the spans kernel below finishes.  A row gathered by every sample of every
+// rank (small-vocabulary fields: runs of tens of thousands of positions) thus costs kSuper + run/(kChunk*kSuper)
+// dependent steps instead of run/kChunk.
+constexpr int kSuper = 32;
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                           float4* __restrict__ V, int64_t chunks,
+                                                           const float4* __restrict__ partial,
+                                                           const int32_t* __restrict__ info,
+                                                           const int32_t* __restrict__ trail_row,
+                                                           float4* __restrict__ partial2, int32_t* __restrict__ info2,
+                                                           int32_t* __restrict__ trail_row2, AdamK k,
+                                                           double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    const int64_t c0 = group * kSuper;
+    double reg = 0.0;
+    if (c0 < chunks) {
+        const int64_t c1 = min(chunks, c0 + (int64_t)kSuper);
+        int f[kSuper];
+#pragma unroll
+        for (int u = 0; u < kSuper; ++u) f[u] = c0 + u < c1 ? info[c0 + u] : 0;
+        bool open = f[0] & 2, is_lead = open;
+        int flags2 = open ? 2 : 0;
+        int32_t row = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kSuper; ++u) {
+            const int64_t c = c0 + u;
+            if (f[u] & 2) {
+                const float4 g = partial[(c * 2 + 0) * LPR + q];
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+                if (f[u] & 4) {
+                    if (is_lead) {
+                        partial2[(group * 2 + 0) * LPR + q] = acc;
+                        flags2 |= 4;
+                    } else {
+                        const int64_t at = (int64_t)row * LPR + q;
+                        float4 p = P[at], m = M[at], v = V[at];
+                        reg += adam4(p, m, v, acc, k);
+                        P[at] = p; M[at] = m; V[at] = v;
+                    }
+                    open = false;
+                    is_lead = false;
+                }
+            }
+            if (f[u] & 1) {
+                acc = partial[(c * 2 + 1) * LPR + q];
+                row = trail_row[c];
+                open = true;
+                is_lead = false;
+            }
+        }
+        if (open) {
+            if (is_lead) {
+                partial2[(group * 2 + 0) * LPR + q] = acc;
+            } else {
+                partial2[(group * 2 + 1) * LPR + q] = acc;
+                flags2 |= 1;
+                if (q == 0) trail_row2[group] = row;
+            }
+        }
+        if (q == 0) info2[group] = flags2;
+    }
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// third level: one lane group per superchunk that owns a trail piece walks the following superchunks' lead pieces in order
 template <int LPR>
 __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__ P, float4* __restrict__ M,
                                                            float4* __restrict__ V, int64_t chunks,
@@ -521,10 +593,11 @@ extern "C" int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int
     return kStreamBlocks + 2 * touched_blocks(n, D);
 }
 
-// partial_ws: [chunks][2][D] floats, [chunks] int32 info, [chunks] int32 trail_row, [n][D] run sums, [n] int32 head flags
+// partial_ws: [chunks][2][D] floats, [chunks] int32 info, [chunks] int32 trail_row, [n][D] run sums, [n] int32 head flags,
+// then the same three record arrays for the superchunks
 extern "C" int64_t satrans_embed_partial_ws_floats(int64_t n, int D) {
-    const int64_t chunks = ceil_div(n, kChunk);
-    return chunks * 2 * D + 2 * chunks + 4 + n * D + n;
+    const int64_t chunks = ceil_div(n, kChunk), supers = ceil_div(chunks, kSuper);
+    return chunks * 2 * D + 2 * chunks + 4 + n * D + n + 4 + supers * 2 * D + 2 * supers;
 }
 
 extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
@@ -553,8 +626,20 @@ extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int 
     DISPATCH_LPR(D, (touched_apply_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, sorted_rows, n, (const float4*)rowsum, head_of, k, reg_a)));
     SATRANS_CHECK_LAUNCH("touched_apply_kernel");
-    DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)partial, info, trail_row, k, reg_b)));
+    const int64_t supers = ceil_div(chunks, kSuper);
+    int64_t off2 = off + n * D + n;
+    off2 = (off2 + 3) & ~(int64_t)3;
+    float4* partial2 = (float4*)(partial_ws + off2);
+    int32_t* info2 = (int32_t*)(partial_ws + off2 + supers * 2 * D);
+    int32_t* trail_row2 = info2 + supers;
+    const int64_t sblocks = ceil_div(supers * (D / 4), 256);
+    double* reg_c = reg_b + sblocks;
+    DISPATCH_LPR(D, (touched_super_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)partial, info, trail_row, partial2,
+                        info2, trail_row2, k, reg_b)));
+    SATRANS_CHECK_LAUNCH("touched_super_kernel");
+    DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, supers, (const float4*)partial2, info2, trail_row2, k, reg_c)));
     SATRANS_CHECK_LAUNCH("touched_spans_kernel");
     return SATRANS_OK;
 }

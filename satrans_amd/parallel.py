@@ -28,18 +28,42 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo moves host memory: device tensors are staged through the host (CPU tests, and the two-ranks-on-one-GPU
+    parity test; production runs use nccl = RCCL, which takes device pointers)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor) -> None:
+    if _host_staged(inp):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def _all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
+    if _host_staged(t):
+        host = t.cpu()
+        dist.all_reduce(host, op=op)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def exchange(flat_grad: torch.Tensor, rows: torch.Tensor, gemb: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-reduce `flat_grad` in place (SUM); return (all rows [W*n], all gradient rows [W*n, D]) in rank order."""
     w = world_size()
     if w == 1:
         return rows.reshape(-1), gemb.reshape(-1, gemb.shape[-1])
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    _all_reduce(flat_grad)
     rows = rows.reshape(-1).contiguous()
     gemb = gemb.reshape(rows.numel(), -1).contiguous()
     all_rows = torch.empty(w * rows.numel(), dtype=rows.dtype, device=rows.device)
     all_gemb = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
-    dist.all_gather_into_tensor(all_rows, rows)
-    dist.all_gather_into_tensor(all_gemb, gemb)
+    _all_gather(all_rows, rows)
+    _all_gather(all_gemb, gemb)
     return all_rows, all_gemb
 
 
@@ -52,7 +76,7 @@ def gather_rows(rows: torch.Tensor) -> torch.Tensor:
     if w == 1:
         return rows
     out = torch.empty(w * rows.numel(), dtype=rows.dtype, device=rows.device)
-    dist.all_gather_into_tensor(out, rows)
+    _all_gather(out, rows)
     return out
 
 
@@ -63,14 +87,14 @@ def exchange_grads(flat_grad: torch.Tensor, gemb: torch.Tensor) -> torch.Tensor:
     gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
     if w == 1:
         return gemb
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    _all_reduce(flat_grad)
     out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
-    dist.all_gather_into_tensor(out, gemb)
+    _all_gather(out, gemb)
     return out
 
 
 def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:
     """Sum of per-rank scalars (losses, counts) for logging."""
     if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t)
     return t

@@ -337,3 +337,52 @@ def test_lazy_adam_is_bitwise_the_streaming_adam():
     assert torch.equal(m_l, m_d) and torch.equal(v_l, v_d)
     assert bce_l == bce_d
     assert reg_l == pytest.approx(reg_d, rel=1e-6)      # lazy sums p^2 per element in fp32 before going to double
+
+
+def _dp_worker(rank, world, port, name, steps, out_dir):
+    """One data-parallel rank of the engine; both ranks share cuda:0 and talk over gloo (host-staged), which runs
+    exactly the code path of an RCCL job: ids all-gathered before the forward, gradient rows after the backward."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = Case(name)
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        model.eval()
+        eng = model._require_engine()
+        n = c.X.shape[0] // world
+        X, y = c.X[rank * n:(rank + 1) * n].to(DEV), c.y[rank * n:(rank + 1) * n].to(DEV)
+        for _ in range(steps):
+            eng.train_step(X, y)
+        torch.save(sd_to_cpu(model), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
+def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, tmp_path):
+    """Reference semantics of several GPUs (meta_basemodel.py:272-275, 317): per-GPU batches, loss SUMMED over all
+    samples, one optimizer step on the summed gradient.  Two ranks with half of the golden batch each must therefore
+    land where the reference's single full-batch steps land, and the two replicas must be bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    c = Case(name)
+    if c.X.shape[0] % 2:
+        pytest.skip("odd golden batch")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    steps = c.meta["adam_steps"]
+    mp.spawn(_dp_worker, args=(2, port, name, steps, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"replicas diverged at {k}"
+    want, grads, init, lr = c.tensors("adam"), c.arrays("grad"), c.tensors("param"), c.meta["lr"]
+    for k, w in want.items():     # same bounds as test_adam_steps_match_reference_golden
+        err = (r0[k] - w).abs().flatten().double()
+        if k in grads and float(np.abs(grads[k]).max()) >= 1e-7 and float((w - init[k]).abs().max()) > 0:
+            assert float(err.median()) <= 2e-3 * lr * steps, (k, float(err.median()))
+            assert float(torch.quantile(err, 0.95)) <= 2e-2 * lr * steps, (k, float(torch.quantile(err, 0.95)))
+        assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
