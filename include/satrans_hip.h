@@ -70,8 +70,8 @@ int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_stride, int 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-table embedding gather: reference meta_basemodel.py:533-535 (one nn.Embedding call per
  * SparseFeat) + concat_fun(axis=1) at satrans.py:211.
- *   arena      [total_rows, D] fp32: all tables back to back, table f starts at row row_off[f]
- *   row_off    [F+1] int64 (device)
+ *   arena      [total_rows, D] fp32: all tables back to back (any order; fields may share a table)
+ *   row_span   [F][2] int64 (device): arena rows [lo, hi) of field f's table
  *   cols       [F] int32 (device): X column of field f
  *   out        [B, F, D]
  *   out        may be NULL: rows-only mode (ids -> arena rows, nothing is moved)
@@ -79,7 +79,7 @@ int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_stride, int 
  *   status     [1] int32: set to 1 when an id falls outside its table
  * Bit-exact: every output element is a copy.
  * ---------------------------------------------------------------------------------------------- */
-int satrans_gather_fwd(const float* arena, const int64_t* row_off, const int32_t* cols, const void* X,
+int satrans_gather_fwd(const float* arena, const int64_t* row_span, const int32_t* cols, const void* X,
                        int id_dtype, int64_t x_stride, int B, int F, int D, float* out,
                        int32_t* rows_out, int32_t* status, void* stream);
 
@@ -187,10 +187,30 @@ int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const in
                                const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
                                const satrans_adam_hparams* h, double* reg_partials, void* stream);
 int64_t satrans_embed_partial_ws_floats(int64_t n, int D);
-/* grid_blocks: 0 = the measured optimum (512 persistent blocks of 256 threads); otherwise the grid size to use */
-int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
+/* rows [first_row, total_rows) that are not in the bitmap; grid_blocks: 0 = the measured optimum (512 persistent blocks
+ * of 256 threads), otherwise the grid size to use */
+int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t first_row, int64_t total_rows, int D,
                                  const uint32_t* touched, const satrans_adam_hparams* h,
                                  double* reg_partials, int grid_blocks, void* stream);
+/* touched-row bitmap [ceil(total_rows/32)] of an already sorted id list (cleared first; n may be 0) */
+int satrans_embed_mark_touched(const int32_t* sorted_rows, int64_t n, int64_t total_rows, uint32_t* touched,
+                               void* stream);
+
+/* Small tables (the caller places them first in the arena): their gradient is a DENSE buffer g_rows [rows, D] - the
+ * ordered segmented sums of satrans_embed_segment_sums over the sorted positions that fall into those tables, stored
+ * instead of applied (rows nobody gathered keep the zeros the caller wrote) - which data-parallel ranks all-reduce, and
+ * satrans_embed_adam_rows then steps EVERY row of [row0, row0+rows) with g = g_rows + 2*l2*p (for an ungathered row that
+ * is exactly the reference's regulariser-only step) and sets last[row] = t when `last` is given.
+ * Workspaces as for satrans_embed_adam_touched; reg_partials of adam_rows: satrans_embed_adam_rows_partials doubles.
+ * satrans_embed_pack_rows: out[j] = gemb[src[j]], the gradient rows of a sorted id list in sorted order (what a rank
+ * contributes to the all-gather of the large tables' gradient rows). */
+int satrans_embed_segment_sums(const int32_t* sorted_rows, const int32_t* src, int64_t n, const float* gemb, int D,
+                               float* partial_ws, double* reg_partials, float* g_rows, void* stream);
+int64_t satrans_embed_adam_rows_partials(int64_t rows, int D);
+int satrans_embed_adam_rows(float* arena, float* m, float* v, int32_t* last, int64_t row0, int64_t rows, int D,
+                            const float* g_rows, const satrans_adam_hparams* h, int t, double* reg_partials,
+                            void* stream);
+int satrans_embed_pack_rows(const int32_t* src, int64_t n, const float* gemb, int D, float* out, void* stream);
 
 /* Lazy-exact form of the dense step (same tables bit for bit, HBM traffic only for touched rows): instead of
  * satrans_embed_adam_untouched every step, the regulariser-only Adam steps of a row are postponed and replayed with

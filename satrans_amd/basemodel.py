@@ -29,6 +29,11 @@ from .callbacks import CallbackList, History
 from .inputs import DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, split_columns
 
 
+# tables of at most this many rows (and this many in total) form the "small" class of the optimizer
+SMALL_TABLE_ROWS = 16384
+SMALL_TABLE_TOTAL_ROWS = 65536
+
+
 def make_embedding_tables(feature_columns, init_std=0.0001, linear=False, skip_init=False) -> nn.ModuleDict:
     """One table per SparseFeat, keyed by `embedding_name`; N(0, init_std) after torch's default N(0,1)
     draw, exactly the sequence of generator draws of reference models/meta_basemodel.py:95-121."""
@@ -131,6 +136,17 @@ class BaseModel(nn.Module):
         """(Re)build the arena and the flat buffer on the parameters' current device and turn the
         parameters into views of them.  Called after construction and after every `.to()`."""
         names = self._table_order()
+        # Arena order: small tables first (stable), then the large ones.  The optimizer treats the two classes
+        # differently (satrans_amd/engine.py: dense all-reduced gradient + dense step for the small tables, sorted
+        # (row, gradient) lists for the large ones) and relies on "arena row < _arena_small_rows <=> small table".
+        # state_dict keys and values do not depend on the order: the parameters are views at their offsets.
+        small, budget = [], SMALL_TABLE_TOTAL_ROWS
+        for n in names:
+            rows = self.embedding_dict[n].weight.shape[0]
+            if rows <= SMALL_TABLE_ROWS and rows <= budget:
+                small.append(n)
+                budget -= rows
+        names = small + [n for n in names if n not in small]
         tables = [self.embedding_dict[n].weight for n in names]
         dev = tables[0].device
         arena = torch.cat([t.data.reshape(-1, t.shape[1]) for t in tables], dim=0).contiguous()
@@ -141,6 +157,7 @@ class BaseModel(nn.Module):
             t.data = arena[off:off + rows]
             self._table_rows[n] = (off, rows)
             off += rows
+        self._arena_small_rows = sum(self.embedding_dict[n].weight.shape[0] for n in small)
         self.embedding_arena = arena
         flat = self._trainable_flat()
         if flat:

@@ -98,11 +98,15 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // ---------------------------------------------------------------------------------------------------------
 template <int LPR, int UNR, bool NT, bool CHUNKED = false>
 __global__ __launch_bounds__(kStreamBlock) void adam_untouched_kernel(float4* __restrict__ P, float4* __restrict__ M,
-                                                                    float4* __restrict__ V, int64_t n4,
+                                                                    float4* __restrict__ V, int64_t first4, int64_t n4,
                                                                     const uint32_t* __restrict__ touched, AdamK k,
                                                                     double* __restrict__ reg_partials) {
     __shared__ double s_red[kStreamBlock];
     double reg = 0.0;
+    // elements [first4, n4): the rows before first4 / LPR belong to the small tables, which take a dense step of their own
+    P += first4; M += first4; V += first4;
+    n4 -= first4;
+    const int64_t first_row = first4 / LPR;
     // CHUNKED: every block sweeps one contiguous slice of the arrays (DRAM-page friendly) instead of a grid-wide stride
     const int64_t stride = CHUNKED ? (int64_t)kStreamBlock : (int64_t)gridDim.x * kStreamBlock;
     const int64_t slice = (((n4 + gridDim.x - 1) / gridDim.x) + kStreamBlock * UNR - 1) / (kStreamBlock * UNR) * (kStreamBlock * UNR);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(kStreamBlock) void adam_untouched_kernel(float4* __
             const int64_t i = i0 + u * stride;
             live[u] = false;
             if (i < limit) {
-                const int64_t row = i / LPR;
+                const int64_t row = first_row + i / LPR;
                 live[u] = !((touched[row >> 5] >> (row & 31)) & 1u);
             }
             if (live[u]) {
@@ -235,22 +239,29 @@ __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict_
     }
 }
 
-// Adam on every row whose run was complete inside one chunk: one lane group per sorted position
+// Adam on every row whose run was complete inside one chunk: one lane group per sorted position.
+// All three finishing kernels (this one, the superchunk and the spans kernel) have a second mode: with G != nullptr the
+// finished sum of a row is STORED into the dense gradient buffer G[row] instead of being applied (small tables, whose
+// gradient is all-reduced as a dense buffer across data-parallel ranks).
 template <int LPR>
 __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__ P, float4* __restrict__ M,
                                                            float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
                                                            int64_t n, const float4* __restrict__ rowsum,
                                                            const int32_t* __restrict__ head_of, AdamK k,
-                                                           double* __restrict__ reg_partials) {
+                                                           double* __restrict__ reg_partials, float4* __restrict__ G) {
     __shared__ double s_red[256];
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
     double reg = 0.0;
     if (j < n && head_of[j] == 1) {
         const int64_t at = (int64_t)sorted_rows[j] * LPR + q;
-        float4 p = P[at], m = M[at], v = V[at];
-        reg += adam4(p, m, v, rowsum[j * LPR + q], k);
-        P[at] = p; M[at] = m; V[at] = v;
+        if (G) {
+            G[at] = rowsum[j * LPR + q];
+        } else {
+            float4 p = P[at], m = M[at], v = V[at];
+            reg += adam4(p, m, v, rowsum[j * LPR + q], k);
+            P[at] = p; M[at] = m; V[at] = v;
+        }
     }
     const double total = block_sum(reg, s_red);
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__
                                                            const int32_t* __restrict__ trail_row,
                                                            float4* __restrict__ partial2, int32_t* __restrict__ info2,
                                                            int32_t* __restrict__ trail_row2, AdamK k,
-                                                           double* __restrict__ reg_partials) {
+                                                           double* __restrict__ reg_partials, float4* __restrict__ G) {
     __shared__ double s_red[256];
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
@@ -298,9 +309,13 @@ __global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__
                         flags2 |= 4;
                     } else {
                         const int64_t at = (int64_t)row * LPR + q;
-                        float4 p = P[at], m = M[at], v = V[at];
-                        reg += adam4(p, m, v, acc, k);
-                        P[at] = p; M[at] = m; V[at] = v;
+                        if (G) {
+                            G[at] = acc;
+                        } else {
+                            float4 p = P[at], m = M[at], v = V[at];
+                            reg += adam4(p, m, v, acc, k);
+                            P[at] = p; M[at] = m; V[at] = v;
+                        }
                     }
                     open = false;
                     is_lead = false;
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__
                                                            const float4* __restrict__ partial,
                                                            const int32_t* __restrict__ info,
                                                            const int32_t* __restrict__ trail_row, AdamK k,
-                                                           double* __restrict__ reg_partials) {
+                                                           double* __restrict__ reg_partials, float4* __restrict__ G) {
     __shared__ double s_red[256];
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
@@ -350,12 +365,46 @@ __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__
             if (f & 4) break;
         }
         const int64_t at = (int64_t)trail_row[group] * LPR + q;
-        float4 p = P[at], m = M[at], v = V[at];
-        reg += adam4(p, m, v, acc, k);
-        P[at] = p; M[at] = m; V[at] = v;
+        if (G) {
+            G[at] = acc;
+        } else {
+            float4 p = P[at], m = M[at], v = V[at];
+            reg += adam4(p, m, v, acc, k);
+            P[at] = p; M[at] = m; V[at] = v;
+        }
     }
     const double total = block_sum(reg, s_red);
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// Dense step over the arena rows [row0, row0 + rows) with a dense gradient buffer G [rows, D] (small tables: every row
+// takes g = G + 2*l2*p - for a row nobody gathered G is 0 and that is exactly the regulariser-only step).  last[row] = t.
+template <int LPR>
+__global__ __launch_bounds__(256) void adam_rows_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                       float4* __restrict__ V, int64_t row0, int64_t rows,
+                                                       const float4* __restrict__ G, int32_t* __restrict__ last, int t,
+                                                       AdamK k, double* __restrict__ reg_partials) {
+    __shared__ double s_red[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double reg = 0.0;
+    if (i < rows * LPR) {
+        const int64_t at = row0 * LPR + i;
+        float4 p = P[at], m = M[at], v = V[at];
+        reg = adam4(p, m, v, G[i], k);
+        P[at] = p; M[at] = m; V[at] = v;
+        if (last && i % LPR == 0) last[row0 + i / LPR] = t;
+    }
+    const double total = block_sum(reg, s_red);
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// out[j] = gemb[src[j]]: the gradient rows of a sorted id list in sorted order (what a rank contributes to the all-gather)
+template <int LPR>
+__global__ void pack_rows_kernel(const int32_t* __restrict__ src, int64_t n, const float4* __restrict__ gemb,
+                                 float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * LPR) return;
+    out[i] = gemb[(int64_t)src[i / LPR] * LPR + i % LPR];
 }
 
 
@@ -600,14 +649,11 @@ extern "C" int64_t satrans_embed_partial_ws_floats(int64_t n, int D) {
     return chunks * 2 * D + 2 * chunks + 4 + n * D + n + 4 + supers * 2 * D + 2 * supers;
 }
 
-extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
-                                          const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
-                                          const satrans_adam_hparams* h, double* reg_partials, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    SATRANS_REQUIRE(arena && m && v && sorted_rows && src && gemb && partial_ws && h && reg_partials, SATRANS_E_BADARG,
-                    "embed_adam_touched: null pointer");
-    SATRANS_REQUIRE(n > 0, SATRANS_E_BADARG, "embed_adam_touched: n=%lld", (long long)n);
-    const AdamK k = make_adamk(*h);
+// shared by the two entry points below: segmented sums in position order, then either the optimizer step (G == nullptr)
+// or a store into the dense gradient buffer G
+static int run_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows, const int32_t* src, int64_t n,
+                       const float* gemb, float* partial_ws, const AdamK& k, double* reg_partials, float* G,
+                       hipStream_t stream) {
     const int64_t chunks = ceil_div(n, kChunk);
     float4* partial = (float4*)partial_ws;
     int32_t* info = (int32_t*)(partial_ws + chunks * 2 * D);
@@ -624,7 +670,8 @@ extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int 
                         trail_row, rowsum, head_of)));
     SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
     DISPATCH_LPR(D, (touched_apply_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, n, (const float4*)rowsum, head_of, k, reg_a)));
+                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, n, (const float4*)rowsum, head_of, k, reg_a,
+                        (float4*)G)));
     SATRANS_CHECK_LAUNCH("touched_apply_kernel");
     const int64_t supers = ceil_div(chunks, kSuper);
     int64_t off2 = off + n * D + n;
@@ -636,22 +683,82 @@ extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int 
     double* reg_c = reg_b + sblocks;
     DISPATCH_LPR(D, (touched_super_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)partial, info, trail_row, partial2,
-                        info2, trail_row2, k, reg_b)));
+                        info2, trail_row2, k, reg_b, (float4*)G)));
     SATRANS_CHECK_LAUNCH("touched_super_kernel");
     DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, supers, (const float4*)partial2, info2, trail_row2, k, reg_c)));
+                        (float4*)arena, (float4*)m, (float4*)v, supers, (const float4*)partial2, info2, trail_row2, k, reg_c,
+                        (float4*)G)));
     SATRANS_CHECK_LAUNCH("touched_spans_kernel");
     return SATRANS_OK;
 }
 
-extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t total_rows, int D,
+extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
+                                          const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
+                                          const satrans_adam_hparams* h, double* reg_partials, void* stream_) {
+    SATRANS_REQUIRE(arena && m && v && sorted_rows && src && gemb && partial_ws && h && reg_partials, SATRANS_E_BADARG,
+                    "embed_adam_touched: null pointer");
+    SATRANS_REQUIRE(n > 0, SATRANS_E_BADARG, "embed_adam_touched: n=%lld", (long long)n);
+    return run_touched(arena, m, v, D, sorted_rows, src, n, gemb, partial_ws, make_adamk(*h), reg_partials, nullptr,
+                       (hipStream_t)stream_);
+}
+
+extern "C" int satrans_embed_segment_sums(const int32_t* sorted_rows, const int32_t* src, int64_t n, const float* gemb,
+                                          int D, float* partial_ws, double* reg_partials, float* g_rows, void* stream_) {
+    SATRANS_REQUIRE(sorted_rows && src && gemb && partial_ws && reg_partials && g_rows, SATRANS_E_BADARG,
+                    "embed_segment_sums: null pointer");
+    SATRANS_REQUIRE(n > 0, SATRANS_E_BADARG, "embed_segment_sums: n=%lld", (long long)n);
+    AdamK k = {};
+    return run_touched(nullptr, nullptr, nullptr, D, sorted_rows, src, n, gemb, partial_ws, k, reg_partials, g_rows,
+                       (hipStream_t)stream_);
+}
+
+extern "C" int64_t satrans_embed_adam_rows_partials(int64_t rows, int D) { return ceil_div(rows * (D / 4), 256); }
+
+extern "C" int satrans_embed_adam_rows(float* arena, float* m, float* v, int32_t* last, int64_t row0, int64_t rows, int D,
+                                       const float* g_rows, const satrans_adam_hparams* h, int t, double* reg_partials,
+                                       void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && m && v && g_rows && h && reg_partials, SATRANS_E_BADARG, "embed_adam_rows: null pointer");
+    SATRANS_REQUIRE(row0 >= 0 && rows > 0, SATRANS_E_BADARG, "embed_adam_rows: rows=%lld", (long long)rows);
+    const AdamK k = make_adamk(*h);
+    DISPATCH_LPR(D, (adam_rows_kernel<LPR><<<(unsigned)ceil_div(rows * LPR, 256), 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, row0, rows, (const float4*)g_rows, last, t, k, reg_partials)));
+    SATRANS_CHECK_LAUNCH("adam_rows_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_embed_pack_rows(const int32_t* src, int64_t n, const float* gemb, int D, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(src && gemb && out && n > 0, SATRANS_E_BADARG, "embed_pack_rows: bad arguments");
+    DISPATCH_LPR(D, (pack_rows_kernel<LPR><<<(unsigned)ceil_div(n * LPR, 256), 256, 0, stream>>>(src, n, (const float4*)gemb,
+                                                                                              (float4*)out)));
+    SATRANS_CHECK_LAUNCH("pack_rows_kernel");
+    return SATRANS_OK;
+}
+
+// touched-row bitmap of an already sorted id list (the every-step streaming Adam skips these rows)
+extern "C" int satrans_embed_mark_touched(const int32_t* sorted_rows, int64_t n, int64_t total_rows, uint32_t* touched,
+                                          void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(touched && total_rows > 0 && (n == 0 || sorted_rows), SATRANS_E_BADARG, "embed_mark_touched: bad arguments");
+    hipError_t e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)ceil_div(total_rows, 32), stream);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_mark_touched: memset: %s", hipGetErrorString(e));
+    if (n > 0) {
+        mark_heads_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(sorted_rows, n, touched);
+        SATRANS_CHECK_LAUNCH("mark_heads_kernel");
+    }
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, int64_t first_row, int64_t total_rows, int D,
                                             const uint32_t* touched, const satrans_adam_hparams* h, double* reg_partials,
                                             int grid_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(arena && m && v && touched && h && reg_partials, SATRANS_E_BADARG, "embed_adam_untouched: null pointer");
-    SATRANS_REQUIRE(total_rows > 0, SATRANS_E_BADARG, "embed_adam_untouched: total_rows=%lld", (long long)total_rows);
+    SATRANS_REQUIRE(total_rows > 0 && first_row >= 0 && first_row <= total_rows, SATRANS_E_BADARG,
+                    "embed_adam_untouched: rows [%lld, %lld)", (long long)first_row, (long long)total_rows);
     const AdamK k = make_adamk(*h);
-    const int64_t n4 = total_rows * (D / 4);
+    const int64_t n4 = total_rows * (D / 4), first4 = first_row * (D / 4);
     // Grid: measured on MI355X (tools/adam_sweep.sh, 841 MB x 3 arrays): 512-768 persistent blocks of 256 threads reach
     // 5.3-5.4 TB/s, 2048 blocks 4.7 TB/s, 256 blocks 3.8 TB/s; the contiguous-slice-per-block form is 6 % slower than the
     // grid-wide stride.  512 also leaves wave slots to the layer kernels when the call runs on a side stream.
@@ -668,7 +775,7 @@ extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, in
     static const int variant = getenv("SATRANS_ADAM_VARIANT") ? atoi(getenv("SATRANS_ADAM_VARIANT")) : 0;
 #define LAUNCH_ADAM(UNR_, NT_, ...)                                                                              \
     DISPATCH_LPR(D, (adam_untouched_kernel<LPR, UNR_, NT_, ##__VA_ARGS__><<<blocks, kStreamBlock, 0, stream>>>(  \
-                        (float4*)arena, (float4*)m, (float4*)v, n4, touched, k, reg_partials)))
+                        (float4*)arena, (float4*)m, (float4*)v, first4, n4, touched, k, reg_partials)))
     switch (variant) {
         case 1: LAUNCH_ADAM(8, true); break;
         case 2: LAUNCH_ADAM(4, false); break;

@@ -19,7 +19,7 @@ constexpr int kRowsPerThread = 4;
 
 template <int LPR>  // lanes per row = D/4
 __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
-    const float4* __restrict__ arena, const int64_t* __restrict__ row_off, const int32_t* __restrict__ cols,
+    const float4* __restrict__ arena, const int64_t* __restrict__ row_span, const int32_t* __restrict__ cols,
     const void* __restrict__ X, int id_dtype, int64_t x_stride, int64_t n_rows, int F, float4* __restrict__ out,
     int32_t* __restrict__ rows_out, int32_t* __restrict__ status) {
     const int64_t tid = (int64_t)blockIdx.x * kGatherBlock + threadIdx.x;
@@ -29,27 +29,28 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
 
     for (int64_t base = slot0; base < n_rows; base += stride * kRowsPerThread) {
         int64_t row[kRowsPerThread];
+        bool bad[kRowsPerThread];
         float4 val[kRowsPerThread];
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
             const int64_t slot = base + r * stride;
             row[r] = -1;
+            bad[r] = false;
             if (slot < n_rows) {
                 const int64_t b = slot / F;
                 const int f = (int)(slot - b * F);
                 const int64_t id = load_id(X, id_dtype, x_stride, b, cols[f]);
-                const int64_t lo = row_off[f], hi = row_off[f + 1];
-                if (id >= 0 && id < hi - lo) {
-                    row[r] = lo + id;
-                } else {
-                    row[r] = -2;  // out of range: the reference raises IndexError; we flag and write zeros
-                }
+                const int64_t lo = row_span[2 * f], hi = row_span[2 * f + 1];
+                // out of range: the reference raises IndexError; we flag, write zeros and record the table's first row
+                // (the recorded row stays inside the field's own table, which the optimizer's table classes rely on)
+                bad[r] = id < 0 || id >= hi - lo;
+                row[r] = bad[r] ? lo : lo + id;
             }
         }
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
             val[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row[r] >= 0 && out) val[r] = arena[row[r] * LPR + q];
+            if (row[r] >= 0 && !bad[r] && out) val[r] = arena[row[r] * LPR + q];
         }
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
             if (slot < n_rows) {
                 if (out) out[slot * LPR + q] = val[r];
                 if (q == 0) {
-                    if (rows_out) rows_out[slot] = (int32_t)(row[r] >= 0 ? row[r] : 0);
-                    if (row[r] == -2) atomicOr(status, 1);
+                    if (rows_out) rows_out[slot] = (int32_t)row[r];
+                    if (bad[r]) atomicOr(status, 1);
                 }
             }
         }
@@ -151,11 +152,11 @@ extern "C" int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_s
     return SATRANS_OK;
 }
 
-extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_off, const int32_t* cols, const void* X,
+extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_span, const int32_t* cols, const void* X,
                                   int id_dtype, int64_t x_stride, int B, int F, int D, float* out,
                                   int32_t* rows_out, int32_t* status, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SATRANS_REQUIRE(arena && row_off && cols && X && status && (out || rows_out), SATRANS_E_BADARG, "gather_fwd: null pointer");
+    SATRANS_REQUIRE(arena && row_span && cols && X && status && (out || rows_out), SATRANS_E_BADARG, "gather_fwd: null pointer");
     SATRANS_REQUIRE(B > 0 && F > 0, SATRANS_E_BADARG, "gather_fwd: bad sizes B=%d F=%d", B, F);
     SATRANS_REQUIRE(id_dtype >= 0 && id_dtype <= 2, SATRANS_E_BADARG, "gather_fwd: id_dtype %d", id_dtype);
     SATRANS_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, SATRANS_E_UNSUPPORTED,
@@ -168,7 +169,7 @@ extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_off, co
     if (blocks < 1) blocks = 1;
 #define LAUNCH(LPR)                                                                                            \
     gather_rows_kernel<LPR><<<(unsigned)blocks, kGatherBlock, 0, stream>>>(                                    \
-        (const float4*)arena, row_off, cols, X, id_dtype, x_stride, n_rows, F, (float4*)out, rows_out, status)
+        (const float4*)arena, row_span, cols, X, id_dtype, x_stride, n_rows, F, (float4*)out, rows_out, status)
     switch (lpr) {
         case 4: LAUNCH(4); break;
         case 8: LAUNCH(8); break;

@@ -14,6 +14,7 @@ applies the identical update in the identical order (satrans_amd/parallel.py).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import Dict, List, Optional
@@ -100,21 +101,22 @@ class PathEngine:
             self._multi_cols = torch.tensor([fi[c.name][0] for c in m.domain_feature_columns], dtype=torch.int64,
                                             device=self.dev)
         self.n_cols = max(e for _, e in fi.values())
-        # arena row offset of every FIELD (fields sharing an embedding_name share a table)
-        offs = [m._table_rows[c.embedding_name][0] for c in sparse]
-        ends = [m._table_rows[c.embedding_name][0] + m._table_rows[c.embedding_name][1] for c in sparse]
+        # arena rows [lo, hi) of every FIELD's table (fields sharing an embedding_name share a table)
+        spans = [(m._table_rows[c.embedding_name][0], m._table_rows[c.embedding_name][0] + m._table_rows[c.embedding_name][1])
+                 for c in sparse]
         self.total_rows = m.embedding_arena.shape[0]
-        # the gather kernel takes [lo_f, hi_f) per field as row_off[f], row_off[f+1]; with shared tables the spans
-        # are not consecutive, so they are passed as an explicit (lo, hi) pair table laid out [F+1] when they are
-        self._consecutive = all(ends[i] == offs[i + 1] for i in range(len(offs) - 1))
-        if not self._consecutive:
-            raise NotImplementedError("fields sharing one embedding table (embedding_name reuse)")
-        self.row_off = torch.tensor(offs + [ends[-1]], dtype=torch.int64, device=self.dev)
+        self.row_span = torch.tensor(spans, dtype=torch.int64, device=self.dev).contiguous()
+        # optimizer classes (basemodel._rebind_storage puts the small tables first in the arena): arena row < small_rows
+        # <=> small table.  Every sample contributes exactly one row per field, so after sorting a batch's rows the first
+        # B * F_small positions are the small-table ones.
+        self.small_rows = int(m._arena_small_rows)
+        self.F_small = sum(1 for lo, _ in spans if lo < self.small_rows)
 
         self._ws: Dict[int, dict] = {}
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.reg_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.reg_sum_side = torch.zeros(1, dtype=torch.float64, device=self.dev)   # accumulated on the side stream
         self.adam_t = 0
         self.adam_m = self.adam_v = None
         self.flat_m = self.flat_v = self.flat_g = None
@@ -133,6 +135,8 @@ class PathEngine:
         # replayed - same arithmetic, same result bit for bit - when a row is next gathered, or for all rows by
         # flush_lazy() (epoch end, before predict / state_dict).  SATRANS_LAZY_ADAM=0: streaming kernel every step.
         self.lazy = os.environ.get("SATRANS_LAZY_ADAM", "1") != "0"
+        # SATRANS_SPLIT_TABLES=1: use the small/large table classes of the multi-rank step on a single rank too (tests)
+        self.force_split = os.environ.get("SATRANS_SPLIT_TABLES", "0") == "1"
         self.last_step = None            # [R] int32: last Adam step applied to every table row
         self._hp_table = None            # [cap, 2] fp32: (lr / (1 - beta1^s), sqrt(1 - beta2^s)) for step s
         self._hp_cfg = None
@@ -182,27 +186,38 @@ class PathEngine:
         self._ws[B] = ws
         return ws
 
-    def train_workspace(self, B: int, n_rows: int) -> dict:
+    def train_workspace(self, B: int, world: int = 1) -> dict:
         ws = self.workspace(B)
-        key = ("train", n_rows)
+        key = ("train", world)
         if key in ws:
             return ws
-        dev, F, D = self.dev, self.F, self.D
+        dev, F, D, lib = self.dev, self.F, self.D, self.lib
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        n_loc = B * F
+        n_s = B * self.F_small                       # sorted positions [0, n_s): small tables; [n_s, n_loc): large tables
+        n_big = (n_loc - n_s) * world                # large-table positions of ALL ranks
+        n_max = max(n_loc, n_big)
         ws["dact"] = [torch.empty(B, F, D, **f32) for _ in range(2)]
-        ws["head_scratch"] = torch.empty(int(self.lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
+        ws["head_scratch"] = torch.empty(int(lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
         desc = self._layer_desc(ws, 0, B, None, None, True)
-        ws["slabs"] = torch.empty(int(self.lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
-        ws["sorted_rows"] = torch.empty(n_rows, **i32)
-        ws["src"] = torch.empty(n_rows, **i32)
+        ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
+        ws["sorted_rows"] = torch.empty(n_loc, **i32)           # this rank's rows, sorted, and their source positions
+        ws["src"] = torch.empty(n_loc, **i32)
+        if world > 1:
+            ws["g_sorted"] = torch.empty(max(n_big, 1), **i32)  # every rank's large-table rows, sorted
+            ws["g_src"] = torch.empty(max(n_big, 1), **i32)
+            ws["packed"] = torch.empty(max(n_loc - n_s, 1), D, **f32)
         ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
-        ws["sort_ws"] = torch.empty(int(self.lib.satrans_embed_sort_workspace_bytes(n_rows, self.total_rows)),
+        ws["sort_ws"] = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n_max, self.total_rows)),
                                     dtype=torch.uint8, device=dev)
-        ws["partial_ws"] = torch.empty(int(self.lib.satrans_embed_partial_ws_floats(n_rows, D)), **f32)
-        ws["reg_partials"] = torch.zeros(int(self.lib.satrans_embed_reg_partials(self.total_rows, n_rows, D)),
-                                         dtype=torch.float64, device=dev)
-        ws["replay_reg"] = torch.zeros((n_rows * D + 255) // 256, dtype=torch.float64, device=dev)
+        ws["partial_ws"] = torch.empty(int(lib.satrans_embed_partial_ws_floats(n_max, D)), **f32)
+        ws["reg_partials"] = torch.zeros(int(lib.satrans_embed_reg_partials(self.total_rows, n_max, D)), **f64)
+        ws["reg_unused"] = torch.zeros(int(lib.satrans_embed_reg_partials(self.total_rows, max(n_s, 1), D)), **f64)
+        ws["reg_rows"] = torch.zeros(max(1, int(lib.satrans_embed_adam_rows_partials(max(self.small_rows, 1), D))), **f64)
+        ws["replay_reg"] = torch.zeros((n_loc * D + 255) // 256, **f64)
+        ws["replay_reg_g"] = torch.zeros((max(n_big, 1) * D + 255) // 256, **f64)
         ws[key] = True
         return ws
 
@@ -279,7 +294,7 @@ class PathEngine:
             raise NotImplementedError("integer id matrix together with dense features")
         return X
 
-    def _run_forward(self, X, ws, training, tabs, att_list=None, after_gather=None):
+    def _run_forward(self, X, ws, training, tabs, att_list=None):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         sx, sidt, sstride, scol = X, idt, X.stride(0), self.dom_col
@@ -291,12 +306,10 @@ class PathEngine:
                                              self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
                 "satrans_bucket_scenarios")
         with self.phase("gather_fwd"):
-            N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_off.data_ptr(),
+            N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
                                            self.cols.data_ptr(), X.data_ptr(), idt, X.stride(0), B, self.F, self.D,
                                            ws["acts"][0].data_ptr(), ws["rows"].data_ptr(), self.status.data_ptr(), st),
                     "satrans_gather_fwd")
-        if after_gather is not None:
-            after_gather(ws)
         for l in range(self.L):
             desc = self._layer_desc(ws, l, B, None, tabs, training)
             att = att_list[l].data_ptr() if att_list is not None else None
@@ -362,7 +375,10 @@ class PathEngine:
     def _ensure_train_state(self):
         m = self.m
         if self.flat_g is None:
-            self.flat_g = torch.zeros_like(m.flat_params)
+            # [flat parameters | dense gradient of the small tables]: ONE all-reduce moves both
+            n_flat = m.flat_params.numel()
+            self.flat_g = torch.zeros(n_flat + self.small_rows * self.D, dtype=torch.float32, device=self.dev)
+            self.g_small = self.flat_g[n_flat:].view(self.small_rows, self.D)
             self.flat_m = torch.zeros_like(m.flat_params)
             self.flat_v = torch.zeros_like(m.flat_params)
             self.adam_m = torch.zeros_like(m.embedding_arena)
@@ -381,10 +397,12 @@ class PathEngine:
     def reset_epoch_sums(self):
         self.loss_sum.zero_()
         self.reg_sum.zero_()
+        self.reg_sum_side.zero_()
 
     def epoch_sums(self):
         self.flush_lazy()          # the regulariser sums of postponed steps belong to this epoch
-        return float(self.loss_sum.item()), float(self.reg_sum.item())
+        torch.cuda.synchronize(self.dev)
+        return float(self.loss_sum.item()), float(self.reg_sum.item()) + float(self.reg_sum_side.item())
 
     def _hparams(self, l2: float) -> N.AdamHParams:
         cfg = self.m._adam_cfg
@@ -396,7 +414,7 @@ class PathEngine:
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
         return h
 
-    def backward(self, X, y, ws, after_gather=None):
+    def backward(self, X, y, ws):
         """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
         `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
         lib, B, st = self.lib, X.shape[0], self._stream()
@@ -408,7 +426,7 @@ class PathEngine:
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
         tabs = self.scenario_tables(grad=modulated)
         g_tabs = torch.zeros_like(tabs) if modulated else None
-        self._run_forward(X, ws, training, tabs.detach(), after_gather=after_gather)
+        self._run_forward(X, ws, training, tabs.detach())
         self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
@@ -437,94 +455,134 @@ class PathEngine:
         return ws["dact"][cur]
 
     def train_step(self, X: torch.Tensor, y: torch.Tensor):
-        """One optimizer step.  Launch order on the main stream: bucket, gather, [sort of the gathered row ids],
-        forward, head, backward, touched-row Adam, flat Adam.  The streaming Adam of all OTHER rows needs only the
-        touched-row bitmap, so it is issued right after the sort on a side stream and runs (HBM-bound) underneath
-        the compute-bound layer kernels; the main stream joins it at the end of the step."""
+        """One optimizer step of every data-parallel rank.
+
+        main stream: ids -> arena rows, sort, [lazy: replay of the rows this rank is about to read], bucket, gather,
+          forward, head, backward; small tables: ordered segmented sums into a dense gradient, all-reduced together with
+          the flat gradient, dense step; large tables: [all-gather of the gradient rows], ordered segmented sums + step
+          over the sorted (row, gradient) list of all ranks; flat Adam.
+        side stream (several ranks, or the streaming form of the dense step): all-gather of the other ranks' large-table
+          rows, their sort, [lazy: their replay | streaming: Adam of every other row], underneath the layer kernels.
+        Every rank applies the same updates in the same order, so the replicas stay bit-identical (parallel.py)."""
         from . import parallel
         X = self._prepare_input(X)
         y = y.reshape(-1).to(torch.float32).contiguous()
         B = X.shape[0]
         self._ensure_train_state()
         world = parallel.world_size()
-        n_rows = B * self.F * world
-        ws = self.train_workspace(B, n_rows)
+        ws = self.train_workspace(B, world)
         lib, m, D = self.lib, self.m, self.D
         main = torch.cuda.current_stream(self.dev)
-        side_done = None
-        h_emb = None
-
-        def sort_rows(ws_, rows):
-            with self.phase("embed_sort"):
-                N.check(lib.satrans_embed_sort(rows.data_ptr(), n_rows, self.total_rows, ws_["sorted_rows"].data_ptr(),
-                                               ws_["src"].data_ptr(), None if self.lazy else ws_["touched"].data_ptr(),
-                                               ws_["sort_ws"].data_ptr(), ws_["sort_ws"].numel(), self._stream()),
-                        "satrans_embed_sort")
-
-        def early(ws_):
-            nonlocal side_done, h_emb
-            rows = parallel.gather_rows(ws_["rows"]) if world > 1 else ws_["rows"]
-            self.adam_t += 1
-            h_emb = self._hparams(m.l2_reg_embedding)
-            sort_rows(ws_, rows)
-            if self.overlap:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(self.dev)
-                ready = torch.cuda.Event()
-                ready.record(main)
-                self._side.wait_event(ready)
-                with torch.cuda.stream(self._side):
-                    self._launch_untouched(ws_, h_emb)
-                    side_done = torch.cuda.Event()
-                    side_done.record(self._side)
-            else:
-                self._launch_untouched(ws_, h_emb)
-
-        if self.lazy:
-            # rows of this batch first (ids -> arena rows, nothing moved), sort them, and replay the postponed
-            # regulariser-only steps of exactly those rows up to step t-1, so that the gather below reads current values
-            idt = N.id_dtype_of(X)
-            st0 = self._stream()
-            N.check(lib.satrans_gather_fwd(m.embedding_arena.data_ptr(), self.row_off.data_ptr(), self.cols.data_ptr(),
-                                           X.data_ptr(), idt, X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
-                                           self.status.data_ptr(), st0), "satrans_gather_fwd(rows)")
-            rows = parallel.gather_rows(ws["rows"]) if world > 1 else ws["rows"]
-            sort_rows(ws, rows)
-            h_emb = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
-            self.adam_t += 1
-            if self.adam_t > 1:
-                table = self._table(self.adam_t)
-                with self.phase("lazy_replay"):
-                    N.check(lib.satrans_embed_lazy_replay(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                                          self.adam_v.data_ptr(), self.last_step.data_ptr(), D,
-                                                          ws["sorted_rows"].data_ptr(), n_rows, self.adam_t - 1,
-                                                          table.data_ptr(), C.byref(h_emb), ws["replay_reg"].data_ptr(),
-                                                          st0), "satrans_embed_lazy_replay")
-                N.check(lib.satrans_sum_f64(ws["replay_reg"].data_ptr(), ws["replay_reg"].numel(),
-                                            self.reg_sum.data_ptr(), 1, st0), "satrans_sum_f64")
-            h_emb = self._hparams(m.l2_reg_embedding)
-            early = None
-
-        gemb = self.backward(X, y, ws, after_gather=early)
-        if world > 1:
-            gemb = parallel.exchange_grads(self.flat_g, gemb)
         st = self._stream()
-        with self.phase("adam_touched"):
-            N.check(lib.satrans_embed_adam_touched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                                   self.adam_v.data_ptr(), D, ws["sorted_rows"].data_ptr(),
-                                                   ws["src"].data_ptr(), n_rows, gemb.data_ptr(),
-                                                   ws["partial_ws"].data_ptr(), C.byref(h_emb),
-                                                   ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_touched")
+        # table classes only pay off when there is an exchange to shrink (one rank: +5 launches for nothing)
+        split = world > 1 or self.force_split
+        small_rows = self.small_rows if split else 0
+        n_loc = B * self.F
+        n_s = B * self.F_small if split else 0
+        n_b = n_loc - n_s
+        n_big = n_b * world
+        l2 = m.l2_reg_embedding
+        arena, am, av = m.embedding_arena.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
+
+        def sort(rows, n, out_rows, out_src, touched):
+            N.check(lib.satrans_embed_sort(rows.data_ptr(), n, self.total_rows, out_rows.data_ptr(), out_src.data_ptr(),
+                                           touched, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(), self._stream()),
+                    "satrans_embed_sort")
+
+        def replay(sorted_rows, n, reg, reg_sum):
+            table = self._table(self.adam_t)
+            h = self._hparams(l2)
+            N.check(lib.satrans_embed_lazy_replay(arena, am, av, self.last_step.data_ptr(), D, sorted_rows.data_ptr(), n,
+                                                  self.adam_t - 1, table.data_ptr(), C.byref(h), reg.data_ptr(),
+                                                  self._stream()), "satrans_embed_lazy_replay")
+            N.check(lib.satrans_sum_f64(reg.data_ptr(), reg.numel(), reg_sum.data_ptr(), 1, self._stream()),
+                    "satrans_sum_f64")
+
+        # ---- 1. this batch's arena rows (nothing is moved yet), sorted -----------------------------------------------
+        N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
+                                       N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
+                                       self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
+        with self.phase("embed_sort"):
+            sort(ws["rows"], n_loc, ws["sorted_rows"], ws["src"], None)
+        self.adam_t += 1
+        h_emb = self._hparams(l2)
+        # ---- 2. lazy form: replay the postponed steps of exactly these rows up to t-1, so that the gather reads current
+        #         values (small-table rows are always current: they take a dense step every step) --------------------------
+        if self.lazy and self.adam_t > 1:
+            with self.phase("lazy_replay"):
+                replay(ws["sorted_rows"], n_loc, ws["replay_reg"], self.reg_sum)
+        # ---- 3. the sorted list of the large-table rows of ALL ranks; side stream work --------------------------------------
+        side_done = None
+        big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
+        use_side = (world > 1 and n_b > 0) or (not self.lazy and self.overlap)
+        if use_side:
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.dev)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            self._side.wait_event(ready)
+        with torch.cuda.stream(self._side) if use_side else contextlib.nullcontext():
+            touched = None if self.lazy else ws["touched"].data_ptr()
+            if world > 1 and n_b > 0:
+                all_rows = parallel.gather_rows(big_sorted)
+                sort(all_rows, n_big, ws["g_sorted"], ws["g_src"], touched)
+                big_sorted, big_src = ws["g_sorted"], ws["g_src"]
+                if self.lazy and self.adam_t > 1:
+                    replay(big_sorted, n_big, ws["replay_reg_g"], self.reg_sum_side)
+            elif not self.lazy:
+                N.check(lib.satrans_embed_mark_touched(big_sorted.data_ptr() if n_b else None, n_b, self.total_rows,
+                                                       ws["touched"].data_ptr(), self._stream()),
+                        "satrans_embed_mark_touched")
+            if not self.lazy and self.total_rows > small_rows:
+                # streaming form: every large-table row outside the bitmap takes its regulariser-only step now
+                with self.phase("adam_untouched"):
+                    N.check(lib.satrans_embed_adam_untouched(arena, am, av, small_rows, self.total_rows, D,
+                                                             ws["touched"].data_ptr(), C.byref(h_emb),
+                                                             ws["reg_partials"].data_ptr(), 0, self._stream()),
+                            "satrans_embed_adam_untouched")
+            if use_side:
+                side_done = torch.cuda.Event()
+                side_done.record(self._side)
+
+        # ---- 4. forward, loss, backward ---------------------------------------------------------------------------------
+        gemb = self.backward(X, y, ws)
+        # ---- 5. small tables: dense gradient (tail of the flat gradient buffer), one all-reduce, dense step -----------------
+        with self.phase("adam_small"):
+            if n_s > 0:
+                N.check(lib.satrans_embed_segment_sums(ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(), n_s,
+                                                       gemb.data_ptr(), D, ws["partial_ws"].data_ptr(),
+                                                       ws["reg_unused"].data_ptr(), self.g_small.data_ptr(), st),
+                        "satrans_embed_segment_sums")
+            if world > 1:
+                parallel.all_reduce_flat(self.flat_g)
+            if small_rows > 0:
+                N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, small_rows, D,
+                                                    self.g_small.data_ptr(), C.byref(h_emb), self.adam_t,
+                                                    ws["reg_rows"].data_ptr(), st), "satrans_embed_adam_rows")
+                N.check(lib.satrans_sum_f64(ws["reg_rows"].data_ptr(), ws["reg_rows"].numel(), self.reg_sum.data_ptr(), 1,
+                                            st), "satrans_sum_f64")
+        # ---- 6. large tables: (row, gradient row) lists of all ranks ----------------------------------------------------------
+        grads = gemb
+        if world > 1 and n_b > 0:
+            N.check(lib.satrans_embed_pack_rows(ws["src"][n_s:].data_ptr(), n_b, gemb.data_ptr(), D,
+                                                ws["packed"].data_ptr(), st), "satrans_embed_pack_rows")
+            grads = parallel.gather_grad_rows(ws["packed"])
+        if side_done is not None:
+            main.wait_event(side_done)
+        if n_big > 0:
+            with self.phase("adam_touched"):
+                N.check(lib.satrans_embed_adam_touched(arena, am, av, D, big_sorted.data_ptr(), big_src.data_ptr(), n_big,
+                                                       grads.data_ptr(), ws["partial_ws"].data_ptr(), C.byref(h_emb),
+                                                       ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_touched")
+                if self.lazy:
+                    N.check(lib.satrans_embed_lazy_mark(big_sorted.data_ptr(), n_big, self.last_step.data_ptr(),
+                                                        self.adam_t, st), "satrans_embed_lazy_mark")
         if self.lazy:
-            N.check(lib.satrans_embed_lazy_mark(ws["sorted_rows"].data_ptr(), n_rows, self.last_step.data_ptr(),
-                                                self.adam_t, st), "satrans_embed_lazy_mark")
             self._lazy_pending = True
         h_flat = self._hparams(0.0)
         N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                       self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st),
                 "satrans_adam_flat")
-        if side_done is not None:
-            main.wait_event(side_done)
         N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(),
                                     1, st), "satrans_sum_f64")
 
@@ -556,16 +614,6 @@ class PathEngine:
                                          1, st), "satrans_sum_f64")
         self._lazy_pending = False
 
-    def _launch_untouched(self, ws, h_emb):
-        m = self.m
-        with self.phase("adam_untouched"):
-            N.check(self.lib.satrans_embed_adam_untouched(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                                          self.adam_v.data_ptr(), self.total_rows, self.D,
-                                                          ws["touched"].data_ptr(), C.byref(h_emb),
-                                                          ws["reg_partials"].data_ptr(),
-                                                          0, self._stream()),
-                    "satrans_embed_adam_untouched")
-
     # ------------------------------------------------------------------------------------------------
     # inspection for the parity tests: one forward+backward, gradients by state_dict key (dense tables)
     # ------------------------------------------------------------------------------------------------
@@ -576,7 +624,7 @@ class PathEngine:
         B = X.shape[0]
         self._ensure_train_state()
         n_rows = B * self.F
-        ws = self.train_workspace(B, n_rows)
+        ws = self.train_workspace(B, 1)
         lib, st, m, D = self.lib, self._stream(), self.m, self.D
         self.loss_sum.zero_()
         gemb = self.backward(X, y, ws)

@@ -70,8 +70,14 @@ SIGNATURES = {
     "satrans_embed_partial_ws_floats": (C.c_int64, [C.c_int64, C.c_int]),
     "satrans_embed_adam_touched": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64, _vp, _vp,
                                              C.POINTER(AdamHParams), _vp, _vp]),
-    "satrans_embed_adam_untouched": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams), _vp,
-                                               C.c_int, _vp]),
+    "satrans_embed_adam_untouched": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams),
+                                               _vp, C.c_int, _vp]),
+    "satrans_embed_mark_touched": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp]),
+    "satrans_embed_segment_sums": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "satrans_embed_adam_rows_partials": (C.c_int64, [C.c_int64, C.c_int]),
+    "satrans_embed_adam_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams),
+                                          C.c_int, _vp, _vp]),
+    "satrans_embed_pack_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp, _vp]),
     "satrans_embed_lazy_reg_partials": (C.c_int64, [C.c_int64, C.c_int]),
     "satrans_embed_lazy_replay": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp,
                                             C.POINTER(AdamHParams), _vp, _vp]),

@@ -80,6 +80,24 @@ def gather_rows(rows: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def all_reduce_flat(flat_grad: torch.Tensor) -> None:
+    """SUM over ranks, in place, of the flat gradient buffer (dense parameters + the dense gradient of the small
+    embedding tables, which the engine keeps at its tail): the loss is a sum over samples, so gradients add."""
+    if world_size() > 1:
+        _all_reduce(flat_grad)
+
+
+def gather_grad_rows(gemb: torch.Tensor) -> torch.Tensor:
+    """All-gather of gradient rows ([W*n, D], rank-major: the same order as `gather_rows`)."""
+    w = world_size()
+    gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
+    if w == 1:
+        return gemb
+    out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
+    _all_gather(out, gemb)
+    return out
+
+
 def exchange_grads(flat_grad: torch.Tensor, gemb: torch.Tensor) -> torch.Tensor:
     """All-reduce `flat_grad` in place (SUM) and all-gather the gradient rows ([W*n, D], rank-major: the same order
     as `gather_rows`)."""

@@ -153,7 +153,7 @@ def test_optimizer_kernels_exact():
     N.check(lib.satrans_embed_adam_touched(Pd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), D, sorted_rows.data_ptr(),
                                            src.data_ptr(), nrow, gemb_d.data_ptr(), part.data_ptr(), C.byref(hp(l2)),
                                            regp.data_ptr(), st), "touched")
-    N.check(lib.satrans_embed_adam_untouched(Pd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), R, D, touched.data_ptr(),
+    N.check(lib.satrans_embed_adam_untouched(Pd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), 0, R, D, touched.data_ptr(),
                                              C.byref(hp(l2)), regp.data_ptr(), 0, st), "untouched")
     np.testing.assert_allclose(Md.cpu().numpy(), Mr.numpy(), rtol=1e-6, atol=2e-7 * float(Mr.abs().max()))
     np.testing.assert_allclose(Vd.cpu().numpy(), Vr.numpy(), rtol=1e-6, atol=2e-7 * float(Vr.abs().max()))
@@ -163,6 +163,41 @@ def test_optimizer_kernels_exact():
     N.check(lib.satrans_sum_f64(regp.data_ptr(), regp.numel(), reg.data_ptr(), 0, st), "sum")
     # the reference multiplies fp32 tensors by the python float l2, i.e. by float32(l2)
     assert float(reg.item()) == pytest.approx(float(np.float32(l2)) * float((P.double() ** 2).sum()), rel=1e-12)
+
+    # ---- the same step in the form the engine uses: rows < RS are "small tables" (ordered sums stored into a dense
+    # gradient, dense step over ALL of them), the others go through the sorted list, whose gradient rows are first packed
+    # in sorted order (what a rank contributes to the all-gather); untouched rows from RS on ----
+    RS = 64
+    n_s = int((sr < RS).sum())
+    Pd2, Md2, Vd2 = (x.to(DEV) for x in (P, M, V))
+    last = torch.zeros(R, dtype=torch.int32, device=DEV)
+    G = torch.zeros(RS, D, device=DEV)
+    regu = torch.zeros_like(regp)
+    N.check(lib.satrans_embed_segment_sums(sorted_rows.data_ptr(), src.data_ptr(), n_s, gemb_d.data_ptr(), D, part.data_ptr(),
+                                           regu.data_ptr(), G.data_ptr(), st), "segment_sums")
+    assert torch.equal(G.cpu(), torch.zeros(R, D).index_add_(0, rows.long(), gemb)[:RS]), "dense gradient of the small rows"
+    regr = torch.zeros(int(lib.satrans_embed_adam_rows_partials(RS, D)), dtype=torch.float64, device=DEV)
+    N.check(lib.satrans_embed_adam_rows(Pd2.data_ptr(), Md2.data_ptr(), Vd2.data_ptr(), last.data_ptr(), 0, RS, D, G.data_ptr(),
+                                        C.byref(hp(l2)), t, regr.data_ptr(), st), "adam_rows")
+    n_b = nrow - n_s
+    packed = torch.empty(n_b, D, device=DEV)
+    N.check(lib.satrans_embed_pack_rows(src[n_s:].data_ptr(), n_b, gemb_d.data_ptr(), D, packed.data_ptr(), st), "pack")
+    assert torch.equal(packed.cpu(), gemb[sc[n_s:]])
+    ident = torch.arange(n_b, dtype=torch.int32, device=DEV)
+    regp2 = torch.zeros_like(regp)
+    N.check(lib.satrans_embed_adam_touched(Pd2.data_ptr(), Md2.data_ptr(), Vd2.data_ptr(), D, sorted_rows[n_s:].data_ptr(),
+                                           ident.data_ptr(), n_b, packed.data_ptr(), part.data_ptr(), C.byref(hp(l2)),
+                                           regp2.data_ptr(), st), "touched(big)")
+    N.check(lib.satrans_embed_mark_touched(sorted_rows[n_s:].data_ptr(), n_b, R, touched.data_ptr(), st), "mark")
+    N.check(lib.satrans_embed_adam_untouched(Pd2.data_ptr(), Md2.data_ptr(), Vd2.data_ptr(), RS, R, D, touched.data_ptr(),
+                                             C.byref(hp(l2)), regp2.data_ptr(), 0, st), "untouched(big)")
+    # exact gradient sums => bit-identical tables, whichever path a row took
+    assert torch.equal(Pd2, Pd) and torch.equal(Md2, Md) and torch.equal(Vd2, Vd)
+    assert bool((last[:RS] == t).all()) and bool((last[RS:] == 0).all())
+    reg2 = torch.zeros(1, dtype=torch.float64, device=DEV)
+    N.check(lib.satrans_sum_f64(regp2.data_ptr(), regp2.numel(), reg2.data_ptr(), 0, st), "sum")
+    N.check(lib.satrans_sum_f64(regr.data_ptr(), regr.numel(), reg2.data_ptr(), 1, st), "sum")
+    assert float(reg2.item()) == pytest.approx(float(reg.item()), rel=1e-12)
 
 
 @pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
@@ -382,6 +417,31 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, tmp_path):
     want, grads, init, lr = c.tensors("adam"), c.arrays("grad"), c.tensors("param"), c.meta["lr"]
     for k, w in want.items():     # same bounds as test_adam_steps_match_reference_golden
         err = (r0[k] - w).abs().flatten().double()
+        if k in grads and float(np.abs(grads[k]).max()) >= 1e-7 and float((w - init[k]).abs().max()) > 0:
+            assert float(err.median()) <= 2e-3 * lr * steps, (k, float(err.median()))
+            assert float(torch.quantile(err, 0.95)) <= 2e-2 * lr * steps, (k, float(torch.quantile(err, 0.95)))
+        assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
+
+
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_table_classes_on_one_rank_match_reference_golden(monkeypatch, lazy):
+    """The small/large table classes of the multi-rank step (dense all-reduced gradient + dense step for small tables,
+    sorted lists for large ones), forced on a single rank, in both forms of the dense step."""
+    monkeypatch.setenv("SATRANS_SPLIT_TABLES", "1")
+    monkeypatch.setenv("SATRANS_LAZY_ADAM", lazy)
+    c = Case("aliccp_sota")
+    model = build_model(c, DEV)
+    model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+    model.eval()
+    eng = model._require_engine()
+    assert eng.force_split and eng.small_rows > 0
+    X, y = c.X.to(DEV), c.y.to(DEV)
+    steps, lr = c.meta["adam_steps"], c.meta["lr"]
+    for _ in range(steps):
+        eng.train_step(X, y)
+    got, want, grads, init = sd_to_cpu(model), c.tensors("adam"), c.arrays("grad"), c.tensors("param")
+    for k, w in want.items():
+        err = (got[k] - w).abs().flatten().double()
         if k in grads and float(np.abs(grads[k]).max()) >= 1e-7 and float((w - init[k]).abs().max()) > 0:
             assert float(err.median()) <= 2e-3 * lr * steps, (k, float(err.median()))
             assert float(torch.quantile(err, 0.95)) <= 2e-2 * lr * steps, (k, float(torch.quantile(err, 0.95)))
