@@ -80,6 +80,41 @@ def cpu_baseline(state, X, y, batch, lr, steps):
     return batch / (sum(timed) / len(timed)), len(timed)
 
 
+def gather_microbench(eng, Xd, B, F, D, launches=48):
+    """K1 alone (ids -> [B,F,D] rows + the arena row of every id): `launches` back-to-back launches between two HIP events
+    on the launch stream, every launch on a different batch of ids (the 841 MB table does not fit the 256 MiB Infinity
+    Cache and uniform ids never repeat a row soon), algorithmic bytes F*(D*4+4) read + F*D*4 written per sample."""
+    import ctypes as C
+    from satrans_amd import native as N
+    out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    for nb in (B, 4 * B):
+        n_batches = Xd.shape[0] // nb
+        if n_batches < 2:
+            continue
+        dst = torch.empty(nb, F, D, dtype=torch.float32, device=Xd.device)
+        rows = torch.empty(nb, F, dtype=torch.int32, device=Xd.device)
+
+        def launch(i):
+            xb = Xd[(i % n_batches) * nb:(i % n_batches + 1) * nb]
+            N.check(eng.lib.satrans_gather_fwd(eng.m.embedding_arena.data_ptr(), eng.row_span.data_ptr(), eng.cols.data_ptr(),
+                                               xb.data_ptr(), N.id_dtype_of(xb), xb.stride(0), nb, F, D, dst.data_ptr(),
+                                               rows.data_ptr(), eng.status.data_ptr(), stream), "satrans_gather_fwd")
+        for i in range(4):
+            launch(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(launches):
+            launch(i)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / launches
+        gbs = nb * F * (2 * D * 4 + 4) / 1e9 / (ms / 1e3)
+        out[f"batch_{nb}"] = {"ms_per_launch": round(ms, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(gbs / HBM_PEAK_GBS, 4), "distinct_id_batches": n_batches}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +258,21 @@ def main():
                             "fixed-order reduction kernels; `kernels_serial` repeats the measurement without the "
                             "side-stream overlap"}
 
+    # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (tools/pmc_passes.sh: FETCH_SIZE
+    # and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+    if roofline:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")))
+            rec = next(v for k, v in pmc.items() if k.startswith(roofline["kernel"]))
+            roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
+            roofline["traffic_source"] = "profiles/r01_f_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+        except (OSError, StopIteration, KeyError):
+            pass
+
+    # ---- the gather on its own: achieved HBM GB/s at the training batch and at the reference's prediction batch
+    #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
+    gather = gather_microbench(eng, Xd, B, 19, 32)
+
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = None
     try:
@@ -258,7 +308,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": 32, "layers": 3, "heads": 4,
                    "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
-        "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "cpu_baseline": cpu,
+        "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
+        "cpu_baseline": cpu,
     }
     print(json.dumps(out))
     if world > 1:

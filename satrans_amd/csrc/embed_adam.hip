@@ -275,24 +275,27 @@ __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__
 // dependent steps instead of run/kChunk.
 constexpr int kSuper = 32;
 template <int LPR>
-__global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__ P, float4* __restrict__ M,
-                                                           float4* __restrict__ V, int64_t chunks,
+__global__ __launch_bounds__(256) void touched_super_kernel(int64_t chunks,
                                                            const float4* __restrict__ partial,
                                                            const int32_t* __restrict__ info,
                                                            const int32_t* __restrict__ trail_row,
                                                            float4* __restrict__ partial2, int32_t* __restrict__ info2,
-                                                           int32_t* __restrict__ trail_row2, AdamK k,
-                                                           double* __restrict__ reg_partials, float4* __restrict__ G) {
-    __shared__ double s_red[256];
+                                                           int32_t* __restrict__ trail_row2,
+                                                           float4* __restrict__ done_sum, int32_t* __restrict__ done_row) {
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
     const int64_t c0 = group * kSuper;
-    double reg = 0.0;
     if (c0 < chunks) {
         const int64_t c1 = min(chunks, c0 + (int64_t)kSuper);
+        // flags and lead partials of all chunks first (independent loads, issued together; a lead slot that was not written
+        // this step holds stale numbers, which are read but never used)
         int f[kSuper];
+        float4 lead[kSuper];
 #pragma unroll
         for (int u = 0; u < kSuper; ++u) f[u] = c0 + u < c1 ? info[c0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kSuper; ++u)
+            lead[u] = c0 + u < c1 ? partial[((c0 + u) * 2 + 0) * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
         bool open = f[0] & 2, is_lead = open;
         int flags2 = open ? 2 : 0;
         int32_t row = -1;
@@ -300,22 +303,17 @@ __global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__
 #pragma unroll
         for (int u = 0; u < kSuper; ++u) {
             const int64_t c = c0 + u;
+            int32_t ended = -1;
             if (f[u] & 2) {
-                const float4 g = partial[(c * 2 + 0) * LPR + q];
+                const float4 g = lead[u];
                 acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                 if (f[u] & 4) {
                     if (is_lead) {
                         partial2[(group * 2 + 0) * LPR + q] = acc;
                         flags2 |= 4;
-                    } else {
-                        const int64_t at = (int64_t)row * LPR + q;
-                        if (G) {
-                            G[at] = acc;
-                        } else {
-                            float4 p = P[at], m = M[at], v = V[at];
-                            reg += adam4(p, m, v, acc, k);
-                            P[at] = p; M[at] = m; V[at] = v;
-                        }
+                    } else {            // a run that ended in chunk c: its step is taken by the parallel finish kernel
+                        done_sum[c * LPR + q] = acc;
+                        ended = row;
                     }
                     open = false;
                     is_lead = false;
@@ -327,6 +325,7 @@ __global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__
                 open = true;
                 is_lead = false;
             }
+            if (q == 0 && c < c1) done_row[c] = ended;
         }
         if (open) {
             if (is_lead) {
@@ -338,6 +337,32 @@ __global__ __launch_bounds__(256) void touched_super_kernel(float4* __restrict__
             }
         }
         if (q == 0) info2[group] = flags2;
+    }
+}
+
+// the runs the superchunk kernel finished, one lane group per chunk (at most one run ends in a chunk that began in an earlier one)
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_finish_kernel(float4* __restrict__ P, float4* __restrict__ M,
+                                                            float4* __restrict__ V, int64_t chunks,
+                                                            const float4* __restrict__ done_sum,
+                                                            const int32_t* __restrict__ done_row, AdamK k,
+                                                            double* __restrict__ reg_partials, float4* __restrict__ G) {
+    __shared__ double s_red[256];
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    double reg = 0.0;
+    if (c < chunks) {
+        const int32_t row = done_row[c];
+        if (row >= 0) {
+            const int64_t at = (int64_t)row * LPR + q;
+            if (G) {
+                G[at] = done_sum[c * LPR + q];
+            } else {
+                float4 p = P[at], m = M[at], v = V[at];
+                reg += adam4(p, m, v, done_sum[c * LPR + q], k);
+                P[at] = p; M[at] = m; V[at] = v;
+            }
+        }
     }
     const double total = block_sum(reg, s_red);
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
@@ -643,10 +668,10 @@ extern "C" int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int
 }
 
 // partial_ws: [chunks][2][D] floats, [chunks] int32 info, [chunks] int32 trail_row, [n][D] run sums, [n] int32 head flags,
-// then the same three record arrays for the superchunks
+// then the same three record arrays for the superchunks, then [chunks][D] + [chunks] int32 for the runs they finish
 extern "C" int64_t satrans_embed_partial_ws_floats(int64_t n, int D) {
     const int64_t chunks = ceil_div(n, kChunk), supers = ceil_div(chunks, kSuper);
-    return chunks * 2 * D + 2 * chunks + 4 + n * D + n + 4 + supers * 2 * D + 2 * supers;
+    return chunks * 2 * D + 2 * chunks + 4 + n * D + n + 4 + supers * 2 * D + 2 * supers + 4 + chunks * D + chunks;
 }
 
 // shared by the two entry points below: segmented sums in position order, then either the optimizer step (G == nullptr)
@@ -680,11 +705,18 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
     int32_t* info2 = (int32_t*)(partial_ws + off2 + supers * 2 * D);
     int32_t* trail_row2 = info2 + supers;
     const int64_t sblocks = ceil_div(supers * (D / 4), 256);
-    double* reg_c = reg_b + sblocks;
+    int64_t off3 = off2 + supers * 2 * D + 2 * supers;
+    off3 = (off3 + 3) & ~(int64_t)3;
+    float4* done_sum = (float4*)(partial_ws + off3);
+    int32_t* done_row = (int32_t*)(partial_ws + off3 + chunks * D);
+    double* reg_c = reg_b + cblocks;
     DISPATCH_LPR(D, (touched_super_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)partial, info, trail_row, partial2,
-                        info2, trail_row2, k, reg_b, (float4*)G)));
+                        chunks, (const float4*)partial, info, trail_row, partial2, info2, trail_row2, done_sum, done_row)));
     SATRANS_CHECK_LAUNCH("touched_super_kernel");
+    DISPATCH_LPR(D, (touched_finish_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)done_sum, done_row, k, reg_b,
+                        (float4*)G)));
+    SATRANS_CHECK_LAUNCH("touched_finish_kernel");
     DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, supers, (const float4*)partial2, info2, trail_row2, k, reg_c,
                         (float4*)G)));

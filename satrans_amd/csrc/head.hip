@@ -91,14 +91,15 @@ __global__ __launch_bounds__(kHeadBlock) void head_kernel(const float* __restric
     }
 }
 
-// block = 32 columns x 8 groups of partial rows (contiguous shares, index order), group sums combined in group order
-__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ partial, int nblk, int ncol,
-                                                        float* __restrict__ g_w, float* __restrict__ g_b,
-                                                        double* __restrict__ loss_sum) {
-    __shared__ double s_acc[8][32];
+// block = 32 columns x 32 groups of partial rows (contiguous shares, index order), group sums combined in group order
+constexpr int kReduceGroups = 32;
+__global__ __launch_bounds__(32 * kReduceGroups) void head_reduce_kernel(const float* __restrict__ partial, int nblk, int ncol,
+                                                                       float* __restrict__ g_w, float* __restrict__ g_b,
+                                                                       double* __restrict__ loss_sum) {
+    __shared__ double s_acc[kReduceGroups][32];
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + lane;
-    const int share = (nblk + 7) / 8;
+    const int share = (nblk + kReduceGroups - 1) / kReduceGroups;
     const int lo = grp * share, hi = min(nblk, lo + share);
     double acc = 0.0;
     if (c < ncol + 2) {
@@ -115,12 +116,12 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     if (grp != 0 || c >= ncol + 2) return;
     if (c == ncol + 1) {
         double t = 0.0;
-        for (int k = 0; k < 8; ++k) t += s_acc[k][lane];
+        for (int k = 0; k < kReduceGroups; ++k) t += s_acc[k][lane];
         loss_sum[0] += t;
         return;
     }
     float t = 0.f;
-    for (int k = 0; k < 8; ++k) t += (float)s_acc[k][lane];
+    for (int k = 0; k < kReduceGroups; ++k) t += (float)s_acc[k][lane];
     if (c < ncol) g_w[c] += t;
     else g_b[0] += t;
 }
@@ -149,7 +150,7 @@ extern "C" int satrans_head(const float* a, const float* dense, int64_t dense_st
     SATRANS_CHECK_LAUNCH("head_kernel");
     if (y) {
         const int ncol = FD + n_dense;
-        head_reduce_kernel<<<(unsigned)ceil_div(ncol + 2, 32), 256, 0, stream>>>(scratch, nblk, ncol, g_w, g_b, loss_sum);
+        head_reduce_kernel<<<(unsigned)ceil_div(ncol + 2, 32), 32 * kReduceGroups, 0, stream>>>(scratch, nblk, ncol, g_w, g_b, loss_sum);
         SATRANS_CHECK_LAUNCH("head_reduce_kernel");
     }
     return SATRANS_OK;

@@ -1,0 +1,25 @@
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_passes.sh: per kernel, mean counter value per launch."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = row.get("Kernel_Name") or row.get("Kernel Name")
+            c, v = row["Counter_Name"], float(row["Counter_Value"])
+            short = k.split("(")[0].replace("void ", "").replace("satrans::", "")[:48]
+            a = acc[short][c]
+            a[0] += v
+            a[1] += 1
+out = {}
+for k, cs in acc.items():
+    out[k] = {c: a[0] / a[1] for c, a in cs.items()}
+    out[k]["launches"] = max(a[1] for a in cs.values())
+keep = [k for k in out if "layer_" in k or "gather_rows" in k or "lazy_" in k or "touched" in k or "head_kernel" in k]
+print(json.dumps({k: out[k] for k in sorted(keep)}, indent=1))
