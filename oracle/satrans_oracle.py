@@ -344,7 +344,18 @@ def dropout_keep(seed: int, step: int, layer: int, site: int, sample, elem, p: f
         key = _mix32(np.uint32(seed) ^ (np.uint32(step) * np.uint32(0x9E3779B9)))
         key = _mix32(key ^ np.uint32((layer * 4 + site + 1) * 0x85EBCA6B & 0xFFFFFFFF))
         h = _mix32(np.asarray(sample, dtype=np.uint32) * np.uint32(0xC2B2AE35) ^ key)
-        h = _mix32(h ^ (np.asarray(elem, dtype=np.uint32) * np.uint32(0x27D4EB2F)))
+        # blocks of four consecutive elements: the block's hash is the word of its first element, one xorshift32 step
+        # each of the next three (rng.h: drop_keep4)
+        elem = np.asarray(elem, dtype=np.uint32)
+        h = _mix32(h ^ ((elem >> np.uint32(2)) * np.uint32(0x27D4EB2F)))
+        h, r = np.broadcast_arrays(h, elem & np.uint32(3))
+        h = h.copy()
+        for k in (1, 2, 3):
+            x = h.copy()
+            x ^= (x << np.uint32(13)).astype(np.uint32)
+            x ^= x >> np.uint32(17)
+            x ^= (x << np.uint32(5)).astype(np.uint32)
+            h = np.where(r >= k, x, h)
     thresh = np.uint32(int(p * 16777216.0))
     return (h >> np.uint32(8)) >= thresh
 
@@ -360,7 +371,9 @@ def dropout_masks(seed: int, step: int, B: int, Fn: int, D: int, H: int, L: int,
             e = np.arange(Fn * D, dtype=np.uint32)
             keep = dropout_keep(seed, step, l, site, b[:, None], e[None, :], p)
             masks[(l, name)] = torch.from_numpy((keep * scale).astype(np.float32)).reshape(B, Fn, D)
-        e = np.arange(H * Fn * Fn, dtype=np.uint32)
+        # attention rows are padded to a multiple of four keys in the element index (rng.h: drop_attn_elem)
+        fp = (Fn + 3) & ~3
+        e = (np.arange(H * Fn, dtype=np.uint32)[:, None] * np.uint32(fp) + np.arange(Fn, dtype=np.uint32)[None, :]).reshape(-1)
         keep = dropout_keep(seed, step, l, 2, b[:, None], e[None, :], p)
         masks[(l, "attn")] = torch.from_numpy((keep * scale).astype(np.float32)).reshape(B, H, Fn, Fn)
     return masks

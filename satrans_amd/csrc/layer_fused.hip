@@ -189,6 +189,16 @@ __device__ __forceinline__ FusedDrop fused_drop(const satrans_layer_desc& a) {
     return dc;
 }
 
+// keep flags of one token lane at one dropout site: the lane owns features 16t + 4g + r of token f, i.e. one block of four
+// consecutive element indices per t; bit 4t + r of the result
+template <int KT_>
+__device__ __forceinline__ uint32_t token_keep_bits(uint32_t sample_key, int f, int D, int g4, uint32_t thresh) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) bits |= drop_keep4(sample_key, (uint32_t)(f * D + 16 * t + g4) >> 2, thresh) << (4 * t);
+    return bits;
+}
+
 // weight images resident in LDS for the whole kernel
 template <int D, int U>
 struct FwdImages {
@@ -222,12 +232,13 @@ __device__ __forceinline__ void metanet_frag(const float* w1l, const float* w2l,
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
     chain<UT, KT, D + 4>(w2l, h, out);
+    const uint32_t kb = dc.on ? token_keep_bits<KT>(sample_key, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float m = out[t][r];
-            if (dc.on) m = drop_keep(sample_key, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? m * dc.scale : 0.f;
+            if (dc.on) m = (kb >> (4 * t + r)) & 1u ? m * dc.scale : 0.f;
             out[t][r] = m + in[t][r];
         }
     layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
@@ -388,19 +399,20 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
             for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
             float sum = 0.f;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)b);
-            const uint32_t elem0 = (uint32_t)((h * F + i) * F);
+            const uint32_t block0 = drop_attn_elem(h, F, i, 0) >> 2;
 #pragma unroll
             for (int c = 0; c < kRowChunks; ++c) {
                 if (4 * c < F) {
                     f32x2 vr[4][d / 2];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) load_row<d>(vbase + (size_t)min(4 * c + u, F - 1) * LD, vr[u]);
+                    const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)c, dc.thresh) : 0xFu;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float ex = __builtin_amdgcn_exp2f(sc[4 * c + u] - mx);
                         sum += ex;
                         float pe = ex;
-                        if (dc.on) pe = drop_keep(skey, elem0 + (uint32_t)(4 * c + u), dc.thresh) ? ex * dc.scale : 0.f;
+                        if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
                         sc[4 * c + u] = pe;
                         axpy_row<d>(pe, vr[u], oacc);
                     }
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                   const float ex = __expf(s * inv_sqrt_d - mx);
                   sum += ex;
                   float pe = ex;
-                  if (dc.on) pe = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? ex * dc.scale : 0.f;
+                  if (dc.on) pe = drop_keep(skey, drop_attn_elem(h, F, i, j), dc.thresh) ? ex * dc.scale : 0.f;
   #pragma unroll
                   for (int e = 0; e < d; e += 4) {
                       const float4 v4 = *reinterpret_cast<const float4*>(vbase + (size_t)j * LD + e);
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                           s = fmaf(qi[e + 2], k4.z, s); s = fmaf(qi[e + 3], k4.w, s);
                       }
                       float pj = __expf(s * inv_sqrt_d - mx) / sum;
-                      if (dc.on) pj = drop_keep(skey, (uint32_t)((h * F + i) * F + j), dc.thresh) ? pj * dc.scale : 0.f;
+                      if (dc.on) pj = drop_keep(skey, drop_attn_elem(h, F, i, j), dc.thresh) ? pj * dc.scale : 0.f;
                       arow[j] = pj;
                   }
               }
@@ -510,6 +522,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
             chain<KT, KT, LD>(wo_l, o, u);
             const float* xrow = a.x + ((size_t)b * F + f) * D + g4;
             const uint32_t skey = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
+            const uint32_t kb = dc.on ? token_keep_bits<KT>(skey, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 const float4 xv = *reinterpret_cast<const float4*>(xrow + 16 * t);
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(kFusedBlock) void layer_fwd_fused_kernel(satrans_la
                 for (int r = 0; r < 4; ++r) {
                     float val = u[t][r];
                     if (a.flags & SATRANS_RELU_OUT) val = fmaxf(val, 0.f);
-                    if (dc.on) val = drop_keep(skey, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? val * dc.scale : 0.f;
+                    if (dc.on) val = (kb >> (4 * t + r)) & 1u ? val * dc.scale : 0.f;
                     if (!(a.flags & SATRANS_NO_RES)) val += xr[r];
                     u[t][r] = val;
                 }
@@ -671,6 +684,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     constexpr int HB = (UT + KT - 1) / KT;          // row buffers needed to hold one U-wide operand (<= 2)
     constexpr int NB = (UT < KT) ? UT : KT;          // 16-feature tiles of such an operand held by one row buffer
     static_assert(HB <= 2 && UT == HB * NB, "MetaNet hidden width must be D/.. or 2*D for the fused backward");
+    static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
     extern __shared__ __align__(16) float lds[];
     const int F = a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -819,6 +833,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // token-wise state that lives from phase A to phase F
         float x[KT][4], q0[KT][4], k0[KT][4], hq[UT][4], hk[UT][4], zhq[KT][4], zhk[KT][4], dr[KT][4];
         float rstd_q = 0.f, rstd_k = 0.f;
+        // keep flags of this token lane at the MetaNet-Q / MetaNet-K / output sites (bits 0-7 / 8-15 / 16-23), generated once
+        uint32_t keepbits = 0xFFFFFFFFu;
+        if (dc.on && has_tile)
+            keepbits = token_keep_bits<KT>(key_q, f, D, g4, dc.thresh) | (token_keep_bits<KT>(key_k, f, D, g4, dc.thresh) << 8) |
+                       (token_keep_bits<KT>(key_o, f, D, g4, dc.thresh) << 16);
 
         STAMP(0);
         // ================= phase A: forward chain ====================================================================
@@ -841,7 +860,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float mm = m[t][r];
-                        if (dc.on) mm = drop_keep(key_q, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? mm * dc.scale : 0.f;
+                        if (dc.on) mm = (keepbits >> (4 * t + r)) & 1u ? mm * dc.scale : 0.f;
                         m[t][r] = mm + q0[t][r];
                     }
                 layer_norm_keep<KT>(m, zhq, rstd_q);
@@ -871,7 +890,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float mm = m[t][r];
-                        if (dc.on) mm = drop_keep(key_k, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? mm * dc.scale : 0.f;
+                        if (dc.on) mm = (keepbits >> (8 + 4 * t + r)) & 1u ? mm * dc.scale : 0.f;
                         m[t][r] = mm + k0[t][r];
                     }
                 layer_norm_keep<KT>(m, zhk, rstd_k);
@@ -930,10 +949,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             float sum = 0.f;
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
-            const uint32_t elem0 = (uint32_t)((h * F + i) * F);
+            const uint32_t block0 = drop_attn_elem(h, F, i, 0) >> 2;
             for (int j0 = 0; j0 < F; j0 += 4) {
                 f32x2 vr[4][d / 2];
                 float ex[4];
+                const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(j0 >> 2), dc.thresh) : 0xFu;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
@@ -947,7 +967,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     sum += ex[u];
                     float pe = ex[u];
                     if (dc.on) {
-                        const bool kp = drop_keep(skey, elem0 + (uint32_t)j, dc.thresh);
+                        const bool kp = (kb >> u) & 1u;
                         pe = kp ? ex[u] * dc.scale : 0.f;
                         keep = kp ? keep : keep & ~(1u << (j & 31));
                     }
@@ -978,7 +998,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     float val = u[t][r], kf = 1.0f;
                     if (relu_out) { kf = val > 0.f ? 1.0f : 0.f; val = fmaxf(val, 0.f); }
                     if (dc.on) {
-                        const float mk = drop_keep(key_o, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? dc.scale : 0.f;
+                        const float mk = (keepbits >> (16 + 4 * t + r)) & 1u ? dc.scale : 0.f;
                         val *= mk; kf *= mk;
                     }
                     keep[t][r] = kf;
@@ -1116,7 +1136,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             // masked when read as a fragment
 
             auto metanet_bwd = [&](float (&gout)[KT][4], const float (&zh)[KT][4], float rstd, const float* gam,
-                                   float (&ag)[KT][4], float (&ab)[KT][4], uint32_t key, float (&h)[UT][4],
+                                   float (&ag)[KT][4], float (&ab)[KT][4], int kshift, float (&h)[UT][4],
                                    const float (&in0)[KT][4], const float* w2T, const float* w1T,
                                    f32x4 (&acc_w1)[KT][UT], f32x4 (&acc_w2)[UT][KT]) {
                 layer_norm_bwd<KT>(gout, zh, rstd, gam, g4, ag, ab);            // gout = dz
@@ -1126,7 +1146,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float mk = 1.0f;
-                        if (dc.on) mk = drop_keep(key, (uint32_t)(f * D + 16 * t + g4 + r), dc.thresh) ? dc.scale : 0.f;
+                        if (dc.on) mk = (keepbits >> (kshift + 4 * t + r)) & 1u ? dc.scale : 0.f;
                         dm[t][r] = gout[t][r] * mk;
                     }
                 // dW2[u][o] += h^T dm : h goes to the q (and o) rows of this tile, dm to the dq rows
@@ -1184,12 +1204,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             };
 
             if (meta_q)
-                metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, key_q, hq, q0, w2qT, w1qT, acc_w1q, acc_w2q);
+                metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, 0, hq, q0, w2qT, w1qT, acc_w1q, acc_w2q);
             if (meta_k) {
                 if constexpr (SAME)   // one table: both roles add into the same accumulators
-                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, key_k, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
                 else
-                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, key_k, hk, k0, w2kT, w1kT, acc_w1k, acc_w2k);
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1k, acc_w2k);
             }
 
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T

@@ -311,7 +311,7 @@ __device__ void forward_tile(const satrans_layer_desc& a, const TileDims& T, int
         const int b = samp[ls];
         float acc = 0.f;
         for (int j = 0; j < F; ++j) {
-            const float p = prow[j] * drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + qi) * F + j));
+            const float p = prow[j] * drop_mask(dc, kSiteAttn, b, drop_attn_elem(h, F, qi, j));
             acc = fmaf(p, L.v[(size_t)(ls * F + j) * L.ldd + c], acc);
         }
         L.o[(size_t)t * L.ldd + c] = acc;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kLayerBlock) void layer_fwd_kernel(satrans_layer_de
                 const int ls = task / (H * F), rem = task - ls * H * F;
                 const int h = rem / F, qi = rem - h * F;
                 const int b = samp[ls];
-                const float pv = L.P[(size_t)task * L.ldp + j] * drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + qi) * F + j));
+                const float pv = L.P[(size_t)task * L.ldp + j] * drop_mask(dc, kSiteAttn, b, drop_attn_elem(h, F, qi, j));
                 att[(((size_t)h * a.B + b) * F + qi) * F + j] = pv;
             }
         }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
                 const float* vj = L.v + (size_t)(ls * F + j) * L.ldd + h * d;
                 float dp = 0.f;
                 for (int e = 0; e < d; ++e) dp = fmaf(go[e], vj[e], dp);
-                dp *= drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + qi) * F + j));
+                dp *= drop_mask(dc, kSiteAttn, b, drop_attn_elem(h, F, qi, j));
                 srow[j] = dp;
                 dot = fmaf(dp, prow[j], dot);
             }
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(kLayerBlock) void layer_bwd_kernel(satrans_layer_de
                 aq = fmaf(dS[(size_t)(task0 + row) * L.ldp + j], L.k[(size_t)(ls * F + j) * L.ldd + c], aq);
                 ak = fmaf(dS[(size_t)(task0 + j) * L.ldp + row], L.q[(size_t)(ls * F + j) * L.ldd + c], ak);
                 const float pd = L.P[(size_t)(task0 + j) * L.ldp + row] *
-                                 drop_mask(dc, kSiteAttn, b, (uint32_t)((h * F + j) * F + row));
+                                 drop_mask(dc, kSiteAttn, b, drop_attn_elem(h, F, j, row));
                 av = fmaf(pd, g_o[(size_t)(ls * F + j) * L.ldd + c], av);
             }
             g_q[(size_t)t * L.ldd + c] = aq;
