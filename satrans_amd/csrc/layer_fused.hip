@@ -817,15 +817,29 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       }
       __syncthreads();
       const int lo = a.seg[scen], hi = a.seg[scen + 1];
+      // The sample index and the input row of a tile are fetched one tile ahead (at the end of phase F, when the registers
+      // of the current x are free): with one wave per SIMD nothing else would hide those two dependent global loads.
+      const int tok = row0 + n;
+      int b_next = 0;
+      float x_next[KT][4];
+      auto fetch_tile = [&](int tile_) {
+          const int first_ = lo + tile_ * Tsamp;
+          const int ntok_ = min(Tsamp, hi - first_) * F;
+          const bool has_ = wave < ((ntok_ + 15) >> 4);
+          const bool valid_ = has_ && tok < ntok_;
+          const int ls_ = valid_ ? tok / F : 0, f_ = valid_ ? tok - ls_ * F : 0;
+          b_next = a.order[first_ + ls_];
+          if (has_) load_frag<KT>(a.x + ((size_t)b_next * F + f_) * D + g4, x_next);
+      };
+      fetch_tile(t0);
       for (int tile = t0; tile < t1; ++tile) {
         const int first = lo + tile * Tsamp;
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
         const bool has_tile = wave < ntt;
-        const int tok = row0 + n;
         const bool valid = has_tile && tok < ntok;
         const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
-        const int b = samp[ls];
+        const int b = b_next;
         const uint32_t key_q = drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b);
         const uint32_t key_k = drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b);
         const uint32_t key_o = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
@@ -842,7 +856,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         STAMP(0);
         // ================= phase A: forward chain ====================================================================
         if (has_tile) {
-            load_frag<KT>(a.x + ((size_t)b * F + f) * D + g4, x);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[t][r] = x_next[t][r];
             float v[KT][4], q[KT][4], k[KT][4];
             chain<KT, KT, LD>(wq + lo_d, x, q0);
             chain<KT, KT, LD>(wk + lo_d, x, k0);
@@ -1238,6 +1255,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
+        if (tile + 1 < t1) fetch_tile(tile + 1);
         __syncthreads();
         STAMP(6);
       }
