@@ -249,11 +249,19 @@ class BaseModel(nn.Module):
 
     def _to_device_matrix(self, packed: np.ndarray) -> torch.Tensor:
         """The reference ships ids as fp32 (exact below 2**24, models/meta_basemodel.py:311).  That layout is kept
-        while every vocabulary is below 2**24; above it ids could not survive the round trip, and int64 ids
-        with a separate dense block are required (not needed by any reference dataset)."""
-        sparse, _, _ = split_columns(self.dnn_feature_columns)
+        while every vocabulary is below 2**24.  Above it an id would not survive the round trip through fp32 (the
+        reference silently gathers the wrong row there): the matrix then travels as int64 and the kernels read the ids
+        as integers (`SATRANS_ID_I64`).  Dense features next to such a vocabulary would need a separate float block,
+        which no reference dataset calls for."""
+        sparse, dense, _ = split_columns(self.dnn_feature_columns)
         if max(c.vocabulary_size for c in sparse) >= (1 << 24):
-            raise NotImplementedError("vocabularies of 2**24 rows or more need the integer-id input layout")
+            if dense:
+                raise NotImplementedError("vocabularies of 2**24 rows or more together with DenseFeat columns")
+            if not np.issubdtype(packed.dtype, np.integer):
+                if np.abs(packed).max() >= (1 << 24) and packed.dtype == np.float32:
+                    raise ValueError("ids of 2**24 and above arrived as float32: they are already rounded; pass integers")
+                packed = packed.astype(np.int64)
+            return torch.from_numpy(np.ascontiguousarray(packed, dtype=np.int64)).to(self.device)
         return torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32)).to(self.device)
 
     # ------------------------------------------------------------------------------------------

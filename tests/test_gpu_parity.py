@@ -493,3 +493,36 @@ def test_size_independent_properties_at_the_baseline_batch():
     assert loss1 == loss2
     for k in sd1:
         assert torch.equal(sd1[k], sd2[k]), f"run-to-run difference in {k}"
+
+
+def test_vocabulary_above_2_pow_24_uses_integer_ids():
+    """Ids of 2**24 and above do not survive the reference's fp32 id matrix (16777217 becomes 16777216).  The integer-id
+    layout must gather exactly the addressed rows, and fit/predict must run on it."""
+    from satrans_amd import SATrans, SparseFeat
+    V = (1 << 24) + 8
+    cols = [SparseFeat("big", vocabulary_size=V, embedding_dim=16), SparseFeat("small", vocabulary_size=10, embedding_dim=16),
+            SparseFeat("dom", vocabulary_size=4, embedding_dim=16)]
+    model = SATrans(cols, cols, ["dom"], [3], att_layer_num=0, domain_att_layer_num=2, att_head_num=2,
+                    use_linear=False, use_dnn=False, meta_mode='QK', meta_dnn_hidden_units=(32, 16), seed=5,
+                    device=DEV, flag='sota')
+    model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy")
+    rng = np.random.RandomState(1)
+    n = 512
+    x = {"big": np.concatenate([np.arange((1 << 24) - 4, (1 << 24) + 8), rng.randint(0, V, size=n - 12)]).astype(np.int64),
+         "small": rng.randint(0, 10, size=n), "dom": rng.randint(1, 4, size=n)}
+    y = (rng.rand(n) < 0.3).astype(np.float32)
+    model.eval()
+    X = model._to_device_matrix(model._pack(x))
+    assert X.dtype == torch.int64
+    model(X)
+    eng = model._require_engine()
+    want = torch.stack([model.embedding_dict[c].weight[torch.from_numpy(x[c]).to(DEV)] for c in ("big", "small", "dom")], dim=1)
+    assert torch.equal(eng.layer_outputs(n)[0], want), "integer ids must address exactly their rows"
+    with pytest.raises(ValueError):
+        model._to_device_matrix(model._pack({k: v.astype(np.float32) for k, v in x.items()}))
+    before = model.embedding_dict["big"].weight[(1 << 24) + 1].clone()
+    hist = model.fit(x=x, y=y, batch_size=256, epochs=2, verbose=0)
+    assert np.isfinite(hist.history["loss"]).all() and hist.history["loss"][1] < hist.history["loss"][0]
+    assert not torch.equal(model.embedding_dict["big"].weight[(1 << 24) + 1], before)
+    p = model.predict(x, 512)
+    assert p.shape == (n, 1) and np.isfinite(p).all()
