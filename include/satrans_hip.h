@@ -84,6 +84,18 @@ int satrans_gather_fwd(const float* arena, const int64_t* row_span, const int32_
                        int32_t* rows_out, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-scenario generated weights (reference satrans.py:213,217-218; encoder = DNN_v2 with one Linear,
+ * submodules.py:31-61): tab[s] = relu(emb[s]) @ W^T + bias for the S scenario rows (not per sample), and its backward.
+ *   emb [S, De], W [P, De] (nn.Linear layout), bias [P], tab / g_tab [S, P]
+ *   backward ADDS into g_emb [S, De], g_W [P, De], g_bias [P]; workspace: satrans_scenario_table_bwd_ws_floats floats
+ * ---------------------------------------------------------------------------------------------- */
+int satrans_scenario_table_fwd(const float* emb, const float* W, const float* bias, int S, int De, int P, float* tab,
+                               void* stream);
+int64_t satrans_scenario_table_bwd_ws_floats(int S, int De);
+int satrans_scenario_table_bwd(const float* emb, const float* W, const float* g_tab, int S, int De, int P,
+                               float* g_emb, float* g_W, float* g_bias, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * One Meta_Transformer_Layer (reference satrans.py:50-100 with MetaNet submodules.py:77-103).
  * The generated MetaNet weights are passed as per-scenario tables (one row per scenario id) instead
  * of the reference's per-sample [B,P] matrices; row s = encoder(relu(domain_embeddings[s])), see

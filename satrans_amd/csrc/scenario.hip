@@ -1,0 +1,109 @@
+// Per-scenario generated weights: tab[s] = relu(emb[s]) @ W^T + bias   (reference satrans.py:213,217-218 with the
+// scenario encoder DNN_v2 = one Linear, submodules.py:31-61), evaluated once per SCENARIO instead of once per sample,
+// and its backward.  S is a handful of rows, so both directions are latency-bound: one launch each instead of the
+// dozen tiny framework kernels an autograd graph over [S,De] x [De,P] costs.
+#include "common.h"
+
+namespace satrans {
+
+// 32 lanes per generated parameter p (coalesced 128-byte reads of its weight row), shuffle reduction per scenario
+__global__ __launch_bounds__(256) void scenario_table_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, int S, int De, int P,
+                                                               float* __restrict__ tab) {
+    const int lane = threadIdx.x & 31;
+    const int p = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (p >= P) return;           // whole 32-lane groups leave together
+    const float* w = W + (size_t)p * De;
+    const float b = bias[p];
+    for (int s = 0; s < S; ++s) {
+        float acc = 0.f;
+        for (int k = lane; k < De; k += 32) acc = fmaf(fmaxf(emb[(size_t)s * De + k], 0.f), w[k], acc);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 32);
+        if (lane == 0) tab[(size_t)s * P + p] = acc + b;
+    }
+}
+
+// g_W[p][k] += sum_s g_tab[s][p] relu(emb[s][k]);  g_bias[p] += sum_s g_tab[s][p]
+__global__ __launch_bounds__(256) void scenario_table_bwd_w_kernel(const float* __restrict__ emb,
+                                                                 const float* __restrict__ g_tab, int S, int De, int P,
+                                                                 float* __restrict__ g_W, float* __restrict__ g_bias) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)P * De) return;
+    const int p = (int)(i / De), k = (int)(i - (int64_t)p * De);
+    float acc = 0.f, accb = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float g = g_tab[(size_t)s * P + p];
+        acc = fmaf(g, fmaxf(emb[(size_t)s * De + k], 0.f), acc);
+        accb += g;
+    }
+    g_W[i] += acc;
+    if (k == 0) g_bias[p] += accb;
+}
+
+// g_emb[s][k] += [emb[s][k] > 0] * sum_p g_tab[s][p] W[p][k] in two fixed-order levels: block (s, slice of p) -> partial
+// sums [S][kSlices][De] (8 sub-slices per block combined in order), then one thread per (s, k) adds the kSlices partials.
+constexpr int kSlices = 32, kSub = 8;
+__global__ __launch_bounds__(256) void scenario_table_bwd_e1_kernel(const float* __restrict__ W, const float* __restrict__ g_tab,
+                                                                  int De, int P, float* __restrict__ partial) {
+    extern __shared__ float s_part[];   // [kSub][De]
+    const int s = blockIdx.x, slice = blockIdx.y;
+    const int per = 256 / kSub;         // columns k handled per pass
+    const int sub = threadIdx.x / per, kk = threadIdx.x % per;
+    const int span = (P + kSlices - 1) / kSlices, sspan = (span + kSub - 1) / kSub;
+    const int p0 = min(P, slice * span + sub * sspan), p1 = min(min(P, (slice + 1) * span), p0 + sspan);
+    for (int k0 = 0; k0 < De; k0 += per) {
+        const int k = k0 + kk;
+        if (k < De) {
+            float acc = 0.f;
+            for (int p = p0; p < p1; ++p) acc = fmaf(g_tab[(size_t)s * P + p], W[(size_t)p * De + k], acc);
+            s_part[sub * De + k] = acc;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < De; k += blockDim.x) {
+        float t = 0.f;
+        for (int sh = 0; sh < kSub; ++sh) t += s_part[sh * De + k];
+        partial[((size_t)s * kSlices + slice) * De + k] = t;
+    }
+}
+
+__global__ void scenario_table_bwd_e2_kernel(const float* __restrict__ emb, const float* __restrict__ partial, int S, int De,
+                                             float* __restrict__ g_emb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * De) return;
+    const int s = i / De, k = i - s * De;
+    float t = 0.f;
+    for (int sl = 0; sl < kSlices; ++sl) t += partial[((size_t)s * kSlices + sl) * De + k];
+    if (emb[i] > 0.f) g_emb[i] += t;
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+extern "C" int satrans_scenario_table_fwd(const float* emb, const float* W, const float* bias, int S, int De, int P,
+                                          float* tab, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(emb && W && bias && tab, SATRANS_E_BADARG, "scenario_table_fwd: null pointer");
+    SATRANS_REQUIRE(S > 0 && De > 0 && P > 0, SATRANS_E_BADARG, "scenario_table_fwd: S=%d De=%d P=%d", S, De, P);
+    scenario_table_fwd_kernel<<<(unsigned)ceil_div(P, 8), 256, 0, stream>>>(emb, W, bias, S, De, P, tab);
+    SATRANS_CHECK_LAUNCH("scenario_table_fwd_kernel");
+    return SATRANS_OK;
+}
+
+extern "C" int64_t satrans_scenario_table_bwd_ws_floats(int S, int De) { return (int64_t)S * kSlices * De; }
+
+extern "C" int satrans_scenario_table_bwd(const float* emb, const float* W, const float* g_tab, int S, int De, int P,
+                                          float* g_emb, float* g_W, float* g_bias, float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(emb && W && g_tab && g_emb && g_W && g_bias && workspace, SATRANS_E_BADARG, "scenario_table_bwd: null pointer");
+    SATRANS_REQUIRE(S > 0 && De > 0 && P > 0, SATRANS_E_BADARG, "scenario_table_bwd: S=%d De=%d P=%d", S, De, P);
+    scenario_table_bwd_w_kernel<<<(unsigned)ceil_div((int64_t)P * De, 256), 256, 0, stream>>>(emb, g_tab, S, De, P, g_W, g_bias);
+    SATRANS_CHECK_LAUNCH("scenario_table_bwd_w_kernel");
+    scenario_table_bwd_e1_kernel<<<dim3(S, kSlices), 256, sizeof(float) * kSub * De, stream>>>(W, g_tab, De, P, workspace);
+    SATRANS_CHECK_LAUNCH("scenario_table_bwd_e1_kernel");
+    scenario_table_bwd_e2_kernel<<<(unsigned)ceil_div(S * De, 256), 256, 0, stream>>>(emb, workspace, S, De, g_emb);
+    SATRANS_CHECK_LAUNCH("scenario_table_bwd_e2_kernel");
+    return SATRANS_OK;
+}

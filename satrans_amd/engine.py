@@ -74,6 +74,9 @@ class PathEngine:
             self._multi_strides = torch.tensor(strides, dtype=torch.int64, device=self.dev)
         self.pos = 'pos' in flag
         self.onlyemb = 'onlyemb' in flag
+        self.native_tabs = not (self.multi or self.pos or self.onlyemb)   # scenario table by one HIP kernel each way
+        self._tab_ws = torch.empty(int(self.lib.satrans_scenario_table_bwd_ws_floats(self.S, m.domain_embeddings.weight.shape[1])),
+                                   dtype=torch.float32, device=self.dev) if self.native_tabs else None
         self.flags = 0
         if not self.bilinear and 'Q' in m.meta_mode:       # MetaNet or gate on the queries
             self.flags |= N.META_Q
@@ -228,6 +231,15 @@ class PathEngine:
     def scenario_tables(self, grad: bool) -> torch.Tensor:
         """-> [L, 2, S, P'] when 'pos' is in the flag (role 0 = Q, 1 = K), else [1, 1, S, P']."""
         m = self.m
+        if self.native_tabs:
+            # common case (one scenario column, no 'pos', no 'onlyemb'): one kernel; its backward is one call in backward()
+            lin = m.domain_map_dnn_Q.linears[0]
+            emb = m.domain_embeddings.weight
+            tab = torch.empty(1, 1, self.S, self.P, dtype=torch.float32, device=self.dev)
+            N.check(self.lib.satrans_scenario_table_fwd(emb.data_ptr(), lin.weight.data_ptr(), lin.bias.data_ptr(), self.S,
+                                                        emb.shape[1], self.P, tab.data_ptr(), self._stream()),
+                    "satrans_scenario_table_fwd")
+            return tab
         with torch.set_grad_enabled(grad):
             if self.multi:                                                          # satrans.py:205-207
                 emb = torch.stack([t.weight[i] for t, i in zip(self._multi_tables, self._multi_index)], dim=-1).mean(-1)
@@ -449,7 +461,15 @@ class PathEngine:
                     self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
                     self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
             cur = 1 - cur
-        if modulated:
+        if modulated and self.native_tabs:
+            lin, emb = m.domain_map_dnn_Q.linears[0], m.domain_embeddings.weight
+            N.check(lib.satrans_scenario_table_bwd(
+                emb.data_ptr(), lin.weight.data_ptr(), g_tabs.data_ptr(), self.S, emb.shape[1], self.P,
+                self._grad_view("domain_embeddings.weight").data_ptr(),
+                self._grad_view("domain_map_dnn_Q.linears.0.weight").data_ptr(),
+                self._grad_view("domain_map_dnn_Q.linears.0.bias").data_ptr(), self._tab_ws.data_ptr(), st),
+                    "satrans_scenario_table_bwd")
+        elif modulated:
             tabs.backward(g_tabs)                              # tiny: [S,P] through one Linear + two embeddings
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
