@@ -191,13 +191,16 @@ int satrans_adam_flat(float* p, const float* g, float* m, float* v, int64_t n,
  * pre-update values (reference `reg_loss`), filled by step 2 and 3 into disjoint slots.
  */
 int64_t satrans_embed_sort_workspace_bytes(int64_t n, int64_t total_rows);
+/* positions: optional [n] int32 with positions[i] = i kept by the caller (saves the launch that would write it) */
 int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32_t* sorted_rows,
                        int32_t* src, uint32_t* touched, void* workspace, int64_t workspace_bytes,
-                       void* stream);
+                       const int32_t* positions, void* stream);
 int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D);
+/* last / t: optional (lazy form): last[row] = t for every row stepped */
 int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
                                const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
-                               const satrans_adam_hparams* h, double* reg_partials, void* stream);
+                               const satrans_adam_hparams* h, double* reg_partials, int32_t* last, int t,
+                               void* stream);
 int64_t satrans_embed_partial_ws_floats(int64_t n, int D);
 /* rows [first_row, total_rows) that are not in the bitmap; grid_blocks: 0 = the measured optimum (512 persistent blocks
  * of 256 threads), otherwise the grid size to use */

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__
                                                            float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
                                                            int64_t n, const float4* __restrict__ rowsum,
                                                            const int32_t* __restrict__ head_of, AdamK k,
-                                                           double* __restrict__ reg_partials, float4* __restrict__ G) {
+                                                           double* __restrict__ reg_partials, float4* __restrict__ G,
+                                                           int32_t* __restrict__ last, int t) {
     __shared__ double s_red[256];
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__
             float4 p = P[at], m = M[at], v = V[at];
             reg += adam4(p, m, v, rowsum[j * LPR + q], k);
             P[at] = p; M[at] = m; V[at] = v;
+            if (last && q == 0) last[sorted_rows[j]] = t;      // lazy form: the row is current as of step t
         }
     }
     const double total = block_sum(reg, s_red);
@@ -346,7 +348,8 @@ __global__ __launch_bounds__(256) void touched_finish_kernel(float4* __restrict_
                                                             float4* __restrict__ V, int64_t chunks,
                                                             const float4* __restrict__ done_sum,
                                                             const int32_t* __restrict__ done_row, AdamK k,
-                                                            double* __restrict__ reg_partials, float4* __restrict__ G) {
+                                                            double* __restrict__ reg_partials, float4* __restrict__ G,
+                                                            int32_t* __restrict__ last, int t) {
     __shared__ double s_red[256];
     const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(256) void touched_finish_kernel(float4* __restrict_
                 float4 p = P[at], m = M[at], v = V[at];
                 reg += adam4(p, m, v, done_sum[c * LPR + q], k);
                 P[at] = p; M[at] = m; V[at] = v;
+                if (last && q == 0) last[row] = t;
             }
         }
     }
@@ -375,7 +379,8 @@ __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__
                                                            const float4* __restrict__ partial,
                                                            const int32_t* __restrict__ info,
                                                            const int32_t* __restrict__ trail_row, AdamK k,
-                                                           double* __restrict__ reg_partials, float4* __restrict__ G) {
+                                                           double* __restrict__ reg_partials, float4* __restrict__ G,
+                                                           int32_t* __restrict__ last, int t) {
     __shared__ double s_red[256];
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__
             float4 p = P[at], m = M[at], v = V[at];
             reg += adam4(p, m, v, acc, k);
             P[at] = p; M[at] = m; V[at] = v;
+            if (last && q == 0) last[trail_row[group]] = t;
         }
     }
     const double total = block_sum(reg, s_red);
@@ -635,7 +641,8 @@ extern "C" int64_t satrans_embed_sort_workspace_bytes(int64_t n, int64_t total_r
 }
 
 extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32_t* sorted_rows, int32_t* src,
-                                  uint32_t* touched, void* workspace, int64_t workspace_bytes, void* stream_) {
+                                  uint32_t* touched, void* workspace, int64_t workspace_bytes, const int32_t* positions,
+                                  void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(rows && sorted_rows && src && workspace, SATRANS_E_BADARG, "embed_sort: null pointer");
     SATRANS_REQUIRE(n > 0 && total_rows > 0 && n < ((int64_t)1 << 31) && total_rows < ((int64_t)1 << 31), SATRANS_E_BADARG,
@@ -649,11 +656,18 @@ extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_
     hipError_t e = hipSuccess;
     if (touched) e = hipMemsetAsync(touched, 0, sizeof(uint32_t) * (size_t)ceil_div(total_rows, 32), stream);
     SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: memset: %s", hipGetErrorString(e));
-    iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(rows, n, keys_in, pos_in);
-    SATRANS_CHECK_LAUNCH("iota_kernel");
+    const uint32_t* keys = keys_in;
+    const int32_t* pos = pos_in;
+    if (positions) {     // the caller keeps positions[i] = i around: the rows are the keys as they are, no preparation launch
+        keys = (const uint32_t*)rows;
+        pos = positions;
+    } else {
+        iota_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(rows, n, keys_in, pos_in);
+        SATRANS_CHECK_LAUNCH("iota_kernel");
+    }
     size_t temp_bytes = L.temp_bytes;
-    e = rocprim::radix_sort_pairs(ws + L.temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)sorted_rows,
-                                  (const int32_t*)pos_in, src, (unsigned)n, 0u, (unsigned)bits_for(total_rows), stream);
+    e = rocprim::radix_sort_pairs(ws + L.temp, temp_bytes, keys, (uint32_t*)sorted_rows, pos, src, (unsigned)n, 0u,
+                                  (unsigned)bits_for(total_rows), stream);
     SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_sort: radix sort: %s", hipGetErrorString(e));
     if (touched) {   // only the every-step streaming Adam needs the bitmap
         mark_heads_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(sorted_rows, n, touched);
@@ -677,8 +691,8 @@ extern "C" int64_t satrans_embed_partial_ws_floats(int64_t n, int D) {
 // shared by the two entry points below: segmented sums in position order, then either the optimizer step (G == nullptr)
 // or a store into the dense gradient buffer G
 static int run_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows, const int32_t* src, int64_t n,
-                       const float* gemb, float* partial_ws, const AdamK& k, double* reg_partials, float* G,
-                       hipStream_t stream) {
+                       const float* gemb, float* partial_ws, const AdamK& k, double* reg_partials, float* G, int32_t* last,
+                       int t, hipStream_t stream) {
     const int64_t chunks = ceil_div(n, kChunk);
     float4* partial = (float4*)partial_ws;
     int32_t* info = (int32_t*)(partial_ws + chunks * 2 * D);
@@ -696,7 +710,7 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
     SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
     DISPATCH_LPR(D, (touched_apply_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, sorted_rows, n, (const float4*)rowsum, head_of, k, reg_a,
-                        (float4*)G)));
+                        (float4*)G, last, t)));
     SATRANS_CHECK_LAUNCH("touched_apply_kernel");
     const int64_t supers = ceil_div(chunks, kSuper);
     int64_t off2 = off + n * D + n;
@@ -715,22 +729,23 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
     SATRANS_CHECK_LAUNCH("touched_super_kernel");
     DISPATCH_LPR(D, (touched_finish_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)done_sum, done_row, k, reg_b,
-                        (float4*)G)));
+                        (float4*)G, last, t)));
     SATRANS_CHECK_LAUNCH("touched_finish_kernel");
     DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
                         (float4*)arena, (float4*)m, (float4*)v, supers, (const float4*)partial2, info2, trail_row2, k, reg_c,
-                        (float4*)G)));
+                        (float4*)G, last, t)));
     SATRANS_CHECK_LAUNCH("touched_spans_kernel");
     return SATRANS_OK;
 }
 
 extern "C" int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,
                                           const int32_t* src, int64_t n, const float* gemb, float* partial_ws,
-                                          const satrans_adam_hparams* h, double* reg_partials, void* stream_) {
+                                          const satrans_adam_hparams* h, double* reg_partials, int32_t* last, int t,
+                                          void* stream_) {
     SATRANS_REQUIRE(arena && m && v && sorted_rows && src && gemb && partial_ws && h && reg_partials, SATRANS_E_BADARG,
                     "embed_adam_touched: null pointer");
     SATRANS_REQUIRE(n > 0, SATRANS_E_BADARG, "embed_adam_touched: n=%lld", (long long)n);
-    return run_touched(arena, m, v, D, sorted_rows, src, n, gemb, partial_ws, make_adamk(*h), reg_partials, nullptr,
+    return run_touched(arena, m, v, D, sorted_rows, src, n, gemb, partial_ws, make_adamk(*h), reg_partials, nullptr, last, t,
                        (hipStream_t)stream_);
 }
 
@@ -740,8 +755,8 @@ extern "C" int satrans_embed_segment_sums(const int32_t* sorted_rows, const int3
                     "embed_segment_sums: null pointer");
     SATRANS_REQUIRE(n > 0, SATRANS_E_BADARG, "embed_segment_sums: n=%lld", (long long)n);
     AdamK k = {};
-    return run_touched(nullptr, nullptr, nullptr, D, sorted_rows, src, n, gemb, partial_ws, k, reg_partials, g_rows,
-                       (hipStream_t)stream_);
+    return run_touched(nullptr, nullptr, nullptr, D, sorted_rows, src, n, gemb, partial_ws, k, reg_partials, g_rows, nullptr,
+                       0, (hipStream_t)stream_);
 }
 
 extern "C" int64_t satrans_embed_adam_rows_partials(int64_t rows, int D) { return ceil_div(rows * (D / 4), 256); }

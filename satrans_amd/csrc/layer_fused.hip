@@ -1310,57 +1310,56 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 //   common  [G][CSZ]   CSZ = 4*D*D + 6*D : [wq|wk|wv|wo|ln g,b|lnq g,b|lnk g,b] per workgroup
 //   records [G+S][TSZ] TSZ = 4*D*U       : [w1q|w2q|w1k|w2k] of (workgroup w, scenario s) at index w + s
 // -------------------------------------------------------------------------------------------------------------------
-constexpr int kFusedSplit = 16;
-
-__global__ void fused_common_partial_kernel(const float* __restrict__ common, int G, int CSZ, float* __restrict__ partial) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= CSZ) return;
-    const int per = (G + kFusedSplit - 1) / kFusedSplit;
-    const int lo = blockIdx.y * per, hi = min(G, lo + per);
-    float acc = 0.f;
-    for (int w = lo; w < hi; ++w) acc += common[(size_t)w * CSZ + e];
-    partial[(size_t)blockIdx.y * CSZ + e] = acc;
-}
-
-__global__ void fused_common_final_kernel(const float* __restrict__ partial, int D, int flags, float* g_wq, float* g_wk,
-                                          float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk) {
-    const int CSZ = 4 * D * D + 6 * D;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= CSZ) return;
-    auto total = [&](int at) {
-        float acc = 0.f;
-        for (int k = 0; k < kFusedSplit; ++k) acc += partial[(size_t)k * CSZ + at];
-        return acc;
-    };
-    const int DD = D * D;
-    if (e < DD) { g_wq[e] += total(e); return; }
-    if (e < 2 * DD) { g_wk[e - DD] += total(e); return; }
-    if (e < 3 * DD) { g_wv[e - 2 * DD] += total(e); return; }
-    if (e < 4 * DD) { g_wo[e - 3 * DD] += total(e); return; }
-    const int r = e - 4 * DD;                                   // [ln 2D | lnq 2D | lnk 2D]
+// One launch per layer.  Blocks [0, common_blocks): the scenario-independent part; the others: the generated-weight records.
+// Both use blocks of 32 elements x 8 groups of workgroups: every group adds its contiguous share of the workgroup range in
+// index order, the 8 group sums are then combined in group order (fixed order => bitwise reproducible).
+__device__ __forceinline__ void fused_common_reduce(const float* __restrict__ common, int G, int D, int flags, int block,
+                                                    float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
+                                                    float* g_lnq, float* g_lnk) {
+    __shared__ float s_a[8][32], s_b[8][32];
+    const int CSZ = 4 * D * D + 6 * D, DD = D * D;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = block * 32 + lane;
     const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
-    if (r < 2 * D) { g_ln[r] += total(e); return; }
     // without 'pos' the Q and K MetaNets share ONE LayerNorm (satrans.py:46): one thread adds both roles, Q first
     const bool shared = mq && mk && g_lnq == g_lnk;
+    const int r = e - 4 * DD;
+    const bool second = shared && r >= 2 * D && r < 4 * D;       // this thread also needs the K-role element e + 2D
+    const int share = (G + 7) / 8;
+    const int lo = grp * share, hi = min(G, lo + share);
+    float acc = 0.f, acc2 = 0.f;
+    if (e < CSZ) {
+        for (int w = lo; w < hi; ++w) {
+            acc += common[(size_t)w * CSZ + e];
+            if (second) acc2 += common[(size_t)w * CSZ + e + 2 * D];
+        }
+    }
+    s_a[grp][lane] = acc;
+    s_b[grp][lane] = acc2;
+    __syncthreads();
+    if (grp != 0 || e >= CSZ) return;
+    float t = 0.f, t2 = 0.f;
+    for (int k = 0; k < 8; ++k) { t += s_a[k][lane]; t2 += s_b[k][lane]; }
+    if (e < DD) { g_wq[e] += t; return; }
+    if (e < 2 * DD) { g_wk[e - DD] += t; return; }
+    if (e < 3 * DD) { g_wv[e - 2 * DD] += t; return; }
+    if (e < 4 * DD) { g_wo[e - 3 * DD] += t; return; }
+    if (r < 2 * D) { g_ln[r] += t; return; }                     // [ln 2D | lnq 2D | lnk 2D]
     if (r < 4 * D) {
-        if (shared) g_lnq[r - 2 * D] += total(e) + total(e + 2 * D);
-        else if (mq) g_lnq[r - 2 * D] += total(e);
+        if (shared) g_lnq[r - 2 * D] += t + t2;
+        else if (mq) g_lnq[r - 2 * D] += t;
         return;
     }
-    if (mk && !shared) g_lnk[r - 4 * D] += total(e);
+    if (mk && !shared) g_lnk[r - 4 * D] += t;
 }
 
-// block = 32 elements x 8 groups of workgroups; every group adds its contiguous share of the workgroup range in index
-// order, the 8 group sums are then combined in group order (fixed order => bitwise reproducible)
-__global__ __launch_bounds__(256) void fused_records_kernel(const float* __restrict__ records,
-                                                          const int32_t* __restrict__ seg, int S, int T, int G, int D,
-                                                          int U, int flags, int64_t tab_stride, float* g_tab_q,
-                                                          float* g_tab_k) {
+__device__ __forceinline__ void fused_records_reduce(const float* __restrict__ records, const int32_t* __restrict__ seg,
+                                                     int S, int T, int G, int D, int U, int flags, int64_t tab_stride,
+                                                     float* g_tab_q, float* g_tab_k, int block, int s) {
     __shared__ float s_q[8][32], s_k[8][32];
     const int half = 2 * D * U;                                  // one role: [W1 D*U | W2 U*D] = the generated row layout
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + lane;
-    const int s = blockIdx.y;
+    const int e = block * 32 + lane;
     // the workgroups whose tile range intersects scenario s (same arithmetic as work_range in the kernel)
     int total = 0, pre = 0;
     for (int k = 0; k < S; ++k) {
@@ -1393,6 +1392,21 @@ __global__ __launch_bounds__(256) void fused_records_kernel(const float* __restr
     } else {
         if (mq) g_tab_q[(size_t)s * tab_stride + e] += aq;
         if (mk) g_tab_k[(size_t)s * tab_stride + e] += ak;
+    }
+}
+
+__global__ __launch_bounds__(256) void fused_reduce_kernel(const float* __restrict__ common, const float* __restrict__ records,
+                                                         const int32_t* __restrict__ seg, int S, int T, int G, int D, int U,
+                                                         int flags, int64_t tab_stride, int common_blocks, int record_blocks,
+                                                         float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
+                                                         float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k) {
+    const int bx = blockIdx.x;
+    if (bx < common_blocks) {
+        fused_common_reduce(common, G, D, flags, bx, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk);
+    } else {
+        const int rb = bx - common_blocks;
+        fused_records_reduce(records, seg, S, T, G, D, U, flags, tab_stride, g_tab_q, g_tab_k, rb % record_blocks,
+                             rb / record_blocks);
     }
 }
 
@@ -1528,7 +1542,7 @@ extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc*
     FusedBwdPlan p;
     if (!d || !fused_bwd_plan(d, p)) return -1;
     const int64_t CSZ = 4 * (int64_t)d->D * d->D + 6 * d->D, TSZ = 4 * (int64_t)d->D * d->U;
-    return (int64_t)p.G * CSZ + (int64_t)(p.G + d->S) * TSZ + (int64_t)kFusedSplit * CSZ;
+    return (int64_t)p.G * CSZ + (int64_t)(p.G + d->S) * TSZ;
 }
 
 extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
@@ -1545,19 +1559,14 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     else rc = same ? launch_bwd<16, 32, 2, true>(d, p, dy, dx, slabs, stream)
                    : launch_bwd<16, 32, 2, false>(d, p, dy, dx, slabs, stream);
     if (rc) return rc;
-    const int D = d->D, U = d->U, CSZ = 4 * D * D + 6 * D, TSZ = 4 * D * U;
+    const int D = d->D, U = d->U, CSZ = 4 * D * D + 6 * D;
     float* records = slabs + (size_t)p.G * CSZ;
-    float* partial = records + (size_t)(p.G + d->S) * TSZ;
-    fused_common_partial_kernel<<<dim3((unsigned)ceil_div(CSZ, 256), kFusedSplit), 256, 0, stream>>>(slabs, p.G, CSZ, partial);
-    SATRANS_CHECK_LAUNCH("fused_common_partial_kernel");
-    fused_common_final_kernel<<<(unsigned)ceil_div(CSZ, 256), 256, 0, stream>>>(partial, D, d->flags, g_wq, g_wk, g_wv, g_wo,
-                                                                            g_ln, g_lnq, g_lnk);
-    SATRANS_CHECK_LAUNCH("fused_common_final_kernel");
-    if (d->flags & (SATRANS_META_Q | SATRANS_META_K)) {
-        fused_records_kernel<<<dim3((unsigned)ceil_div(2 * D * U, 32), d->S), 256, 0, stream>>>(
-            records, d->seg, d->S, p.T, p.G, D, U, d->flags, d->tab_stride, g_tab_q, g_tab_k);
-        SATRANS_CHECK_LAUNCH("fused_records_kernel");
-    }
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
+    const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(2 * D * U, 32);
+    fused_reduce_kernel<<<(unsigned)(common_blocks + (meta ? record_blocks * d->S : 0)), 256, 0, stream>>>(
+        slabs, records, d->seg, d->S, p.T, p.G, D, U, d->flags, d->tab_stride, common_blocks, record_blocks, g_wq, g_wk, g_wv,
+        g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
+    SATRANS_CHECK_LAUNCH("fused_reduce_kernel");
     return SATRANS_OK;
 }
 

@@ -213,13 +213,16 @@ class PathEngine:
             ws["g_src"] = torch.empty(max(n_big, 1), **i32)
             ws["packed"] = torch.empty(max(n_loc - n_s, 1), D, **f32)
         ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
+        ws["iota"] = torch.arange(n_max, **i32)                 # positions for the (row, position) sorts, written once
         ws["sort_ws"] = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n_max, self.total_rows)),
                                     dtype=torch.uint8, device=dev)
         ws["partial_ws"] = torch.empty(int(lib.satrans_embed_partial_ws_floats(n_max, D)), **f32)
-        ws["reg_partials"] = torch.zeros(int(lib.satrans_embed_reg_partials(self.total_rows, n_max, D)), **f64)
+        # [untouched | touched-row kernels | replay of this rank's rows]: one fixed-order sum per step covers all three
+        n_reg = int(lib.satrans_embed_reg_partials(self.total_rows, n_max, D))
+        ws["reg_partials"] = torch.zeros(n_reg + (n_loc * D + 255) // 256, **f64)
+        ws["replay_reg"] = ws["reg_partials"][n_reg:]
         ws["reg_unused"] = torch.zeros(int(lib.satrans_embed_reg_partials(self.total_rows, max(n_s, 1), D)), **f64)
         ws["reg_rows"] = torch.zeros(max(1, int(lib.satrans_embed_adam_rows_partials(max(self.small_rows, 1), D))), **f64)
-        ws["replay_reg"] = torch.zeros((n_loc * D + 255) // 256, **f64)
         ws["replay_reg_g"] = torch.zeros((max(n_big, 1) * D + 255) // 256, **f64)
         ws[key] = True
         return ws
@@ -389,8 +392,11 @@ class PathEngine:
         if self.flat_g is None:
             # [flat parameters | dense gradient of the small tables]: ONE all-reduce moves both
             n_flat = m.flat_params.numel()
-            self.flat_g = torch.zeros(n_flat + self.small_rows * self.D, dtype=torch.float32, device=self.dev)
-            self.g_small = self.flat_g[n_flat:].view(self.small_rows, self.D)
+            n_tabs = int(self.scenario_tables(grad=False).numel())
+            self.flat_g = torch.zeros(n_flat + self.small_rows * self.D + n_tabs, dtype=torch.float32, device=self.dev)
+            self.g_small = self.flat_g[n_flat:n_flat + self.small_rows * self.D].view(self.small_rows, self.D)
+            self.g_exchange = self.flat_g[:n_flat + self.small_rows * self.D]      # what data-parallel ranks all-reduce
+            self._g_tabs_flat = self.flat_g[n_flat + self.small_rows * self.D:]    # gradient of the generated-weight table
             self.flat_m = torch.zeros_like(m.flat_params)
             self.flat_v = torch.zeros_like(m.flat_params)
             self.adam_m = torch.zeros_like(m.embedding_arena)
@@ -437,7 +443,7 @@ class PathEngine:
             self.drop_step += 1
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
         tabs = self.scenario_tables(grad=modulated)
-        g_tabs = torch.zeros_like(tabs) if modulated else None
+        g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
         self._run_forward(X, ws, training, tabs.detach())
         self._head(X, ws, y)
         cur = 0
@@ -506,7 +512,8 @@ class PathEngine:
 
         def sort(rows, n, out_rows, out_src, touched):
             N.check(lib.satrans_embed_sort(rows.data_ptr(), n, self.total_rows, out_rows.data_ptr(), out_src.data_ptr(),
-                                           touched, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(), self._stream()),
+                                           touched, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
+                                           ws["iota"].data_ptr(), self._stream()),
                     "satrans_embed_sort")
 
         def replay(sorted_rows, n, reg, reg_sum):
@@ -515,8 +522,9 @@ class PathEngine:
             N.check(lib.satrans_embed_lazy_replay(arena, am, av, self.last_step.data_ptr(), D, sorted_rows.data_ptr(), n,
                                                   self.adam_t - 1, table.data_ptr(), C.byref(h), reg.data_ptr(),
                                                   self._stream()), "satrans_embed_lazy_replay")
-            N.check(lib.satrans_sum_f64(reg.data_ptr(), reg.numel(), reg_sum.data_ptr(), 1, self._stream()),
-                    "satrans_sum_f64")
+            if reg_sum is not None:      # (the main-stream replay's partials are summed with the others at the end of the step)
+                N.check(lib.satrans_sum_f64(reg.data_ptr(), reg.numel(), reg_sum.data_ptr(), 1, self._stream()),
+                        "satrans_sum_f64")
 
         # ---- 1. this batch's arena rows (nothing is moved yet), sorted -----------------------------------------------
         N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
@@ -530,7 +538,9 @@ class PathEngine:
         #         values (small-table rows are always current: they take a dense step every step) --------------------------
         if self.lazy and self.adam_t > 1:
             with self.phase("lazy_replay"):
-                replay(ws["sorted_rows"], n_loc, ws["replay_reg"], self.reg_sum)
+                replay(ws["sorted_rows"], n_loc, ws["replay_reg"], None)
+        elif self.lazy:
+            ws["replay_reg"].zero_()
         # ---- 3. the sorted list of the large-table rows of ALL ranks; side stream work --------------------------------------
         side_done = None
         big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
@@ -574,7 +584,7 @@ class PathEngine:
                                                        ws["reg_unused"].data_ptr(), self.g_small.data_ptr(), st),
                         "satrans_embed_segment_sums")
             if world > 1:
-                parallel.all_reduce_flat(self.flat_g)
+                parallel.all_reduce_flat(self.g_exchange)
             if small_rows > 0:
                 N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, small_rows, D,
                                                     self.g_small.data_ptr(), C.byref(h_emb), self.adam_t,
@@ -593,10 +603,9 @@ class PathEngine:
             with self.phase("adam_touched"):
                 N.check(lib.satrans_embed_adam_touched(arena, am, av, D, big_sorted.data_ptr(), big_src.data_ptr(), n_big,
                                                        grads.data_ptr(), ws["partial_ws"].data_ptr(), C.byref(h_emb),
-                                                       ws["reg_partials"].data_ptr(), st), "satrans_embed_adam_touched")
-                if self.lazy:
-                    N.check(lib.satrans_embed_lazy_mark(big_sorted.data_ptr(), n_big, self.last_step.data_ptr(),
-                                                        self.adam_t, st), "satrans_embed_lazy_mark")
+                                                       ws["reg_partials"].data_ptr(),
+                                                       self.last_step.data_ptr() if self.lazy else None, self.adam_t, st),
+                        "satrans_embed_adam_touched")
         if self.lazy:
             self._lazy_pending = True
         h_flat = self._hparams(0.0)
@@ -650,7 +659,7 @@ class PathEngine:
         gemb = self.backward(X, y, ws)
         N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
                                        ws["src"].data_ptr(), ws["touched"].data_ptr(), ws["sort_ws"].data_ptr(),
-                                       ws["sort_ws"].numel(), st), "satrans_embed_sort")
+                                       ws["sort_ws"].numel(), None, st), "satrans_embed_sort")
         g_arena = torch.zeros_like(m.embedding_arena)
         N.check(lib.satrans_embed_grad_dense(m.embedding_arena.data_ptr(), ws["sorted_rows"].data_ptr(),
                                              ws["src"].data_ptr(), n_rows, gemb.data_ptr(), self.total_rows, D,

@@ -65,14 +65,14 @@ SIGNATURES = {
                                _vp, _vp, _vp, _vp, _vp]),
     "satrans_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamHParams), _vp]),
     "satrans_embed_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
-    "satrans_embed_sort": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "satrans_embed_sort": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "satrans_embed_reg_partials": (C.c_int64, [C.c_int64, C.c_int64, C.c_int]),
     "satrans_embed_partial_ws_floats": (C.c_int64, [C.c_int64, C.c_int]),
     "satrans_scenario_table_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "satrans_scenario_table_bwd_ws_floats": (C.c_int64, [C.c_int, C.c_int]),
     "satrans_scenario_table_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "satrans_embed_adam_touched": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64, _vp, _vp,
-                                             C.POINTER(AdamHParams), _vp, _vp]),
+                                             C.POINTER(AdamHParams), _vp, _vp, C.c_int, _vp]),
     "satrans_embed_adam_untouched": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams),
                                                _vp, C.c_int, _vp]),
     "satrans_embed_mark_touched": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp]),

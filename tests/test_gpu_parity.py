@@ -146,13 +146,18 @@ def test_optimizer_kernels_exact():
     part = torch.empty(int(lib.satrans_embed_partial_ws_floats(nrow, D)), device=DEV)
     regp = torch.zeros(int(lib.satrans_embed_reg_partials(R, nrow, D)), dtype=torch.float64, device=DEV)
     N.check(lib.satrans_embed_sort(rows_d.data_ptr(), nrow, R, sorted_rows.data_ptr(), src.data_ptr(), touched.data_ptr(),
-                                   sort_ws.data_ptr(), sort_ws.numel(), st), "sort")
+                                   sort_ws.data_ptr(), sort_ws.numel(), None, st), "sort")
+    s2, c2 = torch.empty_like(sorted_rows), torch.empty_like(src)
+    iota = torch.arange(nrow, dtype=torch.int32, device=DEV)
+    N.check(lib.satrans_embed_sort(rows_d.data_ptr(), nrow, R, s2.data_ptr(), c2.data_ptr(), None, sort_ws.data_ptr(),
+                                   sort_ws.numel(), iota.data_ptr(), st), "sort(positions given)")
+    assert torch.equal(s2, sorted_rows) and torch.equal(c2, src)
     sr, sc = sorted_rows.cpu(), src.cpu().long()
     assert torch.equal(sr, torch.sort(rows, stable=True).values)
     assert torch.equal(rows[sc], sr) and bool((sc[1:][sr[1:] == sr[:-1]] > sc[:-1][sr[1:] == sr[:-1]]).all()), "stable"
     N.check(lib.satrans_embed_adam_touched(Pd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), D, sorted_rows.data_ptr(),
                                            src.data_ptr(), nrow, gemb_d.data_ptr(), part.data_ptr(), C.byref(hp(l2)),
-                                           regp.data_ptr(), st), "touched")
+                                           regp.data_ptr(), None, 0, st), "touched")
     N.check(lib.satrans_embed_adam_untouched(Pd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), 0, R, D, touched.data_ptr(),
                                              C.byref(hp(l2)), regp.data_ptr(), 0, st), "untouched")
     np.testing.assert_allclose(Md.cpu().numpy(), Mr.numpy(), rtol=1e-6, atol=2e-7 * float(Mr.abs().max()))
@@ -187,13 +192,16 @@ def test_optimizer_kernels_exact():
     regp2 = torch.zeros_like(regp)
     N.check(lib.satrans_embed_adam_touched(Pd2.data_ptr(), Md2.data_ptr(), Vd2.data_ptr(), D, sorted_rows[n_s:].data_ptr(),
                                            ident.data_ptr(), n_b, packed.data_ptr(), part.data_ptr(), C.byref(hp(l2)),
-                                           regp2.data_ptr(), st), "touched(big)")
+                                           regp2.data_ptr(), last.data_ptr(), t, st), "touched(big)")
     N.check(lib.satrans_embed_mark_touched(sorted_rows[n_s:].data_ptr(), n_b, R, touched.data_ptr(), st), "mark")
     N.check(lib.satrans_embed_adam_untouched(Pd2.data_ptr(), Md2.data_ptr(), Vd2.data_ptr(), RS, R, D, touched.data_ptr(),
                                              C.byref(hp(l2)), regp2.data_ptr(), 0, st), "untouched(big)")
     # exact gradient sums => bit-identical tables, whichever path a row took
     assert torch.equal(Pd2, Pd) and torch.equal(Md2, Md) and torch.equal(Vd2, Vd)
-    assert bool((last[:RS] == t).all()) and bool((last[RS:] == 0).all())
+    stepped = torch.zeros(R, dtype=torch.bool)
+    stepped[sr[n_s:].long()] = True
+    stepped[:RS] = True
+    assert torch.equal(last.cpu() == t, stepped), "last[row] = t exactly for the rows that took their step"
     reg2 = torch.zeros(1, dtype=torch.float64, device=DEV)
     N.check(lib.satrans_sum_f64(regp2.data_ptr(), regp2.numel(), reg2.data_ptr(), 0, st), "sum")
     N.check(lib.satrans_sum_f64(regr.data_ptr(), regr.numel(), reg2.data_ptr(), 1, st), "sum")
