@@ -232,17 +232,18 @@ int satrans_embed_pack_rows(const int32_t* src, int64_t n, const float* gemb, in
  * identical arithmetic when the row is next gathered (replay, over the distinct rows of the sorted ids, BEFORE the
  * gather of that step) or for all rows (flush: epoch end, before predict / state_dict).
  *   last   [total_rows] int32: last step applied to each row (0 initially)
- *   table  [>= target+1][2] fp32: table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s)), filled by the host
+ *   table  [>= target+1][2] fp64: table[s] = (fp32(lr / (1 - beta1^s)), 1 / (double)fp32(sqrt(1 - beta2^s))), filled by
+ *          the host (the kernels divide by the per-step constant through its double reciprocal, exactly: embed_adam.hip)
  *   h      beta1, beta2, eps, l2 (lr_over_bc1 / bc2_sqrt are ignored)
  *   reg_partials [satrans_embed_lazy_reg_partials(n, D)] doubles (zero-initialised by the caller): per-block sums of
  *          l2*p^2 over the replayed steps; replay writes the first ceil(n*D/256) slots, flush the 4096 after them.
  * satrans_embed_lazy_mark sets last[r] = t for the distinct rows of a step after their Adam update. */
 int64_t satrans_embed_lazy_reg_partials(int64_t n, int D);
 int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32_t* last, int D, const int32_t* sorted_rows,
-                              int64_t n, int target, const float* table, const satrans_adam_hparams* h,
+                              int64_t n, int target, const double* table, const satrans_adam_hparams* h,
                               double* reg_partials, void* stream);
 int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_t* last, int64_t total_rows, int D, int target,
-                             const float* table, const satrans_adam_hparams* h, int64_t n, double* reg_partials,
+                             const double* table, const satrans_adam_hparams* h, int64_t n, double* reg_partials,
                              void* stream);
 int satrans_embed_lazy_mark(const int32_t* sorted_rows, int64_t n, int32_t* last, int t, void* stream);
 

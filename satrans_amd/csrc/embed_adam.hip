@@ -29,13 +29,14 @@ constexpr int kStreamBlock = 256;
 constexpr int kStreamBlocks = 2048;  // upper bound of the streaming grid = slots reserved for its partial sums
 
 struct AdamK {
-    float neg_step, bc2_sqrt, w1, beta2, w2, eps, l2x2, l2;
+    float neg_step, w1, beta2, w2, eps, l2x2, l2;
+    double rbc2;   // 1 / (double)bc2_sqrt, see adam_core
 };
 
 __host__ inline AdamK make_adamk(const satrans_adam_hparams& h) {
     AdamK k;
     k.neg_step = -h.lr_over_bc1;
-    k.bc2_sqrt = h.bc2_sqrt;
+    k.rbc2 = 1.0 / (double)h.bc2_sqrt;
     k.w1 = (float)(1.0 - (double)h.beta1);
     k.beta2 = h.beta2;
     k.w2 = (float)(1.0 - (double)h.beta2);
@@ -48,16 +49,22 @@ __host__ inline AdamK make_adamk(const satrans_adam_hparams& h) {
 // One Adam update of one element.  Every product / sum is spelled out (fmaf, __fmul_rn, ...) so that hipcc cannot
 // contract the expression differently in different kernels: the streaming kernel, the touched-row kernels and the
 // lazy replay must produce bit-identical tables.
-__device__ __forceinline__ void adam_core(float& p, float& m, float& v, float g, float neg_step, float bc2_sqrt, float w1,
+// sqrt(v) / bc2_sqrt is a division by a per-step constant c.  It is evaluated as RN32((double)sqrt(v) * RN64(1/c)), which is the
+// correctly rounded fp32 quotient (so bit for bit torch's division): for fp32 s and c the quotient s/c lies at a relative
+// distance > 2^-49 from every rounding boundary of fp32 (a boundary m has a 25-bit significand, and s - m*c is a non-zero
+// multiple of the last place of m*c, whose significand has at most 49 bits), while the double product is within 2^-52 of s/c;
+// results are never subnormal here (sqrt(v) >= 3.7e-23, c <= 1).  Four instructions instead of the eleven of an IEEE
+// division - the lazy replay and flush kernels are bound by exactly this arithmetic.
+__device__ __forceinline__ void adam_core(float& p, float& m, float& v, float g, float neg_step, double rbc2, float w1,
                                           float beta2, float w2, float eps) {
     m = fmaf(w1, __fsub_rn(g, m), m);                               // exp_avg.lerp_(grad, 1 - beta1), weight < 0.5 branch
     v = fmaf(__fmul_rn(w2, g), g, __fmul_rn(v, beta2));             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+    const float denom = __fadd_rn((float)__dmul_rn((double)sqrtf(v), rbc2), eps);   // sqrt(v) / bc2_sqrt + eps
     p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step, m), denom));     // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, const AdamK& k) {
-    adam_core(p, m, v, g, k.neg_step, k.bc2_sqrt, k.w1, k.beta2, k.w2, k.eps);
+    adam_core(p, m, v, g, k.neg_step, k.rbc2, k.w1, k.beta2, k.w2, k.eps);
 }
 
 __device__ __forceinline__ double adam4(float4& p, float4& m, float4& v, float4 g, const AdamK& k) {
@@ -463,19 +470,19 @@ __host__ inline LazyK make_lazyk(const satrans_adam_hparams& h) {
     return k;
 }
 
-// one element per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s))
+// one element per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s) as fp32, 1 / (double)fp32(sqrt(1 - beta2^s))) as doubles
 __device__ __forceinline__ double replay_element(float& p, float& m, float& v, int from, int to,
-                                                 const float2* __restrict__ table, const LazyK& k) {
+                                                 const double2* __restrict__ table, const LazyK& k) {
     // sum of p^2 over the replayed steps in fp32 (<= a few thousand terms of one element: relative error ~1e-7 x steps,
     // far inside the fp32 reduction the reference itself uses), converted to double once; the sums over elements,
     // blocks and steps stay in double
     float sq = 0.f;
     for (int s = from + 1; s <= to; ++s) {
-        const float2 hp = table[s];
+        const double2 hp = table[s];
         sq = fmaf(p, p, sq);
         // gradient of a row that was not gathered: 0 + 2*l2*p, the same expression the streaming kernel evaluates
         const float g = __fadd_rn(0.f, __fmul_rn(k.l2x2, p));
-        adam_core(p, m, v, g, -hp.x, hp.y, k.w1, k.beta2, k.w2, k.eps);
+        adam_core(p, m, v, g, -(float)hp.x, hp.y, k.w1, k.beta2, k.w2, k.eps);
     }
     return (double)k.l2 * (double)sq;
 }
@@ -484,7 +491,7 @@ __device__ __forceinline__ double replay_element(float& p, float& m, float& v, i
 template <int D>
 __global__ __launch_bounds__(256) void lazy_replay_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
                                                          int32_t* __restrict__ last, const int32_t* __restrict__ sorted_rows,
-                                                         int64_t n, int target, const float2* __restrict__ table, LazyK k,
+                                                         int64_t n, int target, const double2* __restrict__ table, LazyK k,
                                                          double* __restrict__ reg_partials) {
     __shared__ double s_red[256];
     const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D;
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256) void lazy_replay_kernel(float* __restrict__ P,
 template <int D>
 __global__ __launch_bounds__(256) void lazy_flush_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
                                                         int32_t* __restrict__ last, int64_t total_rows, int target,
-                                                        const float2* __restrict__ table, LazyK k,
+                                                        const double2* __restrict__ table, LazyK k,
                                                         double* __restrict__ reg_partials) {
     __shared__ double s_red[256];
     double reg = 0.0;
@@ -890,10 +897,10 @@ extern "C" int64_t satrans_embed_lazy_reg_partials(int64_t n, int D) { return ce
     }
 
 // Replays the pending regulariser-only steps (last[r], target] of every distinct row in sorted_rows.
-// table [>= target + 1] float2: table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s)); h supplies beta1, beta2, eps, l2.
+// table [>= target + 1] double2: table[s] = (fp32(lr / (1 - beta1^s)), 1 / (double)fp32(sqrt(1 - beta2^s))); h supplies beta1, beta2, eps, l2.
 // reg_partials: satrans_embed_lazy_reg_partials(n, D) doubles; this call writes the first ceil(n*D/256).
 extern "C" int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32_t* last, int D,
-                                         const int32_t* sorted_rows, int64_t n, int target, const float* table,
+                                         const int32_t* sorted_rows, int64_t n, int target, const double* table,
                                          const satrans_adam_hparams* h, double* reg_partials, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(arena && m && v && last && sorted_rows && table && h && reg_partials, SATRANS_E_BADARG,
@@ -902,7 +909,7 @@ extern "C" int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32
     const LazyK k = make_lazyk(*h);
     const int64_t blocks = ceil_div(n * D, 256);
     DISPATCH_D(D, (lazy_replay_kernel<DD><<<(unsigned)blocks, 256, 0, stream>>>(arena, m, v, last, sorted_rows, n, target,
-                                                                                (const float2*)table, k, reg_partials)));
+                                                                                (const double2*)table, k, reg_partials)));
     SATRANS_CHECK_LAUNCH("lazy_replay_kernel");
     return SATRANS_OK;
 }
@@ -910,14 +917,14 @@ extern "C" int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32
 // Brings EVERY row to step `target`.  Writes reg_partials[ceil(n*D/256) ...+kFlushBlocks) where n is the batch row count
 // the workspace was sized for (pass the same n).
 extern "C" int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_t* last, int64_t total_rows, int D,
-                                        int target, const float* table, const satrans_adam_hparams* h, int64_t n,
+                                        int target, const double* table, const satrans_adam_hparams* h, int64_t n,
                                         double* reg_partials, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(arena && m && v && last && table && h && reg_partials, SATRANS_E_BADARG, "embed_lazy_flush: null pointer");
     const LazyK k = make_lazyk(*h);
     double* reg = reg_partials + ceil_div(n * D, 256);
     DISPATCH_D(D, (lazy_flush_kernel<DD><<<kFlushBlocks, 256, 0, stream>>>(arena, m, v, last, total_rows, target,
-                                                                          (const float2*)table, k, reg)));
+                                                                          (const double2*)table, k, reg)));
     SATRANS_CHECK_LAUNCH("lazy_flush_kernel");
     return SATRANS_OK;
 }

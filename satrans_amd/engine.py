@@ -141,7 +141,7 @@ class PathEngine:
         # SATRANS_SPLIT_TABLES=1: use the small/large table classes of the multi-rank step on a single rank too (tests)
         self.force_split = os.environ.get("SATRANS_SPLIT_TABLES", "0") == "1"
         self.last_step = None            # [R] int32: last Adam step applied to every table row
-        self._hp_table = None            # [cap, 2] fp32: (lr / (1 - beta1^s), sqrt(1 - beta2^s)) for step s
+        self._hp_table = None            # [cap, 2] fp64: (fp32(lr / (1 - beta1^s)), 1 / fp32(sqrt(1 - beta2^s))) for step s
         self._hp_cfg = None
         self._lazy_pending = False
 
@@ -622,8 +622,10 @@ class PathEngine:
         if self._hp_table is None or self._hp_cfg != key or self._hp_table.shape[0] <= upto:
             cap = max(4096, 2 * (upto + 1))
             b1, b2 = cfg["betas"]
-            rows = [(0.0, 1.0)] + [(cfg["lr"] / (1.0 - b1 ** s), math.sqrt(1.0 - b2 ** s)) for s in range(1, cap)]
-            self._hp_table = torch.tensor(rows, dtype=torch.float32, device=self.dev).contiguous()
+            import numpy as np
+            f32 = lambda x: float(np.float32(x))          # the value the fp32 kernels (and torch's fp32 step) see
+            rows = [(0.0, 1.0)] + [(f32(cfg["lr"] / (1.0 - b1 ** s)), 1.0 / f32(math.sqrt(1.0 - b2 ** s))) for s in range(1, cap)]
+            self._hp_table = torch.tensor(rows, dtype=torch.float64, device=self.dev).contiguous()
             self._hp_cfg = key
         return self._hp_table
 

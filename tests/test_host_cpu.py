@@ -98,3 +98,22 @@ def test_dropout_mask_statistics():
     assert abs(k0.mean() - 0.9) < 0.005
     for other in (k1, k2):
         assert abs((k0 & other).mean() - 0.81) < 0.01
+
+
+def test_division_by_a_constant_through_its_double_reciprocal_is_the_fp32_quotient():
+    """embed_adam.hip: adam_core evaluates sqrt(v) / bc2_sqrt as float32(float64(s) * (1 / float64(c))).  The header gives the
+    argument why that is the correctly rounded fp32 quotient; this checks it on 40 M random pairs over the ranges the
+    optimizer sees (s = sqrt(v) from 1e-22 to 1e3, c = sqrt(1 - beta2^t) in (0.03, 1]) plus adversarial neighbours."""
+    rng = np.random.RandomState(0)
+    for _ in range(4):
+        s = np.exp(rng.uniform(np.log(1e-22), np.log(1e3), size=10_000_000)).astype(np.float32)
+        c = rng.uniform(0.03, 1.0, size=10_000_000).astype(np.float32)
+        want = s / c                                                     # IEEE fp32 division
+        got = (s.astype(np.float64) * (1.0 / c.astype(np.float64))).astype(np.float32)
+        assert np.array_equal(want, got)
+    # quotients that land next to a rounding boundary: s = nextafter(q * c) for q with a long run of ones / zeros
+    q = (np.float32(1.0) + np.arange(1, 200001, dtype=np.float32) * np.float32(2.0 ** -23))
+    c = rng.uniform(0.03, 1.0, size=q.size).astype(np.float32)
+    for s in (q * c, np.nextafter(q * c, np.float32(0)), np.nextafter(q * c, np.float32(10))):
+        s = s.astype(np.float32)
+        assert np.array_equal(s / c, (s.astype(np.float64) * (1.0 / c.astype(np.float64))).astype(np.float32))
