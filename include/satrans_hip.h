@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SATRANS_ABI_VERSION 1
+#define SATRANS_ABI_VERSION 2
 
 /* error codes */
 #define SATRANS_OK 0
