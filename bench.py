@@ -35,12 +35,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
 
 
-def synth_batches(n_rows, seed):
+def synth_batches(n_rows, seed, ids="uniform"):
+    """AliCCP-shaped id matrix.  `uniform`: every id of a field equally likely (the HBM worst case, the bench default);
+    `skewed`: log-uniform ranks, P(id) ~ 1/(id+1), i.e. Zipf with exponent 1 (real CTR ids are skewed: a few hot rows)."""
     rng = np.random.RandomState(seed)
     cols = []
     for f in ALICCP_FIELDS:
         lo = 1 if f == '301' else 0                                                # scenario ids start at 1 (main.py:112-114)
-        cols.append(rng.randint(lo, ALICCP_MAX[f] + 1, size=n_rows))
+        if ids == "skewed" and f != '301':
+            col = np.minimum((np.exp(rng.uniform(0.0, np.log(ALICCP_MAX[f] + 1.0), size=n_rows)) - 1.0).astype(np.int64),
+                             ALICCP_MAX[f])
+        else:
+            col = rng.randint(lo, ALICCP_MAX[f] + 1, size=n_rows)
+        cols.append(col)
     X = np.stack(cols, axis=1).astype(np.float32)                                  # ids travel as fp32 (meta_basemodel.py:311)
     y = (rng.rand(n_rows) < 0.04).astype(np.float32)                               # assumed CTR level (BASELINE.md §3)
     return X, y
@@ -124,6 +131,8 @@ def main():
     ap.add_argument("--lr", type=float, default=0.005)
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (0 = skip)")
     ap.add_argument("--no-phase-timing", action="store_true")
+    ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
+                    help="id distribution of the synthetic batches (uniform = HBM worst case, the reported configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,7 +171,7 @@ def main():
         print(f"[bench] model built in {time.time() - t_build:.1f}s; tables {model.embedding_arena.numel() * 4 / 1e6:.0f} MB",
               file=sys.stderr)
 
-    X, y = synth_batches((K + W) * B, seed=100 + rank)
+    X, y = synth_batches((K + W) * B, seed=100 + rank, ids=args.ids)
     Xd, yd = torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)
     model.train()
 
@@ -304,7 +313,7 @@ def main():
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: AliCCP-shaped SATrans training step, 19 fields, 6,571,961 table rows "
-                               "(841 MB fp32), uniform ids, dropout on, dense-Adam+L2 semantics over all rows",
+                               f"(841 MB fp32), {args.ids} ids, dropout on, dense-Adam+L2 semantics over all rows",
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": 32, "layers": 3, "heads": 4,
                    "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
