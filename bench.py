@@ -53,28 +53,28 @@ def synth_batches(n_rows, seed, ids="uniform"):
     return X, y
 
 
-def build_model(device, lr):
+def build_model(device, lr, flag='sota'):
     from satrans_amd import SATrans, SparseFeat
     cols = [SparseFeat(f, vocabulary_size=ALICCP_MAX[f] + 2, embedding_dim=32) for f in ALICCP_FIELDS]
     model = SATrans(cols, cols, ['301'], [3], att_layer_num=0, domain_att_layer_num=3, att_head_num=4,
-                    use_linear=False, use_dnn=False, meta_mode='QK', seed='1021', device=device, flag='sota')
+                    use_linear=False, use_dnn=False, meta_mode='QK', seed='1021', device=device, flag=flag)
     model.compile(torch.optim.Adam(model.parameters(), lr=lr), "binary_crossentropy",
                   metrics=["binary_crossentropy", "auc"])                          # main.py:343
     return model
 
 
-def oracle_spec():
+def oracle_spec(flag='sota'):
     from oracle.satrans_oracle import PathSpec
     return PathSpec(sparse=[(f, i) for i, f in enumerate(ALICCP_FIELDS)], dense=[], domain_cols=[18],
-                    embedding_dim=32, head_num=4, layer_num=3, flag='sota', meta_mode='QK', meta_units=[32, 64, 32])
+                    embedding_dim=32, head_num=4, layer_num=3, flag=flag, meta_mode='QK', meta_units=[32, 64, 32])
 
 
-def cpu_baseline(state, X, y, batch, lr, steps):
+def cpu_baseline(state, X, y, batch, lr, steps, flag='sota'):
     """The reference's training step restated op for op (oracle/satrans_oracle.py: per-sample generated weights,
     torch CPU dropout, dense L2 over all rows, dense torch.optim.Adam), timed on this box's host cores."""
     from oracle import satrans_oracle as O
     torch.set_num_threads(min(os.cpu_count(), 32))  # more threads only add contention (256-core box: 70 s/step)
-    tr = O.OracleTrainer(state, oracle_spec(), lr=lr)
+    tr = O.OracleTrainer(state, oracle_spec(flag), lr=lr)
     drop = O.Dropper("torch", 0.1)
     times = []
     for s in range(steps + 1):
@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--lr", type=float, default=0.005)
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (0 = skip)")
     ap.add_argument("--no-phase-timing", action="store_true")
+    ap.add_argument("--flag", default="sota", help="SATrans flag (reference main.py --flag); 'sota-pos' = the positional variant")
     ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
                     help="id distribution of the synthetic batches (uniform = HBM worst case, the reported configuration)")
     args = ap.parse_args()
@@ -156,7 +157,7 @@ def main():
 
     B, K, W = args.batch, args.steps, args.warmup
     t_build = time.time()
-    model = build_model("cpu", args.lr)                                            # seeded init on CPU, as the reference
+    model = build_model("cpu", args.lr, args.flag)                                 # seeded init on CPU, as the reference
     do_cpu = world == 1 and args.cpu_steps > 0
     state_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if do_cpu else None
     if do_cpu:                                                                     # keep the reference's aliasing
@@ -291,7 +292,7 @@ def main():
         model(Xd[:nb])
         gpu_logit = eng.last_logit().cpu()
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        _, ref_logit = O.forward(sd, torch.from_numpy(X[:nb]), oracle_spec())
+        _, ref_logit = O.forward(sd, torch.from_numpy(X[:nb]), oracle_spec(args.flag))
         err = float((gpu_logit - ref_logit).abs().max())
         del sd
     except Exception as ex:                                                        # the number is informative only
@@ -301,14 +302,14 @@ def main():
     if do_cpu:
         t_cpu = time.time()
         Xc, yc = synth_batches((args.cpu_steps + 1) * B, seed=7)
-        v, n = cpu_baseline(state_cpu, Xc, yc, B, args.lr, args.cpu_steps)
+        v, n = cpu_baseline(state_cpu, Xc, yc, B, args.lr, args.cpu_steps, args.flag)
         cpu = {"value": round(v, 1), "unit": "samples/s", "cores": min(os.cpu_count(), 32), "kind": "port",
                "sample": f"{n} timed training steps of B={B} after 1 untimed step (dropout on, dense L2 + dense Adam, "
                          f"no per-step sklearn metrics), {time.time() - t_cpu:.0f}s wall"}
 
     value = world * B * K / elapsed
     out = {
-        "metric": "training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)",
+        "metric": "training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)" + ("" if args.flag == "sota" else f" flag={args.flag}"),
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -116,6 +116,32 @@ __device__ __forceinline__ void chain(const float* __restrict__ wl, const float 
     }
 }
 
+// The same product through the TRANSPOSE of an image: out[16 mt + i] = sum_k img[(16 mt + i) * LDW + k] * in[k], i.e. the
+// contraction runs along the image's rows.  `wl` = img + n * LDW + 4 * g.  The reads of one instruction hit every bank four
+// times (row stride = 4 mod 32): 4x the LDS cycles of `chain`'s reads, which is why the backward keeps transposed copies when
+// LDS allows and uses this form only when they do not fit (separate Q/K generated weights, flag 'pos').
+template <int KT_, int MT_, int LDW>
+__device__ __forceinline__ void chain_t(const float* __restrict__ wl, const float (&in)[KT_][4], float (&out)[MT_][4]) {
+    constexpr int NS = 4 * KT_;
+    f32x4 acc[MT_];
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a[NS][MT_];
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) a[st][mt] = wl[16 * mt * LDW + 16 * (st >> 2) + (st & 3)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) acc[mt] = mfma4(a[st][mt], in[st >> 2][st & 3], acc[mt]);
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) {
+        out[mt][0] = acc[mt][0]; out[mt][1] = acc[mt][1]; out[mt][2] = acc[mt][2]; out[mt][3] = acc[mt][3];
+    }
+}
+
 // sum over the D features of each token: registers, then the four lane groups
 __device__ __forceinline__ float token_sum(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -675,7 +701,9 @@ __device__ __forceinline__ void layer_norm_bwd(float (&g)[KT_][4], const float (
         for (int r = 0; r < 4; ++r) g[t][r] = rstd * (g[t][r] - m1 - zh[t][r] * m2);
 }
 
-template <int D, int U, int H, bool SAME>   // SAME: Q and K roles share one generated-weight table (no 'pos' flag)
+// SAME: Q and K roles share one generated-weight table (no 'pos' flag).  TR: transposed copies of every weight image live in LDS
+// too (conflict-free reads for the backward products); without them those products read the forward images by rows (chain_t).
+template <int D, int U, int H, bool SAME, bool TR>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
@@ -700,10 +728,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     float* w1q = take(D * LU); float* w2q = take(U * LD);
     float* w1k = same_tab ? w1q : take(D * LU);
     float* w2k = same_tab ? w2q : take(U * LD);
-    float* wqT = take(D * LD); float* wkT = take(D * LD); float* wvT = take(D * LD); float* wo = take(D * LD);
-    float* w1qT = take(U * LD); float* w2qT = take(D * LU);     // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]
-    float* w1kT = same_tab ? w1qT : take(U * LD);
-    float* w2kT = same_tab ? w2qT : take(D * LU);
+    // transposed copies (TR) or, without them, the forward images again (read by rows: chain_t)
+    float* wqT = TR ? take(D * LD) : wq; float* wkT = TR ? take(D * LD) : wk; float* wvT = TR ? take(D * LD) : wv;
+    float* wo = TR ? take(D * LD) : woT;
+    float* w1qT = TR ? take(U * LD) : w1q; float* w2qT = TR ? take(D * LU) : w2q;   // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]
+    float* w1kT = TR ? (same_tab ? w1qT : take(U * LD)) : w1k;
+    float* w2kT = TR ? (same_tab ? w2qT : take(D * LU)) : w2k;
     float* lnq_g = take(D); float* lnk_g = take(D); float* ln_g = take(D);
     float* lnq_b = take(D); float* lnk_b = take(D); float* ln_b = take(D);
     constexpr int ROWS = 64;
@@ -721,10 +751,16 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
     if (!idle) {
-        stage_image(a.w_query, wq, D, D, LD, false);   stage_image(a.w_query, wqT, D, D, LD, true);
-        stage_image(a.w_key, wk, D, D, LD, false);     stage_image(a.w_key, wkT, D, D, LD, true);
-        stage_image(a.w_value, wv, D, D, LD, false);   stage_image(a.w_value, wvT, D, D, LD, true);
-        stage_image(a.w_out, woT, D, D, LD, true);     stage_image(a.w_out, wo, D, D, LD, false);
+        stage_image(a.w_query, wq, D, D, LD, false);
+        stage_image(a.w_key, wk, D, D, LD, false);
+        stage_image(a.w_value, wv, D, D, LD, false);
+        stage_image(a.w_out, woT, D, D, LD, true);
+        if constexpr (TR) {
+            stage_image(a.w_query, wqT, D, D, LD, true);
+            stage_image(a.w_key, wkT, D, D, LD, true);
+            stage_image(a.w_value, wvT, D, D, LD, true);
+            stage_image(a.w_out, wo, D, D, LD, false);
+        }
         for (int i = threadIdx.x; i < D; i += blockDim.x) {
             ln_g[i] = a.ln_g[i]; ln_b[i] = a.ln_b[i];
             if (meta_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
@@ -737,6 +773,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     __syncthreads();
 
     const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
+    const int lt_d = n * LD + g4, lt_u = n * LU + g4;          // ... for a read by rows (chain_t): row n, column 4g
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);
 
@@ -807,13 +844,21 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       // ---- this scenario's generated MetaNet weights, both orientations (previous tile loop ended on a barrier) -----
       if (meta_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-          stage_image(row, w1q, D, U, LU, false);          stage_image(row, w1qT, D, U, LD, true);
-          stage_image(row + D * U, w2q, U, D, LD, false);  stage_image(row + D * U, w2qT, U, D, LU, true);
+          stage_image(row, w1q, D, U, LU, false);
+          stage_image(row + D * U, w2q, U, D, LD, false);
+          if constexpr (TR) {
+              stage_image(row, w1qT, D, U, LD, true);
+              stage_image(row + D * U, w2qT, U, D, LU, true);
+          }
       }
       if (meta_k && (!same_tab || !meta_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-          stage_image(row, w1k, D, U, LU, false);          stage_image(row, w1kT, D, U, LD, true);
-          stage_image(row + D * U, w2k, U, D, LD, false);  stage_image(row + D * U, w2kT, U, D, LU, true);
+          stage_image(row, w1k, D, U, LU, false);
+          stage_image(row + D * U, w2k, U, D, LD, false);
+          if constexpr (TR) {
+              stage_image(row, w1kT, D, U, LD, true);
+              stage_image(row + D * U, w2kT, U, D, LU, true);
+          }
       }
       __syncthreads();
       const int lo = a.seg[scen], hi = a.seg[scen + 1];
@@ -1035,7 +1080,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             store_frag<KT>(my_g, gy);                                           // du rows (zero for padding tokens)
             wgrad<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
             float go[KT][4];
-            chain<KT, KT, LD>(wo + lo_d, gy, go);                               // go = du Wo
+            if constexpr (TR) chain<KT, KT, LD>(wo + lo_d, gy, go);             // go = du Wo
+            else chain_t<KT, KT, LD>(wo + lt_d, gy, go);
             store_frag<KT>(my_o, go);
         }
         __syncthreads();
@@ -1187,7 +1233,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
-                chain<KT, UT, LU>(w2T + lo_u, dm, dh);
+                if constexpr (TR) chain<KT, UT, LU>(w2T + lo_u, dm, dh);
+                else chain_t<KT, UT, LD>(w2T + lt_d, dm, dh);              // w2T is then the forward image W2 [U][LD]
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
@@ -1213,7 +1260,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
-                chain<UT, KT, LD>(w1T + lo_d, dh, back);
+                if constexpr (TR) chain<UT, KT, LD>(w1T + lo_d, dh, back);
+                else chain_t<UT, KT, LU>(w1T + lt_u, dh, back);            // ... the forward image W1 [D][LU]
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1238,17 +1286,20 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
             float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
-            chain<KT, KT, LD>(wqT + lo_d, gq, back);
+            if constexpr (TR) chain<KT, KT, LD>(wqT + lo_d, gq, back);
+            else chain_t<KT, KT, LD>(wqT + lt_d, gq, back);
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
-            chain<KT, KT, LD>(wkT + lo_d, gk, back);
+            if constexpr (TR) chain<KT, KT, LD>(wkT + lo_d, gk, back);
+            else chain_t<KT, KT, LD>(wkT + lt_d, gk, back);
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
-            chain<KT, KT, LD>(wvT + lo_d, gv, back);
+            if constexpr (TR) chain<KT, KT, LD>(wvT + lo_d, gv, back);
+            else chain_t<KT, KT, LD>(wvT + lt_d, gv, back);
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1469,41 +1520,45 @@ extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d);
 
 namespace satrans {
 
-static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab) {
+static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr) {
     const int LD = D + 4, LU = U + 4;
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
     const int64_t tasks = (int64_t)T * H * F;
-    return 8 * (int64_t)D * LD + (same_tab ? 1 : 2) * 2 * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 5 * 64 * LD +
-           2 * r4(tasks) + 2 * r4(tasks * F) + 64;
+    const int copies = tr ? 2 : 1;         // forward images, and their transposes when they fit
+    return copies * 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * copies * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D +
+           5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + 64;
 }
 
 struct FusedBwdPlan {
     int T, G;
     size_t lds;
+    bool tr;      // transposed weight images in LDS
 };
 
 static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     if (!satrans_layer_fused_supported(d) || d->D > 32 || d->F > 32) return false;   // keep bits: one 32-bit word per row
     const bool same_tab = d->tab_q == d->tab_k;
     p.T = 64 / d->F;
-    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab) * 4;
+    // transposed copies of the weight images when they fit; D = 32 with separate Q/K generated weights ('pos') runs without
+    p.tr = same_tab || d->D < 32;
+    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, p.tr) * 4;
     if (p.lds > 160 * 1024) return false;
     const int64_t tiles = ceil_div(d->B, p.T) + d->S;
     p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
     return true;
 }
 
-template <int D, int U, int H, bool SAME>
+template <int D, int U, int H, bool SAME, bool TR>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
                       hipStream_t stream) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME, TR><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1554,10 +1609,10 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
     const bool same = d->tab_q == d->tab_k;
     int rc;
-    if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true>(d, p, dy, dx, slabs, stream)
-                              : launch_bwd<32, 64, 4, false>(d, p, dy, dx, slabs, stream);
-    else rc = same ? launch_bwd<16, 32, 2, true>(d, p, dy, dx, slabs, stream)
-                   : launch_bwd<16, 32, 2, false>(d, p, dy, dx, slabs, stream);
+    if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true, true>(d, p, dy, dx, slabs, stream)
+                              : launch_bwd<32, 64, 4, false, false>(d, p, dy, dx, slabs, stream);
+    else rc = same ? launch_bwd<16, 32, 2, true, true>(d, p, dy, dx, slabs, stream)
+                   : launch_bwd<16, 32, 2, false, true>(d, p, dy, dx, slabs, stream);
     if (rc) return rc;
     const int D = d->D, U = d->U, CSZ = 4 * D * D + 6 * D;
     float* records = slabs + (size_t)p.G * CSZ;
