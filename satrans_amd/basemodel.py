@@ -140,10 +140,12 @@ class BaseModel(nn.Module):
         # differently (satrans_amd/engine.py: dense all-reduced gradient + dense step for the small tables, sorted
         # (row, gradient) lists for the large ones) and relies on "arena row < _arena_small_rows <=> small table".
         # state_dict keys and values do not depend on the order: the parameters are views at their offsets.
+        import os
+        limit = int(os.environ.get("SATRANS_SMALL_TABLE_ROWS", SMALL_TABLE_ROWS))    # (tests move the class boundary)
         small, budget = [], SMALL_TABLE_TOTAL_ROWS
         for n in names:
             rows = self.embedding_dict[n].weight.shape[0]
-            if rows <= SMALL_TABLE_ROWS and rows <= budget:
+            if rows <= limit and rows <= budget:
                 small.append(n)
                 budget -= rows
         names = small + [n for n in names if n not in small]

@@ -382,12 +382,13 @@ def test_lazy_adam_is_bitwise_the_streaming_adam():
     assert reg_l == pytest.approx(reg_d, rel=1e-6)      # lazy sums p^2 per element in fp32 before going to double
 
 
-def _dp_worker(rank, world, port, name, steps, out_dir):
+def _dp_worker(rank, world, port, name, steps, out_dir, small_rows):
     """One data-parallel rank of the engine; both ranks share cuda:0 and talk over gloo (host-staged), which runs
     exactly the code path of an RCCL job: ids all-gathered before the forward, gradient rows after the backward."""
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["SATRANS_SMALL_TABLE_ROWS"] = str(small_rows)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         c = Case(name)
@@ -404,11 +405,14 @@ def _dp_worker(rank, world, port, name, steps, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("small_rows", [16384, 100, 0])
 @pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
-def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, tmp_path):
+def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows, tmp_path):
     """Reference semantics of several GPUs (meta_basemodel.py:272-275, 317): per-GPU batches, loss SUMMED over all
     samples, one optimizer step on the summed gradient.  Two ranks with half of the golden batch each must therefore
-    land where the reference's single full-batch steps land, and the two replicas must be bit-identical."""
+    land where the reference's single full-batch steps land, and the two replicas must be bit-identical.
+    `small_rows` moves the boundary between the table classes of the exchange: 16384 = every golden table takes the dense
+    all-reduced path, 0 = every table goes through the all-gathered sorted (row, gradient) lists, 100 = a mix."""
     import socket
     import torch.multiprocessing as mp
     c = Case(name)
@@ -418,7 +422,7 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     steps = c.meta["adam_steps"]
-    mp.spawn(_dp_worker, args=(2, port, name, steps, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, name, steps, str(tmp_path), small_rows), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     for k in r0:
         assert torch.equal(r0[k], r1[k]), f"replicas diverged at {k}"
@@ -431,12 +435,14 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, tmp_path):
         assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
 
 
+@pytest.mark.parametrize("small_rows", ["16384", "100"])
 @pytest.mark.parametrize("lazy", ["1", "0"])
-def test_table_classes_on_one_rank_match_reference_golden(monkeypatch, lazy):
+def test_table_classes_on_one_rank_match_reference_golden(monkeypatch, lazy, small_rows):
     """The small/large table classes of the multi-rank step (dense all-reduced gradient + dense step for small tables,
     sorted lists for large ones), forced on a single rank, in both forms of the dense step."""
     monkeypatch.setenv("SATRANS_SPLIT_TABLES", "1")
     monkeypatch.setenv("SATRANS_LAZY_ADAM", lazy)
+    monkeypatch.setenv("SATRANS_SMALL_TABLE_ROWS", small_rows)      # 100: some golden tables small, some large
     c = Case("aliccp_sota")
     model = build_model(c, DEV)
     model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
