@@ -283,6 +283,27 @@ def main():
     #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
     gather = gather_microbench(eng, Xd, B, 19, 32)
 
+    # ---- the evaluation forward alone (predict / evaluate path) at the reference's prediction batch --------------------------
+    forward_only = None
+    try:
+        model.eval()
+        nb = min(4 * B, Xd.shape[0])
+        for _ in range(3):
+            eng.forward(Xd[:nb])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for i in range(reps):
+            lo = (i * nb) % max(1, Xd.shape[0] - nb + 1)
+            eng.forward(Xd[lo:lo + nb])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        forward_only = {"batch": nb, "ms_per_batch": round(ms, 4), "samples_per_s": round(nb / (ms / 1e3), 1)}
+        model.train()
+    except Exception as ex:
+        print(f"[bench] forward-only timing skipped: {ex}", file=sys.stderr)
+
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = None
     try:
@@ -319,7 +340,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
         "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
-        "cpu_baseline": cpu,
+        "forward_only": forward_only, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
     if world > 1:
