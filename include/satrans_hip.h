@@ -177,6 +177,9 @@ typedef struct satrans_adam_hparams {
 /* Flat parameter vector (everything that is not an embedding table): p,g,m,v [n]. */
 int satrans_adam_flat(float* p, const float* g, float* m, float* v, int64_t n,
                       const satrans_adam_hparams* h, void* stream);
+/* the same, and out[0] += sum(vals[0..count)) in fixed order, in one launch (the step's regulariser partial sums) */
+int satrans_adam_flat_sum(float* p, const float* g, float* m, float* v, int64_t n, const satrans_adam_hparams* h,
+                          const double* vals, int64_t count, double* out, void* stream);
 
 /* Embedding-gradient pipeline over n = (ranks*)B*F gathered rows.
  *   rows [n] int32 arena rows, gemb [n, D] gradient of every gathered row.

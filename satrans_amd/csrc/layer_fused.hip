@@ -1380,6 +1380,7 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
     const int lo = grp * share, hi = min(G, lo + share);
     float acc = 0.f, acc2 = 0.f;
     if (e < CSZ) {
+#pragma unroll 4
         for (int w = lo; w < hi; ++w) {
             acc += common[(size_t)w * CSZ + e];
             if (second) acc2 += common[(size_t)w * CSZ + e + 2 * D];
@@ -1426,6 +1427,7 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
     const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
     float aq = 0.f, ak = 0.f;
     if (e < half) {
+#pragma unroll 4
         for (int w = a; w < b; ++w) {
             const float* rec = records + (size_t)(w + s) * 2 * half;
             if (mq) aq += rec[e];

@@ -609,11 +609,10 @@ class PathEngine:
         if self.lazy:
             self._lazy_pending = True
         h_flat = self._hparams(0.0)
-        N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                      self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st),
-                "satrans_adam_flat")
-        N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(),
-                                    1, st), "satrans_sum_f64")
+        N.check(lib.satrans_adam_flat_sum(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                          self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat),
+                                          ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(),
+                                          self.reg_sum.data_ptr(), st), "satrans_adam_flat_sum")
 
     def _table(self, upto: int) -> torch.Tensor:
         """Per-step Adam constants for the replay kernels, computed on the host exactly like `_hparams`."""

@@ -64,6 +64,7 @@ SIGNATURES = {
     "satrans_head": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp]),
     "satrans_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamHParams), _vp]),
+    "satrans_adam_flat_sum": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamHParams), _vp, C.c_int64, _vp, _vp]),
     "satrans_embed_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "satrans_embed_sort": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "satrans_embed_reg_partials": (C.c_int64, [C.c_int64, C.c_int64, C.c_int]),
