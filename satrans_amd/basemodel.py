@@ -301,6 +301,10 @@ class BaseModel(nn.Module):
         labels = torch.from_numpy(y).to(self.device)
         self.train()
 
+        # SATRANS_HOST_METRICS=1: per-step train metrics through sklearn on host copies, as the reference does
+        from . import device_metrics as DM
+        import os
+        device_metrics = os.environ.get("SATRANS_HOST_METRICS", "0") != "1" and all(n in DM.BY_NAME for n in self.metrics)
         cbs = CallbackList((callbacks or []) + [self.history])
         cbs.set_model(self)
         cbs.on_train_begin()
@@ -330,8 +334,13 @@ class BaseModel(nn.Module):
                     idx = order[lo:hi]
                     xb, yb = data.index_select(0, idx), labels.index_select(0, idx)
                 engine.train_step(xb, yb)
-                if verbose > 0 and self.metrics:
-                    # per-step host metrics as the reference computes them (:330-337); forces a device sync
+                if verbose > 0 and self.metrics and device_metrics:
+                    # the reference's per-step train metrics (:330-337) evaluated on the device: no sync, read once per epoch
+                    prob = engine.last_prob()
+                    for name in self.metrics:
+                        train_result.setdefault(name, []).append(DM.BY_NAME[name](yb, prob))
+                elif verbose > 0 and self.metrics:
+                    # ... or exactly as the reference computes them, on host copies (forces a device sync every step)
                     y_np = yb.cpu().numpy()
                     p_np = engine.last_prob().cpu().numpy().astype("float64")
                     for name, fn in self.metrics.items():
@@ -348,6 +357,8 @@ class BaseModel(nn.Module):
             bce_sum, reg_sum = engine.epoch_sums()
             epoch_logs = {"loss": (bce_sum + reg_sum) / sample_num}
             for name, result in train_result.items():
+                if result and torch.is_tensor(result[0]):
+                    result = torch.stack(result).cpu().numpy()           # the epoch's only read of the per-step metrics
                 epoch_logs[name] = np.sum(result) / steps_per_epoch
             if do_validation:
                 for name, result in self.evaluate(val_x, val_y, batch_size).items():

@@ -1,0 +1,51 @@
+"""The per-step training metrics of `fit(verbose > 0)` evaluated where the predictions are, without a device sync.
+
+The reference computes sklearn metrics on host copies of every batch (models/meta_basemodel.py:330-337:
+`metric_fun(y.cpu().numpy(), y_pred.cpu().numpy().astype("float64"))`), i.e. one device-to-host round trip plus a few
+milliseconds of sklearn per step - more than the whole training step takes here.  These functions return 0-dim float64
+tensors on the inputs' device with the same values (tests/test_host_cpu.py compares them with sklearn, ties included);
+`fit` keeps them on the device and reads them once per epoch.  They are metrics, not part of the hot path: plain
+torch ops.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def log_loss(y: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """sklearn.metrics.log_loss(y, p.astype(float64)): probabilities clipped to [eps, 1 - eps] with float64 eps, mean of
+    -(y log p + (1 - y) log(1 - p))."""
+    y64, p64 = y.double().reshape(-1), p.double().reshape(-1)
+    eps = torch.finfo(torch.float64).eps
+    p64 = p64.clamp(eps, 1.0 - eps)
+    return -(y64 * torch.log(p64) + (1.0 - y64) * torch.log(1.0 - p64)).mean()
+
+
+def roc_auc(y: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """sklearn.metrics.roc_auc_score(y, p): the Mann-Whitney statistic with tied scores counted one half (the area under
+    the trapezoidal ROC curve over the distinct thresholds).  NaN when only one class is present (sklearn raises there)."""
+    y64, s = y.double().reshape(-1), p.reshape(-1).contiguous()
+    s_sorted, order = torch.sort(s)
+    y_sorted = y64[order]
+    # average 1-based rank of every group of tied scores, without data-dependent shapes (nothing here makes the host wait):
+    # a score's group occupies the sorted positions [left, right)
+    left = torch.searchsorted(s_sorted, s_sorted, right=False)
+    right = torch.searchsorted(s_sorted, s_sorted, right=True)
+    ranks = (left + right + 1).double() * 0.5
+    n_pos = y_sorted.sum()
+    n_neg = y_sorted.numel() - n_pos
+    u = (ranks * y_sorted).sum() - n_pos * (n_pos + 1.0) / 2.0
+    return u / (n_pos * n_neg)
+
+
+def mse(y: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    d = y.double().reshape(-1) - p.double().reshape(-1)
+    return (d * d).mean()
+
+
+def accuracy(y: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    return ((p.reshape(-1) > 0.5).double() == y.double().reshape(-1)).double().mean()
+
+
+BY_NAME = {"binary_crossentropy": log_loss, "logloss": log_loss, "auc": roc_auc, "mse": mse, "accuracy": accuracy,
+           "acc": accuracy}

@@ -117,3 +117,23 @@ def test_division_by_a_constant_through_its_double_reciprocal_is_the_fp32_quotie
     for s in (q * c, np.nextafter(q * c, np.float32(0)), np.nextafter(q * c, np.float32(10))):
         s = s.astype(np.float32)
         assert np.array_equal(s / c, (s.astype(np.float64) * (1.0 / c.astype(np.float64))).astype(np.float32))
+
+
+def test_device_metrics_equal_sklearn():
+    """satrans_amd/device_metrics.py (the per-step train metrics of fit, kept on the device) against the sklearn functions the
+    reference calls, on float32 probabilities with many ties and with saturated values."""
+    from sklearn.metrics import accuracy_score, log_loss, mean_squared_error, roc_auc_score
+    from satrans_amd import device_metrics as DM
+    rng = np.random.RandomState(3)
+    for n, levels in ((8192, None), (4096, 17), (300, 3)):
+        p = rng.rand(n).astype(np.float32)
+        if levels:
+            p = (np.floor(p * levels) / levels).astype(np.float32)           # heavy ties
+        p[:5] = [0.0, 1.0, 1e-30, 1 - 1e-7, 0.5]
+        y = (rng.rand(n) < 0.3).astype(np.float32)
+        yt, pt = torch.from_numpy(y), torch.from_numpy(p)
+        p64 = p.astype("float64")
+        assert float(DM.log_loss(yt, pt)) == pytest.approx(log_loss(y, p64), rel=1e-12)
+        assert float(DM.roc_auc(yt, pt)) == pytest.approx(roc_auc_score(y, p64), rel=1e-12, abs=1e-15)
+        assert float(DM.mse(yt, pt)) == pytest.approx(mean_squared_error(y, p64), rel=1e-12)
+        assert float(DM.accuracy(yt, pt)) == pytest.approx(accuracy_score(y, np.where(p64 > 0.5, 1, 0)), rel=1e-12)
