@@ -587,11 +587,11 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 }
 
 // flat Adam and the step's regulariser sum in one launch: the last block adds the partial sums in a fixed order
-__global__ __launch_bounds__(256) void adam_flat_sum_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void adam_flat_sum_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, AdamK k,
                                                            const double* __restrict__ vals, int64_t count,
                                                            double* __restrict__ out) {
-    __shared__ double s_red[256];
+    __shared__ double s_red[1024];
     if (blockIdx.x + 1 < gridDim.x) {
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (i >= n) return;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void adam_flat_sum_kernel(float* __restrict__ 
         return;
     }
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += 256) acc += vals[i];
+    for (int64_t i = threadIdx.x; i < count; i += 1024) acc += vals[i];
     const double total = block_sum(acc, s_red);
     if (threadIdx.x == 0) out[0] += total;
 }
@@ -897,7 +897,7 @@ extern "C" int satrans_adam_flat_sum(float* p, const float* g, float* m, float* 
                                      const double* vals, int64_t count, double* out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(p && g && m && v && h && vals && out && n >= 0 && count >= 0, SATRANS_E_BADARG, "adam_flat_sum: bad arguments");
-    adam_flat_sum_kernel<<<(unsigned)ceil_div(n, 256) + 1, 256, 0, stream>>>(p, g, m, v, n, make_adamk(*h), vals, count, out);
+    adam_flat_sum_kernel<<<(unsigned)ceil_div(n, 1024) + 1, 1024, 0, stream>>>(p, g, m, v, n, make_adamk(*h), vals, count, out);
     SATRANS_CHECK_LAUNCH("adam_flat_sum_kernel");
     return SATRANS_OK;
 }
