@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__
 // partial sums, flags as for chunks), which the spans kernel below finishes.  A row gathered by every sample of every
 // rank (small-vocabulary fields: runs of tens of thousands of positions) thus costs kSuper + run/(kChunk*kSuper)
 // dependent steps instead of run/kChunk.
-constexpr int kSuper = 32;
+constexpr int kSuper = 16;
 template <int LPR>
 __global__ __launch_bounds__(256) void touched_super_kernel(int64_t chunks,
                                                            const float4* __restrict__ partial,
