@@ -576,7 +576,14 @@ class PathEngine:
 
         # ---- 4. forward, loss, backward ---------------------------------------------------------------------------------
         gemb = self.backward(X, y, ws)
-        # ---- 5. small tables: dense gradient (tail of the flat gradient buffer), one all-reduce, dense step -----------------
+        # ---- 5. large tables, first half: this rank's gradient rows in sorted order start travelling to the other ranks ----
+        grads, pending = gemb, None
+        if world > 1 and n_b > 0:
+            N.check(lib.satrans_embed_pack_rows(ws["src"][n_s:].data_ptr(), n_b, gemb.data_ptr(), D,
+                                                ws["packed"].data_ptr(), st), "satrans_embed_pack_rows")
+            grads, pending = parallel.gather_grad_rows_async(ws["packed"])
+        # ---- 6. small tables (while the rows travel): dense gradient at the tail of the flat gradient buffer, one all-reduce,
+        #         dense step ------------------------------------------------------------------------------------------------------
         with self.phase("adam_small"):
             if n_s > 0:
                 N.check(lib.satrans_embed_segment_sums(ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(), n_s,
@@ -591,12 +598,9 @@ class PathEngine:
                                                     ws["reg_rows"].data_ptr(), st), "satrans_embed_adam_rows")
                 N.check(lib.satrans_sum_f64(ws["reg_rows"].data_ptr(), ws["reg_rows"].numel(), self.reg_sum.data_ptr(), 1,
                                             st), "satrans_sum_f64")
-        # ---- 6. large tables: (row, gradient row) lists of all ranks ----------------------------------------------------------
-        grads = gemb
-        if world > 1 and n_b > 0:
-            N.check(lib.satrans_embed_pack_rows(ws["src"][n_s:].data_ptr(), n_b, gemb.data_ptr(), D,
-                                                ws["packed"].data_ptr(), st), "satrans_embed_pack_rows")
-            grads = parallel.gather_grad_rows(ws["packed"])
+        # ---- 7. large tables, second half: (row, gradient row) lists of all ranks -------------------------------------------
+        if pending is not None:
+            pending.wait()
         if side_done is not None:
             main.wait_event(side_done)
         if n_big > 0:

@@ -98,6 +98,20 @@ def gather_grad_rows(gemb: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_grad_rows_async(gemb: torch.Tensor):
+    """`gather_grad_rows` that returns at once: (out, handle).  The caller keeps issuing independent work on its stream
+    and calls `handle.wait()` (None: nothing to wait for) before it reads `out`."""
+    w = world_size()
+    gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
+    if w == 1:
+        return gemb, None
+    out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
+    if _host_staged(gemb):
+        _all_gather(out, gemb)
+        return out, None
+    return out, dist.all_gather_into_tensor(out, gemb, async_op=True)
+
+
 def exchange_grads(flat_grad: torch.Tensor, gemb: torch.Tensor) -> torch.Tensor:
     """All-reduce `flat_grad` in place (SUM) and all-gather the gradient rows ([W*n, D], rank-major: the same order
     as `gather_rows`)."""

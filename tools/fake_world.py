@@ -1,6 +1,6 @@
 """Diagnostic: compute-side cost of one rank's step in an N-rank job, measured on ONE GPU.
 
-`parallel.world_size / gather_rows / gather_grad_rows / all_reduce_flat` are replaced by stand-ins that append the arena rows of N-1
+`parallel.world_size / gather_rows / gather_grad_rows_async / all_reduce_flat` are replaced by stand-ins that append the arena rows of N-1
 other synthetic batches (what the all-gather of ids would deliver) and tile the local gradient rows N times (what
 the all-gather of gradient rows would deliver; the tiling copy costs about what writing the received buffer does).
 Everything downstream - sort, lazy replay, segmented sums, touched-row Adam over N*B*F rows - is the real code.
@@ -38,7 +38,7 @@ def run(N, steps=12, warmup=4, B=8192):
     state = {"i": 0}
     parallel.world_size = lambda: N
     parallel.gather_rows = lambda rows: torch.cat([rows.reshape(-1), others[state["i"]]]) if N > 1 else rows.reshape(-1)
-    parallel.gather_grad_rows = lambda g: g.reshape(-1, g.shape[-1]).repeat(N, 1) if N > 1 else g.reshape(-1, g.shape[-1])
+    parallel.gather_grad_rows_async = lambda g: ((g.reshape(-1, g.shape[-1]).repeat(N, 1) if N > 1 else g.reshape(-1, g.shape[-1])), None)
     parallel.all_reduce_flat = lambda flat: None
     eng.timers = None
     for i in range(warmup):
