@@ -264,9 +264,9 @@ def main():
                     "unit": e["unit"], "frac": e["frac"], "traffic": None,
                     "algorithmic_per_launch": spec["work"], "launch_ms": e["ms_per_launch"],
                     "launches_per_step": count.get(dominant, 1),
-                    "note": "HIP events on the launch stream over the timed region; layer_bwd includes its three "
-                            "fixed-order reduction kernels; `kernels_serial` repeats the measurement without the "
-                            "side-stream overlap"}
+                    "note": "HIP events on the launch stream over the timed region (every 4th step); layer_bwd includes "
+                            "its fixed-order reduction launch; `kernels_serial` repeats the measurement in an extra "
+                            "untimed pass"}
 
     # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (tools/pmc_passes.sh: FETCH_SIZE
     # and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
