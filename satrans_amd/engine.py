@@ -481,15 +481,13 @@ class PathEngine:
         return ws["dact"][cur]
 
     def train_step(self, X: torch.Tensor, y: torch.Tensor):
-        """One optimizer step of every data-parallel rank.
-
-        main stream: ids -> arena rows, sort, [lazy: replay of the rows this rank is about to read], bucket, gather,
-          forward, head, backward; small tables: ordered segmented sums into a dense gradient, all-reduced together with
-          the flat gradient, dense step; large tables: [all-gather of the gradient rows], ordered segmented sums + step
-          over the sorted (row, gradient) list of all ranks; flat Adam.
-        side stream (several ranks, or the streaming form of the dense step): all-gather of the other ranks' large-table
-          rows, their sort, [lazy: their replay | streaming: Adam of every other row], underneath the layer kernels.
-        Every rank applies the same updates in the same order, so the replicas stay bit-identical (parallel.py)."""
+        """One optimizer step of every data-parallel rank, all on the launch stream: ids -> arena rows, sort, [lazy: replay of
+        the rows this rank is about to read], bucket, gather, forward, head, backward; then the exchange (large-table row ids,
+        flat gradient + dense small-table gradient, large-table gradient rows) with the global sort and the replay of the
+        other ranks' rows underneath the last all-gather; dense step of the small tables; ordered segmented sums + step over
+        the sorted (row, gradient) list of all ranks; flat Adam.  Every rank applies the same updates in the same order, so the
+        replicas stay bit-identical (parallel.py).  One rank in the streaming form runs the every-row step on a side stream
+        underneath the forward."""
         from . import parallel
         X = self._prepare_input(X)
         y = y.reshape(-1).to(torch.float32).contiguous()
@@ -541,64 +539,79 @@ class PathEngine:
                 replay(ws["sorted_rows"], n_loc, ws["replay_reg"], None)
         elif self.lazy:
             ws["replay_reg"].zero_()
-        # ---- 3. the sorted list of the large-table rows of ALL ranks; side stream work --------------------------------------
+        # ---- 3. one rank, streaming form of the dense step: every other row takes its regulariser-only step now, on a side
+        #         stream underneath the forward (several ranks: after the backward, underneath the exchange) -------------------
         side_done = None
         big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
-        use_side = (world > 1 and n_b > 0) or (not self.lazy and self.overlap)
-        if use_side:
-            if self._side is None:
-                self._side = torch.cuda.Stream(self.dev)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            self._side.wait_event(ready)
-        with torch.cuda.stream(self._side) if use_side else contextlib.nullcontext():
-            touched = None if self.lazy else ws["touched"].data_ptr()
-            if world > 1 and n_b > 0:
-                all_rows = parallel.gather_rows(big_sorted)
-                sort(all_rows, n_big, ws["g_sorted"], ws["g_src"], touched)
-                big_sorted, big_src = ws["g_sorted"], ws["g_src"]
-                if self.lazy and self.adam_t > 1:
-                    replay(big_sorted, n_big, ws["replay_reg_g"], self.reg_sum_side)
-            elif not self.lazy:
-                N.check(lib.satrans_embed_mark_touched(big_sorted.data_ptr() if n_b else None, n_b, self.total_rows,
-                                                       ws["touched"].data_ptr(), self._stream()),
-                        "satrans_embed_mark_touched")
-            if not self.lazy and self.total_rows > small_rows:
-                # streaming form: every large-table row outside the bitmap takes its regulariser-only step now
+
+        def untouched():
+            if self.total_rows > small_rows:
                 with self.phase("adam_untouched"):
                     N.check(lib.satrans_embed_adam_untouched(arena, am, av, small_rows, self.total_rows, D,
                                                              ws["touched"].data_ptr(), C.byref(h_emb),
                                                              ws["reg_partials"].data_ptr(), 0, self._stream()),
                             "satrans_embed_adam_untouched")
+
+        if world == 1 and not self.lazy:
+            use_side = self.overlap
             if use_side:
-                side_done = torch.cuda.Event()
-                side_done.record(self._side)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.dev)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                self._side.wait_event(ready)
+            with torch.cuda.stream(self._side) if use_side else contextlib.nullcontext():
+                N.check(lib.satrans_embed_mark_touched(big_sorted.data_ptr() if n_b else None, n_b, self.total_rows,
+                                                       ws["touched"].data_ptr(), self._stream()),
+                        "satrans_embed_mark_touched")
+                untouched()
+                if use_side:
+                    side_done = torch.cuda.Event()
+                    side_done.record(self._side)
 
         # ---- 4. forward, loss, backward ---------------------------------------------------------------------------------
         gemb = self.backward(X, y, ws)
-        # ---- 5. large tables, first half: this rank's gradient rows in sorted order start travelling to the other ranks ----
-        grads, pending = gemb, None
-        if world > 1 and n_b > 0:
-            N.check(lib.satrans_embed_pack_rows(ws["src"][n_s:].data_ptr(), n_b, gemb.data_ptr(), D,
-                                                ws["packed"].data_ptr(), st), "satrans_embed_pack_rows")
-            grads, pending = parallel.gather_grad_rows_async(ws["packed"])
-        # ---- 6. small tables (while the rows travel): dense gradient at the tail of the flat gradient buffer, one all-reduce,
-        #         dense step ------------------------------------------------------------------------------------------------------
-        with self.phase("adam_small"):
-            if n_s > 0:
+
+        # ---- 5. small tables: ordered segmented sums into the dense gradient at the tail of the flat gradient buffer -----------
+        if n_s > 0:
+            with self.phase("adam_small"):
                 N.check(lib.satrans_embed_segment_sums(ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(), n_s,
                                                        gemb.data_ptr(), D, ws["partial_ws"].data_ptr(),
                                                        ws["reg_unused"].data_ptr(), self.g_small.data_ptr(), st),
                         "satrans_embed_segment_sums")
-            if world > 1:
-                parallel.all_reduce_flat(self.g_exchange)
-            if small_rows > 0:
+        # ---- 6. the exchange.  Collectives in this order: large-table row ids (small), flat gradient + small tables (small),
+        #         large-table gradient rows (the big one, asynchronous).  While the rows travel the GPU has nothing else to do,
+        #         so the work that only needs the ids runs now: the global sort and the replay of the other ranks' rows (lazy
+        #         form) or the streaming step of every untouched row.  (The forward's 12-wave workgroups leave no room for other
+        #         kernels, so there is nothing to gain from starting this earlier on a side stream.) ----------------------------
+        grads, pending = gemb, None
+        if world > 1:
+            all_rows = parallel.gather_rows(big_sorted) if n_b > 0 else None
+            parallel.all_reduce_flat(self.g_exchange)
+            if n_b > 0:
+                N.check(lib.satrans_embed_pack_rows(ws["src"][n_s:].data_ptr(), n_b, gemb.data_ptr(), D,
+                                                    ws["packed"].data_ptr(), st), "satrans_embed_pack_rows")
+                grads, pending = parallel.gather_grad_rows_async(ws["packed"])
+                with self.phase("embed_sort_global"):
+                    sort(all_rows, n_big, ws["g_sorted"], ws["g_src"], None if self.lazy else ws["touched"].data_ptr())
+                big_sorted, big_src = ws["g_sorted"], ws["g_src"]
+                if self.lazy and self.adam_t > 1:
+                    with self.phase("lazy_replay_global"):
+                        replay(big_sorted, n_big, ws["replay_reg_g"], self.reg_sum)
+            elif not self.lazy:
+                N.check(lib.satrans_embed_mark_touched(None, 0, self.total_rows, ws["touched"].data_ptr(), st),
+                        "satrans_embed_mark_touched")
+            if not self.lazy:
+                untouched()
+        # ---- 7. small tables: dense step over all their rows -----------------------------------------------------------------------
+        if small_rows > 0:
+            with self.phase("adam_small"):
                 N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, small_rows, D,
                                                     self.g_small.data_ptr(), C.byref(h_emb), self.adam_t,
                                                     ws["reg_rows"].data_ptr(), st), "satrans_embed_adam_rows")
                 N.check(lib.satrans_sum_f64(ws["reg_rows"].data_ptr(), ws["reg_rows"].numel(), self.reg_sum.data_ptr(), 1,
                                             st), "satrans_sum_f64")
-        # ---- 7. large tables, second half: (row, gradient row) lists of all ranks -------------------------------------------
+        # ---- 8. large tables: (row, gradient row) lists of all ranks ------------------------------------------------------------
         if pending is not None:
             pending.wait()
         if side_done is not None:
