@@ -10,6 +10,16 @@ sys.path.insert(0, ROOT)
 subprocess.run(["touch", os.path.join(ROOT, "satrans_amd/csrc/layer_fused.hip")], check=True)
 subprocess.run(["bash", os.path.join(ROOT, "satrans_amd/csrc/build.sh")], check=True,
                env=dict(os.environ, SATRANS_EXTRA_FLAGS="-DSATRANS_STAMPS"), stdout=subprocess.DEVNULL)
+import atexit  # noqa: E402
+
+
+def _restore():
+    """Leave the product library behind, not the instrumented one."""
+    subprocess.run(["touch", os.path.join(ROOT, "satrans_amd/csrc/layer_fused.hip")], check=False)
+    subprocess.run(["bash", os.path.join(ROOT, "satrans_amd/csrc/build.sh")], check=False, stdout=subprocess.DEVNULL)
+
+
+atexit.register(_restore)
 import torch  # noqa: E402
 import bench  # noqa: E402
 
