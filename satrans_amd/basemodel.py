@@ -359,6 +359,10 @@ class BaseModel(nn.Module):
             for name, result in train_result.items():
                 if result and torch.is_tensor(result[0]):
                     result = torch.stack(result).cpu().numpy()           # the epoch's only read of the per-step metrics
+                    if name == "auc" and np.isnan(result).any():
+                        # sklearn (the reference's per-step call) raises on such a batch; here it surfaces at the epoch end
+                        raise ValueError("Only one class present in y_true of a training batch. ROC AUC score is not "
+                                         "defined in that case.")
                 epoch_logs[name] = np.sum(result) / steps_per_epoch
             if do_validation:
                 for name, result in self.evaluate(val_x, val_y, batch_size).items():
