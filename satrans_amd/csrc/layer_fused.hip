@@ -872,6 +872,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       // The sample index and the input row of a tile are fetched one tile ahead (at the end of phase F, when the registers
       // of the current x are free): with one wave per SIMD nothing else would hide those two dependent global loads.
       const int tok = row0 + n;
+      const int ls_tok = tok / F, f_tok = tok - ls_tok * F;      // this lane's (sample, field) inside any tile that holds it
       int b_next = 0;
       float x_next[KT][4];
       auto fetch_tile = [&](int tile_) {
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
           const int ntok_ = min(Tsamp, hi - first_) * F;
           const bool has_ = wave < ((ntok_ + 15) >> 4);
           const bool valid_ = has_ && tok < ntok_;
-          const int ls_ = valid_ ? tok / F : 0, f_ = valid_ ? tok - ls_ * F : 0;
+          const int ls_ = valid_ ? ls_tok : 0, f_ = valid_ ? f_tok : 0;
           b_next = a.order[first_ + ls_];
           if (has_) load_frag<KT>(a.x + ((size_t)b_next * F + f_) * D + g4, x_next);
       };
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
         const bool has_tile = wave < ntt;
         const bool valid = has_tile && tok < ntok;
-        const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
+        const int f = valid ? f_tok : 0;
         const int b = b_next;
         const uint32_t key_q = drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b);
         const uint32_t key_k = drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b);
