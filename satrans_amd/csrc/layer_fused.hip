@@ -781,6 +781,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
     const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
     const int lt_d = n * LD + g4, lt_u = n * LU + g4;          // ... for a read by rows (chain_t): row n, column 4g
+    // (sample, head, row) of this thread's attention task - the same in every tile and every attention phase
+    const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
+    const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);
 
@@ -989,8 +992,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // four with all loads of a chunk issued before its results are stored; padding keys of the last chunk read the
         // last real row and are masked arithmetically.
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
-            const int tls = task / (H * F), rem = task - tls * H * F;
-            const int h = rem / F, i = rem - h * F;
+            int tls = t0_ls, h = t0_h, i = t0_i;
+            if (task != (int)threadIdx.x) {          // only when a tile holds more tasks than the workgroup has threads
+                tls = task / (H * F);
+                const int rem = task - tls * H * F;
+                h = rem / F;
+                i = rem - h * F;
+            }
             const int tb = samp[tls];
             f32x2 qi[d / 2];
             load_row<d>(sq + (size_t)(tls * F + i) * LD + h * d, qi);
@@ -1100,8 +1108,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // pass 2: dS_ij = P_ij (dP_ij - dot_i) / sqrt(d) replaces it, the numerator cache row becomes P_ij * mask_ij
         //         (the coefficient of dv_j), dq_i = sum_j dS_ij k_j.
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
-            const int tls = task / (H * F), rem = task - tls * H * F;
-            const int h = rem / F, i = rem - h * F;
+            int tls = t0_ls, h = t0_h, i = t0_i;
+            if (task != (int)threadIdx.x) {          // only when a tile holds more tasks than the workgroup has threads
+                tls = task / (H * F);
+                const int rem = task - tls * H * F;
+                h = rem / F;
+                i = rem - h * F;
+            }
             f32x2 gi[d / 2];
             load_row<d>(so + (size_t)(tls * F + i) * LD + h * d, gi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
@@ -1165,8 +1178,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         STAMP(4);
         // ================= phase E: by columns: dk_j = sum_i dS_ij q_i, dv_j = sum_i P_ij mask_ij go_i (in place of k_j, v_j)
         for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
-            const int tls = task / (H * F), rem = task - tls * H * F;
-            const int h = rem / F, j = rem - h * F;
+            int tls = t0_ls, h = t0_h, j = t0_i;
+            if (task != (int)threadIdx.x) {          // only when a tile holds more tasks than the workgroup has threads
+                tls = task / (H * F);
+                const int rem = task - tls * H * F;
+                h = rem / F;
+                j = rem - h * F;
+            }
             f32x2 dk[d / 2], dv[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) { dk[e] = f32x2{0.f, 0.f}; dv[e] = f32x2{0.f, 0.f}; }
