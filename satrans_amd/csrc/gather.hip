@@ -27,6 +27,13 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
     const int q = (int)(tid % LPR);         // which 16-byte piece of the row
     const int64_t stride = (int64_t)gridDim.x * kGatherBlock / LPR;
 
+    // (sample, field) of a slot without a division per slot: one division for the first slot and one for the stride, then
+    // incremental updates (a runtime integer division costs as much as the rest of a slot's address arithmetic)
+    // (32-bit: n_rows = B * F < 2^31 is checked by the caller; a 64-bit division would cost several times more still)
+    const int sb = (int)stride / F;
+    const int sf = (int)stride - sb * F;
+    int b0 = (int)min(slot0, n_rows) / F;
+    int f0 = (int)min(slot0, n_rows) - b0 * F;
     for (int64_t base = slot0; base < n_rows; base += stride * kRowsPerThread) {
         int64_t row[kRowsPerThread];
         bool bad[kRowsPerThread];
@@ -37,8 +44,8 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
             row[r] = -1;
             bad[r] = false;
             if (slot < n_rows) {
-                const int64_t b = slot / F;
-                const int f = (int)(slot - b * F);
+                const int64_t b = b0;
+                const int f = f0;
                 const int64_t id = load_id(X, id_dtype, x_stride, b, cols[f]);
                 const int64_t lo = row_span[2 * f], hi = row_span[2 * f + 1];
                 // out of range: the reference raises IndexError; we flag, write zeros and record the table's first row
@@ -46,6 +53,9 @@ __global__ __launch_bounds__(kGatherBlock) void gather_rows_kernel(
                 bad[r] = id < 0 || id >= hi - lo;
                 row[r] = bad[r] ? lo : lo + id;
             }
+            b0 += sb;                       // next slot of this thread: + stride
+            f0 += sf;
+            if (f0 >= F) { f0 -= F; ++b0; }
         }
 #pragma unroll
         for (int r = 0; r < kRowsPerThread; ++r) {
@@ -162,6 +172,7 @@ extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_span, c
     SATRANS_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, SATRANS_E_UNSUPPORTED,
                     "gather_fwd: embedding_dim %d not in {16,32,64,128}", D);
     const int64_t n_rows = (int64_t)B * F;
+    SATRANS_REQUIRE(n_rows < ((int64_t)1 << 31), SATRANS_E_BADARG, "gather_fwd: B * F = %lld does not fit 31 bits", (long long)n_rows);
     const int lpr = D / 4;
     // enough threads for every row once, capped at 8 blocks per CU (256 CUs) and grid-strided beyond that
     int64_t blocks = ceil_div(ceil_div(n_rows, kRowsPerThread) * lpr, kGatherBlock);
