@@ -28,9 +28,9 @@ __global__ __launch_bounds__(256) void scenario_table_fwd_kernel(const float* __
 __global__ __launch_bounds__(256) void scenario_table_bwd_w_kernel(const float* __restrict__ emb,
                                                                  const float* __restrict__ g_tab, int S, int De, int P,
                                                                  float* __restrict__ g_W, float* __restrict__ g_bias) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)P * De) return;
-    const int p = (int)(i / De), k = (int)(i - (int64_t)p * De);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // P * De fits 31 bits (checked by the caller)
+    if (i >= P * De) return;
+    const int p = i / De, k = i - p * De;
     float acc = 0.f, accb = 0.f;
     for (int s = 0; s < S; ++s) {
         const float g = g_tab[(size_t)s * P + p];
@@ -98,7 +98,8 @@ extern "C" int satrans_scenario_table_bwd(const float* emb, const float* W, cons
                                           float* g_emb, float* g_W, float* g_bias, float* workspace, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(emb && W && g_tab && g_emb && g_W && g_bias && workspace, SATRANS_E_BADARG, "scenario_table_bwd: null pointer");
-    SATRANS_REQUIRE(S > 0 && De > 0 && P > 0, SATRANS_E_BADARG, "scenario_table_bwd: S=%d De=%d P=%d", S, De, P);
+    SATRANS_REQUIRE(S > 0 && De > 0 && P > 0 && (int64_t)P * De < ((int64_t)1 << 31), SATRANS_E_BADARG,
+                    "scenario_table_bwd: S=%d De=%d P=%d", S, De, P);
     scenario_table_bwd_w_kernel<<<(unsigned)ceil_div((int64_t)P * De, 256), 256, 0, stream>>>(emb, g_tab, S, De, P, g_W, g_bias);
     SATRANS_CHECK_LAUNCH("scenario_table_bwd_w_kernel");
     scenario_table_bwd_e1_kernel<<<dim3(S, kSlices), 256, sizeof(float) * kSub * De, stream>>>(W, g_tab, De, P, workspace);
