@@ -119,7 +119,6 @@ class PathEngine:
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.reg_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
-        self.reg_sum_side = torch.zeros(1, dtype=torch.float64, device=self.dev)   # accumulated on the side stream
         self.adam_t = 0
         self.adam_m = self.adam_v = None
         self.flat_m = self.flat_v = self.flat_g = None
@@ -415,12 +414,10 @@ class PathEngine:
     def reset_epoch_sums(self):
         self.loss_sum.zero_()
         self.reg_sum.zero_()
-        self.reg_sum_side.zero_()
 
     def epoch_sums(self):
         self.flush_lazy()          # the regulariser sums of postponed steps belong to this epoch
-        torch.cuda.synchronize(self.dev)
-        return float(self.loss_sum.item()), float(self.reg_sum.item()) + float(self.reg_sum_side.item())
+        return float(self.loss_sum.item()), float(self.reg_sum.item())
 
     def _hparams(self, l2: float) -> N.AdamHParams:
         cfg = self.m._adam_cfg
