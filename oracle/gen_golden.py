@@ -14,6 +14,7 @@ of `oracle/shims/` on sys.path.  For every case below this script builds the ref
   train/bce|reg    loss pieces of ONE train-mode step with every dropout probability set to 0
   grad/<key>       gradients of that step (keys without gradient are absent)
   adam/<key>       every unique tensor after `adam_steps` steps of torch.optim.Adam at `lr`
+  opt/exp_avg/<key>, opt/exp_avg_sq/<key>   torch.optim.Adam's moments after those steps
   fit/*            History['loss'] and predict() output of the reference's own fit()/predict()
 
 Nothing here runs on the GPU box; the fixtures are data (inputs + expected outputs).
@@ -209,6 +210,15 @@ def run_case(name, outdir):
         optim.step()
     if cfg['train']:
         pack_state(model, "adam", out)
+        # torch.optim.Adam's own state after those steps: well-conditioned where the parameters are not (a parameter
+        # element with |g| ~ eps moves by up to lr per step whatever its moments' last bits are), so these pin the
+        # optimizer trajectory tightly
+        seen = set()
+        for k, p in model.named_parameters():
+            if p in optim.state and p.data_ptr() not in seen and 'exp_avg' in optim.state[p]:
+                seen.add(p.data_ptr())
+                out[f"opt/exp_avg/{k}"] = optim.state[p]['exp_avg'].detach().numpy().copy()
+                out[f"opt/exp_avg_sq/{k}"] = optim.state[p]['exp_avg_sq'].detach().numpy().copy()
 
     # ---- the reference's own fit()/predict() on a fresh model -------------------------------------
     if cfg['with_fit']:

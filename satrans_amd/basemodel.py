@@ -88,6 +88,13 @@ class BaseModel(nn.Module):
         self.gpus = gpus
         if gpus and str(self.gpus[0]) not in self.device:
             raise ValueError("`gpus[0]` should be the same gpu with `device`")
+        if gpus and len(gpus) > 1:
+            # reference: single-process torch.nn.DataParallel over `gpus` (models/meta_basemodel.py:272-275).  Here data
+            # parallelism is one PROCESS per GPU (torchrun + RCCL, satrans_amd/parallel.py) with the same semantics
+            # (batch_size per GPU, summed gradients); a model constructed in one process drives one GPU.
+            import warnings
+            warnings.warn("gpus=%s: this build is data-parallel with one process per GPU (launch with torchrun; fit() "
+                          "then shards by rank). Inside one process only `device` is used." % (list(gpus),))
         self.l2_reg_embedding = float(l2_reg_embedding)
         self.l2_reg_linear = float(l2_reg_linear)
 
@@ -175,13 +182,84 @@ class BaseModel(nn.Module):
         self._engine = None
 
     def _apply(self, fn, *args, **kwargs):
+        # A device / dtype move rebuilds the arena and the engine that drives it.  The engine is the only holder of the
+        # optimizer state (Adam moments, step count, dropout step): it is taken out first and handed to the next engine,
+        # so `.to()` in the middle of training continues the run as torch.optim.Adam would (its state follows the
+        # parameters), instead of silently restarting Adam from step 0.
         eng = getattr(self, "_engine", None)
+        carried = getattr(self, "_pending_opt_state", None)
         if eng is not None:
             eng.flush_lazy()          # postponed optimizer steps must land before the storage is rebuilt
+            if eng.adam_t > 0:
+                carried = eng.optimizer_state()
         out = super()._apply(fn, *args, **kwargs)
         if self.embedding_arena is not None:
             self._rebind_storage()
+            self._pending_opt_state = carried
         return out
+
+    # ------------------------------------------------------------------------------------------
+    # optimizer state (resume): the torch optimizer handed to compile() is only read for its hyper-parameters, the
+    # moments live in the engine.  These two calls are the counterpart of optimizer.state_dict()/load_state_dict().
+    # ------------------------------------------------------------------------------------------
+    def optimizer_state_dict(self) -> dict:
+        """Adam state of every trained tensor by state_dict key (`exp_avg`, `exp_avg_sq`: CPU tensors) plus the step
+        count and the dropout step; {} before the first step."""
+        eng = getattr(self, "_engine", None)
+        if eng is None or eng.adam_t == 0:
+            pend = getattr(self, "_pending_opt_state", None)
+            if pend is None:
+                return {}
+            raw = pend
+        else:
+            eng.flush_lazy()
+            raw = eng.optimizer_state()
+        out = {"step": int(raw["adam_t"]), "drop_step": int(raw["drop_step"]), "state": {}}
+        for name, (off, rows) in self._table_rows.items():
+            out["state"][f"embedding_dict.{name}.weight"] = {
+                "exp_avg": raw["adam_m"][off:off + rows].detach().cpu().clone(),
+                "exp_avg_sq": raw["adam_v"][off:off + rows].detach().cpu().clone()}
+        for name, p in self._trainable_flat().items():
+            off, cnt = self._flat_slices[name]
+            out["state"][name] = {"exp_avg": raw["flat_m"][off:off + cnt].view(p.shape).detach().cpu().clone(),
+                                  "exp_avg_sq": raw["flat_v"][off:off + cnt].view(p.shape).detach().cpu().clone()}
+        return out
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Inverse of `optimizer_state_dict` (call after `load_state_dict`, on the device the run continues on)."""
+        if not sd:
+            return
+        dev = self.embedding_arena.device
+        raw = {"adam_t": int(sd["step"]), "drop_step": int(sd.get("drop_step", 0)),
+               "adam_m": torch.zeros_like(self.embedding_arena), "adam_v": torch.zeros_like(self.embedding_arena),
+               "flat_m": torch.zeros_like(self.flat_params), "flat_v": torch.zeros_like(self.flat_params)}
+        for name, (off, rows) in self._table_rows.items():
+            st = sd["state"][f"embedding_dict.{name}.weight"]
+            raw["adam_m"][off:off + rows] = st["exp_avg"].to(dev)
+            raw["adam_v"][off:off + rows] = st["exp_avg_sq"].to(dev)
+        for name, p in self._trainable_flat().items():
+            off, cnt = self._flat_slices[name]
+            st = sd["state"][name]
+            raw["flat_m"][off:off + cnt] = st["exp_avg"].to(dev).reshape(-1)
+            raw["flat_v"][off:off + cnt] = st["exp_avg_sq"].to(dev).reshape(-1)
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.flush_lazy()
+            eng.load_optimizer_state(raw)
+        else:
+            self._pending_opt_state = raw
+
+    def _refresh_adam_cfg(self):
+        """Re-read lr / betas / eps from the torch optimizer given to compile() (LR schedulers and manual edits of
+        `param_groups` take effect at the next step, as they do for torch.optim.Adam).  Steps that are still postponed
+        (lazy-exact form) belong to the old values and are applied first."""
+        opt = getattr(self, "optim", None)
+        if isinstance(opt, torch.optim.Adam):
+            new = self._read_optimizer(opt)
+            if new != self._adam_cfg:
+                self._flush_engine()
+                self._adam_cfg = new
+        return self._adam_cfg
 
     # ------------------------------------------------------------------------------------------
     # compile
@@ -294,6 +372,7 @@ class BaseModel(nn.Module):
         if batch_size is None:
             batch_size = 256
         sample_num = packed.shape[0]
+        self._check_ranks_agree(sample_num, batch_size)
         steps_per_epoch = (sample_num - 1) // batch_size + 1
         steps_to_valid = steps_per_epoch // valid_cnt_per_epoch + 1
 
@@ -382,6 +461,26 @@ class BaseModel(nn.Module):
                 break
         cbs.on_train_end()
         return self.history
+
+    def _check_ranks_agree(self, sample_num: int, batch_size: int) -> None:
+        """Data-parallel runs: every rank must bring the same number of samples and the same batch size, because
+        the step's collectives are sized from the local batch (all_gather_into_tensor of B*F_large rows per rank) and
+        every rank must take the same number of steps.  A mismatch would hang or mis-size a collective, so it is an
+        error here (the ragged LAST batch is fine: it has the same size on every rank)."""
+        from . import parallel
+        if parallel.world_size() == 1:
+            return
+        import torch.distributed as dist
+        dev = self.device if (str(self.device).startswith("cuda") and dist.get_backend() != "gloo") else "cpu"
+        lo = torch.tensor([sample_num, batch_size], dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise ValueError(
+                f"data-parallel fit(): ranks disagree on (samples, batch_size): min {lo.tolist()} max {hi.tolist()}, "
+                f"this rank ({sample_num}, {batch_size}). Give every rank an equally long shard (drop or pad the tail) "
+                f"and the same batch_size.")
 
     def _epoch_order(self, n: int, shuffle: bool) -> Optional[torch.Tensor]:
         """Sample order of one epoch.  With shuffle the permutation is drawn the way

@@ -705,7 +705,10 @@ extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_
 
 extern "C" int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D) {
     (void)total_rows;
-    return kStreamBlocks + 2 * touched_blocks(n, D);
+    // run_touched writes three groups of partials behind the streaming kernel's slots: one per apply block, one per chunk
+    // block (finish kernel) and one per superchunk block (spans kernel, which writes its slot unconditionally)
+    const int64_t supers = ceil_div(ceil_div(n, kChunk), kSuper);
+    return kStreamBlocks + touched_blocks(n, D) + chunk_blocks(n, D) + ceil_div(supers * (D / 4), 256);
 }
 
 // partial_ws: [chunks][2][D] floats, [chunks] int32 info, [chunks] int32 trail_row, [n][D] run sums, [n] int32 head flags,

@@ -188,9 +188,9 @@ class PathEngine:
         self._ws[B] = ws
         return ws
 
-    def train_workspace(self, B: int, world: int = 1) -> dict:
+    def train_workspace(self, B: int, world: int = 1, exchange: bool = False) -> dict:
         ws = self.workspace(B)
-        key = ("train", world)
+        key = ("train", world, exchange)
         if key in ws:
             return ws
         dev, F, D, lib = self.dev, self.F, self.D, self.lib
@@ -207,7 +207,7 @@ class PathEngine:
         ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
         ws["sorted_rows"] = torch.empty(n_loc, **i32)           # this rank's rows, sorted, and their source positions
         ws["src"] = torch.empty(n_loc, **i32)
-        if world > 1:
+        if exchange:
             ws["g_sorted"] = torch.empty(max(n_big, 1), **i32)  # every rank's large-table rows, sorted
             ws["g_src"] = torch.empty(max(n_big, 1), **i32)
             ws["packed"] = torch.empty(max(n_loc - n_s, 1), D, **f32)
@@ -411,6 +411,23 @@ class PathEngine:
         off, cnt = self.m._flat_slices[name]
         return self.flat_g[off:off + cnt]
 
+    def optimizer_state(self) -> dict:
+        """Everything a new engine needs to continue this run (call flush_lazy() first: every row is then at adam_t)."""
+        self._ensure_train_state()
+        return dict(adam_t=self.adam_t, drop_step=self.drop_step, adam_m=self.adam_m, adam_v=self.adam_v,
+                    flat_m=self.flat_m, flat_v=self.flat_v)
+
+    def load_optimizer_state(self, st: dict) -> None:
+        self._ensure_train_state()
+        self.adam_t = int(st["adam_t"])
+        self.drop_step = int(st["drop_step"])
+        self.adam_m.copy_(st["adam_m"].to(self.dev))
+        self.adam_v.copy_(st["adam_v"].to(self.dev))
+        self.flat_m.copy_(st["flat_m"].to(self.dev))
+        self.flat_v.copy_(st["flat_v"].to(self.dev))
+        self.last_step.fill_(self.adam_t)            # the state was taken after a flush: every row is current
+        self._lazy_pending = False
+
     def reset_epoch_sums(self):
         self.loss_sum.zero_()
         self.reg_sum.zero_()
@@ -490,13 +507,15 @@ class PathEngine:
         y = y.reshape(-1).to(torch.float32).contiguous()
         B = X.shape[0]
         self._ensure_train_state()
+        self.m._refresh_adam_cfg()                    # lr schedulers / edited param_groups take effect at this step
         world = parallel.world_size()
-        ws = self.train_workspace(B, world)
+        exch = parallel.exchange_enabled()            # several ranks (or one rank made to run its collectives: tests)
+        ws = self.train_workspace(B, world, exch)
         lib, m, D = self.lib, self.m, self.D
         main = torch.cuda.current_stream(self.dev)
         st = self._stream()
         # table classes only pay off when there is an exchange to shrink (one rank: +5 launches for nothing)
-        split = world > 1 or self.force_split
+        split = exch or self.force_split
         small_rows = self.small_rows if split else 0
         n_loc = B * self.F
         n_s = B * self.F_small if split else 0
@@ -549,7 +568,7 @@ class PathEngine:
                                                              ws["reg_partials"].data_ptr(), 0, self._stream()),
                             "satrans_embed_adam_untouched")
 
-        if world == 1 and not self.lazy:
+        if not exch and not self.lazy:
             use_side = self.overlap
             if use_side:
                 if self._side is None:
@@ -582,7 +601,7 @@ class PathEngine:
         #         form) or the streaming step of every untouched row.  (The forward's 12-wave workgroups leave no room for other
         #         kernels, so there is nothing to gain from starting this earlier on a side stream.) ----------------------------
         grads, pending = gemb, None
-        if world > 1:
+        if exch:
             all_rows = parallel.gather_rows(big_sorted) if n_b > 0 else None
             parallel.all_reduce_flat(self.g_exchange)
             if n_b > 0:

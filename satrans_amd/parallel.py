@@ -14,6 +14,7 @@ per iteration:
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -22,6 +23,31 @@ import torch.distributed as dist
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def exchange_enabled() -> bool:
+    """True when the training step runs its exchange branch: more than one rank, or SATRANS_FORCE_EXCHANGE=1 with an
+    initialised process group of ONE rank (every collective is then an identity, but it really goes through the backend
+    - this is how a one-GPU box exercises RCCL: device-pointer int32 all-gather, async fp32 all-gather + wait, SUM
+    all-reduce; tests/test_gpu_parity.py::test_rccl_single_rank_exchange...)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SATRANS_FORCE_EXCHANGE", "0") == "1"
+
+
+# bytes this rank handed to / received from each collective since the last reset (bench.py reports them per step)
+STATS = {}
+
+
+def _count(name: str, sent: int, received: int) -> None:
+    st = STATS.setdefault(name, {"calls": 0, "bytes_in": 0, "bytes_out": 0})
+    st["calls"] += 1
+    st["bytes_in"] += int(sent)
+    st["bytes_out"] += int(received)
+
+
+def reset_stats() -> None:
+    STATS.clear()
 
 
 def rank() -> int:
@@ -52,50 +78,26 @@ def _all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
         dist.all_reduce(t, op=op)
 
 
-def exchange(flat_grad: torch.Tensor, rows: torch.Tensor, gemb: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-reduce `flat_grad` in place (SUM); return (all rows [W*n], all gradient rows [W*n, D]) in rank order."""
-    w = world_size()
-    if w == 1:
-        return rows.reshape(-1), gemb.reshape(-1, gemb.shape[-1])
-    _all_reduce(flat_grad)
-    rows = rows.reshape(-1).contiguous()
-    gemb = gemb.reshape(rows.numel(), -1).contiguous()
-    all_rows = torch.empty(w * rows.numel(), dtype=rows.dtype, device=rows.device)
-    all_gemb = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
-    _all_gather(all_rows, rows)
-    _all_gather(all_gemb, gemb)
-    return all_rows, all_gemb
-
-
 def gather_rows(rows: torch.Tensor) -> torch.Tensor:
     """All-gather of the arena row ids every rank gathered this step ([W*n] int32, rank-major).  Issued right after
     the gather kernel so that the sort (and the streaming Adam that only needs the touched-row bitmap) can start
     while the layers are still computing."""
     w = world_size()
     rows = rows.reshape(-1).contiguous()
-    if w == 1:
+    if not exchange_enabled():
         return rows
     out = torch.empty(w * rows.numel(), dtype=rows.dtype, device=rows.device)
     _all_gather(out, rows)
+    _count("all_gather_rows_i32", rows.numel() * rows.element_size(), out.numel() * out.element_size())
     return out
 
 
 def all_reduce_flat(flat_grad: torch.Tensor) -> None:
     """SUM over ranks, in place, of the flat gradient buffer (dense parameters + the dense gradient of the small
     embedding tables, which the engine keeps at its tail): the loss is a sum over samples, so gradients add."""
-    if world_size() > 1:
+    if exchange_enabled():
         _all_reduce(flat_grad)
-
-
-def gather_grad_rows(gemb: torch.Tensor) -> torch.Tensor:
-    """All-gather of gradient rows ([W*n, D], rank-major: the same order as `gather_rows`)."""
-    w = world_size()
-    gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
-    if w == 1:
-        return gemb
-    out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
-    _all_gather(out, gemb)
-    return out
+        _count("all_reduce_flat_f32", flat_grad.numel() * 4, flat_grad.numel() * 4)
 
 
 def gather_grad_rows_async(gemb: torch.Tensor):
@@ -103,30 +105,18 @@ def gather_grad_rows_async(gemb: torch.Tensor):
     and calls `handle.wait()` (None: nothing to wait for) before it reads `out`."""
     w = world_size()
     gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
-    if w == 1:
+    if not exchange_enabled():
         return gemb, None
     out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
+    _count("all_gather_grad_rows_f32", gemb.numel() * 4, out.numel() * 4)
     if _host_staged(gemb):
         _all_gather(out, gemb)
         return out, None
     return out, dist.all_gather_into_tensor(out, gemb, async_op=True)
 
 
-def exchange_grads(flat_grad: torch.Tensor, gemb: torch.Tensor) -> torch.Tensor:
-    """All-reduce `flat_grad` in place (SUM) and all-gather the gradient rows ([W*n, D], rank-major: the same order
-    as `gather_rows`)."""
-    w = world_size()
-    gemb = gemb.reshape(-1, gemb.shape[-1]).contiguous()
-    if w == 1:
-        return gemb
-    _all_reduce(flat_grad)
-    out = torch.empty(w * gemb.shape[0], gemb.shape[1], dtype=gemb.dtype, device=gemb.device)
-    _all_gather(out, gemb)
-    return out
-
-
 def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:
     """Sum of per-rank scalars (losses, counts) for logging."""
-    if world_size() > 1:
+    if exchange_enabled():
         _all_reduce(t)
     return t

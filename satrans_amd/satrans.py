@@ -73,11 +73,15 @@ class SATrans(BaseModel):
                  meta_mode='Q',
                  l2_reg_dnn=0, l2_reg_embedding=1e-5, dnn_use_bn=False, dnn_dropout=0, init_std=0.0001, seed=1024,
                  task='binary', device='cpu', gpus=None, flag=None):
+        # The reference calls BaseModel.__init__ WITHOUT the flag (models/satrans.py:120-122), so the base class's
+        # 'noembinit' test (models/meta_basemodel.py:114) never fires for SATrans: the tables are always re-drawn
+        # from N(0, init_std).  The flag is stored afterwards for the layer variants.
         super().__init__(linear_feature_columns, dnn_feature_columns, l2_reg_linear=0,
                          l2_reg_embedding=l2_reg_embedding, init_std=init_std, seed=seed, task=task,
-                         device=device, gpus=gpus, flag=flag)
+                         device=device, gpus=gpus, flag=None)
         if not isinstance(flag, str):
             raise TypeError("`flag` must be a string (the reference tests substrings of it, e.g. 'pos' in flag)")
+        self.flag = flag
         sparse, dense, varlen = split_columns(dnn_feature_columns)
         if varlen:
             raise NotImplementedError("VarLenSparseFeat columns (reference main.py never passes any)")
@@ -94,6 +98,11 @@ class SATrans(BaseModel):
         self.domain_column_list = domain_column_list
         embedding_size = self.embedding_size
         field_num = len(self.embedding_dict)
+        if field_num != len(sparse):
+            # the reference sizes dnn_linear by the number of distinct tables and then fails with a shape error in
+            # forward when two columns share an embedding_name; fail at construction instead of reading past the weight
+            raise ValueError(f"{len(sparse)} sparse columns share {field_num} embedding tables: SATrans needs one "
+                             f"embedding_name per column (dnn_linear is sized by the number of tables)")
         dense_in = sum(c.dimension for c in linear_feature_columns if isinstance(c, DenseFeat))
         self.domain_embedding_dim = embedding_size
 
@@ -178,6 +187,10 @@ class SATrans(BaseModel):
         if self._engine is None:
             from .engine import PathEngine
             self._engine = PathEngine(self)
+            pend = getattr(self, "_pending_opt_state", None)
+            if pend is not None:                      # optimizer state carried over a .to() or loaded for a resume
+                self._engine.load_optimizer_state(pend)
+                self._pending_opt_state = None
         return self._engine
 
     def forward(self, X):

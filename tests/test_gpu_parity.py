@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against golden vectors recorded from the reference and against
 the CPU oracle on the same seeded inputs.  Run on an MI355X:  python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -81,6 +83,81 @@ def test_adam_steps_match_reference_golden(name):
             assert float(err.median()) <= 2e-3 * lr * steps, (k, float(err.median()))
             assert float(torch.quantile(err, 0.95)) <= 2e-2 * lr * steps, (k, float(torch.quantile(err, 0.95)))
         assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
+    # The moments ARE well-conditioned (exp_avg linear, exp_avg_sq quadratic in the gradients of the steps), so they pin the
+    # trajectory tightly: torch.optim.Adam's own state after the same steps of the reference, element by element.
+    opt = model.optimizer_state_dict()
+    assert opt["step"] == steps
+    checked = 0
+    for kind, tol in (("exp_avg", 5e-5), ("exp_avg_sq", 2e-4)):
+        for k, w in c.arrays(f"opt/{kind}").items():
+            assert k in opt["state"], k
+            checked += 1
+            if k in grads and float(np.abs(grads[k]).max()) < 1e-7:
+                continue                                   # mathematically-zero gradient: its moments are rounding noise
+            g = opt["state"][k][kind].numpy()
+            scale = float(np.abs(w).max())
+            np.testing.assert_allclose(g, w, rtol=1e-5, atol=tol * scale + 1e-30, err_msg=f"{kind}/{k}")
+    assert checked >= 2 * len(grads)
+
+
+def test_optimizer_state_survives_a_device_move_and_a_resume():
+    """`.to()` in the middle of training keeps the Adam state (torch.optim.Adam's state follows its parameters), and
+    optimizer_state_dict()/load_optimizer_state_dict() resume a run: both continue bit for bit like an uninterrupted run."""
+    c = Case("small_qkv")
+    X, y = c.X.to(DEV), c.y.to(DEV)
+
+    def fresh():
+        m = build_model(c, DEV)
+        m.compile(torch.optim.Adam(m.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        m.train()
+        return m
+
+    ref = fresh()
+    for _ in range(4):
+        ref._require_engine().train_step(X, y)
+    want = sd_to_cpu(ref)
+
+    moved = fresh()
+    for _ in range(2):
+        moved._require_engine().train_step(X, y)
+    moved.to(DEV)                                   # rebuilds the arena and the engine
+    assert moved._engine is None
+    for _ in range(2):
+        moved._require_engine().train_step(X, y)
+    got = sd_to_cpu(moved)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+    first = fresh()
+    for _ in range(2):
+        first._require_engine().train_step(X, y)
+    params, opt = sd_to_cpu(first), first.optimizer_state_dict()
+    resumed = fresh()
+    resumed.load_state_dict(params)
+    resumed.load_optimizer_state_dict(opt)
+    for _ in range(2):
+        resumed._require_engine().train_step(X, y)
+    got = sd_to_cpu(resumed)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_learning_rate_changes_take_effect():
+    """param_groups edits (what an LR scheduler does) are read at every step; postponed lazy steps use the old value."""
+    c = Case("small_qkv")
+    X, y = c.X.to(DEV), c.y.to(DEV)
+    m = build_model(c, DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=c.meta["lr"])
+    m.compile(opt, "binary_crossentropy")
+    m.eval()
+    eng = m._require_engine()
+    eng.train_step(X, y)
+    opt.param_groups[0]["lr"] = 0.0                 # from now on nothing may move
+    before = sd_to_cpu(m)
+    eng.train_step(X, y)
+    after = sd_to_cpu(m)
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
 
 
 def _adam_reference(p, g, lr, steps_done, m, v):
@@ -433,6 +510,68 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows,
             assert float(err.median()) <= 2e-3 * lr * steps, (k, float(err.median()))
             assert float(torch.quantile(err, 0.95)) <= 2e-2 * lr * steps, (k, float(torch.quantile(err, 0.95)))
         assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_regulariser_sum_of_tiny_batches(monkeypatch, B):
+    """A batch of one or two samples makes every partial-sum group of the touched-row kernels a single block (their slots
+    must not overlap the replay's): the logged regulariser sum must agree between the lazy and the streaming form and with
+    the oracle's dense sum(l2 * w^2) over the same steps."""
+    c = Case("aliccp_sota")
+    sums = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("SATRANS_LAZY_ADAM", lazy)
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        model.eval()
+        eng = model._require_engine()
+        X, y = c.X[:B].to(DEV), c.y[:B].to(DEV)
+        eng.reset_epoch_sums()
+        for _ in range(3):
+            eng.train_step(X, y)
+        sums[lazy] = eng.epoch_sums()
+    tr = O.OracleTrainer(c.tensors("param"), c.spec(), lr=c.meta["lr"])
+    bce = reg = 0.0
+    for _ in range(3):
+        b_, r_ = tr.step(c.X[:B], c.y[:B])
+        bce, reg = bce + b_, reg + r_
+    for lazy in ("1", "0"):
+        assert sums[lazy][0] == pytest.approx(bce, rel=1e-5), (lazy, sums[lazy], bce)
+        assert sums[lazy][1] == pytest.approx(reg, rel=2e-5), (lazy, sums[lazy], reg)
+    assert sums["1"][1] == pytest.approx(sums["0"][1], rel=1e-9)
+
+
+def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path):
+    """RCCL for real on a one-GPU box: a ONE-rank nccl process group, created before anything touches the GPU, with the
+    training step forced through its multi-rank branch (SATRANS_FORCE_EXCHANGE=1): device-pointer int32 all-gather of the
+    row ids, SUM all-reduce of the flat gradient, asynchronous fp32 all-gather of the gradient rows + wait(), global sort.
+    With one rank every collective is an identity, so the result must equal the local step with the same table classes
+    bit for bit - parameters, tables and both Adam moments."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank.py")
+    outs = {}
+    for mode in ("nccl", "plain"):
+        out = str(tmp_path / f"{mode}.pt")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("SATRANS_FORCE_EXCHANGE", None)
+        r = subprocess.run([sys.executable, script, mode, "aliccp_sota", "3", out, str(port)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-4000:]
+        outs[mode] = torch.load(out)
+    a, b = outs["nccl"], outs["plain"]
+    assert a["__backend__"] == "nccl" and a["__exchange__"] and not b["__exchange__"]
+    stats = a["__stats__"]
+    for name in ("all_gather_rows_i32", "all_reduce_flat_f32", "all_gather_grad_rows_f32"):
+        assert stats[name]["calls"] == 3 and stats[name]["bytes_in"] > 0, (name, stats)
+    assert not b["__stats__"]
+    for k in a:
+        if not k.startswith("__"):
+            assert torch.equal(a[k], b[k]), f"RCCL single-rank exchange changed {k}"
 
 
 @pytest.mark.parametrize("small_rows", ["16384", "100"])

@@ -61,6 +61,16 @@ def test_adam_steps_match_reference(name):
             # constant added to every key) is rounding noise that Adam's g/(sqrt(v)+eps) amplifies
             atol = 0.05 * c.meta["lr"]
         np.testing.assert_allclose(got[k].numpy(), w.numpy(), rtol=0, atol=atol, err_msg=k)
+    # torch.optim.Adam's moments on the reference's trajectory: these are well-conditioned (linear / quadratic in the
+    # gradients), so they pin the optimizer far more tightly than the parameters can
+    for kind in ("exp_avg", "exp_avg_sq"):
+        for k, w in c.arrays(f"opt/{kind}").items():
+            if k in grads and float(np.abs(grads[k]).max()) < 1e-7:
+                continue                                   # mathematically-zero gradient: its moments are rounding noise
+            st = tr.optim.state[tr.leaves[k]][kind].numpy()
+            scale = float(np.abs(w).max())
+            np.testing.assert_allclose(st, w, rtol=1e-5, atol=(2e-5 if kind == "exp_avg" else 1e-4) * scale + 1e-30,
+                                       err_msg=f"{kind}/{k}")
 
 
 def test_fp64_oracle_agrees_with_fp32():

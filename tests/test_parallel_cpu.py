@@ -55,9 +55,16 @@ def _worker(rank, world, port, name, out):
         flat, rows, gemb = _local_grads(case, Xs, ys)
         keys = sorted(flat)
         flat_buf = torch.cat([flat[k].reshape(-1) for k in keys])
+        # the three calls of engine.train_step's exchange, in its order
         all_rows = parallel.gather_rows(rows)
-        all_gemb = parallel.exchange_grads(flat_buf, gemb)
-        assert parallel.world_size() == world and parallel.rank() == rank
+        parallel.all_reduce_flat(flat_buf)
+        all_gemb, pending = parallel.gather_grad_rows_async(gemb)
+        if pending is not None:
+            pending.wait()
+        assert parallel.world_size() == world and parallel.rank() == rank and parallel.exchange_enabled()
+        assert parallel.STATS["all_gather_rows_i32"]["bytes_out"] == world * rows.numel() * 4
+        assert parallel.STATS["all_gather_grad_rows_f32"]["bytes_out"] == world * gemb.numel() * 4
+        assert parallel.STATS["all_reduce_flat_f32"]["calls"] == 1
         torch.save(dict(keys=keys, flat=flat_buf, rows=all_rows, gemb=all_gemb, local_rows=rows, local_gemb=gemb),
                    os.path.join(out, f"rank{rank}.pt"))
     finally:
@@ -93,5 +100,8 @@ def test_single_process_is_a_no_op():
     g = torch.randn(6, 4)
     flat = torch.randn(5)
     before = flat.clone()
+    assert not parallel.exchange_enabled()
     assert torch.equal(parallel.gather_rows(rows), rows.reshape(-1))
-    assert torch.equal(parallel.exchange_grads(flat, g), g) and torch.equal(flat, before)
+    parallel.all_reduce_flat(flat)
+    out, pending = parallel.gather_grad_rows_async(g)
+    assert torch.equal(out, g) and pending is None and torch.equal(flat, before)
