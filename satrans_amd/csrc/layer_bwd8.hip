@@ -1,0 +1,749 @@
+// Meta_Transformer_Layer backward, 8-wave version: two waves per SIMD.
+//
+// Reference: models/satrans.py:50-100 (layer), models/submodules.py:77-103 (MetaNet).  Same mathematics, inputs, outputs and
+// slab layout as layer_bwd_fused_kernel (layer_fused.hip); what differs is how the work sits on the CU:
+//
+//   * one workgroup of EIGHT waves per CU on tiles of up to 128 tokens (T samples, T*F <= 128), one copy of the weight
+//     images in LDS: two waves share every SIMD, so LDS / HBM latency and the VALU work of one wave hide behind the MFMAs
+//     of the other (the 4-wave kernel holds a full copy of every weight-gradient accumulator per wave - 128 registers -
+//     and is stuck at one wave per SIMD with every latency exposed);
+//   * the weight-gradient accumulators are SPLIT: of an (MT x NT)-tile gradient matrix every wave owns ONE 16x16 output
+//     tile (or one tile over a share of the token rows when there are fewer than eight tiles) and contracts it over the
+//     token rows of ALL waves: 24 accumulator registers per wave instead of 128.  The token-row operands of those products
+//     (h, dm, in0, dh, x, gq, gk, dv, du, o) are exchanged through the six row buffers in three rounds per tile;
+//   * LayerNorm gamma / beta gradients are reduced over the 16 token lanes with DPP adds as they are produced and kept in
+//     8 registers (lane n of a 16-lane row holds vector n) instead of 48;
+//   * nothing F x F is cached: the softmax backward recomputes P_ij from q_i, k_j and the row statistics (max, 1/sum) of
+//     the forward pass, and uses dot_i = sum_j P_ij dP_ij = go_i . o_i (computed in the token phase), so the row pass
+//     (dq_i) and the column pass (dk_i, dv_i) of a lane need no data from other lanes' passes and run back to back without
+//     a barrier.  Pure VALU work instead of 35 KB of LDS per 64 tokens;
+//   * fixed summation orders everywhere (no float atomics): bitwise reproducible from run to run.
+//
+// Phases per tile (all eight waves; || = workgroup barrier):
+//   A  token   forward chain x -> q0,k0,v -> MetaNet(q0), MetaNet(k0) -> q,k,v rows                                  ||
+//   B  task    attention forward: o_i, row statistics (max, 1/sum), dropout keep word                               ||
+//   C  token   Out_linear + residual + LayerNorm forward/backward -> dr, du rows, go rows, dot_i                    ||
+//   D  split   dWo += du^T o ; task: dq_i (row pass), dk_i, dv_i (column pass) in registers                         ||
+//      task    write dq, dk, dv rows                                                                              ||
+//   F  token   MetaNet backward (Q, K), projections backward, dx; split weight gradients in three exchange rounds  (6 ||)
+#include "layer_fused_common.h"
+
+namespace satrans {
+
+constexpr int kB8Waves = 8;
+constexpr int kB8Block = 64 * kB8Waves;
+constexpr int kB8Rows = 16 * kB8Waves;      // token rows of a workgroup tile
+
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (= the 16 tokens of a fragment), result in every lane, fixed order
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    return v;
+}
+
+// LayerNorm backward on a D-layout fragment (see layer_norm_bwd): the gamma / beta gradient contributions of the 16 tokens
+// are summed across the row at once and added to slot `vg` / `vb` (= lane n) of the compact accumulator.
+template <int KT_>
+__device__ __forceinline__ void layer_norm_bwd_c(float (&g)[KT_][4], const float (&zh)[KT_][4], float rstd, const float* gam,
+                                                 int g4, int n, int vg, int vb, float (&acc)[KT_][4]) {
+    constexpr float invD = 1.0f / (16 * KT_);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) {
+        const float4 gm4 = *reinterpret_cast<const float4*>(gam + 16 * t + g4);
+        const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg_ = row16_sum(g[t][r] * zh[t][r]);
+            const float sb_ = row16_sum(g[t][r]);
+            acc[t][r] += n == vg ? sg_ : (n == vb ? sb_ : 0.f);
+            g[t][r] *= gm[r];
+            m1 += g[t][r];
+            m2 = fmaf(g[t][r], zh[t][r], m2);
+        }
+    }
+    m1 = token_sum(m1) * invD;
+    m2 = token_sum(m2) * invD;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[t][r] = rstd * (g[t][r] - m1 - zh[t][r] * m2);
+}
+
+// One wave's share of a weight-gradient product  dW[16 mt + i][16 nt + j] += sum_rows A[row][16 mt + i] * G[row][16 nt + j].
+// The MT x NT output tiles (TILES = 1, 2, 4 or 8) times KS = 8 / TILES shares of the 128 token rows make eight work items,
+// one per wave: wave w owns tile w % TILES over rows [(w / TILES) * 128 / KS, ...).  An operand wider than one row buffer
+// (the U-wide hidden rows) spans two buffers: its first NB* tiles in X0, the rest in X1.
+template <int MT, int NT, int NBA, int NBG, int LDX>
+__device__ __forceinline__ void wgrad_split(const float* A0, const float* A1, const float* G0, const float* G1, int wave, int n,
+                                            int g, f32x4& acc) {
+    constexpr int TILES = MT * NT;
+    static_assert(TILES == 1 || TILES == 2 || TILES == 4 || TILES == 8, "tiles per gradient matrix");
+    constexpr int KS = kB8Waves / TILES, NK = (kB8Rows / 4) / KS;       // k-steps (4 token rows each) of one share
+    const int tile = wave % TILES, kpart = wave / TILES;
+    const int mt = tile / NT, nt = tile - mt * NT;
+    const float* al = (mt < NBA ? A0 + 16 * mt : A1 + 16 * (mt - NBA)) + (kpart * NK * 4 + g) * LDX + n;
+    const float* gl = (nt < NBG ? G0 + 16 * nt : G1 + 16 * (nt - NBG)) + (kpart * NK * 4 + g) * LDX + n;
+    constexpr int CH = NK < 8 ? NK : 8;
+#pragma unroll
+    for (int k0 = 0; k0 < NK; k0 += CH) {
+        float av[CH], gv[CH];
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) {
+            av[ks] = al[4 * (k0 + ks) * LDX];
+            gv[ks] = gl[4 * (k0 + ks) * LDX];
+        }
+#pragma unroll
+        for (int ks = 0; ks < CH; ++ks) acc = mfma4(av[ks], gv[ks], acc);
+    }
+}
+
+// SAME: the Q and K roles share one generated-weight table (no 'pos' in the flag).  FC: 4-key chunks of a score row (4 FC >= F).
+template <int D, int U, int H, bool SAME, int FC>
+__global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc a, int Tsamp, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, float* __restrict__ slabs) {
+    constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
+    static_assert(UT == 2 * KT, "the hidden rows span exactly two row buffers (U = 2 D)");
+    static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
+    static_assert(d == 8, "head dimension 8 (two lane groups of a token share a head)");
+    static_assert(H <= 4, "one attention task per thread: T * H * F <= 128 * H <= 512");
+    extern __shared__ __align__(16) float lds[];
+    const int F = a.F;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
+    const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
+    const bool relu_out = a.flags & SATRANS_RELU_OUT, use_res = !(a.flags & SATRANS_NO_RES);
+
+    // ---- LDS: forward weight images (read by rows for the transposed products), LN vectors, six row buffers, row statistics
+    float* p = lds;
+    auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
+    float* wq = take(D * LD); float* wk = take(D * LD); float* wv = take(D * LD); float* woT = take(D * LD);
+    float* w1q = take(D * LU); float* w2q = take(U * LD);
+    float* w1k = SAME ? w1q : take(D * LU);
+    float* w2k = SAME ? w2q : take(U * LD);
+    float* lnq_g = take(D); float* lnk_g = take(D); float* ln_g = take(D);
+    float* lnq_b = take(D); float* lnk_b = take(D); float* ln_b = take(D);
+    float* sq = take(kB8Rows * LD);     // q            | F: exchange E0
+    float* sk = take(kB8Rows * LD);     // k  -> dk     | F: exchange E4
+    float* sv = take(kB8Rows * LD);     // v  -> dv     | F: exchange (after dWv)
+    float* so = take(kB8Rows * LD);     // o            | F: exchange E1
+    float* x1 = take(kB8Rows * LD);     // du -> dq     | F: exchange E3
+    float* x2 = take(kB8Rows * LD);     // go           | F: exchange E2
+    const int ntask_max = Tsamp * H * F;
+    float4* st = (float4*)take(4 * ntask_max);        // per (sample, head, row): max, 1/sum, dot, keep word
+
+    const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
+    const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
+    if (!idle) {
+        stage_image(a.w_query, wq, D, D, LD, false);
+        stage_image(a.w_key, wk, D, D, LD, false);
+        stage_image(a.w_value, wv, D, D, LD, false);
+        stage_image(a.w_out, woT, D, D, LD, true);
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+            ln_g[i] = a.ln_g[i]; ln_b[i] = a.ln_b[i];
+            if (meta_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
+            if (meta_k) { lnk_g[i] = a.lnk_g[i]; lnk_b[i] = a.lnk_b[i]; }
+        }
+        // rows of padding tokens meet exact zeros in the token-contraction products: they must hold finite numbers from the
+        // start (0 * NaN would poison an accumulator)
+        for (int i = threadIdx.x; i < 6 * kB8Rows * LD; i += blockDim.x) sq[i] = 0.f;
+    }
+    __syncthreads();
+
+    const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
+    const int lt_d = n * LD + g4, lt_u = n * LU + g4;          // ... for a read by rows (chain_t): row n, column 4g
+    // (sample, head, row) of this thread's attention task - the same in every tile
+    const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
+    const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
+    const FusedDrop dc = fused_drop(a);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d);
+    const float sc_scale = inv_sqrt_d * kLog2e;
+
+    // ---- this wave's accumulators: one output tile (or tile share) of every gradient matrix; compact LN gradients ------
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_wq = zero4, acc_wk = zero4, acc_wv = zero4, acc_wo = zero4;
+    f32x4 acc_w1q = zero4, acc_w2q = zero4, acc_w1k = zero4, acc_w2k = zero4;
+    float aln[KT][4];       // lane n: 0 = ln gamma, 1 = ln beta, 2 = lnq gamma, 3 = lnq beta, 4 = lnk gamma, 5 = lnk beta
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) aln[t][r] = 0.f;
+
+    // this wave's 16 token rows of every row buffer: D-layout row access (float4 per t)
+    const int row0 = 16 * wave;
+    const int my = (row0 + n) * LD + g4;
+
+    constexpr int CSZ = 4 * D * D + 6 * D, TSZ = 4 * D * U;
+    float* common = slabs + (size_t)blockIdx.x * CSZ;
+    float* records = slabs + (size_t)gridDim.x * CSZ;
+    float* stage = sq;   // the six row buffers are contiguous
+    // combine the shares of one matrix (KS = 8 / TILES row shares per tile) through LDS in share order, write it out, clear
+    auto flush = [&](f32x4& acc, auto mtc, auto ntc, float* dst, bool live) {
+        constexpr int MT_ = decltype(mtc)::value, NT_ = decltype(ntc)::value;
+        constexpr int TILES = MT_ * NT_, KS = kB8Waves / TILES, ncols = 16 * NT_;
+        if (live) {
+            const int tile = wave % TILES, kpart = wave / TILES;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(kpart * TILES + tile) * 256 + (g4 + r) * 16 + n] = acc[r];
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < TILES * 256; e += kB8Block) {
+            const int tile = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+            const int mt = tile / NT_, nt = tile - mt * NT_;
+            float s = 0.f;
+            if (live) {
+                s = stage[e];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) s += stage[k * TILES * 256 + e];
+            }
+            dst[(16 * mt + rr) * ncols + 16 * nt + cc] = s;
+        }
+        __syncthreads();
+    };
+    using KTc = std::integral_constant<int, KT>;
+    using UTc = std::integral_constant<int, UT>;
+
+    int pre = 0;
+    for (int scen = 0; scen < a.S && pre < wr.g1; ++scen) {
+      const int nt_s = tiles_of(a.seg, scen, Tsamp);
+      const int t0 = max(wr.g0, pre) - pre, t1 = min(wr.g1, pre + nt_s) - pre;
+      pre += nt_s;
+      if (t0 >= t1) continue;
+      // ---- this scenario's generated MetaNet weights (the previous tile loop ended on a barrier) ----------------------
+      if (meta_q) {
+          const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+          stage_image(row, w1q, D, U, LU, false);
+          stage_image(row + D * U, w2q, U, D, LD, false);
+      }
+      if (meta_k && (!SAME || !meta_q)) {
+          const float* row = a.tab_k + (size_t)scen * a.tab_stride;
+          stage_image(row, w1k, D, U, LU, false);
+          stage_image(row + D * U, w2k, U, D, LD, false);
+      }
+      __syncthreads();
+      const int lo = a.seg[scen], hi = a.seg[scen + 1];
+      const int tok = row0 + n;
+      const int ls_tok = tok / F, f_tok = tok - ls_tok * F;      // this lane's (sample, field) inside any tile that holds it
+      for (int tile = t0; tile < t1; ++tile) {
+        const int first = lo + tile * Tsamp;
+        const int32_t* samp = a.order + first;
+        const int nS = min(Tsamp, hi - first), ntok = nS * F;
+        const bool valid = tok < ntok;
+        const int f = valid ? f_tok : 0;
+        const int b = samp[valid ? ls_tok : 0];
+        const size_t grow = ((size_t)b * F + f) * D + g4;       // this lane's row of x / dy / dx
+        const int ntask = nS * H * F;
+        const bool task_ok = (int)threadIdx.x < ntask;
+        const int task = task_ok ? (int)threadIdx.x : 0;
+        const int tls = task_ok ? t0_ls : 0, th = task_ok ? t0_h : 0, ti = task_ok ? t0_i : 0;
+
+        // token-wise state that lives from phase A to phase F
+        float q0[KT][4], k0[KT][4], hq[UT][4], hk[UT][4], zhq[KT][4], zhk[KT][4], dr[KT][4];
+        float rstd_q = 0.f, rstd_k = 0.f;
+        // keep flags of this token lane at the MetaNet-Q / MetaNet-K / output sites (bits 0-7 / 8-15 / 16-23), generated once
+        uint32_t keepbits = 0xFFFFFFFFu;
+        if (dc.on)
+            keepbits = token_keep_bits<KT>(drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, D, g4, dc.thresh) |
+                       (token_keep_bits<KT>(drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, D, g4, dc.thresh) << 8) |
+                       (token_keep_bits<KT>(drop_sample_key(dc.key[kSiteOut], (uint32_t)b), f, D, g4, dc.thresh) << 16);
+
+        // ================= phase A: forward chain (every wave, also one whose rows lie beyond the tile: x = 0 there) =======
+        {
+            float x[KT][4], v[KT][4], q[KT][4], k[KT][4];
+            load_frag<KT>(a.x + grow, x, valid);
+            chain<KT, KT, LD>(wq + lo_d, x, q0);
+            chain<KT, KT, LD>(wk + lo_d, x, k0);
+            chain<KT, KT, LD>(wv + lo_d, x, v);
+            if (meta_q) {
+                float m[KT][4];
+                chain<KT, UT, LU>(w1q + lo_u, q0, hq);
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hq[t][r] = fmaxf(hq[t][r], 0.f);
+                chain<UT, KT, LD>(w2q + lo_d, hq, m);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mm = m[t][r];
+                        if (dc.on) mm = (keepbits >> (4 * t + r)) & 1u ? mm * dc.scale : 0.f;
+                        m[t][r] = mm + q0[t][r];
+                    }
+                layer_norm_keep<KT>(m, zhq, rstd_q);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 gg = *reinterpret_cast<const float4*>(lnq_g + 16 * t + g4);
+                    const float4 bb = *reinterpret_cast<const float4*>(lnq_b + 16 * t + g4);
+                    q[t][0] = zhq[t][0] * gg.x + bb.x; q[t][1] = zhq[t][1] * gg.y + bb.y;
+                    q[t][2] = zhq[t][2] * gg.z + bb.z; q[t][3] = zhq[t][3] * gg.w + bb.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[t][r] = q0[t][r];
+            }
+            if (meta_k) {
+                float m[KT][4];
+                chain<KT, UT, LU>(w1k + lo_u, k0, hk);
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hk[t][r] = fmaxf(hk[t][r], 0.f);
+                chain<UT, KT, LD>(w2k + lo_d, hk, m);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mm = m[t][r];
+                        if (dc.on) mm = (keepbits >> (8 + 4 * t + r)) & 1u ? mm * dc.scale : 0.f;
+                        m[t][r] = mm + k0[t][r];
+                    }
+                layer_norm_keep<KT>(m, zhk, rstd_k);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 gg = *reinterpret_cast<const float4*>(lnk_g + 16 * t + g4);
+                    const float4 bb = *reinterpret_cast<const float4*>(lnk_b + 16 * t + g4);
+                    k[t][0] = zhk[t][0] * gg.x + bb.x; k[t][1] = zhk[t][1] * gg.y + bb.y;
+                    k[t][2] = zhk[t][2] * gg.z + bb.z; k[t][3] = zhk[t][3] * gg.w + bb.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) k[t][r] = k0[t][r];
+            }
+            store_frag<KT>(sq + my, q);
+            store_frag<KT>(sk + my, k);
+            store_frag<KT>(sv + my, v);
+        }
+        __syncthreads();
+
+        // ================= phase B: attention forward: o_i, row statistics, dropout keep word ===============================
+        // the score row of a query stays in registers (FC chunks of four keys); exp2 of pre-scaled scores; padding keys of
+        // the last chunk read the last real row and are masked
+        if (task_ok) {
+            const int tb = samp[tls];
+            f32x2 qi[d / 2];
+            load_row<d>(sq + (tls * F + ti) * LD + th * d, qi);
+            const float* kbase = sk + (tls * F) * LD + th * d;
+            const float* vbase = sv + (tls * F) * LD + th * d;
+            float sc[4 * FC];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) {
+                if (4 * c < F) {
+                    f32x2 kr[4][d / 2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) load_row<d>(kbase + min(4 * c + u, F - 1) * LD, kr[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float s_ = 4 * c + u < F ? dot_row<d>(qi, kr[u]) * sc_scale : -INFINITY;
+                        sc[4 * c + u] = s_;
+                        mx = fmaxf(mx, s_);
+                    }
+                }
+            }
+            f32x2 oacc[d / 2];
+#pragma unroll
+            for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
+            float sum = 0.f;
+            uint32_t keep = 0xFFFFFFFFu;
+            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
+            const uint32_t block0 = drop_attn_elem(th, F, ti, 0) >> 2;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) {
+                if (4 * c < F) {
+                    f32x2 vr[4][d / 2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) load_row<d>(vbase + min(4 * c + u, F - 1) * LD, vr[u]);
+                    const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)c, dc.thresh) : 0xFu;
+                    if (dc.on) keep = (keep & ~(0xFu << (4 * c))) | (kb << (4 * c));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float ex = __builtin_amdgcn_exp2f(sc[4 * c + u] - mx);      // padding keys: exp2(-inf) = 0
+                        sum += ex;
+                        float pe = ex;
+                        if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
+                        axpy_row<d>(pe, vr[u], oacc);
+                    }
+                }
+            }
+            const float inv = 1.0f / sum;
+            st[task] = make_float4(mx, inv, 0.f, __uint_as_float(keep));
+            store_row<d>(so + (tls * F + ti) * LD + th * d, oacc, inv);
+        }
+        __syncthreads();
+
+        // ================= phase C: output block forward + backward ======================================================
+        {
+            float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4], x[KT][4];
+            load_frag<KT>(so + my, o);
+            load_frag<KT>(a.x + grow, x, valid);
+            chain<KT, KT, LD>(woT + lo_d, o, u);
+            float keep[KT][4];      // multiplicative factor of du: dropout mask times ReLU mask
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = u[t][r], kf = 1.0f;
+                    if (relu_out) { kf = val > 0.f ? 1.0f : 0.f; val = fmaxf(val, 0.f); }
+                    if (dc.on) {
+                        const float mk = (keepbits >> (16 + 4 * t + r)) & 1u ? dc.scale : 0.f;
+                        val *= mk; kf *= mk;
+                    }
+                    keep[t][r] = kf;
+                    u[t][r] = use_res ? val + x[t][r] : val;
+                }
+            float rstd_o;
+            layer_norm_keep<KT>(u, zh, rstd_o);
+            load_frag<KT>(dy + grow, gy, valid);
+            layer_norm_bwd_c<KT>(gy, zh, rstd_o, ln_g, g4, n, 0, 1, aln);       // gy is now dr
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dr[t][r] = use_res ? gy[t][r] : 0.f;
+                    gy[t][r] *= keep[t][r];                                     // du
+                }
+            store_frag<KT>(x1 + my, gy);                                        // du rows (zero for padding tokens)
+            float go[KT][4];
+            chain_t<KT, KT, LD>(woT + lt_d, gy, go);                            // go = du Wo
+            store_frag<KT>(x2 + my, go);
+            // dot_i = sum_j P_ij dP_ij = go_i . o_i per head: features 16 t + 4 g + r belong to head 2 t + g / 2
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                float part = (go[t][0] * o[t][0] + go[t][1] * o[t][1]) + (go[t][2] * o[t][2] + go[t][3] * o[t][3]);
+                part += __shfl_xor(part, 16, 64);
+                if (valid && !(g & 1)) {
+                    const int hh = 2 * t + (g >> 1);
+                    reinterpret_cast<float*>(st + (ls_tok * H + hh) * F + f)[2] = part;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= phase D: dWo; softmax backward, row pass and column pass of every task =========================
+        wgrad_split<KT, KT, KT, KT, LD>(x1, x1, so, so, wave, n, g, acc_wo);    // dWo[o][i] += du^T o
+        f32x2 dq[d / 2], dk[d / 2], dv[d / 2];
+#pragma unroll
+        for (int e = 0; e < d / 2; ++e) { dq[e] = f32x2{0.f, 0.f}; dk[e] = f32x2{0.f, 0.f}; dv[e] = f32x2{0.f, 0.f}; }
+        if (task_ok) {
+            const float* qbase = sq + (tls * F) * LD + th * d;
+            const float* kbase = sk + (tls * F) * LD + th * d;
+            const float* vbase = sv + (tls * F) * LD + th * d;
+            const float* gbase = x2 + (tls * F) * LD + th * d;
+            const float4* stb = st + (tls * H + th) * F;
+            const float scale = dc.scale;
+            {   // row i: dq_i = sum_j dS_ij k_j,  dS_ij = P_ij (dP_ij - dot_i) / sqrt(d),  dP_ij = mask_ij (go_i . v_j)
+                f32x2 qi[d / 2], gi[d / 2];
+                load_row<d>(qbase + ti * LD, qi);
+                load_row<d>(gbase + ti * LD, gi);
+                const float4 s4 = stb[ti];
+                const uint32_t keep = __float_as_uint(s4.w);
+#pragma unroll
+                for (int c = 0; c < FC; ++c) {
+                    if (4 * c < F) {
+                        float dp[4];
+                        {
+                            f32x2 vr[4][d / 2];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) load_row<d>(vbase + min(4 * c + u, F - 1) * LD, vr[u]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                dp[u] = (keep >> (4 * c + u)) & 1u ? dot_row<d>(gi, vr[u]) * scale : 0.f;
+                        }
+                        f32x2 kr[4][d / 2];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) load_row<d>(kbase + min(4 * c + u, F - 1) * LD, kr[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float s_ = dot_row<d>(qi, kr[u]) * sc_scale;
+                            const float pj = 4 * c + u < F ? __builtin_amdgcn_exp2f(s_ - s4.x) * s4.y : 0.f;
+                            axpy_row<d>(pj * (dp[u] - s4.z) * inv_sqrt_d, kr[u], dq);
+                        }
+                    }
+                }
+            }
+            {   // column i: dk_i = sum_r dS_ri q_r,  dv_i = sum_r P_ri mask_ri go_r
+                f32x2 ki[d / 2], vi[d / 2];
+                load_row<d>(kbase + ti * LD, ki);
+                load_row<d>(vbase + ti * LD, vi);
+#pragma unroll
+                for (int c = 0; c < 2 * FC; ++c) {
+                    if (2 * c < F) {
+                        f32x2 qr[2][d / 2], gr[2][d / 2];
+                        float4 sr[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int r = min(2 * c + u, F - 1);
+                            sr[u] = stb[r];
+                            load_row<d>(qbase + r * LD, qr[u]);
+                            load_row<d>(gbase + r * LD, gr[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const bool real = 2 * c + u < F;
+                            const float s_ = dot_row<d>(qr[u], ki) * sc_scale;
+                            const float pr = real ? __builtin_amdgcn_exp2f(s_ - sr[u].x) * sr[u].y : 0.f;
+                            const bool kp = (__float_as_uint(sr[u].w) >> ti) & 1u;
+                            const float dp = kp ? dot_row<d>(gr[u], vi) * scale : 0.f;
+                            axpy_row<d>(pr * (dp - sr[u].z) * inv_sqrt_d, qr[u], dk);
+                            axpy_row<d>(kp ? pr * scale : 0.f, gr[u], dv);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (task_ok) {      // every q, k, v, go row has been read (and du, o by the dWo product)
+            store_row<d>(x1 + (tls * F + ti) * LD + th * d, dq, 1.0f);
+            store_row<d>(sk + (tls * F + ti) * LD + th * d, dk, 1.0f);
+            store_row<d>(sv + (tls * F + ti) * LD + th * d, dv, 1.0f);
+        }
+        __syncthreads();
+
+        // ================= phase F: MetaNet and projection backward, dx; split weight gradients in three rounds ============
+        // Exchange buffers: E0 = sq, E1 = so, E2 = x2, E3 = x1 (after gq is loaded), E4 = sk (after gk is loaded), sv after dWv.
+        // A wave only ever writes its OWN 16 rows; the split products read all 128 rows, hence the barriers.
+        {
+            float gq[KT][4], gk[KT][4], x[KT][4];
+            load_frag<KT>(x1 + my, gq, valid);      // gradient of the (post-MetaNet) queries
+            load_frag<KT>(sk + my, gk, valid);      // ... keys
+            load_frag<KT>(a.x + grow, x, valid);
+            {   // dx so far: dr + gv Wv^T   (rows >= ntok of sv still hold forward values: masked here, and neutralised by
+                // x = 0 in the dWv product)
+                float gv[KT][4], back[KT][4];
+                load_frag<KT>(sv + my, gv, valid);
+                chain_t<KT, KT, LD>(wv + lt_d, gv, back);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            }
+            // MetaNet backward of one role up to the point where its two exchange rounds start: LN backward (gout becomes
+            // dz), dm = dz * mask, dh = (dm W2^T) * [h > 0], gout = dz + dh W1^T
+            auto metanet_bwd = [&](float (&gout)[KT][4], const float (&zh)[KT][4], float rstd, const float* gam, int vg,
+                                   int kshift, const float (&h)[UT][4], const float* w2, const float* w1,
+                                   float (&dm)[KT][4], float (&dh)[UT][4]) {
+                layer_norm_bwd_c<KT>(gout, zh, rstd, gam, g4, n, vg, vg + 1, aln);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mk = 1.0f;
+                        if (dc.on) mk = (keepbits >> (kshift + 4 * t + r)) & 1u ? dc.scale : 0.f;
+                        dm[t][r] = gout[t][r] * mk;
+                    }
+                chain_t<KT, UT, LD>(w2 + lt_d, dm, dh);                      // w2: forward image W2 [U][LD]
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dh[t][r] = h[t][r] > 0.f ? dh[t][r] : 0.f;
+                float back[KT][4];
+                chain_t<UT, KT, LU>(w1 + lt_u, dh, back);                    // w1: forward image W1 [D][LU]
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gout[t][r] += back[t][r];
+            };
+            auto store_wide = [&](float* b0, float* b1, const float (&w)[UT][4]) {
+                float part[KT][4];
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[t][r] = w[t][r];
+                store_frag<KT>(b0 + my, part);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[t][r] = w[KT + t][r];
+                store_frag<KT>(b1 + my, part);
+            };
+
+            // ---- round 1: {x, dv} -> dWv ; {hq, dmq} -> dW2 (Q role) -------------------------------------------------------
+            float dhq[UT][4];
+            store_frag<KT>(sq + my, x);
+            if (meta_q) {
+                float dm[KT][4];
+                metanet_bwd(gq, zhq, rstd_q, lnq_g, 2, 0, hq, w2q, w1q, dm, dhq);
+                store_wide(so, x2, hq);
+                store_frag<KT>(x1 + my, dm);
+            }
+            __syncthreads();
+            wgrad_split<KT, KT, KT, KT, LD>(sq, sq, sv, sv, wave, n, g, acc_wv);                 // dWv[i][o] += x^T dv
+            if (meta_q) wgrad_split<UT, KT, KT, KT, LD>(so, x2, x1, x1, wave, n, g, acc_w2q);   // dW2[u][o] += hq^T dm
+            __syncthreads();
+            // ---- round 2: {q0, dhq} -> dW1 (Q role) ; {hk, dmk} -> dW2 (K role) ---------------------------------------------
+            float dhk[UT][4];
+            if (meta_q) {
+                store_frag<KT>(sq + my, q0, valid);
+                store_wide(so, x2, dhq);
+            }
+            if (meta_k) {
+                float dm[KT][4];
+                metanet_bwd(gk, zhk, rstd_k, lnk_g, 4, 8, hk, w2k, w1k, dm, dhk);
+                store_wide(x1, sv, hk);
+                store_frag<KT>(sk + my, dm);
+            }
+            __syncthreads();
+            if (meta_q) wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1q);   // dW1[i][u] += q0^T dhq
+            if (meta_k) {
+                if constexpr (SAME) wgrad_split<UT, KT, KT, KT, LD>(x1, sv, sk, sk, wave, n, g, acc_w2q);
+                else wgrad_split<UT, KT, KT, KT, LD>(x1, sv, sk, sk, wave, n, g, acc_w2k);
+            }
+            __syncthreads();
+            // ---- round 3: {k0, dhk} -> dW1 (K role) ; {x, gq, gk} -> dWq, dWk -------------------------------------------------
+            if (meta_k) {
+                store_frag<KT>(sq + my, k0, valid);
+                store_wide(so, x2, dhk);
+            }
+            store_frag<KT>(x1 + my, x);
+            store_frag<KT>(sv + my, gq);
+            store_frag<KT>(sk + my, gk);
+            __syncthreads();
+            if (meta_k) {
+                if constexpr (SAME) wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1q);
+                else wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1k);
+            }
+            wgrad_split<KT, KT, KT, KT, LD>(x1, x1, sv, sv, wave, n, g, acc_wq);                 // dWq[i][o] += x^T gq
+            wgrad_split<KT, KT, KT, KT, LD>(x1, x1, sk, sk, wave, n, g, acc_wk);
+            // dx = dr + gq Wq^T + gk Wk^T (+ gv Wv^T above)
+            float back[KT][4];
+            chain_t<KT, KT, LD>(wq + lt_d, gq, back);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            chain_t<KT, KT, LD>(wk + lt_d, gk, back);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            if (valid) store_frag<KT>(dx + grow, dr);
+        }
+        __syncthreads();
+      }
+      // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
+      // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the part of a role only
+      // when that role is active, so the sums go to the Q part when Q is modulated, else to the K part
+      {
+          float* rec = records + (size_t)(blockIdx.x + scen) * TSZ;
+          const bool to_k = SAME && !meta_q;
+          flush(acc_w1q, KTc{}, UTc{}, rec + (to_k ? 2 * D * U : 0), true);
+          flush(acc_w2q, UTc{}, KTc{}, rec + (to_k ? 3 * D * U : D * U), true);
+          flush(acc_w1k, KTc{}, UTc{}, rec + (to_k ? 0 : 2 * D * U), !SAME);
+          flush(acc_w2k, UTc{}, KTc{}, rec + (to_k ? D * U : 3 * D * U), !SAME);
+      }
+    }
+
+    // ---- scenario-independent gradients of this workgroup ------------------------------------------------------------------
+    flush(acc_wq, KTc{}, KTc{}, common, true);
+    flush(acc_wk, KTc{}, KTc{}, common + D * D, true);
+    flush(acc_wv, KTc{}, KTc{}, common + 2 * D * D, true);
+    flush(acc_wo, KTc{}, KTc{}, common + 3 * D * D, true);
+    // LayerNorm gradients: lane n < 6 of every 16-lane row holds vector n (features 16 t + 4 g + r); waves in wave order
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n < 6) stage[(wave * 6 + n) * D + 16 * t + g4 + r] = aln[t][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 6 * D; e += kB8Block) {
+        float s = stage[e];
+#pragma unroll
+        for (int w = 1; w < kB8Waves; ++w) s += stage[w * 6 * D + e];
+        common[4 * D * D + e] = s;
+    }
+}
+
+static int64_t bwd8_lds_floats(int T, int F, int D, int U, int H, bool same_tab) {
+    const int LD = D + 4, LU = U + 4;
+    auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
+    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 6 * (int64_t)kB8Rows * LD +
+           r4(4 * (int64_t)T * H * F) + 64;
+}
+
+struct Bwd8Plan {
+    int T, G, FC;
+    size_t lds;
+};
+
+static bool bwd8_plan(const satrans_layer_desc* d, Bwd8Plan& p) {
+    static const int enabled = getenv("SATRANS_BWD8") ? atoi(getenv("SATRANS_BWD8")) : 1;
+    if (!enabled) return false;
+    if (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) return false;
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
+    const bool shape = (d->D == 32 && d->H == 4 && (!meta || d->U == 64)) || (d->D == 16 && d->H == 2 && (!meta || d->U == 32));
+    if (!shape || d->F > 32 || d->F < 1) return false;
+    const bool same_tab = d->tab_q == d->tab_k;
+    const int U = 2 * d->D;
+    p.T = kB8Rows / d->F;
+    p.FC = d->F <= 20 ? 5 : 8;
+    p.lds = (size_t)bwd8_lds_floats(p.T, d->F, d->D, U, d->H, same_tab) * 4;
+    if (p.lds > 160 * 1024) return false;
+    if (d->D == 32 && !same_tab) return false;                               // (not instantiated: does not fit LDS)
+    const int64_t tiles = ceil_div(d->B, p.T) + d->S;
+    p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
+    return true;
+}
+
+template <int D, int U, int H, bool SAME, int FC>
+static int launch_bwd8(const satrans_layer_desc* d, const Bwd8Plan& p, const float* dy, float* dx, float* slabs,
+                       hipStream_t stream) {
+    static size_t attr_set = 0;
+    if (p.lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd8_kernel<D, U, H, SAME, FC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd8: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = p.lds;
+    }
+    layer_bwd8_kernel<D, U, H, SAME, FC><<<p.G, kB8Block, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    SATRANS_CHECK_LAUNCH("layer_bwd8_kernel");
+    return SATRANS_OK;
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+extern "C" int satrans_layer_bwd8_supported(const satrans_layer_desc* d) {
+    Bwd8Plan p;
+    return d && bwd8_plan(d, p) ? 1 : 0;
+}
+
+extern "C" int64_t satrans_layer_bwd8_slab_floats(const satrans_layer_desc* d) {
+    Bwd8Plan p;
+    if (!d || !bwd8_plan(d, p)) return -1;
+    const int64_t U = 2 * (int64_t)d->D;
+    const int64_t CSZ = 4 * (int64_t)d->D * d->D + 6 * d->D, TSZ = 4 * (int64_t)d->D * U;
+    return (int64_t)p.G * CSZ + (int64_t)(p.G + d->S) * TSZ;
+}
+
+// launches the kernel; *T_out / *G_out: the tile size and grid the fixed-order reduction must use
+extern "C" int satrans_layer_bwd8_launch(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, int* T_out,
+                                         int* G_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    Bwd8Plan p;
+    SATRANS_REQUIRE(bwd8_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd8: shape not built");
+    const bool same = d->tab_q == d->tab_k;
+    int rc;
+    if (d->D == 32) rc = p.FC == 5 ? launch_bwd8<32, 64, 4, true, 5>(d, p, dy, dx, slabs, stream)
+                                   : launch_bwd8<32, 64, 4, true, 8>(d, p, dy, dx, slabs, stream);
+    else if (same) rc = p.FC == 5 ? launch_bwd8<16, 32, 2, true, 5>(d, p, dy, dx, slabs, stream)
+                                  : launch_bwd8<16, 32, 2, true, 8>(d, p, dy, dx, slabs, stream);
+    else rc = p.FC == 5 ? launch_bwd8<16, 32, 2, false, 5>(d, p, dy, dx, slabs, stream)
+                        : launch_bwd8<16, 32, 2, false, 8>(d, p, dy, dx, slabs, stream);
+    *T_out = p.T;
+    *G_out = p.G;
+    return rc;
+}

@@ -88,7 +88,13 @@ def test_adam_steps_match_reference_golden(name):
     opt = model.optimizer_state_dict()
     assert opt["step"] == steps
     checked = 0
-    for kind, tol in (("exp_avg", 5e-5), ("exp_avg_sq", 2e-4)):
+    # Free-running, the steps after the first see parameters that already differ in their ill-conditioned elements (an
+    # embedding element whose gradient is ~eps moves by up to lr = 50x its init scale whichever way the rounding falls), and
+    # that feeds back into the LATER gradients at the 1e-3..1e-2 level (measured: 7e-3 of the largest moment on W_Query
+    # after three steps).  So against the reference's own end state the moments are only held to 2e-2 of their largest
+    # element; the TIGHT pin of the trajectory is test_adam_trajectory_step_by_step_against_the_oracle below, where every
+    # step starts from identical state.
+    for kind, tol in (("exp_avg", 2e-2), ("exp_avg_sq", 2e-2)):
         for k, w in c.arrays(f"opt/{kind}").items():
             assert k in opt["state"], k
             checked += 1
@@ -98,6 +104,53 @@ def test_adam_steps_match_reference_golden(name):
             scale = float(np.abs(w).max())
             np.testing.assert_allclose(g, w, rtol=1e-5, atol=tol * scale + 1e-30, err_msg=f"{kind}/{k}")
     assert checked >= 2 * len(grads)
+
+
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_qkv"])
+def test_adam_trajectory_step_by_step_against_the_oracle(name):
+    """The optimizer on the reference's trajectory, without the chaos: before every step the CPU oracle (torch.optim.Adam on
+    the reference's arithmetic, pinned to the reference's own moments at 2e-5 in tests/test_oracle_golden.py) is given the
+    GPU's current parameters and moments bit for bit; both then take ONE step on the same batch.  Moments after the step must
+    agree element by element at single-gradient accuracy, parameters wherever the update is well-conditioned."""
+    c = Case(name)
+    model = build_model(c, DEV)
+    lr = c.meta["lr"]
+    model.compile(torch.optim.Adam(model.parameters(), lr=lr), "binary_crossentropy")
+    model.eval()
+    eng = model._require_engine()
+    X, y = c.X.to(DEV), c.y.to(DEV)
+    tr = O.OracleTrainer(c.tensors("param"), c.spec(), lr=lr)
+    for step in range(3):
+        sd, opt = sd_to_cpu(model), model.optimizer_state_dict()
+        for k, leaf in tr.leaves.items():
+            leaf.data.copy_(sd[k])
+            st = opt.get("state", {}).get(k)
+            if st is not None:
+                tr.optim.state[leaf] = dict(step=torch.tensor(float(step)), exp_avg=st["exp_avg"].clone(),
+                                            exp_avg_sq=st["exp_avg_sq"].clone())
+        tr.step(c.X, c.y)
+        eng.train_step(X, y)
+        got, gopt = sd_to_cpu(model), model.optimizer_state_dict()
+        assert gopt["step"] == step + 1
+        for k, leaf in tr.leaves.items():
+            if leaf not in tr.optim.state or k not in gopt["state"]:
+                continue
+            ref_m, ref_v = tr.optim.state[leaf]["exp_avg"], tr.optim.state[leaf]["exp_avg_sq"]
+            if float(ref_m.abs().max()) < 1e-8:
+                continue                                  # mathematically-zero gradient: rounding noise
+            m, v = gopt["state"][k]["exp_avg"], gopt["state"][k]["exp_avg_sq"]
+            np.testing.assert_allclose(m.numpy(), ref_m.numpy(), rtol=1e-5, atol=1e-4 * float(ref_m.abs().max()),
+                                       err_msg=f"step {step} exp_avg/{k}")
+            np.testing.assert_allclose(v.numpy(), ref_v.numpy(), rtol=1e-5, atol=2e-4 * float(ref_v.abs().max()),
+                                       err_msg=f"step {step} exp_avg_sq/{k}")
+            # the parameter itself: tight where |m_hat| / (sqrt(v_hat) + eps) is insensitive to 1e-4 relative changes of m
+            # and v, i.e. where sqrt(v_hat) >> eps; elsewhere one step can differ by up to lr
+            delta = (got[k] - leaf.detach()).abs()
+            vhat = ref_v / (1 - 0.999 ** (step + 1))
+            ok = vhat.sqrt() > 1e-4 * max(float(vhat.sqrt().max()), 1e-30)
+            if bool(ok.any()):
+                assert float(delta[ok].max()) <= 2e-2 * lr, (step, k, float(delta[ok].max()))
+            assert float(delta.max()) <= 2.0 * lr + 1e-6, (step, k)
 
 
 def test_optimizer_state_survives_a_device_move_and_a_resume():
