@@ -69,22 +69,58 @@ def oracle_spec(flag='sota'):
                     embedding_dim=32, head_num=4, layer_num=3, flag=flag, meta_mode='QK', meta_units=[32, 64, 32])
 
 
-def cpu_baseline(state, X, y, batch, lr, steps, flag='sota'):
-    """The reference's training step restated op for op (oracle/satrans_oracle.py: per-sample generated weights,
-    torch CPU dropout, dense L2 over all rows, dense torch.optim.Adam), timed on this box's host cores."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(state, X, y, batch, lr, flag='sota', timed=10, warm=2, timed_verbose=5):
+    """The reference's training step restated op for op (oracle/satrans_oracle.py: per-sample generated weights, torch CPU
+    dropout, dense L2 over all rows, dense torch.optim.Adam), timed on this box's host cores with the protocol of SURVEY
+    §8d / BASELINE.md §3: thread count chosen by a one-step sweep, `warm` untimed steps, MEDIAN of `timed` steps; then a
+    second leg with the per-step sklearn log_loss / roc_auc_score of `fit(verbose=1)` (what reference main.py does)."""
     from oracle import satrans_oracle as O
-    torch.set_num_threads(min(os.cpu_count(), 32))  # more threads only add contention (256-core box: 70 s/step)
+    from sklearn.metrics import log_loss, roc_auc_score
+    ncpu = os.cpu_count()
     tr = O.OracleTrainer(state, oracle_spec(flag), lr=lr)
     drop = O.Dropper("torch", 0.1)
-    times = []
-    for s in range(steps + 1):
+    cursor = [0]
+
+    def one(verbose=False):
+        s = cursor[0]
+        cursor[0] += 1
         xb = torch.from_numpy(X[s * batch:(s + 1) * batch])
         yb = torch.from_numpy(y[s * batch:(s + 1) * batch])
         t0 = time.perf_counter()
-        tr.step(xb, yb, drop)
-        times.append(time.perf_counter() - t0)
-    timed = times[1:]                                                              # first step allocates Adam state
-    return batch / (sum(timed) / len(timed)), len(timed)
+        prob = tr.step(xb, yb, drop, return_prob=verbose)
+        if verbose:                                                                # meta_basemodel.py:330-337
+            p64 = prob.numpy().astype("float64")
+            log_loss(yb.numpy(), p64, labels=[0, 1])
+            if 0 < float(yb.sum()) < len(yb):
+                roc_auc_score(yb.numpy(), p64)
+        return time.perf_counter() - t0
+
+    torch.set_num_threads(min(ncpu, 32))
+    one()                                                                          # allocates Adam state
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(th)
+        sweep[th] = one()
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for _ in range(max(0, warm - 1)):
+        one()
+    t_plain = sorted(one() for _ in range(timed))
+    t_verb = sorted(one(True) for _ in range(timed_verbose))
+    med = lambda v: v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    return dict(value=batch / med(t_plain), value_verbose1=batch / med(t_verb), threads=best, timed=timed,
+                timed_verbose=timed_verbose, sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
+                steps_used=cursor[0])
 
 
 def gather_microbench(eng, Xd, B, F, D, launches=48):
@@ -129,7 +165,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8192, help="samples per GPU per step (reference main.py:80)")
     ap.add_argument("--lr", type=float, default=0.005)
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-baseline steps, median reported (0 = skip)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="only the timed training steps (profiling runs: every kernel row is then one configuration)")
     ap.add_argument("--no-phase-timing", action="store_true")
     ap.add_argument("--flag", default="sota", help="SATrans flag (reference main.py --flag); 'sota-pos' = the positional variant")
     ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
@@ -158,7 +196,7 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     t_build = time.time()
     model = build_model("cpu", args.lr, args.flag)                                 # seeded init on CPU, as the reference
-    do_cpu = world == 1 and args.cpu_steps > 0
+    do_cpu = world == 1 and args.cpu_steps > 0 and not args.train_only
     state_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if do_cpu else None
     if do_cpu:                                                                     # keep the reference's aliasing
         sd = model.state_dict()
@@ -197,10 +235,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / K * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        cdev = "cpu" if dist.get_backend() == "gloo" else device
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        every = torch.zeros(world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_ms = [float(v) / K * 1e3 for v in every.cpu()]
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        elapsed = float(mine.item())
+    from satrans_amd import parallel as _par
+    collectives = {k: {"calls_per_step": v["calls"] / (K + W), "bytes_sent_per_step": v["bytes_in"] / (K + W),
+                       "bytes_received_per_step": v["bytes_out"] / (K + W)} for k, v in _par.STATS.items()}
     eng.raise_if_bad_ids()
     phases = eng.phase_ms() if eng.timers is not None else {}
     eng.timers = None
@@ -208,7 +254,7 @@ def main():
     # Extra, untimed pass with the streaming Adam back on the main stream: clean per-kernel durations (in the timed
     # region it overlaps the layer kernels on a side stream, which stretches both sides' event intervals).
     phases_serial = {}
-    if not args.no_phase_timing and eng.overlap:
+    if not args.no_phase_timing and eng.overlap and not args.train_only:
         eng.overlap = False
         eng.timers = {}
         for i in range(W, W + min(K, 5)):
@@ -231,7 +277,7 @@ def main():
     per_launch = {
         "adam_untouched": dict(kernel="adam_untouched_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                                work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
-        "layer_bwd": dict(kernel="layer_bwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
+        "layer_bwd": dict(kernel=os.environ.get("SATRANS_BWD8", "1") != "0" and "layer_bwd8_kernel" or "layer_bwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                           work=2.0 * fwd_flops / 1e12),
         "layer_fwd": dict(kernel="layer_fwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                           work=fwd_flops / 1e12),
@@ -268,24 +314,33 @@ def main():
                             "its fixed-order reduction launch; `kernels_serial` repeats the measurement in an extra "
                             "untimed pass"}
 
-    # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (tools/pmc_passes.sh: FETCH_SIZE
-    # and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+    # HBM bytes per launch of that kernel from the PMC passes under profiles/ (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE
+    # in separate passes of `bench.py --train-only`, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The
+    # summary records the sha256 of the library it profiled: a summary of another build is reported as stale, not as traffic.
     if roofline:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_j_pmc_summary.json")))
+            import hashlib
+            sha = hashlib.sha256(open(os.path.join(ROOT, "satrans_amd", "libsatrans_hip.so"), "rb").read()).hexdigest()
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             rec = next(v for k, v in pmc.items() if k.startswith(roofline["kernel"]))
-            roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
-            roofline["traffic_source"] = "profiles/r01_j_pmc_summary.json (rocprofv3 --pmc, bytes per launch)"
+            if pmc.get("_lib_sha256") == sha:
+                roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
+                roofline["traffic_source"] = "profiles/r02_pmc_summary.json (rocprofv3 --pmc of this build, bytes per launch)"
+            else:
+                roofline["traffic_source"] = ("stale: profiles/r02_pmc_summary.json was taken on another build "
+                                              f"({str(pmc.get('_lib_sha256'))[:12]} vs {sha[:12]})")
         except (OSError, StopIteration, KeyError):
             pass
 
     # ---- the gather on its own: achieved HBM GB/s at the training batch and at the reference's prediction batch
     #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
-    gather = gather_microbench(eng, Xd, B, 19, 32)
+    gather = gather_microbench(eng, Xd, B, 19, 32) if not args.train_only else None
 
     # ---- the evaluation forward alone (predict / evaluate path) at the reference's prediction batch --------------------------
     forward_only = None
     try:
+        if args.train_only:
+            raise RuntimeError("--train-only")
         model.eval()
         nb = min(4 * B, Xd.shape[0])
         for _ in range(3):
@@ -307,6 +362,8 @@ def main():
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = None
     try:
+        if args.train_only:
+            raise RuntimeError("--train-only")
         from oracle import satrans_oracle as O
         model.eval()
         nb = 2048
@@ -322,11 +379,17 @@ def main():
     cpu = None
     if do_cpu:
         t_cpu = time.time()
-        Xc, yc = synth_batches((args.cpu_steps + 1) * B, seed=7)
-        v, n = cpu_baseline(state_cpu, Xc, yc, B, args.lr, args.cpu_steps, args.flag)
-        cpu = {"value": round(v, 1), "unit": "samples/s", "cores": min(os.cpu_count(), 32), "kind": "port",
-               "sample": f"{n} timed training steps of B={B} after 1 untimed step (dropout on, dense L2 + dense Adam, "
-                         f"no per-step sklearn metrics), {time.time() - t_cpu:.0f}s wall"}
+        n_need = 1 + 5 + 2 + args.cpu_steps + 5 + 2
+        Xc, yc = synth_batches(n_need * B, seed=7)
+        r = cpu_baseline(state_cpu, Xc, yc, B, args.lr, args.flag, timed=args.cpu_steps)
+        cpu = {"value": round(r["value"], 1), "unit": "samples/s", "cores": r["threads"], "kind": "port",
+               "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(),
+               "value_verbose1": round(r["value_verbose1"], 1),
+               "thread_sweep_s_per_step": r["sweep_s_per_step"],
+               "sample": f"median of {r['timed']} training steps of B={B} after 2 untimed ones at the best thread count of a "
+                         f"one-step sweep (dropout on, dense L2 + dense torch Adam over all 6.57 M rows; `value` = verbose=0, "
+                         f"`value_verbose1` = median of {r['timed_verbose']} steps with the per-step sklearn log_loss + "
+                         f"roc_auc_score of fit(verbose=1), what reference main.py runs); {time.time() - t_cpu:.0f}s wall"}
 
     value = world * B * K / elapsed
     out = {
@@ -341,6 +404,7 @@ def main():
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
         "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
         "forward_only": forward_only, "cpu_baseline": cpu,
+        "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "collectives": collectives,
     }
     print(json.dumps(out))
     if world > 1:

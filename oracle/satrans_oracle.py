@@ -304,13 +304,15 @@ class OracleTrainer:
         uniq = list({id(t): t for t in self.leaves.values()}.values())
         self.optim = torch.optim.Adam(uniq, lr=lr, betas=betas, eps=eps)
 
-    def step(self, X: Tensor, y: Tensor, drop: Optional[Dropper] = None) -> Tuple[float, float]:
+    def step(self, X: Tensor, y: Tensor, drop: Optional[Dropper] = None, return_prob: bool = False):
         prob, _ = forward(self.leaves, X, self.spec, drop)
         self.optim.zero_grad()
         bce = F.binary_cross_entropy(prob.squeeze(-1), y.to(prob.dtype).reshape(-1), reduction="sum")
         reg = regularization_loss(self.leaves, self.spec)
         (bce + reg.sum()).backward()
         self.optim.step()
+        if return_prob:
+            return prob.detach().squeeze(-1)
         return float(bce.detach()), float(reg.detach().sum())
 
     def state(self) -> Dict[str, Tensor]:

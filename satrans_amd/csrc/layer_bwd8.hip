@@ -35,6 +35,12 @@ constexpr int kB8Block = 64 * kB8Waves;
 constexpr int kB8Rows = 16 * kB8Waves;      // token rows of a workgroup tile
 
 
+// Workgroup barrier for LDS hand-offs inside the tile loop.  __syncthreads() makes hipcc wait for EVERY outstanding memory
+// operation (s_waitcnt vmcnt(0)) in front of s_barrier, which would stall all eight waves on the global prefetches that are
+// meant to fly across the phases (next tile's sample index and input row, dy); only the LDS traffic has to be complete here.
+// Global memory is never used to pass data between waves inside the loop.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -89,16 +95,19 @@ __device__ __forceinline__ void wgrad_split(const float* A0, const float* A1, co
     constexpr int KS = kB8Waves / TILES, NK = (kB8Rows / 4) / KS;       // k-steps (4 token rows each) of one share
     const int tile = wave % TILES, kpart = wave / TILES;
     const int mt = tile / NT, nt = tile - mt * NT;
-    const float* al = (mt < NBA ? A0 + 16 * mt : A1 + 16 * (mt - NBA)) + (kpart * NK * 4 + g) * LDX + n;
-    const float* gl = (nt < NBG ? G0 + 16 * nt : G1 + 16 * (nt - NBG)) + (kpart * NK * 4 + g) * LDX + n;
+    // Which four token rows form a contraction step is free (both operands use the same rows): lane group g of step ks takes
+    // row 16 (ks / 4) + 4 g + ks % 4 of the share, so that the two groups of a 32-lane half read rows FOUR apart - with the
+    // row stride LDX = 4 mod 8 that is 16 banks apart, conflict-free (rows one apart collide on 12 of 16 banks)
+    const float* al = (mt < NBA ? A0 + 16 * mt : A1 + 16 * (mt - NBA)) + (kpart * NK * 4 + 4 * g) * LDX + n;
+    const float* gl = (nt < NBG ? G0 + 16 * nt : G1 + 16 * (nt - NBG)) + (kpart * NK * 4 + 4 * g) * LDX + n;
     constexpr int CH = NK < 8 ? NK : 8;
 #pragma unroll
     for (int k0 = 0; k0 < NK; k0 += CH) {
         float av[CH], gv[CH];
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) {
-            av[ks] = al[4 * (k0 + ks) * LDX];
-            gv[ks] = gl[4 * (k0 + ks) * LDX];
+            av[ks] = al[(16 * ((k0 + ks) >> 2) + ((k0 + ks) & 3)) * LDX];
+            gv[ks] = gl[(16 * ((k0 + ks) >> 2) + ((k0 + ks) & 3)) * LDX];
         }
 #pragma unroll
         for (int ks = 0; ks < CH; ++ks) acc = mfma4(av[ks], gv[ks], acc);
@@ -106,7 +115,9 @@ __device__ __forceinline__ void wgrad_split(const float* A0, const float* A1, co
 }
 
 // SAME: the Q and K roles share one generated-weight table (no 'pos' in the flag).  FC: 4-key chunks of a score row (4 FC >= F).
-template <int D, int U, int H, bool SAME, int FC>
+// FT: the number of fields when it is known at compile time (every row offset, clamp and loop bound of the attention phases
+// then folds into an immediate), 0 = read it from the descriptor.
+template <int D, int U, int H, bool SAME, int FC, int FT>
 __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc a, int Tsamp, const float* __restrict__ dy,
                                                                float* __restrict__ dx, float* __restrict__ slabs) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
     static_assert(d == 8, "head dimension 8 (two lane groups of a token share a head)");
     static_assert(H <= 4, "one attention task per thread: T * H * F <= 128 * H <= 512");
     extern __shared__ __align__(16) float lds[];
-    const int F = a.F;
+    const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
     const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
@@ -211,6 +222,8 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
     using KTc = std::integral_constant<int, KT>;
     using UTc = std::integral_constant<int, UT>;
 
+    STAMP_DECL
+    STAMP(13);
     int pre = 0;
     for (int scen = 0; scen < a.S && pre < wr.g1; ++scen) {
       const int nt_s = tiles_of(a.seg, scen, Tsamp);
@@ -232,13 +245,24 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
       const int lo = a.seg[scen], hi = a.seg[scen + 1];
       const int tok = row0 + n;
       const int ls_tok = tok / F, f_tok = tok - ls_tok * F;      // this lane's (sample, field) inside any tile that holds it
+      // The sample index and the input row of a tile are fetched one tile ahead (at the end of phase F): the eight waves run
+      // the phases in lockstep, so nothing else would hide those two dependent global loads at the top of a tile.
+      int b_next = 0;
+      float x_next[KT][4];
+      auto fetch_tile = [&](int tile_) {
+          const int first_ = lo + tile_ * Tsamp;
+          const bool valid_ = tok < min(Tsamp, hi - first_) * F;
+          b_next = a.order[first_ + (valid_ ? ls_tok : 0)];
+          load_frag<KT>(a.x + ((size_t)b_next * F + (valid_ ? f_tok : 0)) * D + g4, x_next, valid_);
+      };
+      fetch_tile(t0);
       for (int tile = t0; tile < t1; ++tile) {
         const int first = lo + tile * Tsamp;
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F;
         const bool valid = tok < ntok;
         const int f = valid ? f_tok : 0;
-        const int b = samp[valid ? ls_tok : 0];
+        const int b = b_next;
         const size_t grow = ((size_t)b * F + f) * D + g4;       // this lane's row of x / dy / dx
         const int ntask = nS * H * F;
         const bool task_ok = (int)threadIdx.x < ntask;
@@ -246,7 +270,9 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
         const int tls = task_ok ? t0_ls : 0, th = task_ok ? t0_h : 0, ti = task_ok ? t0_i : 0;
 
         // token-wise state that lives from phase A to phase F
-        float q0[KT][4], k0[KT][4], hq[UT][4], hk[UT][4], zhq[KT][4], zhk[KT][4], dr[KT][4];
+        // (the MetaNet hidden rows are NOT kept: 32 registers for the whole tile against 2 x 32 MFMAs to rebuild them in phase F,
+        // on a matrix pipe that idles two thirds of the time)
+        float q0[KT][4], k0[KT][4], zhq[KT][4], zhk[KT][4], dr[KT][4];
         float rstd_q = 0.f, rstd_k = 0.f;
         // keep flags of this token lane at the MetaNet-Q / MetaNet-K / output sites (bits 0-7 / 8-15 / 16-23), generated once
         uint32_t keepbits = 0xFFFFFFFFu;
@@ -255,10 +281,14 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                        (token_keep_bits<KT>(drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, D, g4, dc.thresh) << 8) |
                        (token_keep_bits<KT>(drop_sample_key(dc.key[kSiteOut], (uint32_t)b), f, D, g4, dc.thresh) << 16);
 
+        STAMP(0);
         // ================= phase A: forward chain (every wave, also one whose rows lie beyond the tile: x = 0 there) =======
         {
-            float x[KT][4], v[KT][4], q[KT][4], k[KT][4];
-            load_frag<KT>(a.x + grow, x, valid);
+            float x[KT][4], v[KT][4], q[KT][4], k[KT][4], hq[UT][4], hk[UT][4];
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[t][r] = x_next[t][r];
             chain<KT, KT, LD>(wq + lo_d, x, q0);
             chain<KT, KT, LD>(wk + lo_d, x, k0);
             chain<KT, KT, LD>(wv + lo_d, x, v);
@@ -326,32 +356,28 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             store_frag<KT>(sk + my, k);
             store_frag<KT>(sv + my, v);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(1);
 
         // ================= phase B: attention forward: o_i, row statistics, dropout keep word ===============================
-        // the score row of a query stays in registers (FC chunks of four keys); exp2 of pre-scaled scores; padding keys of
-        // the last chunk read the last real row and are masked
+        // two passes over the keys in chunks of four (rolled loops: the live set stays small next to the token state that
+        // sleeps in registers): maximum of the scaled scores, then exp2 / sum / PV with the scores recomputed (4 packed FMAs
+        // per key - cheaper than keeping the row in registers at two waves per SIMD); padding keys of the last chunk read the
+        // last real row and are masked
         if (task_ok) {
             const int tb = samp[tls];
             f32x2 qi[d / 2];
             load_row<d>(sq + (tls * F + ti) * LD + th * d, qi);
             const float* kbase = sk + (tls * F) * LD + th * d;
             const float* vbase = sv + (tls * F) * LD + th * d;
-            float sc[4 * FC];
             float mx = -INFINITY;
+#pragma unroll 1
+            for (int j0 = 0; j0 < F; j0 += 4) {
+                f32x2 kr[4][d / 2];
 #pragma unroll
-            for (int c = 0; c < FC; ++c) {
-                if (4 * c < F) {
-                    f32x2 kr[4][d / 2];
+                for (int u = 0; u < 4; ++u) load_row<d>(kbase + min(j0 + u, F - 1) * LD, kr[u]);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) load_row<d>(kbase + min(4 * c + u, F - 1) * LD, kr[u]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float s_ = 4 * c + u < F ? dot_row<d>(qi, kr[u]) * sc_scale : -INFINITY;
-                        sc[4 * c + u] = s_;
-                        mx = fmaxf(mx, s_);
-                    }
-                }
+                for (int u = 0; u < 4; ++u) mx = fmaxf(mx, dot_row<d>(qi, kr[u]) * sc_scale);   // a padding key repeats the last score
             }
             f32x2 oacc[d / 2];
 #pragma unroll
@@ -360,35 +386,38 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
             const uint32_t block0 = drop_attn_elem(th, F, ti, 0) >> 2;
+#pragma unroll 1
+            for (int j0 = 0; j0 < F; j0 += 4) {
+                f32x2 kr[4][d / 2], vr[4][d / 2];
 #pragma unroll
-            for (int c = 0; c < FC; ++c) {
-                if (4 * c < F) {
-                    f32x2 vr[4][d / 2];
+                for (int u = 0; u < 4; ++u) {
+                    load_row<d>(kbase + min(j0 + u, F - 1) * LD, kr[u]);
+                    load_row<d>(vbase + min(j0 + u, F - 1) * LD, vr[u]);
+                }
+                const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(j0 >> 2), dc.thresh) : 0xFu;
+                if (dc.on) keep = (keep & ~(0xFu << j0)) | (kb << j0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) load_row<d>(vbase + min(4 * c + u, F - 1) * LD, vr[u]);
-                    const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)c, dc.thresh) : 0xFu;
-                    if (dc.on) keep = (keep & ~(0xFu << (4 * c))) | (kb << (4 * c));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float ex = __builtin_amdgcn_exp2f(sc[4 * c + u] - mx);      // padding keys: exp2(-inf) = 0
-                        sum += ex;
-                        float pe = ex;
-                        if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
-                        axpy_row<d>(pe, vr[u], oacc);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const float ex = j0 + u < F ? __builtin_amdgcn_exp2f(dot_row<d>(qi, kr[u]) * sc_scale - mx) : 0.f;
+                    sum += ex;
+                    float pe = ex;
+                    if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
+                    axpy_row<d>(pe, vr[u], oacc);
                 }
             }
             const float inv = 1.0f / sum;
             st[task] = make_float4(mx, inv, 0.f, __uint_as_float(keep));
             store_row<d>(so + (tls * F + ti) * LD + th * d, oacc, inv);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(2);
 
         // ================= phase C: output block forward + backward ======================================================
         {
             float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4], x[KT][4];
+            load_frag<KT>(a.x + grow, x, valid);              // (L1 / L2 hits: phase A read these rows)
+            load_frag<KT>(dy + grow, gy, valid);
             load_frag<KT>(so + my, o);
-            load_frag<KT>(a.x + grow, x, valid);
             chain<KT, KT, LD>(woT + lo_d, o, u);
             float keep[KT][4];      // multiplicative factor of du: dropout mask times ReLU mask
 #pragma unroll
@@ -406,7 +435,6 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 }
             float rstd_o;
             layer_norm_keep<KT>(u, zh, rstd_o);
-            load_frag<KT>(dy + grow, gy, valid);
             layer_norm_bwd_c<KT>(gy, zh, rstd_o, ln_g, g4, n, 0, 1, aln);       // gy is now dr
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -430,7 +458,8 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(3);
 
         // ================= phase D: dWo; softmax backward, row pass and column pass of every task =========================
         wgrad_split<KT, KT, KT, KT, LD>(x1, x1, so, so, wave, n, g, acc_wo);    // dWo[o][i] += du^T o
@@ -450,27 +479,24 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 load_row<d>(gbase + ti * LD, gi);
                 const float4 s4 = stb[ti];
                 const uint32_t keep = __float_as_uint(s4.w);
+#pragma unroll 1
+                for (int j0 = 0; j0 < F; j0 += 4) {
+                    float dp[4];
+                    {
+                        f32x2 vr[4][d / 2];
 #pragma unroll
-                for (int c = 0; c < FC; ++c) {
-                    if (4 * c < F) {
-                        float dp[4];
-                        {
-                            f32x2 vr[4][d / 2];
+                        for (int u = 0; u < 4; ++u) load_row<d>(vbase + min(j0 + u, F - 1) * LD, vr[u]);
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) load_row<d>(vbase + min(4 * c + u, F - 1) * LD, vr[u]);
+                        for (int u = 0; u < 4; ++u) dp[u] = (keep >> (j0 + u)) & 1u ? dot_row<d>(gi, vr[u]) * scale : 0.f;
+                    }
+                    f32x2 kr[4][d / 2];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                dp[u] = (keep >> (4 * c + u)) & 1u ? dot_row<d>(gi, vr[u]) * scale : 0.f;
-                        }
-                        f32x2 kr[4][d / 2];
+                    for (int u = 0; u < 4; ++u) load_row<d>(kbase + min(j0 + u, F - 1) * LD, kr[u]);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) load_row<d>(kbase + min(4 * c + u, F - 1) * LD, kr[u]);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float s_ = dot_row<d>(qi, kr[u]) * sc_scale;
-                            const float pj = 4 * c + u < F ? __builtin_amdgcn_exp2f(s_ - s4.x) * s4.y : 0.f;
-                            axpy_row<d>(pj * (dp[u] - s4.z) * inv_sqrt_d, kr[u], dq);
-                        }
+                    for (int u = 0; u < 4; ++u) {
+                        const float s_ = dot_row<d>(qi, kr[u]) * sc_scale;
+                        const float pj = j0 + u < F ? __builtin_amdgcn_exp2f(s_ - s4.x) * s4.y : 0.f;
+                        axpy_row<d>(pj * (dp[u] - s4.z) * inv_sqrt_d, kr[u], dq);
                     }
                 }
             }
@@ -478,48 +504,48 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 f32x2 ki[d / 2], vi[d / 2];
                 load_row<d>(kbase + ti * LD, ki);
                 load_row<d>(vbase + ti * LD, vi);
+#pragma unroll 1
+                for (int r0 = 0; r0 < F; r0 += 2) {
+                    f32x2 qr[2][d / 2], gr[2][d / 2];
+                    float4 sr[2];
 #pragma unroll
-                for (int c = 0; c < 2 * FC; ++c) {
-                    if (2 * c < F) {
-                        f32x2 qr[2][d / 2], gr[2][d / 2];
-                        float4 sr[2];
+                    for (int u = 0; u < 2; ++u) {
+                        const int r = min(r0 + u, F - 1);
+                        sr[u] = stb[r];
+                        load_row<d>(qbase + r * LD, qr[u]);
+                        load_row<d>(gbase + r * LD, gr[u]);
+                    }
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int r = min(2 * c + u, F - 1);
-                            sr[u] = stb[r];
-                            load_row<d>(qbase + r * LD, qr[u]);
-                            load_row<d>(gbase + r * LD, gr[u]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const bool real = 2 * c + u < F;
-                            const float s_ = dot_row<d>(qr[u], ki) * sc_scale;
-                            const float pr = real ? __builtin_amdgcn_exp2f(s_ - sr[u].x) * sr[u].y : 0.f;
-                            const bool kp = (__float_as_uint(sr[u].w) >> ti) & 1u;
-                            const float dp = kp ? dot_row<d>(gr[u], vi) * scale : 0.f;
-                            axpy_row<d>(pr * (dp - sr[u].z) * inv_sqrt_d, qr[u], dk);
-                            axpy_row<d>(kp ? pr * scale : 0.f, gr[u], dv);
-                        }
+                    for (int u = 0; u < 2; ++u) {
+                        const bool real = r0 + u < F;
+                        const float s_ = dot_row<d>(qr[u], ki) * sc_scale;
+                        const float pr = real ? __builtin_amdgcn_exp2f(s_ - sr[u].x) * sr[u].y : 0.f;
+                        const bool kp = (__float_as_uint(sr[u].w) >> ti) & 1u;
+                        const float dp = kp ? dot_row<d>(gr[u], vi) * scale : 0.f;
+                        axpy_row<d>(pr * (dp - sr[u].z) * inv_sqrt_d, qr[u], dk);
+                        axpy_row<d>(kp ? pr * scale : 0.f, gr[u], dv);
                     }
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(4);
         if (task_ok) {      // every q, k, v, go row has been read (and du, o by the dWo product)
             store_row<d>(x1 + (tls * F + ti) * LD + th * d, dq, 1.0f);
             store_row<d>(sk + (tls * F + ti) * LD + th * d, dk, 1.0f);
             store_row<d>(sv + (tls * F + ti) * LD + th * d, dv, 1.0f);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(5);
 
         // ================= phase F: MetaNet and projection backward, dx; split weight gradients in three rounds ============
         // Exchange buffers: E0 = sq, E1 = so, E2 = x2, E3 = x1 (after gq is loaded), E4 = sk (after gk is loaded), sv after dWv.
         // A wave only ever writes its OWN 16 rows; the split products read all 128 rows, hence the barriers.
         {
             float gq[KT][4], gk[KT][4], x[KT][4];
+            load_frag<KT>(a.x + grow, x, valid);
             load_frag<KT>(x1 + my, gq, valid);      // gradient of the (post-MetaNet) queries
             load_frag<KT>(sk + my, gk, valid);      // ... keys
-            load_frag<KT>(a.x + grow, x, valid);
             {   // dx so far: dr + gv Wv^T   (rows >= ntok of sv still hold forward values: masked here, and neutralised by
                 // x = 0 in the dWv product)
                 float gv[KT][4], back[KT][4];
@@ -533,8 +559,13 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             // MetaNet backward of one role up to the point where its two exchange rounds start: LN backward (gout becomes
             // dz), dm = dz * mask, dh = (dm W2^T) * [h > 0], gout = dz + dh W1^T
             auto metanet_bwd = [&](float (&gout)[KT][4], const float (&zh)[KT][4], float rstd, const float* gam, int vg,
-                                   int kshift, const float (&h)[UT][4], const float* w2, const float* w1,
+                                   int kshift, const float (&in0)[KT][4], float (&h)[UT][4], const float* w2, const float* w1,
                                    float (&dm)[KT][4], float (&dh)[UT][4]) {
+                chain<KT, UT, LU>(w1 + lo_u, in0, h);                        // the hidden rows again: relu(in0 W1)
+#pragma unroll
+                for (int t = 0; t < UT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
                 layer_norm_bwd_c<KT>(gout, zh, rstd, gam, g4, n, vg, vg + 1, aln);
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
@@ -574,15 +605,17 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             float dhq[UT][4];
             store_frag<KT>(sq + my, x);
             if (meta_q) {
-                float dm[KT][4];
-                metanet_bwd(gq, zhq, rstd_q, lnq_g, 2, 0, hq, w2q, w1q, dm, dhq);
+                float dm[KT][4], hq[UT][4];
+                metanet_bwd(gq, zhq, rstd_q, lnq_g, 2, 0, q0, hq, w2q, w1q, dm, dhq);
                 store_wide(so, x2, hq);
                 store_frag<KT>(x1 + my, dm);
             }
-            __syncthreads();
+            lds_barrier();
+            STAMP(6);
             wgrad_split<KT, KT, KT, KT, LD>(sq, sq, sv, sv, wave, n, g, acc_wv);                 // dWv[i][o] += x^T dv
             if (meta_q) wgrad_split<UT, KT, KT, KT, LD>(so, x2, x1, x1, wave, n, g, acc_w2q);   // dW2[u][o] += hq^T dm
-            __syncthreads();
+            lds_barrier();
+            STAMP(7);
             // ---- round 2: {q0, dhq} -> dW1 (Q role) ; {hk, dmk} -> dW2 (K role) ---------------------------------------------
             float dhk[UT][4];
             if (meta_q) {
@@ -590,18 +623,20 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 store_wide(so, x2, dhq);
             }
             if (meta_k) {
-                float dm[KT][4];
-                metanet_bwd(gk, zhk, rstd_k, lnk_g, 4, 8, hk, w2k, w1k, dm, dhk);
+                float dm[KT][4], hk[UT][4];
+                metanet_bwd(gk, zhk, rstd_k, lnk_g, 4, 8, k0, hk, w2k, w1k, dm, dhk);
                 store_wide(x1, sv, hk);
                 store_frag<KT>(sk + my, dm);
             }
-            __syncthreads();
+            lds_barrier();
+            STAMP(8);
             if (meta_q) wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1q);   // dW1[i][u] += q0^T dhq
             if (meta_k) {
                 if constexpr (SAME) wgrad_split<UT, KT, KT, KT, LD>(x1, sv, sk, sk, wave, n, g, acc_w2q);
                 else wgrad_split<UT, KT, KT, KT, LD>(x1, sv, sk, sk, wave, n, g, acc_w2k);
             }
-            __syncthreads();
+            lds_barrier();
+            STAMP(9);
             // ---- round 3: {k0, dhk} -> dW1 (K role) ; {x, gq, gk} -> dWq, dWk -------------------------------------------------
             if (meta_k) {
                 store_frag<KT>(sq + my, k0, valid);
@@ -610,7 +645,9 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             store_frag<KT>(x1 + my, x);
             store_frag<KT>(sv + my, gq);
             store_frag<KT>(sk + my, gk);
-            __syncthreads();
+            if (tile + 1 < t1) fetch_tile(tile + 1);
+            lds_barrier();
+            STAMP(10);
             if (meta_k) {
                 if constexpr (SAME) wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1q);
                 else wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1k);
@@ -631,7 +668,8 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
             if (valid) store_frag<KT>(dx + grow, dr);
         }
-        __syncthreads();
+        lds_barrier();
+        STAMP(11);
       }
       // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
       // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the part of a role only
@@ -646,6 +684,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
       }
     }
 
+    STAMP(12);
     // ---- scenario-independent gradients of this workgroup ------------------------------------------------------------------
     flush(acc_wq, KTc{}, KTc{}, common, true);
     flush(acc_wk, KTc{}, KTc{}, common + D * D, true);
@@ -678,9 +717,12 @@ struct Bwd8Plan {
     size_t lds;
 };
 
+// -1: not decided yet (SATRANS_BWD8 in the environment, default 0); 0 / 1: off / on (satrans_set_layer_bwd8)
+static int g_bwd8 = -1;
+
 static bool bwd8_plan(const satrans_layer_desc* d, Bwd8Plan& p) {
-    static const int enabled = getenv("SATRANS_BWD8") ? atoi(getenv("SATRANS_BWD8")) : 1;
-    if (!enabled) return false;
+    if (g_bwd8 < 0) g_bwd8 = getenv("SATRANS_BWD8") ? (atoi(getenv("SATRANS_BWD8")) != 0) : 0;
+    if (!g_bwd8) return false;
     if (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) return false;
     const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
     const bool shape = (d->D == 32 && d->H == 4 && (!meta || d->U == 64)) || (d->D == 16 && d->H == 2 && (!meta || d->U == 32));
@@ -688,6 +730,8 @@ static bool bwd8_plan(const satrans_layer_desc* d, Bwd8Plan& p) {
     const bool same_tab = d->tab_q == d->tab_k;
     const int U = 2 * d->D;
     p.T = kB8Rows / d->F;
+    static const int force_t = getenv("SATRANS_BWD8_T") ? atoi(getenv("SATRANS_BWD8_T")) : 0;   // (experiments)
+    if (force_t > 0 && force_t < p.T) p.T = force_t;
     p.FC = d->F <= 20 ? 5 : 8;
     p.lds = (size_t)bwd8_lds_floats(p.T, d->F, d->D, U, d->H, same_tab) * 4;
     if (p.lds > 160 * 1024) return false;
@@ -697,17 +741,17 @@ static bool bwd8_plan(const satrans_layer_desc* d, Bwd8Plan& p) {
     return true;
 }
 
-template <int D, int U, int H, bool SAME, int FC>
+template <int D, int U, int H, bool SAME, int FC, int FT>
 static int launch_bwd8(const satrans_layer_desc* d, const Bwd8Plan& p, const float* dy, float* dx, float* slabs,
                        hipStream_t stream) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd8_kernel<D, U, H, SAME, FC>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd8_kernel<D, U, H, SAME, FC, FT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd8: LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd8_kernel<D, U, H, SAME, FC><<<p.G, kB8Block, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd8_kernel<D, U, H, SAME, FC, FT><<<p.G, kB8Block, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd8_kernel");
     return SATRANS_OK;
 }
@@ -715,6 +759,22 @@ static int launch_bwd8(const satrans_layer_desc* d, const Bwd8Plan& p, const flo
 }  // namespace satrans
 
 using namespace satrans;
+
+#ifdef SATRANS_STAMPS
+extern "C" int satrans_debug_read_stamps8(unsigned long long* h_out, int reset) {
+    if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(satrans::g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(satrans::g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+extern "C" int satrans_set_layer_bwd8(int on) {
+    satrans::g_bwd8 = on < 0 ? -1 : (on != 0);
+    return SATRANS_OK;
+}
 
 extern "C" int satrans_layer_bwd8_supported(const satrans_layer_desc* d) {
     Bwd8Plan p;
@@ -737,12 +797,13 @@ extern "C" int satrans_layer_bwd8_launch(const satrans_layer_desc* d, const floa
     SATRANS_REQUIRE(bwd8_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd8: shape not built");
     const bool same = d->tab_q == d->tab_k;
     int rc;
-    if (d->D == 32) rc = p.FC == 5 ? launch_bwd8<32, 64, 4, true, 5>(d, p, dy, dx, slabs, stream)
-                                   : launch_bwd8<32, 64, 4, true, 8>(d, p, dy, dx, slabs, stream);
-    else if (same) rc = p.FC == 5 ? launch_bwd8<16, 32, 2, true, 5>(d, p, dy, dx, slabs, stream)
-                                  : launch_bwd8<16, 32, 2, true, 8>(d, p, dy, dx, slabs, stream);
-    else rc = p.FC == 5 ? launch_bwd8<16, 32, 2, false, 5>(d, p, dy, dx, slabs, stream)
-                        : launch_bwd8<16, 32, 2, false, 8>(d, p, dy, dx, slabs, stream);
+    if (d->D == 32 && d->F == 19) rc = launch_bwd8<32, 64, 4, true, 5, 19>(d, p, dy, dx, slabs, stream);   // the AliCCP shape
+    else if (d->D == 32) rc = p.FC == 5 ? launch_bwd8<32, 64, 4, true, 5, 0>(d, p, dy, dx, slabs, stream)
+                                        : launch_bwd8<32, 64, 4, true, 8, 0>(d, p, dy, dx, slabs, stream);
+    else if (same) rc = p.FC == 5 ? launch_bwd8<16, 32, 2, true, 5, 0>(d, p, dy, dx, slabs, stream)
+                                  : launch_bwd8<16, 32, 2, true, 8, 0>(d, p, dy, dx, slabs, stream);
+    else rc = p.FC == 5 ? launch_bwd8<16, 32, 2, false, 5, 0>(d, p, dy, dx, slabs, stream)
+                        : launch_bwd8<16, 32, 2, false, 8, 0>(d, p, dy, dx, slabs, stream);
     *T_out = p.T;
     *G_out = p.G;
     return rc;

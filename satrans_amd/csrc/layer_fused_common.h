@@ -17,7 +17,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // Diagnostic build only (-DSATRANS_STAMPS): per-phase cycle totals of wave 0 of every workgroup, summed with atomics
 // into a module-level array that satrans_debug_read_stamps copies out.  Never compiled into the shipped library.
 #ifdef SATRANS_STAMPS
-__device__ unsigned long long g_stamps[16];
+static __device__ unsigned long long g_stamps[16];
 #define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #define STAMP(slot)                                                                  \
     do {                                                                             \
@@ -112,11 +112,16 @@ __device__ __forceinline__ void chain_t(const float* __restrict__ wl, const floa
     f32x4 acc[MT_];
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the four contraction steps of one 16-feature input tile are four CONSECUTIVE floats of an image row: one 16-byte read
+    // instead of four 4-byte reads that hit every bank four times
     float a[NS][MT_];
 #pragma unroll
-    for (int st = 0; st < NS; ++st)
+    for (int q = 0; q < KT_; ++q)
 #pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) a[st][mt] = wl[16 * mt * LDW + 16 * (st >> 2) + (st & 3)];
+        for (int mt = 0; mt < MT_; ++mt) {
+            const float4 v = *reinterpret_cast<const float4*>(wl + 16 * mt * LDW + 16 * q);
+            a[4 * q][mt] = v.x; a[4 * q + 1][mt] = v.y; a[4 * q + 2][mt] = v.z; a[4 * q + 3][mt] = v.w;
+        }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < NS; ++st)

@@ -447,6 +447,44 @@ def test_other_layer_implementations_match_golden_too(name, impl):
         N.check(N.lib().satrans_set_layer_impl(0), "set_layer_impl")
 
 
+@pytest.mark.parametrize("name", ["aliccp_sota", "small_qkv", "small_q", "small_k", "small_none", "small_pos_dense",
+                                  "small_relu", "small_onlyemb", "small_multidomain"])
+def test_eight_wave_backward_kernel_matches_golden_and_the_oracle(name):
+    """The 8-wave backward kernel (csrc/layer_bwd8.hip: two waves per SIMD, split weight-gradient accumulators, recomputed
+    softmax backward), selected explicitly: every gradient against the reference's golden vectors, a ragged batch, and a
+    training-mode step whose counter-based dropout masks are replayed through the oracle."""
+    from satrans_amd import native as N
+    c = Case(name)
+    N.check(N.lib().satrans_set_layer_bwd8(1), "set_layer_bwd8")
+    try:
+        model = build_model(c, DEV)
+        model.compile("adam", "binary_crossentropy")
+        model.eval()
+        eng = model._require_engine()
+        if name != "small_relu":
+            bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+            assert bce == pytest.approx(float(c.z["train/bce"]), rel=2e-6)
+            for k, g in c.arrays("grad").items():
+                scale = max(1e-6, float(np.abs(g).max()))
+                np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
+        for B, train in ((5, False), (c.X.shape[0], True)):
+            model.train(train)
+            X, y = c.X[:B], c.y[:B]
+            bce, reg, grads = eng.loss_and_grads(X.to(DEV), y.to(DEV))
+            m = c.meta
+            drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, len(m["fields"]), m["D"],
+                                                            m["H"], m["L"], 0.1)) if train else None
+            bce_ref, reg_ref, g_ref = O.loss_and_grads(c.tensors("param"), X, y, c.spec(), drop)
+            assert bce == pytest.approx(bce_ref, rel=5e-6)
+            for k, g in g_ref.items():
+                if k in grads:
+                    scale = max(1e-6, float(g.abs().max()))
+                    np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=5e-5 * scale + 1e-9,
+                                               err_msg=f"{k} B={B} train={train}")
+    finally:
+        N.check(N.lib().satrans_set_layer_bwd8(-1), "set_layer_bwd8")
+
+
 def test_fit_predict_at_baseline_config_scale():
     """BASELINE configs[1] through the public API: 50,000 AliCCP-shaped rows (tables capped at 20k rows per field to
     keep the test light), batch 8192 with a partial last batch, shuffle on, verbose=2 (per-step sklearn metrics),

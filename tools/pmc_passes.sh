@@ -7,7 +7,7 @@ out=gpurun_out/pmc
 mkdir -p $out
 run() {  # name, counters...
   name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/$name -o p -- python3 bench.py --steps 4 --warmup 2 --cpu-steps 0 --no-phase-timing < /dev/null > $out/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/$name -o p -- python3 bench.py --steps 4 --warmup 2 --train-only --no-phase-timing < /dev/null > $out/$name.log 2>&1
   echo "$name rc=$?"
 }
 run fetch FETCH_SIZE

@@ -21,5 +21,10 @@ out = {}
 for k, cs in acc.items():
     out[k] = {c: a[0] / a[1] for c, a in cs.items()}
     out[k]["launches"] = max(a[1] for a in cs.values())
+import hashlib
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "satrans_amd", "libsatrans_hip.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
 keep = [k for k in out if "layer_" in k or "gather_rows" in k or "lazy_" in k or "touched" in k or "head_kernel" in k]
-print(json.dumps({k: out[k] for k in sorted(keep)}, indent=1))
+res = {k: out[k] for k in sorted(keep)}
+res["_lib_sha256"] = sha
+print(json.dumps(res, indent=1))

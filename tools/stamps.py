@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-subprocess.run(["touch", os.path.join(ROOT, "satrans_amd/csrc/layer_fused.hip")], check=True)
+subprocess.run(["touch", os.path.join(ROOT, "satrans_amd/csrc/layer_fused_common.h")], check=True)
 subprocess.run(["bash", os.path.join(ROOT, "satrans_amd/csrc/build.sh")], check=True,
                env=dict(os.environ, SATRANS_EXTRA_FLAGS="-DSATRANS_STAMPS"), stdout=subprocess.DEVNULL)
 import atexit  # noqa: E402
@@ -15,7 +15,7 @@ import atexit  # noqa: E402
 
 def _restore():
     """Leave the product library behind, not the instrumented one."""
-    subprocess.run(["touch", os.path.join(ROOT, "satrans_amd/csrc/layer_fused.hip")], check=False)
+    subprocess.run(["touch", os.path.join(ROOT, "satrans_amd/csrc/layer_fused_common.h")], check=False)
     subprocess.run(["bash", os.path.join(ROOT, "satrans_amd/csrc/build.sh")], check=False, stdout=subprocess.DEVNULL)
 
 
@@ -37,10 +37,22 @@ for i in range(2):
     eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
 torch.cuda.synchronize()
 lib.satrans_debug_read_stamps(buf, 1)
+if os.environ.get("SATRANS_BWD8", "1") != "0":
+    lib.satrans_debug_read_stamps8(buf, 1)
 for i in range(2, 4):
     eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
 torch.cuda.synchronize()
 lib.satrans_debug_read_stamps(buf, 0)
+if os.environ.get("SATRANS_BWD8", "1") != "0":
+    lib.satrans_debug_read_stamps8(buf, 0)
+    names8 = ["tile top", "A fwd chain", "B attn fwd", "C out block", "D dWo + softmax bwd", "D write-back", "F round 1 compute",
+              "F round 1 products", "F round 2 compute", "F round 2 products", "F round 3 stores", "F round 3 products + dx",
+              "flush records", "prologue"]
+    vals = [buf[i] for i in range(14)]
+    tot = sum(vals)
+    for n, v in zip(names8, vals):
+        print(f"{n:26s} {v / tot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
+    sys.exit(0)
 names = ["stage weights(scenario)", "A fwd chain", "B attn fwd", "C out block", "D rows", "E cols", "F metanet/proj bwd",
          "rec flush", "prologue"]
 vals = [buf[i] for i in range(9)]
