@@ -95,6 +95,21 @@ int64_t satrans_scenario_table_bwd_ws_floats(int S, int De);
 int satrans_scenario_table_bwd(const float* emb, const float* W, const float* g_tab, int S, int De, int P,
                                float* g_emb, float* g_W, float* g_bias, float* workspace, void* stream);
 
+/* Encoder inputs of the variants (reference satrans.py:203-207 several scenario columns, :167-171,225-234 flag 'pos'):
+ * row (lr * S + s) of E [LR * S, De], lr = 2 * layer + role (role 0 = Q, 1 = K; LR = 2 L with positions, else 1):
+ *   E[.][0:D)  = mean over the C scenario columns of tables[c][index[c * S + s]]   (index == NULL: C = 1, row s itself)
+ *   E[.][D:2D) = lay[layer] + role[role]                                           (lay / role given: De = 2 D)
+ * The table kernels above then run on LR * S rows.  `tables` / `g_tables` / `table_rows` are HOST arrays of C entries
+ * (device pointers / row counts), `index` is a device array [C, S].  The backward ADDS g_E (the g_emb output of
+ * satrans_scenario_table_bwd) into g_tables[c] [rows_c, D], g_lay [L, D] and the first two rows of g_role, in a fixed order. */
+int satrans_scenario_inputs_fwd(const float* const* tables, const int32_t* index, int C, int S, int D, const float* lay,
+                                const float* role, int L, float* E, void* stream);
+int satrans_scenario_inputs_bwd(float* const* g_tables, const int32_t* table_rows, const int32_t* index, int C, int S, int D,
+                                const float* g_E, float* g_lay, float* g_role, int L, void* stream);
+/* flag 'onlyemb' (satrans.py:173-176): tab = relu(emb) elementwise over n = S * P values; backward ADDS into g_emb */
+int satrans_scenario_relu_fwd(const float* emb, int64_t n, float* tab, void* stream);
+int satrans_scenario_relu_bwd(const float* emb, const float* g_tab, int64_t n, float* g_emb, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * One Meta_Transformer_Layer (reference satrans.py:50-100 with MetaNet submodules.py:77-103).
  * The generated MetaNet weights are passed as per-scenario tables (one row per scenario id) instead

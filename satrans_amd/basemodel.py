@@ -500,6 +500,22 @@ class BaseModel(nn.Module):
         pred = self.predict(x, batch_size, y)
         return {name: fn(y, pred) for name, fn in self.metrics.items()}
 
+    def evaluate_domains(self, x, y, batch_size=256, domain_col=None):
+        """The test report of reference main.py:353-374 in one call: predict, overall ROC AUC, one AUC per scenario id of
+        `domain_col` (default: the model's first scenario column) and the test BCE.  The metrics are evaluated on the device
+        (satrans_amd/device_metrics.py, equal to sklearn's), one host read at the end.
+        -> {"auc": float, "domain_auc": {id: float}, "loss": float, "pred": float64 [N,1]}"""
+        from . import device_metrics as DM
+        if domain_col is None:
+            domain_col = self.domain_column_list[0]
+        pred = self.predict(x, batch_size)
+        dev = self.device
+        ids = x[domain_col] if isinstance(x, dict) else self._pack(x)[:, self.feature_index[domain_col][0]]
+        auc, per, loss = DM.per_domain_auc(torch.as_tensor(np.asarray(y, dtype=np.float64)).to(dev),
+                                           torch.from_numpy(pred).to(dev),
+                                           torch.as_tensor(np.asarray(ids).astype(np.int64)).to(dev))
+        return {"auc": auc, "domain_auc": per, "loss": loss, "pred": pred}
+
     def predict(self, x, batch_size=256, y=None, domain_ids=None):
         """float64 [N,1] probabilities; models/meta_basemodel.py:401-517 (without the showattn/instattn
         paper-figure branches)."""

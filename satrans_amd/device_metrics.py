@@ -47,5 +47,23 @@ def accuracy(y: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
     return ((p.reshape(-1) > 0.5).double() == y.double().reshape(-1)).double().mean()
 
 
+def per_domain_auc(y: torch.Tensor, p: torch.Tensor, domain_ids: torch.Tensor):
+    """The evaluation report of reference main.py:355-374 on the device: overall ROC AUC, then one AUC per scenario id from
+    the smallest to the largest id present (`for i in range(ids.min(), ids.max() + 1)`), plus the test loss
+    F.binary_cross_entropy(pred, labels.double()) of main.py:359 (mean; float64, log clamped at -100 as torch does).
+    -> (auc, {id: auc}, loss) as Python floats (one host read at the end of an evaluation; not a per-step metric)."""
+    y, p, ids = y.reshape(-1), p.reshape(-1), domain_ids.reshape(-1).long()
+    overall = roc_auc(y, p)
+    lo, hi = int(ids.min()), int(ids.max())
+    per = {}
+    for i in range(lo, hi + 1):
+        sel = ids == i
+        per[i] = roc_auc(y[sel], p[sel])
+    p64, y64 = p.double(), y.double()
+    loss = -(y64 * torch.log(p64).clamp_min(-100.0) + (1.0 - y64) * torch.log(1.0 - p64).clamp_min(-100.0)).mean()
+    vals = torch.stack([overall, loss] + [per[i] for i in range(lo, hi + 1)]).cpu().tolist()
+    return vals[0], {i: vals[2 + k] for k, i in enumerate(range(lo, hi + 1))}, vals[1]
+
+
 BY_NAME = {"binary_crossentropy": log_loss, "logloss": log_loss, "auc": roc_auc, "mse": mse, "accuracy": accuracy,
            "acc": accuracy}

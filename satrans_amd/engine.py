@@ -74,9 +74,26 @@ class PathEngine:
             self._multi_strides = torch.tensor(strides, dtype=torch.int64, device=self.dev)
         self.pos = 'pos' in flag
         self.onlyemb = 'onlyemb' in flag
-        self.native_tabs = not (self.multi or self.pos or self.onlyemb)   # scenario table by one HIP kernel each way
-        self._tab_ws = torch.empty(int(self.lib.satrans_scenario_table_bwd_ws_floats(self.S, m.domain_embeddings.weight.shape[1])),
-                                   dtype=torch.float32, device=self.dev) if self.native_tabs else None
+        if self.onlyemb and self.pos:
+            raise NotImplementedError("'onlyemb' together with 'pos' (the reference concatenates a width-P embedding with a "
+                                      "width-D position vector there and fails in the layer)")
+        # scenario tables: HIP kernels in every variant (csrc/scenario.hip).  plain = one scenario column, no positions: the
+        # encoder reads the scenario embedding directly; otherwise its input rows E [LR*S, De] are assembled first.
+        self.plain_tabs = not (self.multi or self.pos or self.onlyemb)
+        self.LR = 2 * self.L if self.pos else 1
+        De = (2 if self.pos else 1) * m.domain_embeddings.weight.shape[1]
+        self.De = De
+        if not self.onlyemb:
+            self._tab_ws = torch.empty(int(self.lib.satrans_scenario_table_bwd_ws_floats(self.LR * self.S, De)),
+                                       dtype=torch.float32, device=self.dev)
+        if not self.plain_tabs and not self.onlyemb:
+            self._E = torch.empty(self.LR * self.S, De, dtype=torch.float32, device=self.dev)
+            self._gE = torch.empty_like(self._E)
+            tabs_ = self._multi_tables if self.multi else [m.domain_embeddings]
+            self._scen_tables = tabs_
+            self._scen_ptrs = (C.c_void_p * len(tabs_))(*[t.weight.data_ptr() for t in tabs_])
+            self._scen_rows = (C.c_int32 * len(tabs_))(*[int(t.weight.shape[0]) for t in tabs_])
+            self._scen_index = torch.stack(self._multi_index).to(torch.int32).contiguous() if self.multi else None
         self.flags = 0
         if not self.bilinear and 'Q' in m.meta_mode:       # MetaNet or gate on the queries
             self.flags |= N.META_Q
@@ -233,35 +250,67 @@ class PathEngine:
     def scenario_tables(self, grad: bool) -> torch.Tensor:
         """-> [L, 2, S, P'] when 'pos' is in the flag (role 0 = Q, 1 = K), else [1, 1, S, P']."""
         m = self.m
-        if self.native_tabs:
-            # common case (one scenario column, no 'pos', no 'onlyemb'): one kernel; its backward is one call in backward()
-            lin = m.domain_map_dnn_Q.linears[0]
+        st = self._stream()
+        if self.onlyemb:                                                            # satrans.py:173-176: relu(embedding of width P)
             emb = m.domain_embeddings.weight
             tab = torch.empty(1, 1, self.S, self.P, dtype=torch.float32, device=self.dev)
-            N.check(self.lib.satrans_scenario_table_fwd(emb.data_ptr(), lin.weight.data_ptr(), lin.bias.data_ptr(), self.S,
-                                                        emb.shape[1], self.P, tab.data_ptr(), self._stream()),
-                    "satrans_scenario_table_fwd")
+            N.check(self.lib.satrans_scenario_relu_fwd(emb.data_ptr(), emb.numel(), tab.data_ptr(), st),
+                    "satrans_scenario_relu_fwd")
             return tab
-        with torch.set_grad_enabled(grad):
-            if self.multi:                                                          # satrans.py:205-207
-                emb = torch.stack([t.weight[i] for t, i in zip(self._multi_tables, self._multi_index)], dim=-1).mean(-1)
-            else:
-                emb = m.domain_embeddings.weight
-            dom = torch.relu(emb)                                                   # satrans.py:213
-            if not self.pos:
-                z = dom.unsqueeze(0).unsqueeze(0)
-            else:
-                lay = m.layerid_embeddings.weight                                  # [L, D]
-                role = m.qkvid_embeddings.weight[:2]                                # [2, D]  (the V row is never used)
-                posv = (lay[:, None, :] + role[None, :, :])                         # [L, 2, D]
-                z = torch.relu(torch.cat([dom[None, None].expand(self.L, 2, -1, -1),
-                                          posv[:, :, None, :].expand(-1, -1, self.S, -1)], dim=-1))
-            if self.onlyemb:
-                tab = z
-            else:
-                lin = m.domain_map_dnn_Q.linears[0]
-                tab = torch.nn.functional.linear(z, lin.weight, lin.bias)
-            return tab.contiguous()
+        lin = m.domain_map_dnn_Q.linears[0]
+        if self.plain_tabs:
+            # common case (one scenario column, no 'pos'): one kernel; its backward is one call in backward()
+            emb, rows, De = m.domain_embeddings.weight, self.S, m.domain_embeddings.weight.shape[1]
+            shape = (1, 1, self.S, self.P)
+        else:
+            # several scenario columns (satrans.py:205-207: mean of the columns' rows per id tuple) and / or 'pos'
+            # (:225-234: [scenario | layer id + q/k id] rows, one table per (layer, role)): assemble the encoder's input rows
+            lay = m.layerid_embeddings.weight.data_ptr() if self.pos else None
+            role = m.qkvid_embeddings.weight.data_ptr() if self.pos else None
+            D0 = m.domain_embeddings.weight.shape[1] if not self.multi else self._scen_tables[0].weight.shape[1]
+            N.check(self.lib.satrans_scenario_inputs_fwd(
+                self._scen_ptrs, self._scen_index.data_ptr() if self._scen_index is not None else None,
+                len(self._scen_tables), self.S, D0, lay, role, self.L, self._E.data_ptr(), st), "satrans_scenario_inputs_fwd")
+            emb, rows, De = self._E, self.LR * self.S, self.De
+            shape = (self.L, 2, self.S, self.P) if self.pos else (1, 1, self.S, self.P)
+        tab = torch.empty(shape, dtype=torch.float32, device=self.dev)
+        N.check(self.lib.satrans_scenario_table_fwd(emb.data_ptr(), lin.weight.data_ptr(), lin.bias.data_ptr(), rows, De, self.P,
+                                                    tab.data_ptr(), st), "satrans_scenario_table_fwd")
+        return tab
+
+    def scenario_tables_backward(self, g_tabs: torch.Tensor) -> None:
+        """Gradient of the generated-weight tables -> scenario / position embeddings and the encoder (flat gradient views)."""
+        m, st = self.m, self._stream()
+        if self.onlyemb:
+            emb = m.domain_embeddings.weight
+            N.check(self.lib.satrans_scenario_relu_bwd(emb.data_ptr(), g_tabs.data_ptr(), emb.numel(),
+                                                       self._grad_view("domain_embeddings.weight").data_ptr(), st),
+                    "satrans_scenario_relu_bwd")
+            return
+        lin = m.domain_map_dnn_Q.linears[0]
+        gW = self._grad_view("domain_map_dnn_Q.linears.0.weight").data_ptr()
+        gb = self._grad_view("domain_map_dnn_Q.linears.0.bias").data_ptr()
+        if self.plain_tabs:
+            emb = m.domain_embeddings.weight
+            N.check(self.lib.satrans_scenario_table_bwd(
+                emb.data_ptr(), lin.weight.data_ptr(), g_tabs.data_ptr(), self.S, emb.shape[1], self.P,
+                self._grad_view("domain_embeddings.weight").data_ptr(), gW, gb, self._tab_ws.data_ptr(), st),
+                    "satrans_scenario_table_bwd")
+            return
+        self._gE.zero_()
+        N.check(self.lib.satrans_scenario_table_bwd(
+            self._E.data_ptr(), lin.weight.data_ptr(), g_tabs.data_ptr(), self.LR * self.S, self.De, self.P,
+            self._gE.data_ptr(), gW, gb, self._tab_ws.data_ptr(), st), "satrans_scenario_table_bwd")
+        keys = [f"domain_embedding_dict.{c.embedding_name}.weight" for c in m.domain_feature_columns] if self.multi \
+            else ["domain_embeddings.weight"]
+        g_ptrs = (C.c_void_p * len(keys))(*[self._grad_view(k).data_ptr() for k in keys])
+        D0 = self._scen_tables[0].weight.shape[1]
+        N.check(self.lib.satrans_scenario_inputs_bwd(
+            g_ptrs, self._scen_rows, self._scen_index.data_ptr() if self._scen_index is not None else None,
+            len(keys), self.S, D0, self._gE.data_ptr(),
+            self._grad_view("layerid_embeddings.weight").data_ptr() if self.pos else None,
+            self._grad_view("qkvid_embeddings.weight").data_ptr() if self.pos else None, self.L, st),
+                "satrans_scenario_inputs_bwd")
 
     def _layer_desc(self, ws, l, B, x, tabs, training) -> N.LayerDesc:
         m = self.m
@@ -456,7 +505,7 @@ class PathEngine:
         if training:
             self.drop_step += 1
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
-        tabs = self.scenario_tables(grad=modulated)
+        tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
         self._run_forward(X, ws, training, tabs.detach())
         self._head(X, ws, y)
@@ -481,16 +530,8 @@ class PathEngine:
                     self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
                     self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
             cur = 1 - cur
-        if modulated and self.native_tabs:
-            lin, emb = m.domain_map_dnn_Q.linears[0], m.domain_embeddings.weight
-            N.check(lib.satrans_scenario_table_bwd(
-                emb.data_ptr(), lin.weight.data_ptr(), g_tabs.data_ptr(), self.S, emb.shape[1], self.P,
-                self._grad_view("domain_embeddings.weight").data_ptr(),
-                self._grad_view("domain_map_dnn_Q.linears.0.weight").data_ptr(),
-                self._grad_view("domain_map_dnn_Q.linears.0.bias").data_ptr(), self._tab_ws.data_ptr(), st),
-                    "satrans_scenario_table_bwd")
-        elif modulated:
-            tabs.backward(g_tabs)                              # tiny: [S,P] through one Linear + two embeddings
+        if modulated:
+            self.scenario_tables_backward(g_tabs)
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
 

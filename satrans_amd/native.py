@@ -73,6 +73,11 @@ SIGNATURES = {
     "satrans_scenario_table_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "satrans_scenario_table_bwd_ws_floats": (C.c_int64, [C.c_int, C.c_int]),
     "satrans_scenario_table_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "satrans_scenario_inputs_fwd": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
+    "satrans_scenario_inputs_bwd": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int32), _vp, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                              _vp, C.c_int, _vp]),
+    "satrans_scenario_relu_fwd": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
+    "satrans_scenario_relu_bwd": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "satrans_embed_adam_touched": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64, _vp, _vp,
                                              C.POINTER(AdamHParams), _vp, _vp, C.c_int, _vp]),
     "satrans_embed_adam_untouched": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams),

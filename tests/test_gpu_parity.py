@@ -478,11 +478,54 @@ def test_eight_wave_backward_kernel_matches_golden_and_the_oracle(name):
             assert bce == pytest.approx(bce_ref, rel=5e-6)
             for k, g in g_ref.items():
                 if k in grads:
+                    # (same bounds as test_ragged_batches_gradients_match_the_oracle: with a handful of samples some
+                    # gradients are ~1e-5 and carry ~1e-9 of fp32 cancellation noise in any fp32 evaluation)
                     scale = max(1e-6, float(g.abs().max()))
-                    np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=5e-5 * scale + 1e-9,
+                    np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9,
                                                err_msg=f"{k} B={B} train={train}")
     finally:
         N.check(N.lib().satrans_set_layer_bwd8(-1), "set_layer_bwd8")
+
+
+def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
+    """satrans_amd/device_metrics.py on device tensors (sort + searchsorted on the GPU) against sklearn on host copies - ties
+    and saturated probabilities included - and `evaluate_domains`, the test report of reference main.py:353-374."""
+    from sklearn.metrics import accuracy_score, log_loss, mean_squared_error, roc_auc_score
+    from satrans_amd import device_metrics as DM
+    rng = np.random.RandomState(5)
+    for n, levels in ((32768, None), (8192, 13), (257, 2)):
+        p = rng.rand(n).astype(np.float32)
+        if levels:
+            p = (np.floor(p * levels) / levels).astype(np.float32)
+        p[:4] = [0.0, 1.0, 1e-30, 1 - 1e-7]
+        y = (rng.rand(n) < 0.2).astype(np.float32)
+        dom = rng.randint(0, 4, size=n)
+        yt, pt, dt = torch.from_numpy(y).to(DEV), torch.from_numpy(p).to(DEV), torch.from_numpy(dom).to(DEV)
+        p64 = p.astype("float64")
+        assert float(DM.log_loss(yt, pt)) == pytest.approx(log_loss(y, p64), rel=1e-12)
+        assert float(DM.roc_auc(yt, pt)) == pytest.approx(roc_auc_score(y, p64), rel=1e-12, abs=1e-15)
+        assert float(DM.mse(yt, pt)) == pytest.approx(mean_squared_error(y, p64), rel=1e-12)
+        assert float(DM.accuracy(yt, pt)) == pytest.approx(accuracy_score(y, np.where(p64 > 0.5, 1, 0)), rel=1e-12)
+        auc, per, loss = DM.per_domain_auc(yt, pt, dt)
+        assert auc == pytest.approx(roc_auc_score(y, p64), rel=1e-12)
+        for i in range(4):
+            assert per[i] == pytest.approx(roc_auc_score(y[dom == i], p64[dom == i]), rel=1e-12, abs=1e-15)
+    c = Case("aliccp_sota")
+    model = build_model(c, DEV)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    names = c.meta["feature_names"]
+    x = {nm: c.z[f"fit/x/{nm}"] for nm in names}
+    y = c.z["fit/y"]
+    rep = model.evaluate_domains(x, y, batch_size=64)
+    pred = model.predict(x, 64)
+    assert np.array_equal(rep["pred"], pred)
+    assert rep["auc"] == pytest.approx(roc_auc_score(y, pred), rel=1e-12)
+    ids = np.asarray(x[c.meta["domain"][0]])
+    assert sorted(rep["domain_auc"]) == list(range(ids.min(), ids.max() + 1))
+    for i, v in rep["domain_auc"].items():
+        assert v == pytest.approx(roc_auc_score(y[ids == i], pred[ids == i]), rel=1e-12)
+    want = torch.nn.functional.binary_cross_entropy(torch.tensor(pred).squeeze(), torch.tensor(y).double()).item()
+    assert rep["loss"] == pytest.approx(want, rel=1e-10)
 
 
 def test_fit_predict_at_baseline_config_scale():

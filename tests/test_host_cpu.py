@@ -137,3 +137,12 @@ def test_device_metrics_equal_sklearn():
         assert float(DM.roc_auc(yt, pt)) == pytest.approx(roc_auc_score(y, p64), rel=1e-12, abs=1e-15)
         assert float(DM.mse(yt, pt)) == pytest.approx(mean_squared_error(y, p64), rel=1e-12)
         assert float(DM.accuracy(yt, pt)) == pytest.approx(accuracy_score(y, np.where(p64 > 0.5, 1, 0)), rel=1e-12)
+        # the per-scenario report of reference main.py:355-374
+        dom = rng.randint(1, 4, size=len(y))
+        auc, per, loss = DM.per_domain_auc(yt, pt, torch.from_numpy(dom))
+        assert auc == pytest.approx(roc_auc_score(y, p64), rel=1e-12)
+        assert sorted(per) == [1, 2, 3]
+        for i in per:
+            assert per[i] == pytest.approx(roc_auc_score(y[dom == i], p64[dom == i]), rel=1e-12, abs=1e-15)
+        want = torch.nn.functional.binary_cross_entropy(torch.tensor(p64), torch.tensor(y).double()).item()
+        assert loss == pytest.approx(want, rel=1e-12)
