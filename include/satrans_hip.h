@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SATRANS_ABI_VERSION 2
+#define SATRANS_ABI_VERSION 3
 
 /* error codes */
 #define SATRANS_OK 0
@@ -134,6 +134,10 @@ typedef struct satrans_layer_desc {
     const float *ln_g, *ln_b;               /* layer_norm                                            */
     const float *lnq_g, *lnq_b, *lnk_g, *lnk_b; /* Q_/K_meta_mlp.ffn_layer_norm                      */
     const float *tab_q, *tab_k;             /* [S, >=P]                                              */
+    const int32_t* x_rows; /* NULL, or [B,F] row numbers (the `rows` output of satrans_gather_fwd): the layer then   *
+                            * reads token (b,f) from x + x_rows[b*F+f]*D, i.e. `x` is the embedding arena and the    *
+                            * gather is fused into the first layer (meta_basemodel.py:533-535 + satrans.py:211 never *
+                            * materialise [B,F,D]); forward and backward alike                                       */
 } satrans_layer_desc;
 
 /* Which implementation evaluates satrans_layer_fwd/_bwd (process-wide; initial value from SATRANS_LAYER_IMPL):

@@ -40,6 +40,13 @@ __device__ __forceinline__ int64_t load_id(const void* X, int id_dtype, int64_t 
     return ((const int64_t*)X)[at];
 }
 
+// Row (sample b, field f) of a layer's input: the [B,F,D] activation, or - gather fused into the first layer - the arena
+// row of that id.
+__device__ __forceinline__ const float* layer_x_row(const satrans_layer_desc& a, int b, int f, int F, int D) {
+    const size_t at = (size_t)b * F + f;
+    return a.x_rows ? a.x + (size_t)a.x_rows[at] * D : a.x + at * D;
+}
+
 // Dense (float) column of X.  Integer id matrices carry no dense columns.
 __device__ __forceinline__ float load_dense(const void* X, int64_t x_stride, int64_t b, int col) {
     return ((const float*)X)[b * x_stride + col];

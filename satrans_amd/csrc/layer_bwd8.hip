@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
           const int first_ = lo + tile_ * Tsamp;
           const bool valid_ = tok < min(Tsamp, hi - first_) * F;
           b_next = a.order[first_ + (valid_ ? ls_tok : 0)];
-          load_frag<KT>(a.x + ((size_t)b_next * F + (valid_ ? f_tok : 0)) * D + g4, x_next, valid_);
+          load_frag<KT>(layer_x_row(a, b_next, valid_ ? f_tok : 0, F, D) + g4, x_next, valid_);
       };
       fetch_tile(t0);
       for (int tile = t0; tile < t1; ++tile) {
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
         // ================= phase C: output block forward + backward ======================================================
         {
             float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4], x[KT][4];
-            load_frag<KT>(a.x + grow, x, valid);              // (L1 / L2 hits: phase A read these rows)
+            load_frag<KT>(layer_x_row(a, b, f, F, D) + g4, x, valid);       // (L1 / L2 hits: phase A read these rows)
             load_frag<KT>(dy + grow, gy, valid);
             load_frag<KT>(so + my, o);
             chain<KT, KT, LD>(woT + lo_d, o, u);
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
         // A wave only ever writes its OWN 16 rows; the split products read all 128 rows, hence the barriers.
         {
             float gq[KT][4], gk[KT][4], x[KT][4];
-            load_frag<KT>(a.x + grow, x, valid);
+            load_frag<KT>(layer_x_row(a, b, f, F, D) + g4, x, valid);
             load_frag<KT>(x1 + my, gq, valid);      // gradient of the (post-MetaNet) queries
             load_frag<KT>(sk + my, gk, valid);      // ... keys
             {   // dx so far: dr + gv Wv^T   (rows >= ntok of sv still hold forward values: masked here, and neutralised by

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             const bool valid = tok < ntok;
             const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
             const int b = samp[ls];
-            const float* xrow = a.x + ((size_t)b * F + f) * D + g4;
+            const float* xrow = layer_x_row(a, b, f, F, D) + g4;
             float x[KT][4], q[KT][4], k[KT][4], v[KT][4];
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 o[t][0] = ov.x; o[t][1] = ov.y; o[t][2] = ov.z; o[t][3] = ov.w;
             }
             chain<KT, KT, LD>(wo_l, o, u);
-            const float* xrow = a.x + ((size_t)b * F + f) * D + g4;
+            const float* xrow = layer_x_row(a, b, f, F, D) + g4;
             const uint32_t skey = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
             const uint32_t kb = dc.on ? token_keep_bits<KT>(skey, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
 #pragma unroll
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
           const bool valid_ = has_ && tok < ntok_;
           const int ls_ = valid_ ? ls_tok : 0, f_ = valid_ ? f_tok : 0;
           b_next = a.order[first_ + ls_];
-          if (has_) load_frag<KT>(a.x + ((size_t)b_next * F + f_) * D + g4, x_next);
+          if (has_) load_frag<KT>(layer_x_row(a, b_next, f_, F, D) + g4, x_next);
       };
       fetch_tile(t0);
       for (int tile = t0; tile < t1; ++tile) {

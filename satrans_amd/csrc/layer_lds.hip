@@ -210,7 +210,7 @@ __device__ void forward_tile(const satrans_layer_desc& a, const TileDims& T, int
     for (int i = threadIdx.x; i < ntok * D; i += blockDim.x) {
         const int t = i / D, c = i - t * D;
         const int ls = t / F, f = t - ls * F;
-        L.x[(size_t)t * L.ldd + c] = a.x[((size_t)samp[ls] * F + f) * D + c];
+        L.x[(size_t)t * L.ldd + c] = layer_x_row(a, samp[ls], f, F, D)[c];
     }
     const int ld3 = 3 * D + L.wp;
     for (int i = threadIdx.x; i < D * D; i += blockDim.x) {

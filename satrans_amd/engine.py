@@ -154,6 +154,9 @@ class PathEngine:
         # replayed - same arithmetic, same result bit for bit - when a row is next gathered, or for all rows by
         # flush_lazy() (epoch end, before predict / state_dict).  SATRANS_LAZY_ADAM=0: streaming kernel every step.
         self.lazy = os.environ.get("SATRANS_LAZY_ADAM", "1") != "0"
+        # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
+        # standalone gather kernel + activation buffer, as in round 1
+        self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
         # SATRANS_SPLIT_TABLES=1: use the small/large table classes of the multi-rank step on a single rank too (tests)
         self.force_split = os.environ.get("SATRANS_SPLIT_TABLES", "0") == "1"
         self.last_step = None            # [R] int32: last Adam step applied to every table row
@@ -312,7 +315,7 @@ class PathEngine:
             self._grad_view("qkvid_embeddings.weight").data_ptr() if self.pos else None, self.L, st),
                 "satrans_scenario_inputs_bwd")
 
-    def _layer_desc(self, ws, l, B, x, tabs, training) -> N.LayerDesc:
+    def _layer_desc(self, ws, l, B, x, tabs, training, fuse=False) -> N.LayerDesc:
         m = self.m
         lay = m.domain_int_layers[l]
         d = N.LayerDesc()
@@ -322,6 +325,11 @@ class PathEngine:
         d.drop_p = self.drop_p
         d.seed, d.step = self.drop_seed, self.drop_step & 0xFFFFFFFF
         d.x = N.ptr(x) if x is not None else ws["acts"][l].data_ptr()
+        d.x_rows = None
+        if fuse and l == 0:
+            # gather fused into the first layer: token (b, f) is read straight from the embedding arena through the row
+            # numbers the rows-only gather launch left in ws["rows"]; [B,F,D] is never written nor read back
+            d.x, d.x_rows = self.m.embedding_arena.data_ptr(), ws["rows"].data_ptr()
         d.sid, d.order, d.seg = ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr()
         d.w_query, d.w_key, d.w_value = lay.W_Query.data_ptr(), lay.W_Key.data_ptr(), lay.W_Value.data_ptr()
         d.w_out = lay.Out_linear.weight.data_ptr()
@@ -357,7 +365,7 @@ class PathEngine:
             raise NotImplementedError("integer id matrix together with dense features")
         return X
 
-    def _run_forward(self, X, ws, training, tabs, att_list=None):
+    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         sx, sidt, sstride, scol = X, idt, X.stride(0), self.dom_col
@@ -368,13 +376,17 @@ class PathEngine:
                                              ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr(),
                                              self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
                 "satrans_bucket_scenarios")
-        with self.phase("gather_fwd"):
-            N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
-                                           self.cols.data_ptr(), X.data_ptr(), idt, X.stride(0), B, self.F, self.D,
-                                           ws["acts"][0].data_ptr(), ws["rows"].data_ptr(), self.status.data_ptr(), st),
-                    "satrans_gather_fwd")
+        fuse = self.fuse_gather
+        ws["acts0_of"] = None if fuse else X
+        if not (fuse and rows_ready):
+            with self.phase("gather_fwd"):
+                N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
+                                               self.cols.data_ptr(), X.data_ptr(), idt, X.stride(0), B, self.F, self.D,
+                                               None if fuse else ws["acts"][0].data_ptr(), ws["rows"].data_ptr(),
+                                               self.status.data_ptr(), st), "satrans_gather_fwd")
+        self._last_X = X
         for l in range(self.L):
-            desc = self._layer_desc(ws, l, B, None, tabs, training)
+            desc = self._layer_desc(ws, l, B, None, tabs, training, fuse)
             att = att_list[l].data_ptr() if att_list is not None else None
             with self.phase("layer_fwd"):
                 N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
@@ -424,8 +436,17 @@ class PathEngine:
         return self._last_logit.clone().unsqueeze(1)
 
     def layer_outputs(self, B: int) -> List[torch.Tensor]:
-        """[att_input, layer 0 output, ...] of the most recent forward at this batch size (tests)."""
-        return [a.clone() for a in self._ws[B]["acts"]]
+        """[att_input, layer 0 output, ...] of the most recent forward at this batch size (tests, attention dumps).  With the
+        gather fused into the first layer `att_input` was never materialised: the standalone gather kernel writes it now."""
+        ws = self._ws[B]
+        if ws.get("acts0_of") is None:
+            X = self._last_X
+            N.check(self.lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
+                                                self.cols.data_ptr(), X.data_ptr(), N.id_dtype_of(X), X.stride(0), B, self.F,
+                                                self.D, ws["acts"][0].data_ptr(), ws["rows"].data_ptr(),
+                                                self.status.data_ptr(), self._stream()), "satrans_gather_fwd")
+            ws["acts0_of"] = X
+        return [a.clone() for a in ws["acts"]]
 
     def raise_if_bad_ids(self):
         if int(self.status.item()) != 0:
@@ -495,7 +516,7 @@ class PathEngine:
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
         return h
 
-    def backward(self, X, y, ws):
+    def backward(self, X, y, ws, rows_ready=False):
         """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
         `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
         lib, B, st = self.lib, X.shape[0], self._stream()
@@ -507,11 +528,11 @@ class PathEngine:
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
         tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
-        self._run_forward(X, ws, training, tabs.detach())
+        self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready)
         self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
-            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training)
+            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather)
             lay = f"domain_int_layers.{l}."
             gq = gk = glnq = glnk = None
             if modulated:
@@ -627,7 +648,7 @@ class PathEngine:
                     side_done.record(self._side)
 
         # ---- 4. forward, loss, backward ---------------------------------------------------------------------------------
-        gemb = self.backward(X, y, ws)
+        gemb = self.backward(X, y, ws, rows_ready=True)
 
         # ---- 5. small tables: ordered segmented sums into the dense gradient at the tail of the flat gradient buffer -----------
         if n_s > 0:

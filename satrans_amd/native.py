@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsatrans_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ID_F32, ID_I32, ID_I64 = 0, 1, 2
 META_Q, META_K, RELU_OUT, NO_RES, TRAIN, GATE, BILINEAR = 1, 2, 4, 8, 16, 32, 64
@@ -37,6 +37,7 @@ class LayerDesc(C.Structure):
         ("ln_g", _vp), ("ln_b", _vp),
         ("lnq_g", _vp), ("lnq_b", _vp), ("lnk_g", _vp), ("lnk_b", _vp),
         ("tab_q", _vp), ("tab_k", _vp),
+        ("x_rows", _vp),
     ]
 
 
