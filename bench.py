@@ -154,7 +154,28 @@ def gather_microbench(eng, Xd, B, F, D, launches=48):
         ms = e0.elapsed_time(e1) / launches
         gbs = nb * F * (2 * D * 4 + 4) / 1e9 / (ms / 1e3)
         rd = nb * F * (D * 4 + 4) / 1e9 / (ms / 1e3)           # READ bytes only: F * (D * 4 + 4) = 2,508 B per sample
-        out[f"batch_{nb}"] = {"ms_per_launch": round(ms, 4), "read_GBps": round(rd, 1), "read_frac_of_peak": round(rd / HBM_PEAK_GBS, 4),
+        # the read side alone, as the first layer sees it with the gather fused in: rows by row number, nothing written
+        sink = torch.empty(int(eng.lib.satrans_gather_read_probe_floats()), dtype=torch.float32, device=Xd.device)
+        # a different set of uniformly random arena rows for EVERY launch (48 launches x nb*F rows x 128 B = several GB: no
+        # row is served from the 256 MiB Infinity Cache because an earlier launch touched it)
+        total = eng.m.embedding_arena.shape[0]
+        row_sets = torch.randint(0, total, (launches + 4, nb * F), dtype=torch.int32, device=Xd.device)
+
+        def probe(i):
+            N.check(eng.lib.satrans_gather_read_probe(eng.m.embedding_arena.data_ptr(), row_sets[i % row_sets.shape[0]].data_ptr(),
+                                                      nb * F, D, sink.data_ptr(), stream), "satrans_gather_read_probe")
+        for i in range(4):
+            probe(launches + i)
+        e0.record()
+        for i in range(launches):
+            probe(i)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_r = e0.elapsed_time(e1) / launches
+        rd_only = nb * F * (D * 4 + 4) / 1e9 / (ms_r / 1e3)
+        out[f"batch_{nb}"] = {"read_only_ms_per_launch": round(ms_r, 4), "read_only_GBps": round(rd_only, 1),
+                              "read_only_frac_of_peak": round(rd_only / HBM_PEAK_GBS, 4),
+                              "ms_per_launch": round(ms, 4), "read_GBps": round(rd, 1), "read_frac_of_peak": round(rd / HBM_PEAK_GBS, 4),
                               "read_plus_write_GBps": round(gbs, 1), "read_plus_write_frac": round(gbs / HBM_PEAK_GBS, 4),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "distinct_id_batches": n_batches}
     return out
@@ -361,6 +382,43 @@ def main():
     except Exception as ex:
         print(f"[bench] forward-only timing skipped: {ex}", file=sys.stderr)
 
+    # ---- the same evaluation forward with the dense products on the bf16 matrix pipe (BASELINE configs[1] "bf16 forward"):
+    #      its own line, never the headline; logit error against the fp32 kernels on the same inputs ---------------------------
+    forward_bf16 = None
+    try:
+        if args.train_only:
+            raise RuntimeError("--train-only")
+        model.eval()
+        nb = min(4 * B, Xd.shape[0])
+        model(Xd[:2048])
+        l32 = eng.last_logit().clone()
+        model.set_forward_precision("bf16")
+        model(Xd[:2048])
+        lb16 = eng.last_logit().clone()
+        for _ in range(3):
+            eng.forward(Xd[:nb])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for i in range(reps):
+            lo = (i * nb) % max(1, Xd.shape[0] - nb + 1)
+            eng.forward(Xd[lo:lo + nb])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        forward_bf16 = {"dtype": "bf16", "batch": nb, "ms_per_batch": round(ms, 4), "samples_per_s": round(nb / (ms / 1e3), 1),
+                        "logit_max_abs_err_vs_fp32_kernels": float((lb16 - l32).abs().max()),
+                        "note": "evaluation forward only; products bf16 x bf16 -> fp32 (v_mfma_f32_16x16x32_bf16), LayerNorm / "
+                                "softmax / attention dots fp32; training stays fp32"}
+        model.set_forward_precision("fp32")
+        model.train()
+    except Exception as ex:
+        print(f"[bench] bf16 forward timing skipped: {ex}", file=sys.stderr)
+        try:
+            model.set_forward_precision("fp32")
+        except Exception:
+            pass
+
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = None
     try:
@@ -405,7 +463,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
         "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
-        "forward_only": forward_only, "cpu_baseline": cpu,
+        "forward_only": forward_only, "forward_only_bf16": forward_bf16, "cpu_baseline": cpu,
         "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "collectives": collectives,
     }
     print(json.dumps(out))

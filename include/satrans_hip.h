@@ -83,6 +83,12 @@ int satrans_gather_fwd(const float* arena, const int64_t* row_span, const int32_
                        int id_dtype, int64_t x_stride, int B, int F, int D, float* out,
                        int32_t* rows_out, int32_t* status, void* stream);
 
+/* Measurement aid (bench.py): the READ side of the gather alone - arena rows by row number (the `rows_out` of
+ * satrans_gather_fwd), eight rows in flight per thread, nothing written but a checksum per thread into `sink`
+ * (satrans_gather_read_probe_floats() floats).  This is the access pattern of the first layer with the gather fused in. */
+int64_t satrans_gather_read_probe_floats(void);
+int satrans_gather_read_probe(const float* arena, const int32_t* rows, int64_t n_rows, int D, float* sink, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-scenario generated weights (reference satrans.py:213,217-218; encoder = DNN_v2 with one Linear,
  * submodules.py:31-61): tab[s] = relu(emb[s]) @ W^T + bias for the S scenario rows (not per sample), and its backward.
@@ -156,6 +162,14 @@ int satrans_set_layer_bwd8(int on);
 
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);
+
+/* Evaluation forward of one layer with the dense products on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, fp32
+ * accumulation; LayerNorm, softmax and the attention dot products in fp32; weights rounded to bf16 once per workgroup while
+ * they are staged into LDS).  BASELINE.json configs[1] "bf16 forward": predict / evaluate only - no dropout (SATRANS_TRAIN
+ * must be clear), no attention capture; results differ from satrans_layer_fwd by bf16 rounding (~1e-2 on the logits).
+ * Built for (D,U,H) = (32,64,4) and (64,128,4). */
+int satrans_layer_fwd_bf16_supported(const satrans_layer_desc* d);
+int satrans_layer_fwd_bf16(const satrans_layer_desc* d, float* y, void* stream);
 
 /* Backward of one layer.  Recomputes the forward from d->x (same dropout counters), so nothing but
  * the layer input is kept between the passes.

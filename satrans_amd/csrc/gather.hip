@@ -191,3 +191,58 @@ extern "C" int satrans_gather_fwd(const float* arena, const int64_t* row_span, c
     SATRANS_CHECK_LAUNCH("gather_rows_kernel");
     return SATRANS_OK;
 }
+
+// ---- measurement aid: the gather's READ side alone -----------------------------------------------------------------
+// With the gather fused into the first layer no kernel writes [B,F,D]; what the fused consumer sees is this access pattern:
+// arena rows by row number, D/4 lanes x 16 bytes per row, eight independent rows in flight per thread, nothing written but
+// one checksum per thread.  bench.py times it to report the achieved HBM READ rate of the gather against the chip's peak
+// (the copy kernel above can never exceed half of its own traffic in reads).
+namespace satrans {
+template <int LPR>
+__global__ __launch_bounds__(kGatherBlock) void gather_read_kernel(const float4* __restrict__ arena,
+                                                                 const int32_t* __restrict__ rows, int64_t n_rows,
+                                                                 float* __restrict__ sink) {
+    constexpr int R = 8;
+    const int64_t tid = (int64_t)blockIdx.x * kGatherBlock + threadIdx.x;
+    const int64_t slot0 = tid / LPR;
+    const int q = (int)(tid % LPR);
+    const int64_t stride = (int64_t)gridDim.x * kGatherBlock / LPR;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t base = slot0; base < n_rows; base += stride * R) {
+        int32_t row[R];
+        float4 val[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t slot = base + r * stride;
+            row[r] = slot < n_rows ? rows[slot] : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) val[r] = row[r] >= 0 ? arena[(int64_t)row[r] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc.x += val[r].x; acc.y += val[r].y; acc.z += val[r].z; acc.w += val[r].w; }
+    }
+    sink[tid] = (acc.x + acc.y) + (acc.z + acc.w);
+}
+}  // namespace satrans
+
+extern "C" int64_t satrans_gather_read_probe_floats(void) { return (int64_t)256 * 8 * satrans::kGatherBlock; }
+
+extern "C" int satrans_gather_read_probe(const float* arena, const int32_t* rows, int64_t n_rows, int D, float* sink,
+                                         void* stream_) {
+    using namespace satrans;
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(arena && rows && sink && n_rows > 0, SATRANS_E_BADARG, "gather_read_probe: bad arguments");
+    SATRANS_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128, SATRANS_E_UNSUPPORTED, "gather_read_probe: embedding_dim %d", D);
+    const int lpr = D / 4;
+    int64_t blocks = ceil_div(ceil_div(n_rows, 8) * lpr, kGatherBlock);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    switch (lpr) {
+        case 4: gather_read_kernel<4><<<(unsigned)blocks, kGatherBlock, 0, stream>>>((const float4*)arena, rows, n_rows, sink); break;
+        case 8: gather_read_kernel<8><<<(unsigned)blocks, kGatherBlock, 0, stream>>>((const float4*)arena, rows, n_rows, sink); break;
+        case 16: gather_read_kernel<16><<<(unsigned)blocks, kGatherBlock, 0, stream>>>((const float4*)arena, rows, n_rows, sink); break;
+        default: gather_read_kernel<32><<<(unsigned)blocks, kGatherBlock, 0, stream>>>((const float4*)arena, rows, n_rows, sink); break;
+    }
+    SATRANS_CHECK_LAUNCH("gather_read_kernel");
+    return SATRANS_OK;
+}

@@ -157,6 +157,10 @@ class PathEngine:
         # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
         # standalone gather kernel + activation buffer, as in round 1
         self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
+        # evaluation forwards (predict / evaluate / model.eval()(X)) with the dense products in bf16 on the matrix pipe
+        # (csrc/layer_fwd_bf16.hip; BASELINE.json configs[1]).  Off by default: fp32 is the parity path.  Also
+        # model.set_forward_precision("bf16" | "fp32").
+        self.fwd_bf16 = os.environ.get("SATRANS_FWD_BF16", "0") == "1"
         # SATRANS_SPLIT_TABLES=1: use the small/large table classes of the multi-rank step on a single rank too (tests)
         self.force_split = os.environ.get("SATRANS_SPLIT_TABLES", "0") == "1"
         self.last_step = None            # [R] int32: last Adam step applied to every table row
@@ -389,7 +393,10 @@ class PathEngine:
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse)
             att = att_list[l].data_ptr() if att_list is not None else None
             with self.phase("layer_fwd"):
-                N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
+                if self.fwd_bf16 and not training and att is None and lib.satrans_layer_fwd_bf16_supported(C.byref(desc)):
+                    N.check(lib.satrans_layer_fwd_bf16(C.byref(desc), ws["acts"][l + 1].data_ptr(), st), "satrans_layer_fwd_bf16")
+                else:
+                    N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
 
     def _head(self, X, ws, y=None, train_ws=None):
         lib, B, st = self.lib, X.shape[0], self._stream()

@@ -193,6 +193,13 @@ class SATrans(BaseModel):
                 self._pending_opt_state = None
         return self._engine
 
+    def set_forward_precision(self, precision: str) -> None:
+        """"fp32" (default, the parity path) or "bf16": evaluation forwards (predict / evaluate / eval-mode calls) then run
+        their dense products on the bf16 matrix pipe with fp32 accumulation (BASELINE.json configs[1]); training is always fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._require_engine().fwd_bf16 = precision == "bf16"
+
     def forward(self, X):
         """X: FloatTensor [B, C] in `feature_index` column order -> probabilities [B, 1]
         (reference models/satrans.py:197-256).  Dropout is applied when the module is in training mode."""
