@@ -171,6 +171,24 @@ int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* s
 int satrans_layer_fwd_bf16_supported(const satrans_layer_desc* d);
 int satrans_layer_fwd_bf16(const satrans_layer_desc* d, float* y, void* stream);
 
+/* General path for shapes the fused kernels are not built for (csrc/layer_generic.hip; first of all BASELINE configs[4]:
+ * 64 fields, embedding_dim 64, MetaNet hidden 128): a layer as a short sequence of grouped f32-MFMA GEMM, LayerNorm and
+ * attention launches over token rows kept in HBM in scenario-sorted order.  The forward SAVES its activations in `saved`
+ * (satrans_layer_generic_saved_floats floats, one buffer per layer between forward and backward); the backward reads them and
+ * uses `scratch` (satrans_layer_generic_scratch_floats floats, shared by all layers).  Arguments otherwise as
+ * satrans_layer_fwd / satrans_layer_bwd (gradients ACCUMULATED in a fixed order; x_rows honoured).  Supported: no gate /
+ * bilinear, D in {16,32,64,128}, head dimension 8 or 16, U a multiple of 16 with D*U <= 8192.
+ * satrans_set_generic_attention: attention arm of the forward - 0 automatic, 1 one lane per query row ("wavefront"),
+ * 2 MFMA (F <= 64, head dimension 16), -1 back to SATRANS_GENERIC_ATTN / automatic. */
+int satrans_layer_generic_supported(const satrans_layer_desc* d);
+int64_t satrans_layer_generic_saved_floats(const satrans_layer_desc* d);
+int64_t satrans_layer_generic_scratch_floats(const satrans_layer_desc* d);
+int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, float* att, float* saved, void* stream);
+int satrans_layer_bwd_generic(const satrans_layer_desc* d, const float* dy, float* dx, const float* saved, float* scratch,
+                              float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk,
+                              float* g_tab_q, float* g_tab_k, void* stream);
+int satrans_set_generic_attention(int mode);
+
 /* Backward of one layer.  Recomputes the forward from d->x (same dropout counters), so nothing but
  * the layer input is kept between the passes.
  *   dy        [B,F,D] gradient of the layer output

@@ -74,6 +74,11 @@ def make_case(name):
         'small_pos_dense': dict(small, flag='sota-pos', dense=['price', 'age']),
         'small_d64': dict(small, D=64, H=4, L=1, units=(16, 64), B=24),
         'small_multidomain': dict(small, domain=['dom', 'f2']),
+        # the shape class of BASELINE configs[4] (embedding_dim 64, MetaNet hidden 128, more fields than one 32-key chunk):
+        # 40 fields, units (128, 64) - served by the general layer path (csrc/layer_generic.hip)
+        'small_d64_u128': dict(small, fields=[f'g{i}' for i in range(39)] + ['dom'],
+                               maxima=dict({f'g{i}': 2 + (5 * i) % 11 for i in range(39)}, dom=3),
+                               D=64, H=4, L=2, units=(128, 64), B=24, save_adam=False),   # (its encoder weight alone is 4 MB)
     }
     return cases[name], list(cases)
 
@@ -208,7 +213,7 @@ def run_case(name, outdir):
                     seen.add(p.data_ptr())
                     out[f"grad/{k}"] = p.grad.detach().numpy().copy()
         optim.step()
-    if cfg['train']:
+    if cfg['train'] and cfg.get('save_adam', True):
         pack_state(model, "adam", out)
         # torch.optim.Adam's own state after those steps: well-conditioned where the parameters are not (a parameter
         # element with |g| ~ eps moves by up to lr per step whatever its moments' last bits are), so these pin the
@@ -243,7 +248,8 @@ def run_case(name, outdir):
     meta = dict(name=name, fields=cfg['fields'], vocab=[vocab[f] for f in cfg['fields']], dense=cfg['dense'],
                 domain=cfg['domain'], num_domains_list=[int(v) for v in num_domains_list], D=cfg['D'], H=cfg['H'],
                 L=cfg['L'], units=list(cfg['units']), flag=cfg['flag'], mode=cfg['mode'], lr=cfg['lr'],
-                seed=cfg['seed'], adam_steps=cfg['adam_steps'] if cfg['train'] else 0, feature_names=names,
+                seed=cfg['seed'], adam_steps=cfg['adam_steps'] if cfg['train'] and cfg.get('save_adam', True) else 0,
+                feature_names=names,
                 torch=torch.__version__)
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(outdir, f"{name}.npz")

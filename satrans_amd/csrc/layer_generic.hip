@@ -1,0 +1,934 @@
+// Meta_Transformer_Layer forward and backward for shapes the fused kernels are not built for - first of all BASELINE
+// configs[4]: 64 fields, embedding_dim 64, MetaNet hidden 128 (generated row 16,384 floats), where the weights alone
+// (138 KB fp32) leave no room in LDS for a token tile.  Reference: models/satrans.py:50-100, models/submodules.py:77-103.
+//
+// Unfused: a layer is a short sequence of launches over token rows kept in HBM in SCENARIO-SORTED sample order (position p
+// holds sample order[p]; a scenario's tokens are one contiguous row range, so a product with that scenario's generated
+// weights is a grouped GEMM):
+//     permute-in -> {q0,k0,v} = x W            (one batched f32-MFMA GEMM)
+//                -> per role: h = relu(z W1[s]), m = h W2[s] (grouped GEMMs), q = LN(drop(m) + z)
+//                -> attention per (sample, head): MFMA kernel (F <= 64, d = 16) or one lane per query row ("wavefront")
+//                -> u = o Wo^T -> y = LN(drop(u) + x), written back in the caller's sample order
+// and the backward mirrors it with the forward activations SAVED (288 GB of HBM: 14 token-row buffers per layer) instead of
+// recomputed; weight gradients are token-contraction GEMMs (split over row chunks, partials summed in a fixed order: no
+// float atomics, bitwise reproducible).  At D = 64 the arithmetic intensity of these K = 64 / 128 products is ~40 MAC per
+// float moved, so the path is HBM-bound by construction (~45 token-row buffers read or written per layer and direction); it
+// is the general, correct path, the fused kernels remain the fast one for the shapes they cover.
+#include "layer_fused_common.h"
+
+namespace satrans {
+
+constexpr int kGM = 128, kGN = 64, kGK = 16;      // GEMM workgroup tile
+constexpr int kTnRows = 512;                        // token rows per workgroup of a weight-gradient product
+
+struct GemmBatch {      // blockIdx.z selects one of up to three products that share shapes (q0 / k0 / v)
+    const float* A[3];
+    const float* B[3];
+    float* C[3];
+};
+
+// C[m][n] (op)= sum_k A[m][k] B(k, n) over the rows of one segment.  Segment s = rows [seg[s] F, seg[s+1] F) and takes
+// B + s * b_seg_stride (seg == nullptr: one segment of M rows).  TRANSB: B(k, n) = B[n * ldb + k], else B[k * ldb + n].
+// EPI: 0 store, 1 relu then store, 2 C += acc, 3 store where mask[m][n] > 0 else 0 (relu backward).
+template <bool TRANSB, int EPI>
+__global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32_t* __restrict__ seg, int M, int F, int K, int N,
+                                                     int lda, int ldb, int ldc, int64_t b_seg_stride,
+                                                     const float* __restrict__ mask) {
+    __shared__ float As[kGK][kGM + 16];
+    __shared__ float Bs[kGK][kGN + 16];
+    const int s = blockIdx.y;
+    const int n_tiles = (N + kGN - 1) / kGN;
+    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+    const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
+    const int64_t row0 = r_lo + (int64_t)mt * kGM;
+    if (row0 >= r_hi) return;
+    const int n0 = nt * kGN;
+    const float* __restrict__ A = gb.A[blockIdx.z];
+    const float* __restrict__ B = gb.B[blockIdx.z] + (size_t)s * b_seg_stride;
+    float* __restrict__ C = gb.C[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += kGK) {
+        {   // A tile: 128 rows x 16 k, transposed into As[k][row]
+            const int r = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int64_t row = row0 + r + 64 * pass;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < r_hi) v = *reinterpret_cast<const float4*>(A + row * lda + k0 + kq);
+                As[kq][r + 64 * pass] = v.x; As[kq + 1][r + 64 * pass] = v.y;
+                As[kq + 2][r + 64 * pass] = v.z; As[kq + 3][r + 64 * pass] = v.w;
+            }
+        }
+        if constexpr (!TRANSB) {
+            const int k = tid >> 4, n4 = (tid & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + n4 < N) v = *reinterpret_cast<const float4*>(B + (size_t)(k0 + k) * ldb + n0 + n4);
+            *reinterpret_cast<float4*>(&Bs[k][n4]) = v;
+        } else {
+            const int nn = tid >> 2, kq = (tid & 3) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + nn < N) v = *reinterpret_cast<const float4*>(B + (size_t)(n0 + nn) * ldb + k0 + kq);
+            Bs[kq][nn] = v.x; Bs[kq + 1][nn] = v.y; Bs[kq + 2][nn] = v.z; Bs[kq + 3][nn] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[4 * ks + g][32 * wave + 16 * i + n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[4 * ks + g][16 * j + n];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 32 * wave + 16 * i + 4 * g + r;
+                const int col = n0 + 16 * j + n;
+                if (row < r_hi && col < N) {
+                    float v = acc[i][j][r];
+                    float* dst = C + row * ldc + col;
+                    if (EPI == 1) v = fmaxf(v, 0.f);
+                    if (EPI == 2) v += *dst;
+                    if (EPI == 3) v = mask[row * ldc + col] > 0.f ? v : 0.f;
+                    *dst = v;
+                }
+            }
+}
+
+// partial[(s * chunks + c)][k][n] = sum over the token rows of chunk c of segment s of A[m][k] G[m][n]   (K, N <= 128,
+// multiples of 16, K * N <= 8192).  Every (s, c) writes its partial (zeros when the chunk holds no row).
+__global__ __launch_bounds__(256) void gen_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ G,
+                                                        const int32_t* __restrict__ seg, int M, int F, int K, int N,
+                                                        float* __restrict__ partial) {
+    extern __shared__ __align__(16) float tn_lds[];
+    const int LA = K + 16, LG = N + 16;
+    float* As = tn_lds;                  // [32][LA]
+    float* Gs = tn_lds + 32 * LA;        // [32][LG]
+    const int s = blockIdx.y, c = blockIdx.x, chunks = gridDim.x;
+    const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
+    const int64_t c_lo = r_lo + (int64_t)c * kTnRows, c_hi = min(r_hi, c_lo + kTnRows);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int NT = N >> 4, tiles = (K >> 4) * NT;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ka4 = K >> 2, kg4 = N >> 2;
+    for (int64_t m0 = c_lo; m0 < c_hi; m0 += 32) {
+        for (int i = tid; i < 32 * ka4; i += 256) {
+            const int r = i / ka4, q = (i - r * ka4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < c_hi) v = *reinterpret_cast<const float4*>(A + (m0 + r) * K + q);
+            *reinterpret_cast<float4*>(As + r * LA + q) = v;
+        }
+        for (int i = tid; i < 32 * kg4; i += 256) {
+            const int r = i / kg4, q = (i - r * kg4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < c_hi) v = *reinterpret_cast<const float4*>(G + (m0 + r) * N + q);
+            *reinterpret_cast<float4*>(Gs + r * LG + q) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int slot = 0; slot < 8; ++slot) {
+            const int t = wave + 4 * slot;
+            if (t < tiles) {
+                const int kt = t / NT, nt = t - kt * NT;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc[slot] = mfma4(As[(4 * ks + g) * LA + 16 * kt + n], Gs[(4 * ks + g) * LG + 16 * nt + n], acc[slot]);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((size_t)s * chunks + c) * K * N;
+#pragma unroll
+    for (int slot = 0; slot < 8; ++slot) {
+        const int t = wave + 4 * slot;
+        if (t < tiles) {
+            const int kt = t / NT, nt = t - kt * NT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * kt + 4 * g + r) * N + 16 * nt + n] = acc[slot][r];
+        }
+    }
+}
+
+// dst[s * dst_seg_stride + e] += sum_c partial[(s * chunks + c)][e]   in chunk order; S segments (grid.y)
+__global__ void gen_tn_reduce_kernel(const float* __restrict__ partial, int chunks, int count, float* __restrict__ dst,
+                                     int64_t dst_seg_stride) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const int s = blockIdx.y;
+    const float* p = partial + (size_t)s * chunks * count + e;
+    float t = 0.f;
+    for (int c = 0; c < chunks; ++c) t += p[(size_t)c * count];
+    dst[(size_t)s * dst_seg_stride + e] += t;
+}
+
+// rows in scenario-sorted order <- the layer input in the caller's order (or the arena rows of the fused gather), and back
+__global__ void gen_permute_in_kernel(satrans_layer_desc a, const float* __restrict__ src, float* __restrict__ dst, bool is_x) {
+    const int q4 = a.D >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.B * a.F * q4) return;
+    const int64_t m = i / q4;
+    const int c = (int)(i - m * q4) * 4;
+    const int p = (int)(m / a.F), f = (int)(m - (int64_t)p * a.F);
+    const int b = a.order[p];
+    const float* row = is_x ? layer_x_row(a, b, f, a.F, a.D) : src + ((size_t)b * a.F + f) * a.D;
+    *reinterpret_cast<float4*>(dst + m * a.D + c) = *reinterpret_cast<const float4*>(row + c);
+}
+__global__ void gen_permute_out_kernel(satrans_layer_desc a, const float* __restrict__ src, float* __restrict__ dst) {
+    const int q4 = a.D >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.B * a.F * q4) return;
+    const int64_t m = i / q4;
+    const int c = (int)(i - m * q4) * 4;
+    const int p = (int)(m / a.F), f = (int)(m - (int64_t)p * a.F);
+    *reinterpret_cast<float4*>(dst + ((size_t)a.order[p] * a.F + f) * a.D + c) = *reinterpret_cast<const float4*>(src + m * a.D + c);
+}
+
+struct GenDrop {
+    bool on;
+    float scale;
+    uint32_t thresh, key;
+};
+
+// t = drop(relu?(a)) + res ; y = LayerNorm(t) * gamma + beta       (submodules.py:96-101, satrans.py:91-99)
+// LPT = D / 4 lanes per token.  y goes to the caller's sample order when `y_orig` is set.
+template <int LPT>
+__global__ __launch_bounds__(256) void gen_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ res,
+                                                       float* __restrict__ t_out, float* __restrict__ y, bool y_orig,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int64_t Ntok, int F, const int32_t* __restrict__ order, GenDrop dc,
+                                                       bool relu) {
+    constexpr int D = 4 * LPT;
+    const int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPT;
+    const int c = (int)(threadIdx.x % LPT) * 4;
+    const bool live = m < Ntok;
+    const int64_t mm = live ? m : 0;
+    const int p = (int)(mm / F), f = (int)(mm - (int64_t)p * F);
+    const int b = order[p];
+    float4 v4 = *reinterpret_cast<const float4*>(a + mm * D + c);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    const uint32_t kb = dc.on ? drop_keep4(drop_sample_key(dc.key, (uint32_t)b), (uint32_t)(f * D + c) >> 2, dc.thresh) : 0xFu;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(res + mm * D + c);
+        rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (relu) x = fmaxf(x, 0.f);
+        if (dc.on) x = (kb >> e) & 1u ? x * dc.scale : 0.f;
+        x += rs[e];
+        v[e] = x;
+        sum += x;
+    }
+#pragma unroll
+    for (int o = 1; o < LPT; o <<= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q = fmaf(v[e] - mean, v[e] - mean, q);
+#pragma unroll
+    for (int o = 1; o < LPT; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-6f);
+    if (!live) return;
+    if (t_out) *reinterpret_cast<float4*>(t_out + m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+    const int64_t dst = y_orig ? (int64_t)b * F + f : m;
+    *reinterpret_cast<float4*>(y + dst * D + c) = make_float4((v[0] - mean) * rstd * gm.x + bt.x, (v[1] - mean) * rstd * gm.y + bt.y,
+                                                              (v[2] - mean) * rstd * gm.z + bt.z, (v[3] - mean) * rstd * gm.w + bt.w);
+}
+
+// LayerNorm backward + the mask of the branch in front of it.  g: gradient of the LayerNorm output (in the caller's sample
+// order when g_orig), t: saved pre-norm rows.  dt: gradient of t (= of the residual input); dm = dt * dropout mask
+// (* [a > 0] with relu).  gamma / beta gradients: per-block partial sums [blocks][2 D], blocks take contiguous token ranges.
+template <int LPT>
+__global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict__ g, bool g_orig, const float* __restrict__ t,
+                                                       const float* __restrict__ a_pre, const float* __restrict__ gamma,
+                                                       float* __restrict__ dt, float* __restrict__ dm, float* __restrict__ part,
+                                                       int64_t Ntok, int F, const int32_t* __restrict__ order, GenDrop dc,
+                                                       bool relu, int tokens_per_block) {
+    constexpr int D = 4 * LPT, TPI = 256 / LPT;      // tokens per iteration
+    __shared__ float red[2][TPI][D];
+    const int sub = threadIdx.x / LPT, c = (int)(threadIdx.x % LPT) * 4;
+    const int64_t t_lo = (int64_t)blockIdx.x * tokens_per_block, t_hi = min(Ntok, t_lo + tokens_per_block);
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 gm4 = *reinterpret_cast<const float4*>(gamma + c);
+    const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+    for (int64_t base = t_lo; base < t_hi; base += TPI) {
+        const int64_t m = base + sub;
+        const bool live = m < t_hi;
+        const int64_t mm = live ? m : t_lo;
+        const int p = (int)(mm / F), f = (int)(mm - (int64_t)p * F);
+        const int b = order[p];
+        const int64_t src = g_orig ? (int64_t)b * F + f : mm;
+        const float4 g4 = *reinterpret_cast<const float4*>(g + src * D + c);
+        const float4 t4 = *reinterpret_cast<const float4*>(t + mm * D + c);
+        float gv[4] = {g4.x, g4.y, g4.z, g4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+        if (!live) { gv[0] = gv[1] = gv[2] = gv[3] = 0.f; }
+        float sum = (tv[0] + tv[1]) + (tv[2] + tv[3]);
+#pragma unroll
+        for (int o = 1; o < LPT; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q = fmaf(tv[e] - mean, tv[e] - mean, q);
+#pragma unroll
+        for (int o = 1; o < LPT; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-6f);
+        float zh[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            zh[e] = (tv[e] - mean) * rstd;
+            ag[e] = fmaf(gv[e], zh[e], ag[e]);
+            ab[e] += gv[e];
+            gv[e] *= gm[e];
+            m1 += gv[e];
+            m2 = fmaf(gv[e], zh[e], m2);
+        }
+#pragma unroll
+        for (int o = 1; o < LPT; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        m1 *= (1.0f / D);
+        m2 *= (1.0f / D);
+        if (live) {
+            float d_[4], dmv[4];
+            const uint32_t kb = dc.on ? drop_keep4(drop_sample_key(dc.key, (uint32_t)b), (uint32_t)(f * D + c) >> 2, dc.thresh) : 0xFu;
+            float pre[4] = {1.f, 1.f, 1.f, 1.f};
+            if (relu) {
+                const float4 p4 = *reinterpret_cast<const float4*>(a_pre + m * D + c);
+                pre[0] = p4.x; pre[1] = p4.y; pre[2] = p4.z; pre[3] = p4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d_[e] = rstd * (gv[e] - m1 - zh[e] * m2);
+                float mk = 1.0f;
+                if (dc.on) mk = (kb >> e) & 1u ? dc.scale : 0.f;
+                if (relu && !(pre[e] > 0.f)) mk = 0.f;
+                dmv[e] = d_[e] * mk;
+            }
+            if (dt) *reinterpret_cast<float4*>(dt + m * D + c) = make_float4(d_[0], d_[1], d_[2], d_[3]);
+            *reinterpret_cast<float4*>(dm + m * D + c) = make_float4(dmv[0], dmv[1], dmv[2], dmv[3]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][sub][c + e] = ag[e]; red[1][sub][c + e] = ab[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int which = i / D, col = i - which * D;
+        float s_ = 0.f;
+        for (int k = 0; k < TPI; ++k) s_ += red[which][k][col];
+        part[(size_t)blockIdx.x * 2 * D + i] = s_;
+    }
+}
+
+__global__ void gen_colsum_reduce_kernel(const float* __restrict__ part, int blocks, int count, float* __restrict__ dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    float t = 0.f;
+    for (int k = 0; k < blocks; ++k) t += part[(size_t)k * count + e];
+    dst[e] += t;
+}
+
+// ---- attention, one lane per (head, query row) of one sample per workgroup: the "wavefront" arm --------------------------------
+// q, k, v: [N, D] sorted rows; o: [N, D]; st: [B, H, F] float2 (max of the scaled scores, 1 / sum); att: optional [H,B,F,F]
+template <int d>
+__global__ __launch_bounds__(256) void gen_attn_fwd_wave_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, float* __restrict__ o,
+                                                              float2* __restrict__ st, float* __restrict__ att, int B, int F,
+                                                              int H, const int32_t* __restrict__ order, GenDrop dc) {
+    extern __shared__ __align__(16) float at_lds[];
+    const int D = H * d, LD = D + 4;
+    float* sk = at_lds;
+    float* sv = at_lds + F * LD;
+    const int p = blockIdx.x;
+    const int64_t base = (int64_t)p * F * D;
+    for (int i = threadIdx.x; i < F * (D >> 2); i += blockDim.x) {
+        const int r = i / (D >> 2), c = (i - r * (D >> 2)) * 4;
+        *reinterpret_cast<float4*>(sk + r * LD + c) = *reinterpret_cast<const float4*>(k + base + r * D + c);
+        *reinterpret_cast<float4*>(sv + r * LD + c) = *reinterpret_cast<const float4*>(v + base + r * D + c);
+    }
+    __syncthreads();
+    const int b = order[p];
+    const float sc_scale = kLog2e / sqrtf((float)d);
+    for (int task = threadIdx.x; task < H * F; task += blockDim.x) {
+        const int h = task / F, i = task - h * F;
+        f32x2 qi[d / 2];
+        load_row<d>(q + base + (int64_t)i * D + h * d, qi);
+        const float* kb_ = sk + h * d;
+        const float* vb_ = sv + h * d;
+        float mx = -INFINITY;
+#pragma unroll 1
+        for (int j0 = 0; j0 < F; j0 += 4) {
+            f32x2 kr[4][d / 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_row<d>(kb_ + min(j0 + u, F - 1) * LD, kr[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mx = fmaxf(mx, dot_row<d>(qi, kr[u]) * sc_scale);
+        }
+        f32x2 oacc[d / 2];
+#pragma unroll
+        for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
+        float sum = 0.f;
+        const uint32_t skey = drop_sample_key(dc.key, (uint32_t)b);
+        const uint32_t block0 = drop_attn_elem(h, F, i, 0) >> 2;
+#pragma unroll 1
+        for (int j0 = 0; j0 < F; j0 += 4) {
+            f32x2 kr[4][d / 2], vr[4][d / 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                load_row<d>(kb_ + min(j0 + u, F - 1) * LD, kr[u]);
+                load_row<d>(vb_ + min(j0 + u, F - 1) * LD, vr[u]);
+            }
+            const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(j0 >> 2), dc.thresh) : 0xFu;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ex = j0 + u < F ? __builtin_amdgcn_exp2f(dot_row<d>(qi, kr[u]) * sc_scale - mx) : 0.f;
+                sum += ex;
+                float pe = ex;
+                if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
+                axpy_row<d>(pe, vr[u], oacc);
+            }
+        }
+        const float inv = 1.0f / sum;
+        st[((size_t)p * H + h) * F + i] = make_float2(mx, inv);
+        float orow[d];
+#pragma unroll
+        for (int e = 0; e < d / 2; ++e) { orow[2 * e] = oacc[e].x * inv; orow[2 * e + 1] = oacc[e].y * inv; }
+#pragma unroll
+        for (int e = 0; e < d; e += 4)
+            *reinterpret_cast<float4*>(o + base + (int64_t)i * D + h * d + e) = make_float4(orow[e], orow[e + 1], orow[e + 2], orow[e + 3]);
+        if (att) {      // normalized_att_scores [H,B,F,F] after dropout (satrans.py:87), in the caller's sample order
+            float* arow = att + (((size_t)h * B + b) * F + i) * F;
+            for (int j = 0; j < F; ++j) {
+                f32x2 kr[d / 2];
+                load_row<d>(kb_ + j * LD, kr);
+                float pj = __builtin_amdgcn_exp2f(dot_row<d>(qi, kr) * sc_scale - mx) * inv;
+                if (dc.on) pj = drop_keep(skey, drop_attn_elem(h, F, i, j), dc.thresh) ? pj * dc.scale : 0.f;
+                arow[j] = pj;
+            }
+        }
+    }
+}
+
+// ---- attention forward on the matrix pipe: F <= 64 keys, head dimension 16, one wave per head, one sample per workgroup ----------
+// Scores are computed TRANSPOSED, S^T[j][i] = sum_e K[j][e] Q[i][e]: the query sits on the MFMA column (= lane & 15), the keys in
+// the accumulator rows (4 key tiles x 4 registers per lane, the rest across the four lane groups), so the softmax over the keys
+// is a register reduction plus two shuffles, and P^T is - as it stands in the accumulators - the B operand of
+// O^T[e][i] = sum_j V[j][e] P^T[j][i]: nothing F x F ever leaves the registers.  O^T comes out in the token-on-lane layout.
+__global__ __launch_bounds__(256) void gen_attn_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, float* __restrict__ o,
+                                                              float2* __restrict__ st, int F, int H,
+                                                              const int32_t* __restrict__ order, GenDrop dc) {
+    constexpr int d = 16;
+    extern __shared__ __align__(16) float at_lds[];
+    const int D = H * d, LD = D + 4;
+    const int FP = (F + 15) & ~15;
+    float* sq = at_lds;
+    float* sk = sq + FP * LD;
+    float* sv = sk + FP * LD;
+    const int p = blockIdx.x;
+    const int64_t base = (int64_t)p * F * D;
+    for (int i = threadIdx.x; i < FP * (D >> 2); i += blockDim.x) {
+        const int r = i / (D >> 2), c = (i - r * (D >> 2)) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a;
+        if (r < F) {
+            a = *reinterpret_cast<const float4*>(q + base + r * D + c);
+            b = *reinterpret_cast<const float4*>(k + base + r * D + c);
+            cc = *reinterpret_cast<const float4*>(v + base + r * D + c);
+        }
+        *reinterpret_cast<float4*>(sq + r * LD + c) = a;
+        *reinterpret_cast<float4*>(sk + r * LD + c) = b;
+        *reinterpret_cast<float4*>(sv + r * LD + c) = cc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    if (h >= H) return;
+    const int b = order[p];
+    const float sc_scale = kLog2e / sqrtf((float)d);
+    const int JT = FP >> 4;
+    const uint32_t skey = drop_sample_key(dc.key, (uint32_t)b);
+    for (int it = 0; it < JT; ++it) {               // query tile: queries 16 it + n on the lanes
+        const int i = 16 * it + n;
+        float qb[4];                                // B operand: Q^T[e = 4 ks + g][i]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qb[ks] = sq[i * LD + h * d + 4 * ks + g];
+        f32x4 s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            s[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (jt < JT) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)      // A operand: K[j = 16 jt + n][e = 4 ks + g]
+                    s[jt] = mfma4(sk[(16 * jt + n) * LD + h * d + 4 * ks + g], qb[ks], s[jt]);
+            }
+        }
+        // lane (n, g), register r of tile jt holds key j = 16 jt + 4 g + r for query i
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool real = 16 * jt + 4 * g + r < F;
+                s[jt][r] = real ? s[jt][r] * sc_scale : -INFINITY;
+                mx = fmaxf(mx, s[jt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        const uint32_t block0 = drop_attn_elem(h, F, i < F ? i : 0, 0) >> 2;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(4 * jt + g), dc.thresh) : 0xFu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ex = __builtin_amdgcn_exp2f(s[jt][r] - mx);     // exp2(-inf) = 0 for padding keys
+                sum += ex;
+                s[jt][r] = dc.on ? ((kb >> r) & 1u ? ex * dc.scale : 0.f) : ex;
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        f32x4 ot = f32x4{0.f, 0.f, 0.f, 0.f};       // O^T[e = 4 g + r][i]
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt < JT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)         // contraction step over keys j = 16 jt + 4 g + r: A = V[j][e = n]
+                    ot = mfma4(sv[(16 * jt + 4 * g + r) * LD + h * d + n], s[jt][r], ot);
+            }
+        if (i < F) {
+            *reinterpret_cast<float4*>(o + base + (int64_t)i * D + h * d + 4 * g) =
+                make_float4(ot[0] * inv, ot[1] * inv, ot[2] * inv, ot[3] * inv);
+            if (g == 0) st[((size_t)p * H + h) * F + i] = make_float2(mx, inv);
+        }
+    }
+}
+
+// ---- attention backward, one lane per (head, row) of one sample per workgroup: dq_i (row pass) and dk_i, dv_i (column pass)
+// with P recomputed from q, k and the saved row statistics; dot_i = go_i . o_i          (same scheme as layer_bwd8.hip)
+template <int d>
+__global__ __launch_bounds__(256) void gen_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ o,
+                                                         const float* __restrict__ go, const float2* __restrict__ st,
+                                                         float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                         int F, int H, const int32_t* __restrict__ order, GenDrop dc) {
+    extern __shared__ __align__(16) float at_lds[];
+    const int D = H * d, LD = D + 4;
+    float* sq = at_lds;
+    float* sk = sq + F * LD;
+    float* sv = sk + F * LD;
+    float* sg = sv + F * LD;
+    float4* sst = reinterpret_cast<float4*>(sg + F * LD);      // [H * F]: max, 1/sum, dot, keep bits low / high
+    const int p = blockIdx.x;
+    const int64_t base = (int64_t)p * F * D;
+    for (int i = threadIdx.x; i < F * (D >> 2); i += blockDim.x) {
+        const int r = i / (D >> 2), c = (i - r * (D >> 2)) * 4;
+        *reinterpret_cast<float4*>(sq + r * LD + c) = *reinterpret_cast<const float4*>(q + base + r * D + c);
+        *reinterpret_cast<float4*>(sk + r * LD + c) = *reinterpret_cast<const float4*>(k + base + r * D + c);
+        *reinterpret_cast<float4*>(sv + r * LD + c) = *reinterpret_cast<const float4*>(v + base + r * D + c);
+        *reinterpret_cast<float4*>(sg + r * LD + c) = *reinterpret_cast<const float4*>(go + base + r * D + c);
+    }
+    __syncthreads();
+    const int b = order[p];
+    const uint32_t skey = drop_sample_key(dc.key, (uint32_t)b);
+    for (int task = threadIdx.x; task < H * F; task += blockDim.x) {
+        const int h = task / F, i = task - h * F;
+        f32x2 gi[d / 2], oi[d / 2];
+        load_row<d>(sg + i * LD + h * d, gi);
+        load_row<d>(o + base + (int64_t)i * D + h * d, oi);
+        const float2 s2 = st[((size_t)p * H + h) * F + i];
+        sst[task] = make_float4(s2.x, s2.y, dot_row<d>(gi, oi), 0.f);
+    }
+    __syncthreads();
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d), sc_scale = inv_sqrt_d * kLog2e, scale = dc.scale;
+    for (int task = threadIdx.x; task < H * F; task += blockDim.x) {
+        const int h = task / F, i = task - h * F;
+        const float* qb_ = sq + h * d;
+        const float* kb_ = sk + h * d;
+        const float* vb_ = sv + h * d;
+        const float* gb_ = sg + h * d;
+        const float4* stb = sst + h * F;
+        f32x2 dqa[d / 2], dka[d / 2], dva[d / 2];
+#pragma unroll
+        for (int e = 0; e < d / 2; ++e) { dqa[e] = f32x2{0.f, 0.f}; dka[e] = f32x2{0.f, 0.f}; dva[e] = f32x2{0.f, 0.f}; }
+        {   // row i
+            f32x2 qi[d / 2], gi[d / 2];
+            load_row<d>(qb_ + i * LD, qi);
+            load_row<d>(gb_ + i * LD, gi);
+            const float4 s4 = stb[i];
+#pragma unroll 1
+            for (int j = 0; j < F; ++j) {
+                f32x2 kr[d / 2], vr[d / 2];
+                load_row<d>(kb_ + j * LD, kr);
+                load_row<d>(vb_ + j * LD, vr);
+                const bool kp = !dc.on || drop_keep(skey, drop_attn_elem(h, F, i, j), dc.thresh);
+                const float dp = kp ? dot_row<d>(gi, vr) * scale : 0.f;
+                const float pj = __builtin_amdgcn_exp2f(dot_row<d>(qi, kr) * sc_scale - s4.x) * s4.y;
+                axpy_row<d>(pj * (dp - s4.z) * inv_sqrt_d, kr, dqa);
+            }
+        }
+        {   // column i
+            f32x2 ki[d / 2], vi[d / 2];
+            load_row<d>(kb_ + i * LD, ki);
+            load_row<d>(vb_ + i * LD, vi);
+#pragma unroll 1
+            for (int r = 0; r < F; ++r) {
+                f32x2 qr[d / 2], gr[d / 2];
+                load_row<d>(qb_ + r * LD, qr);
+                load_row<d>(gb_ + r * LD, gr);
+                const float4 sr = stb[r];
+                const bool kp = !dc.on || drop_keep(skey, drop_attn_elem(h, F, r, i), dc.thresh);
+                const float pr = __builtin_amdgcn_exp2f(dot_row<d>(qr, ki) * sc_scale - sr.x) * sr.y;
+                const float dp = kp ? dot_row<d>(gr, vi) * scale : 0.f;
+                axpy_row<d>(pr * (dp - sr.z) * inv_sqrt_d, qr, dka);
+                axpy_row<d>(kp ? pr * scale : 0.f, gr, dva);
+            }
+        }
+        const int64_t at = base + (int64_t)i * D + h * d;
+#pragma unroll
+        for (int e = 0; e < d / 2; e += 2) {
+            *reinterpret_cast<float4*>(dq + at + 2 * e) = make_float4(dqa[e].x, dqa[e].y, dqa[e + 1].x, dqa[e + 1].y);
+            *reinterpret_cast<float4*>(dk + at + 2 * e) = make_float4(dka[e].x, dka[e].y, dka[e + 1].x, dka[e + 1].y);
+            *reinterpret_cast<float4*>(dv + at + 2 * e) = make_float4(dva[e].x, dva[e].y, dva[e + 1].x, dva[e + 1].y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct GenLayout {          // offsets in floats; nd = B F D, nu = B F U
+    int64_t nd, nu;
+    // saved by the forward, read by the backward
+    int64_t xs, q0, k0, v, hq, hk, mq, mk, tq, tk, q, k, o, u, to, st, saved_total;
+    // scratch
+    int64_t dr, du, go, dq, dk, dv, dt, dm, dh, part, part_floats, ln_part, ln_blocks, scratch_total;
+};
+
+static int gen_attn_mode() {      // 0 = automatic (MFMA forward where it is built), 1 = wavefront, 2 = MFMA
+    static int mode = -1;
+    if (mode < 0) mode = getenv("SATRANS_GENERIC_ATTN") ? atoi(getenv("SATRANS_GENERIC_ATTN")) : 0;
+    return mode;
+}
+static int g_attn_override = -1;
+
+static GenLayout gen_layout(const satrans_layer_desc* d) {
+    GenLayout L;
+    const int64_t N = (int64_t)d->B * d->F;
+    L.nd = N * d->D;
+    L.nu = N * std::max(d->U, 1);
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
+    L.xs = take(L.nd); L.q0 = take(L.nd); L.k0 = take(L.nd); L.v = take(L.nd);
+    L.hq = take(L.nu); L.hk = take(L.nu); L.mq = take(L.nd); L.mk = take(L.nd);
+    L.tq = take(L.nd); L.tk = take(L.nd); L.q = take(L.nd); L.k = take(L.nd);
+    L.o = take(L.nd); L.u = take(L.nd); L.to = take(L.nd); L.st = take(2 * (int64_t)d->B * d->H * d->F);
+    L.saved_total = o;
+    o = 0;
+    L.dr = take(L.nd); L.du = take(L.nd); L.go = take(L.nd); L.dq = take(L.nd); L.dk = take(L.nd); L.dv = take(L.nd);
+    L.dt = take(L.nd); L.dm = take(L.nd); L.dh = take(L.nu);
+    const int64_t chunks = ceil_div(N, kTnRows) + d->S;
+    L.part_floats = (int64_t)d->S * chunks * std::max<int64_t>((int64_t)d->D * std::max(d->U, d->D), 1);
+    L.part = take(L.part_floats);
+    L.ln_blocks = std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
+    L.ln_part = take(L.ln_blocks * 2 * d->D);
+    L.scratch_total = o;
+    return L;
+}
+
+static bool gen_supported(const satrans_layer_desc* d) {
+    if (!d || (d->flags & (SATRANS_GATE | SATRANS_BILINEAR))) return false;
+    const int D = d->D, H = d->H;
+    if (!(D == 16 || D == 32 || D == 64 || D == 128) || D % H) return false;
+    const int dd = D / H;
+    if (dd != 8 && dd != 16) return false;
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
+    if (meta && (d->U % 16 || d->U > 128 || (int64_t)D * d->U > 8192)) return false;
+    if (D > 128 || d->F > 256) return false;
+    if ((int64_t)4 * d->F * (D + 4) * 4 + (int64_t)H * d->F * 16 > 150 * 1024) return false;   // attention backward LDS
+    return true;
+}
+
+static GenDrop gen_drop(const satrans_layer_desc* d, int site) {
+    GenDrop g;
+    g.on = (d->flags & SATRANS_TRAIN) && d->drop_p > 0.f;
+    g.scale = g.on ? 1.0f / (1.0f - d->drop_p) : 1.0f;
+    g.thresh = drop_threshold(d->drop_p);
+    g.key = drop_site_key(d->seed, d->step, d->layer, site);
+    return g;
+}
+
+template <bool TRANSB, int EPI>
+static int gen_gemm(hipStream_t st, int batch, const float* const* A, const float* const* Bm, float* const* C, const int32_t* seg,
+                    int S, int M, int F, int K, int N, int ldb, int64_t b_seg_stride, const float* mask = nullptr) {
+    GemmBatch gb;
+    for (int i = 0; i < 3; ++i) { gb.A[i] = A[i < batch ? i : 0]; gb.B[i] = Bm[i < batch ? i : 0]; gb.C[i] = C[i < batch ? i : 0]; }
+    const int n_tiles = (int)ceil_div(N, kGN);
+    const dim3 grid((unsigned)(ceil_div(M, kGM) * n_tiles), (unsigned)(seg ? S : 1), (unsigned)batch);
+    gen_gemm_kernel<TRANSB, EPI><<<grid, 256, 0, st>>>(gb, seg, M, F, K, N, K, ldb, N, b_seg_stride, mask);
+    SATRANS_CHECK_LAUNCH("gen_gemm_kernel");
+    return SATRANS_OK;
+}
+
+// dst[s] += A^T G over segment s (seg == nullptr: one segment); dst_seg_stride between the segments' outputs
+static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int32_t* seg, int S, int M, int F, int K, int N,
+                       float* partial, float* dst, int64_t dst_seg_stride) {
+    const int segs = seg ? S : 1;
+    const int chunks = (int)ceil_div(M, kTnRows);
+    const size_t lds = sizeof(float) * 32 * ((size_t)K + 16 + N + 16);
+    gen_gemm_tn_kernel<<<dim3((unsigned)chunks, (unsigned)segs), 256, lds, st>>>(A, G, seg, M, F, K, N, partial);
+    SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel");
+    gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)K * N, 256), (unsigned)segs), 256, 0, st>>>(partial, chunks, K * N, dst,
+                                                                                                      dst_seg_stride);
+    SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
+    return SATRANS_OK;
+}
+
+#define GEN_LN_DISPATCH(D, CALL)                                   \
+    switch ((D) / 4) {                                             \
+        case 4: { constexpr int LPT = 4; CALL; } break;            \
+        case 8: { constexpr int LPT = 8; CALL; } break;            \
+        case 16: { constexpr int LPT = 16; CALL; } break;          \
+        default: { constexpr int LPT = 32; CALL; } break;          \
+    }
+
+static int gen_ln_fwd(hipStream_t st, const satrans_layer_desc* d, const float* a, const float* res, float* t_out, float* y,
+                      bool y_orig, const float* gamma, const float* beta, int site, bool relu) {
+    const int64_t N = (int64_t)d->B * d->F;
+    const GenDrop dc = gen_drop(d, site);
+    GEN_LN_DISPATCH(d->D, (gen_ln_fwd_kernel<LPT><<<(unsigned)ceil_div(N * LPT, 256), 256, 0, st>>>(
+                              a, res, t_out, y, y_orig, gamma, beta, N, d->F, d->order, dc, relu)));
+    SATRANS_CHECK_LAUNCH("gen_ln_fwd_kernel");
+    return SATRANS_OK;
+}
+
+static int gen_ln_bwd(hipStream_t st, const satrans_layer_desc* d, const GenLayout& L, float* scratch, const float* g, bool g_orig,
+                      const float* t, const float* a_pre, const float* gamma, float* dt, float* dm, int site, bool relu,
+                      float* g_gamma_beta) {
+    const int64_t N = (int64_t)d->B * d->F;
+    const GenDrop dc = gen_drop(d, site);
+    const int tpi = 256 / (d->D / 4);
+    const int blocks = (int)L.ln_blocks;
+    const int tpb = (int)(ceil_div(ceil_div(N, blocks), tpi) * tpi);
+    float* part = scratch + L.ln_part;
+    GEN_LN_DISPATCH(d->D, (gen_ln_bwd_kernel<LPT><<<(unsigned)blocks, 256, 0, st>>>(g, g_orig, t, a_pre, gamma, dt, dm, part, N,
+                                                                                   d->F, d->order, dc, relu, tpb)));
+    SATRANS_CHECK_LAUNCH("gen_ln_bwd_kernel");
+    if (g_gamma_beta) {
+        gen_colsum_reduce_kernel<<<(unsigned)ceil_div(2 * d->D, 256), 256, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta);
+        SATRANS_CHECK_LAUNCH("gen_colsum_reduce_kernel");
+    }
+    return SATRANS_OK;
+}
+
+}  // namespace satrans
+
+using namespace satrans;
+
+extern "C" int satrans_layer_generic_supported(const satrans_layer_desc* d) { return gen_supported(d) ? 1 : 0; }
+
+// attention arm of the generic forward: 0 = automatic, 1 = one lane per query row ("wavefront"), 2 = MFMA (F <= 64, d = 16);
+// -1 = back to the initial value (SATRANS_GENERIC_ATTN in the environment)
+extern "C" int satrans_set_generic_attention(int mode) {
+    SATRANS_REQUIRE(mode >= -1 && mode <= 2, SATRANS_E_BADARG, "set_generic_attention: %d", mode);
+    satrans::g_attn_override = mode;
+    return SATRANS_OK;
+}
+
+extern "C" int64_t satrans_layer_generic_saved_floats(const satrans_layer_desc* d) {
+    return gen_supported(d) ? gen_layout(d).saved_total : -1;
+}
+extern "C" int64_t satrans_layer_generic_scratch_floats(const satrans_layer_desc* d) {
+    return gen_supported(d) ? gen_layout(d).scratch_total : -1;
+}
+
+extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, float* att, float* saved, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SATRANS_REQUIRE(gen_supported(d), SATRANS_E_UNSUPPORTED, "layer_fwd(generic): shape not supported");
+    SATRANS_REQUIRE(y && saved, SATRANS_E_BADARG, "layer_fwd(generic): null pointer");
+    const GenLayout L = gen_layout(d);
+    const int B = d->B, F = d->F, D = d->D, U = d->U, H = d->H, S = d->S, M = B * F;
+    const bool meta_q = d->flags & SATRANS_META_Q, meta_k = d->flags & SATRANS_META_K;
+    const bool relu = d->flags & SATRANS_RELU_OUT, use_res = !(d->flags & SATRANS_NO_RES);
+    float *xs = saved + L.xs, *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
+    int rc;
+    gen_permute_in_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, nullptr, xs, true);
+    SATRANS_CHECK_LAUNCH("gen_permute_in_kernel");
+    {   // satrans.py:55-57
+        const float* A[3] = {xs, xs, xs};
+        const float* Bw[3] = {d->w_query, d->w_key, d->w_value};
+        float* C[3] = {q0, k0, v};
+        if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+    }
+    auto metanet = [&](const float* z0, float* h, float* m, float* t, float* out, const float* tab, const float* gam,
+                       const float* bet, int site) -> int {      // submodules.py:77-103
+        const float* A1[1] = {z0};
+        const float* B1[1] = {tab};
+        float* C1[1] = {h};
+        int r = gen_gemm<false, 1>(st, 1, A1, B1, C1, d->seg, S, M, F, D, U, U, d->tab_stride);
+        if (r) return r;
+        const float* A2[1] = {h};
+        const float* B2[1] = {tab + (size_t)D * U};
+        float* C2[1] = {m};
+        if ((r = gen_gemm<false, 0>(st, 1, A2, B2, C2, d->seg, S, M, F, U, D, D, d->tab_stride))) return r;
+        return gen_ln_fwd(st, d, m, z0, t, out, false, gam, bet, site, false);
+    };
+    const float* q = q0;
+    const float* k = k0;
+    if (meta_q) {
+        if ((rc = metanet(q0, saved + L.hq, saved + L.mq, saved + L.tq, saved + L.q, d->tab_q, d->lnq_g, d->lnq_b, kSiteMetaQ))) return rc;
+        q = saved + L.q;
+    }
+    if (meta_k) {
+        if ((rc = metanet(k0, saved + L.hk, saved + L.mk, saved + L.tk, saved + L.k, d->tab_k, d->lnk_g, d->lnk_b, kSiteMetaK))) return rc;
+        k = saved + L.k;
+    }
+    {   // satrans.py:75-90
+        const GenDrop dc = gen_drop(d, kSiteAttn);
+        const int dd = D / H;
+        int mode = g_attn_override >= 0 ? g_attn_override : gen_attn_mode();
+        const bool can_mfma = dd == 16 && F <= 64 && H <= 4 && !att;
+        const bool mfma = mode == 2 ? can_mfma : (mode == 0 && can_mfma);
+        SATRANS_REQUIRE(mode != 2 || can_mfma, SATRANS_E_UNSUPPORTED, "generic attention: the MFMA arm needs d = 16, F <= 64, H <= 4");
+        float2* stp = reinterpret_cast<float2*>(saved + L.st);
+        if (mfma) {
+            const int FP = (F + 15) & ~15;
+            const size_t lds = sizeof(float) * 3 * FP * (D + 4);
+            static size_t attr = 0;
+            if (lds > attr) {
+                hipError_t e = hipFuncSetAttribute((const void*)gen_attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention: LDS attribute: %s", hipGetErrorString(e));
+                attr = lds;
+            }
+            gen_attn_fwd_mfma_kernel<<<B, 256, lds, st>>>(q, k, v, saved + L.o, stp, F, H, d->order, dc);
+            SATRANS_CHECK_LAUNCH("gen_attn_fwd_mfma_kernel");
+        } else {
+            const size_t lds = sizeof(float) * 2 * F * (D + 4);
+            static size_t attr8 = 0, attr16 = 0;
+            size_t& attr = dd == 8 ? attr8 : attr16;
+            if (lds > attr) {
+                hipError_t e = dd == 8 ? hipFuncSetAttribute((const void*)gen_attn_fwd_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                       : hipFuncSetAttribute((const void*)gen_attn_fwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention: LDS attribute: %s", hipGetErrorString(e));
+                attr = lds;
+            }
+            if (dd == 8) gen_attn_fwd_wave_kernel<8><<<B, 256, lds, st>>>(q, k, v, saved + L.o, stp, att, B, F, H, d->order, dc);
+            else gen_attn_fwd_wave_kernel<16><<<B, 256, lds, st>>>(q, k, v, saved + L.o, stp, att, B, F, H, d->order, dc);
+            SATRANS_CHECK_LAUNCH("gen_attn_fwd_wave_kernel");
+        }
+    }
+    {   // satrans.py:91-99
+        const float* A[1] = {saved + L.o};
+        const float* Bw[1] = {d->w_out};
+        float* C[1] = {saved + L.u};
+        if ((rc = gen_gemm<true, 0>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+        if ((rc = gen_ln_fwd(st, d, saved + L.u, use_res ? xs : nullptr, saved + L.to, y, true, d->ln_g, d->ln_b, kSiteOut, relu)))
+            return rc;
+    }
+    return SATRANS_OK;
+}
+
+extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const float* dy, float* dx, const float* saved,
+                                         float* scratch, float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
+                                         float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SATRANS_REQUIRE(gen_supported(d), SATRANS_E_UNSUPPORTED, "layer_bwd(generic): shape not supported");
+    SATRANS_REQUIRE(dy && dx && saved && scratch && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd(generic): null pointer");
+    const GenLayout L = gen_layout(d);
+    const int B = d->B, F = d->F, D = d->D, U = d->U, H = d->H, S = d->S, M = B * F;
+    const bool meta_q = d->flags & SATRANS_META_Q, meta_k = d->flags & SATRANS_META_K;
+    const bool relu = d->flags & SATRANS_RELU_OUT, use_res = !(d->flags & SATRANS_NO_RES);
+    const float *xs = saved + L.xs, *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
+    const float* q = meta_q ? saved + L.q : q0;
+    const float* k = meta_k ? saved + L.k : k0;
+    float *dr = scratch + L.dr, *du = scratch + L.du, *go = scratch + L.go, *dq = scratch + L.dq, *dk = scratch + L.dk,
+          *dv = scratch + L.dv, *dt = scratch + L.dt, *dm = scratch + L.dm, *dh = scratch + L.dh, *part = scratch + L.part;
+    int rc;
+    // ---- output block: LayerNorm backward (dy arrives in the caller's sample order), dWo, go = du Wo ----------------------------
+    if ((rc = gen_ln_bwd(st, d, L, scratch, dy, true, saved + L.to, saved + L.u, d->ln_g, dr, du, kSiteOut, relu, g_ln))) return rc;
+    if ((rc = gen_gemm_tn(st, du, saved + L.o, nullptr, 1, M, F, D, D, part, g_wo, 0))) return rc;     // dWo[out][in] += du^T o
+    {
+        const float* A[1] = {du};
+        const float* Bw[1] = {d->w_out};
+        float* C[1] = {go};
+        if ((rc = gen_gemm<false, 0>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+    }
+    if (!use_res) {
+        hipError_t e = hipMemsetAsync(dr, 0, sizeof(float) * (size_t)L.nd, st);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): memset: %s", hipGetErrorString(e));
+    }
+    // ---- attention --------------------------------------------------------------------------------------------------------------
+    {
+        const GenDrop dc = gen_drop(d, kSiteAttn);
+        const int dd = D / H;
+        const size_t lds = sizeof(float) * (4 * (size_t)F * (D + 4) + 4 * (size_t)H * F);
+        static size_t attr8 = 0, attr16 = 0;
+        size_t& attr = dd == 8 ? attr8 : attr16;
+        if (lds > attr) {
+            hipError_t e = dd == 8 ? hipFuncSetAttribute((const void*)gen_attn_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                   : hipFuncSetAttribute((const void*)gen_attn_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention backward: LDS attribute: %s", hipGetErrorString(e));
+            attr = lds;
+        }
+        const float2* stp = reinterpret_cast<const float2*>(saved + L.st);
+        if (dd == 8) gen_attn_bwd_kernel<8><<<B, 256, lds, st>>>(q, k, v, saved + L.o, go, stp, dq, dk, dv, F, H, d->order, dc);
+        else gen_attn_bwd_kernel<16><<<B, 256, lds, st>>>(q, k, v, saved + L.o, go, stp, dq, dk, dv, F, H, d->order, dc);
+        SATRANS_CHECK_LAUNCH("gen_attn_bwd_kernel");
+    }
+    // ---- MetaNet backward of one role: g (gradient of the role's output rows) becomes the gradient of z0 -------------------------
+    auto metanet_bwd = [&](float* g, const float* z0, const float* h, const float* t, const float* tab, const float* gam,
+                           float* g_ln_role, float* g_tab, int site) -> int {
+        int r = gen_ln_bwd(st, d, L, scratch, g, false, t, nullptr, gam, dt, dm, site, false, g_ln_role);
+        if (r) return r;
+        // dW2[u][o] += h^T dm ;  dh = (dm W2^T) * [h > 0] ;  dW1[i][u] += z0^T dh ;  dz0 = dt + dh W1^T
+        if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride))) return r;
+        const float* A1[1] = {dm};
+        const float* B1[1] = {tab + (size_t)D * U};
+        float* C1[1] = {dh};
+        if ((r = gen_gemm<true, 3>(st, 1, A1, B1, C1, d->seg, S, M, F, D, U, D, d->tab_stride, h))) return r;
+        if ((r = gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride))) return r;
+        const float* A2[1] = {dh};
+        const float* B2[1] = {tab};
+        float* C2[1] = {dt};
+        if ((r = gen_gemm<true, 2>(st, 1, A2, B2, C2, d->seg, S, M, F, U, D, U, d->tab_stride))) return r;
+        hipError_t e = hipMemcpyAsync(g, dt, sizeof(float) * (size_t)L.nd, hipMemcpyDeviceToDevice, st);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): copy: %s", hipGetErrorString(e));
+        return SATRANS_OK;
+    };
+    if (meta_q && (rc = metanet_bwd(dq, q0, saved + L.hq, saved + L.tq, d->tab_q, d->lnq_g, g_lnq, g_tab_q, kSiteMetaQ))) return rc;
+    if (meta_k && (rc = metanet_bwd(dk, k0, saved + L.hk, saved + L.tk, d->tab_k, d->lnk_g, g_lnk, g_tab_k, kSiteMetaK))) return rc;
+    // ---- projections: dW{q,k,v}[i][o] += x^T g ;  dx = dr + gq Wq^T + gk Wk^T + gv Wv^T ---------------------------------------------
+    if ((rc = gen_gemm_tn(st, xs, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
+    if ((rc = gen_gemm_tn(st, xs, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
+    if ((rc = gen_gemm_tn(st, xs, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+    {
+        const float* grads[3] = {dq, dk, dv};
+        const float* ws[3] = {d->w_query, d->w_key, d->w_value};
+        for (int i = 0; i < 3; ++i) {
+            const float* A[1] = {grads[i]};
+            const float* Bw[1] = {ws[i]};
+            float* C[1] = {dr};
+            if ((rc = gen_gemm<true, 2>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+        }
+    }
+    gen_permute_out_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, dr, dx);
+    SATRANS_CHECK_LAUNCH("gen_permute_out_kernel");
+    return SATRANS_OK;
+}

@@ -210,6 +210,18 @@ class PathEngine:
             prob=torch.empty(B, **f32), logit=torch.empty(B, **f32),
         )
         self._ws[B] = ws
+        # Which layer kernels serve this shape: the fused / LDS-resident ones behind satrans_layer_fwd/_bwd, or - shapes
+        # they cannot hold, e.g. 64 fields x embedding_dim 64 x MetaNet hidden 128 - the general path (csrc/layer_generic.hip),
+        # which keeps its activations in HBM: one `saved` buffer per layer between forward and backward, one shared scratch.
+        # SATRANS_GENERIC=1 forces the general path where it is supported (tests).
+        probe = self._layer_desc(ws, 0, B, None, None, False)
+        fits = int(self.lib.satrans_layer_bwd_slab_floats(C.byref(probe))) >= 0
+        can = bool(self.lib.satrans_layer_generic_supported(C.byref(probe)))
+        import os
+        ws["generic"] = can and (os.environ.get("SATRANS_GENERIC", "0") == "1" or not fits)
+        if ws["generic"]:
+            n = int(self.lib.satrans_layer_generic_saved_floats(C.byref(probe)))
+            ws["gen_saved"] = [torch.empty(n, **f32)]
         return ws
 
     def train_workspace(self, B: int, world: int = 1, exchange: bool = False) -> dict:
@@ -228,7 +240,13 @@ class PathEngine:
         ws["dact"] = [torch.empty(B, F, D, **f32) for _ in range(2)]
         ws["head_scratch"] = torch.empty(int(lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
         desc = self._layer_desc(ws, 0, B, None, None, True)
-        ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
+        if ws["generic"]:
+            n = int(lib.satrans_layer_generic_saved_floats(C.byref(desc)))
+            ws["gen_saved"] = ws["gen_saved"] + [torch.empty(n, **f32) for _ in range(self.L - 1)]
+            ws["gen_scratch"] = torch.empty(int(lib.satrans_layer_generic_scratch_floats(C.byref(desc))), **f32)
+            ws["slabs"] = torch.empty(1, **f32)
+        else:
+            ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
         ws["sorted_rows"] = torch.empty(n_loc, **i32)           # this rank's rows, sorted, and their source positions
         ws["src"] = torch.empty(n_loc, **i32)
         if exchange:
@@ -393,7 +411,12 @@ class PathEngine:
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse)
             att = att_list[l].data_ptr() if att_list is not None else None
             with self.phase("layer_fwd"):
-                if self.fwd_bf16 and not training and att is None and lib.satrans_layer_fwd_bf16_supported(C.byref(desc)):
+                if ws["generic"] and not (self.fwd_bf16 and not training and att is None
+                                          and lib.satrans_layer_fwd_bf16_supported(C.byref(desc))):
+                    saved = ws["gen_saved"][l if len(ws["gen_saved"]) > l else 0]
+                    N.check(lib.satrans_layer_fwd_generic(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, saved.data_ptr(), st),
+                            "satrans_layer_fwd_generic")
+                elif self.fwd_bf16 and not training and att is None and lib.satrans_layer_fwd_bf16_supported(C.byref(desc)):
                     N.check(lib.satrans_layer_fwd_bf16(C.byref(desc), ws["acts"][l + 1].data_ptr(), st), "satrans_layer_fwd_bf16")
                 else:
                     N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
@@ -551,6 +574,16 @@ class PathEngine:
                 kname = "K_meta_mlp" if m.domain_int_layers[l].K_meta_mlp is not m.domain_int_layers[l].Q_meta_mlp \
                     else "Q_meta_mlp"
                 glnk = self._grad_view(lay + kname + ".ffn_layer_norm.weight").data_ptr()
+            if ws["generic"]:
+                with self.phase("layer_bwd"):
+                    N.check(lib.satrans_layer_bwd_generic(
+                        C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["gen_saved"][l].data_ptr(),
+                        ws["gen_scratch"].data_ptr(),
+                        self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
+                        self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
+                        self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd_generic")
+                cur = 1 - cur
+                continue
             with self.phase("layer_bwd"):
                 N.check(lib.satrans_layer_bwd(
                     C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),

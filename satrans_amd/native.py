@@ -63,6 +63,13 @@ SIGNATURES = {
     "satrans_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp]),
 "satrans_layer_fwd_bf16_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "satrans_layer_fwd_bf16": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
+"satrans_layer_generic_supported": (C.c_int, [C.POINTER(LayerDesc)]),
+    "satrans_layer_generic_saved_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
+    "satrans_layer_generic_scratch_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
+    "satrans_layer_fwd_generic": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp]),
+    "satrans_layer_bwd_generic": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _vp, _vp]),
+    "satrans_set_generic_attention": (C.c_int, [C.c_int]),
     "satrans_layer_bwd_slab_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
     "satrans_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp]),

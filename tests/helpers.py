@@ -65,5 +65,12 @@ def build_model(case: "Case", device: str):
     return model
 
 
+def _adam_steps(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return json.loads(str(z["meta"]))["adam_steps"]
+
+
+ADAM_CASES = [c for c in TRAIN_CASES if _adam_steps(c) > 0]     # cases that carry parameters / moments after Adam steps
 NATIVE_CASES = list(ALL_CASES)
 NATIVE_TRAIN_CASES = [c for c in NATIVE_CASES if c in TRAIN_CASES]
+NATIVE_ADAM_CASES = [c for c in NATIVE_CASES if c in ADAM_CASES]

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import satrans_oracle as O
-from tests.helpers import NATIVE_CASES, NATIVE_TRAIN_CASES, Case, build_model
+from tests.helpers import NATIVE_ADAM_CASES, NATIVE_CASES, NATIVE_TRAIN_CASES, Case, build_model
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -52,12 +52,15 @@ def test_gradients_match_reference_golden(name):
     assert reg == pytest.approx(float(c.z["train/reg"]), rel=1e-5)
     want = c.arrays("grad")
     assert set(grads) == set(want)
+    # 40 fields x 64 dims: longer fp32 sums and projection gradients of ~1e-5 that are differences of nearly equal softmax
+    # terms carry ~5e-9 of cancellation noise in any fp32 evaluation (same floor as the ragged-batch test)
+    rel, floor = (1e-4, 5e-9) if name == "small_d64_u128" else (5e-5, 1e-9)
     for k, g in want.items():
         scale = max(1e-6, float(np.abs(g).max()))
-        np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
+        np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=rel * scale + floor, err_msg=k)
 
 
-@pytest.mark.parametrize("name", NATIVE_TRAIN_CASES)
+@pytest.mark.parametrize("name", NATIVE_ADAM_CASES)
 def test_adam_steps_match_reference_golden(name):
     c = Case(name)
     model = build_model(c, DEV)
@@ -555,6 +558,76 @@ def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
         assert v == pytest.approx(roc_auc_score(y[ids == i], pred[ids == i]), rel=1e-12)
     want = torch.nn.functional.binary_cross_entropy(torch.tensor(pred).squeeze(), torch.tensor(y).double()).item()
     assert rep["loss"] == pytest.approx(want, rel=1e-10)
+
+
+@pytest.mark.parametrize("name", ["small_d64_u128", "aliccp_sota", "alimama_sota_pos", "small_qkv", "small_k", "small_none",
+                                  "small_pos_dense", "small_relu", "small_multidomain"])
+def test_general_layer_path_matches_golden_and_the_oracle(monkeypatch, name):
+    """csrc/layer_generic.hip (grouped f32-MFMA GEMMs + LayerNorm + attention launches over token rows in HBM; the path of
+    BASELINE configs[4]-class shapes), forced also on shapes the fused kernels cover: forward and every gradient against
+    the reference's golden vectors, a ragged batch and a training-mode step with replayed dropout masks against the oracle."""
+    monkeypatch.setenv("SATRANS_GENERIC", "1")
+    c = Case(name)
+    model = build_model(c, DEV)
+    model.compile("adam", "binary_crossentropy")
+    model.eval()
+    model.capture_attention = True
+    prob = model(c.X.to(DEV))
+    eng = model._engine
+    assert eng._ws[c.X.shape[0]]["generic"], "the general path was not selected"
+    want = c.arrays("out")
+    acts = eng.layer_outputs(c.X.shape[0])
+    for l in range(c.meta["L"]):
+        np.testing.assert_allclose(acts[l + 1].cpu().numpy(), want[f"layer{l}"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(model.domain_int_layers[l].normalized_att_scores.cpu().numpy(), want[f"att{l}"],
+                                   rtol=0, atol=2e-6)
+    np.testing.assert_allclose(eng.last_logit().cpu().numpy(), want["logit"], rtol=0, atol=LOGIT_ATOL)
+    model.capture_attention = False
+    if name != "small_relu":
+        bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+        assert bce == pytest.approx(float(c.z["train/bce"]), rel=2e-6)
+        rel, floor = (1e-4, 5e-9) if name == "small_d64_u128" else (5e-5, 1e-9)
+        for k, g in c.arrays("grad").items():
+            scale = max(1e-6, float(np.abs(g).max()))
+            np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=rel * scale + floor, err_msg=k)
+    for B, train in ((5, False), (c.X.shape[0], True)):
+        model.train(train)
+        X, y = c.X[:B], c.y[:B]
+        bce, reg, grads = eng.loss_and_grads(X.to(DEV), y.to(DEV))
+        m = c.meta
+        drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, len(m["fields"]), m["D"],
+                                                        m["H"], m["L"], 0.1)) if train else None
+        bce_ref, reg_ref, g_ref = O.loss_and_grads(c.tensors("param"), X, y, c.spec(), drop)
+        assert bce == pytest.approx(bce_ref, rel=5e-6)
+        for k, g in g_ref.items():
+            if k in grads:
+                scale = max(1e-6, float(g.abs().max()))
+                np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9,
+                                           err_msg=f"{k} B={B} train={train}")
+
+
+def test_general_path_attention_arms_agree():
+    """The two attention arms of the general forward at a configs[4]-class shape (40 fields, head dimension 16): MFMA
+    (transposed scores, softmax in the accumulators, P^T fed straight back as the B operand) and one lane per query row -
+    the MFMA-vs-wavefront ablation - must give the same layer outputs to rounding, with and without dropout."""
+    from satrans_amd import native as N
+    c = Case("small_d64_u128")
+    outs = {}
+    for mode in (1, 2):
+        N.check(N.lib().satrans_set_generic_attention(mode), "set_generic_attention")
+        try:
+            model = build_model(c, DEV)
+            for train in (False, True):
+                model.train(train)
+                model(c.X.to(DEV))
+                outs[(mode, train)] = [a.clone() for a in model._engine.layer_outputs(c.X.shape[0])[1:]]
+            assert model._engine._ws[c.X.shape[0]]["generic"]
+        finally:
+            N.check(N.lib().satrans_set_generic_attention(-1), "set_generic_attention")
+    for train in (False, True):
+        for a, b in zip(outs[(1, train)], outs[(2, train)]):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-6)
+    assert not torch.equal(outs[(1, True)][0], outs[(1, False)][0])
 
 
 def test_fit_predict_at_baseline_config_scale():
