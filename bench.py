@@ -31,42 +31,89 @@ ALICCP_FIELDS = ['101', '121', '122', '124', '125', '126', '127', '128', '129', 
 ALICCP_MAX = {'101': 444861, '121': 97, '122': 13, '124': 2, '125': 7, '126': 3, '127': 3, '128': 2, '129': 4,
               '205': 4348615, '206': 8993, '207': 695124, '210': 99606, '216': 234880, '508': 8185, '509': 472354,
               '702': 167813, '853': 91358, '301': 3}                               # reference main.py:124-127
+ALIMAMA_FIELDS = ['user_id', 'adgroup_id', 'pid', 'cms_segid', 'cms_group_id', 'final_gender_code', 'age_level',
+                  'pvalue_level', 'shopping_level', 'occupation', 'new_user_class_level', 'cate_id', 'campaign_id', 'customer',
+                  'brand']                                                           # reference main.py:143-145
+# column maxima: not in the reference tree; public-dataset magnitudes (labelled assumptions)
+ALIMAMA_MAX = {'user_id': 1141729, 'adgroup_id': 846811, 'pid': 1, 'cms_segid': 97, 'cms_group_id': 13,
+               'final_gender_code': 2, 'age_level': 7, 'pvalue_level': 4, 'shopping_level': 3, 'occupation': 2,
+               'new_user_class_level': 5, 'cate_id': 12977, 'campaign_id': 423436, 'customer': 255875, 'brand': 461497}
+C5_FIELDS = [f'f{i}' for i in range(63)] + ['dom']
+
+
+def make_config(name, table_rows=None):
+    """The BASELINE.json configs this file can time: aliccp = configs[1] (the headline), alimama = configs[3], c5 = configs[4]."""
+    if name == "aliccp":
+        return dict(name=name, fields=ALICCP_FIELDS, maxima=ALICCP_MAX, dense=[], domain='301', dom_lo=1, n_domains=3, D=32,
+                    H=4, L=3, units=(64, 32), flag='sota', lr=0.005, int_ids=False,
+                    label="BASELINE configs[1]: AliCCP-shaped SATrans training step, 19 fields")
+    if name == "alimama":
+        return dict(name=name, fields=ALIMAMA_FIELDS, maxima=ALIMAMA_MAX, dense=['price'], domain='shopping_level', dom_lo=0,
+                    n_domains=3, D=32, H=4, L=3, units=(64, 32), flag='sota-pos', lr=0.001, int_ids=False,
+                    label="BASELINE configs[3]: Alimama-shaped SATrans training step, 15 sparse + 1 dense field, flag sota-pos "
+                          "(column maxima are public-dataset magnitudes, an assumption)")
+    if name == "c5":
+        total = int(table_rows or 20_000_000)
+        per = max(8, total // 63)
+        maxima = {f: per - 2 for f in C5_FIELDS[:-1]}
+        maxima['dom'] = 3
+        return dict(name=name, fields=C5_FIELDS, maxima=maxima, dense=[], domain='dom', dom_lo=1, n_domains=3, D=64, H=4, L=6,
+                    units=(128, 64), flag='sota', lr=0.005, int_ids=True,
+                    label=f"BASELINE configs[4]: synthetic stress, 64 int64 fields, embedding_dim 64, 6 layers, MetaNet hidden 128, "
+                          f"{per * 63 + 5:,} table rows (configs[4] names 100 M rows = 25.6 GB + 51 GB of Adam state; scaled so that "
+                          f"the tables initialise on the host within the lease - pass --table-rows 100000000 for the full size)")
+    raise ValueError(name)
+
+
+CFG = make_config("aliccp")
+
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
 
 
-def synth_batches(n_rows, seed, ids="uniform"):
-    """AliCCP-shaped id matrix.  `uniform`: every id of a field equally likely (the HBM worst case, the bench default);
+def synth_batches(n_rows, seed, ids="uniform", cfg=None):
+    """Shaped id matrix of a config.  `uniform`: every id of a field equally likely (the HBM worst case, the bench default);
     `skewed`: log-uniform ranks, P(id) ~ 1/(id+1), i.e. Zipf with exponent 1 (real CTR ids are skewed: a few hot rows)."""
+    cfg = cfg or CFG
     rng = np.random.RandomState(seed)
     cols = []
-    for f in ALICCP_FIELDS:
-        lo = 1 if f == '301' else 0                                                # scenario ids start at 1 (main.py:112-114)
-        if ids == "skewed" and f != '301':
-            col = np.minimum((np.exp(rng.uniform(0.0, np.log(ALICCP_MAX[f] + 1.0), size=n_rows)) - 1.0).astype(np.int64),
-                             ALICCP_MAX[f])
+    for f in cfg["fields"]:
+        mx = cfg["maxima"][f]
+        lo = cfg["dom_lo"] if f == cfg["domain"] else 0                              # AliCCP scenario ids start at 1 (main.py:112-114)
+        if ids == "skewed" and f != cfg["domain"]:
+            col = np.minimum((np.exp(rng.uniform(0.0, np.log(mx + 1.0), size=n_rows)) - 1.0).astype(np.int64), mx)
         else:
-            col = rng.randint(lo, ALICCP_MAX[f] + 1, size=n_rows)
+            col = rng.randint(lo, mx + 1, size=n_rows)
         cols.append(col)
-    X = np.stack(cols, axis=1).astype(np.float32)                                  # ids travel as fp32 (meta_basemodel.py:311)
+    if cfg["int_ids"]:
+        X = np.stack(cols, axis=1).astype(np.int64)                                # integer ids (vocabularies beyond fp32's 2**24)
+    else:
+        cols += [rng.rand(n_rows) for _ in cfg["dense"]]                           # MinMax-scaled price (main.py:156-157)
+        X = np.stack(cols, axis=1).astype(np.float32)                              # ids travel as fp32 (meta_basemodel.py:311)
     y = (rng.rand(n_rows) < 0.04).astype(np.float32)                               # assumed CTR level (BASELINE.md §3)
     return X, y
 
 
-def build_model(device, lr, flag='sota'):
-    from satrans_amd import SATrans, SparseFeat
-    cols = [SparseFeat(f, vocabulary_size=ALICCP_MAX[f] + 2, embedding_dim=32) for f in ALICCP_FIELDS]
-    model = SATrans(cols, cols, ['301'], [3], att_layer_num=0, domain_att_layer_num=3, att_head_num=4,
-                    use_linear=False, use_dnn=False, meta_mode='QK', seed='1021', device=device, flag=flag)
+def build_model(device, lr, flag=None, cfg=None):
+    from satrans_amd import DenseFeat, SATrans, SparseFeat
+    cfg = cfg or CFG
+    cols = [SparseFeat(f, vocabulary_size=cfg["maxima"][f] + 2, embedding_dim=cfg["D"]) for f in cfg["fields"]] + \
+           [DenseFeat(f, 1) for f in cfg["dense"]]
+    model = SATrans(cols, cols, [cfg["domain"]], [cfg["n_domains"]], att_layer_num=0, domain_att_layer_num=cfg["L"],
+                    att_head_num=cfg["H"], use_linear=False, use_dnn=False, meta_mode='QK', meta_dnn_hidden_units=cfg["units"],
+                    seed='1021', device=device, flag=flag or cfg["flag"])
     model.compile(torch.optim.Adam(model.parameters(), lr=lr), "binary_crossentropy",
                   metrics=["binary_crossentropy", "auc"])                          # main.py:343
     return model
 
 
-def oracle_spec(flag='sota'):
+def oracle_spec(flag=None, cfg=None):
     from oracle.satrans_oracle import PathSpec
-    return PathSpec(sparse=[(f, i) for i, f in enumerate(ALICCP_FIELDS)], dense=[], domain_cols=[18],
-                    embedding_dim=32, head_num=4, layer_num=3, flag=flag, meta_mode='QK', meta_units=[32, 64, 32])
+    cfg = cfg or CFG
+    nf = len(cfg["fields"])
+    return PathSpec(sparse=[(f, i) for i, f in enumerate(cfg["fields"])], dense=[(nf + i, nf + i + 1) for i in range(len(cfg["dense"]))],
+                    domain_cols=[cfg["fields"].index(cfg["domain"])], embedding_dim=cfg["D"], head_num=cfg["H"],
+                    layer_num=cfg["L"], flag=flag or cfg["flag"], meta_mode='QK', meta_units=[cfg["D"]] + list(cfg["units"]))
 
 
 def cpu_model_name():
@@ -192,10 +239,20 @@ def main():
     ap.add_argument("--train-only", action="store_true",
                     help="only the timed training steps (profiling runs: every kernel row is then one configuration)")
     ap.add_argument("--no-phase-timing", action="store_true")
-    ap.add_argument("--flag", default="sota", help="SATrans flag (reference main.py --flag); 'sota-pos' = the positional variant")
+    ap.add_argument("--config", choices=["aliccp", "alimama", "c5"], default="aliccp",
+                    help="aliccp = BASELINE configs[1] (the headline metric), alimama = configs[3] (15 sparse + 1 dense, sota-pos), "
+                         "c5 = configs[4] (64 int64 fields, embedding_dim 64, 6 layers)")
+    ap.add_argument("--table-rows", type=int, default=None, help="c5: total embedding rows (default 20 M; configs[4] names 100 M)")
+    ap.add_argument("--flag", default=None, help="SATrans flag (reference main.py --flag); 'sota-pos' = the positional variant")
     ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
                     help="id distribution of the synthetic batches (uniform = HBM worst case, the reported configuration)")
     args = ap.parse_args()
+    global CFG
+    CFG = make_config(args.config, args.table_rows)
+    if args.flag is None:
+        args.flag = CFG["flag"]
+    if args.config != "aliccp" and args.lr == 0.005:
+        args.lr = CFG["lr"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -293,16 +350,16 @@ def main():
         return
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------------
-    F, D, L = 19, 32, 3
+    F, D, L, U = len(CFG["fields"]), CFG["D"], CFG["L"], CFG["units"][0]
     total_rows = model.embedding_arena.shape[0]
     uniq = int(torch.unique(eng._ws[B]["rows"]).numel()) if B in eng._ws else 0
-    fwd_flops = 2.0 * (12 * F * D * D + 2 * F * F * D) * B                         # per layer launch
+    fwd_flops = 2.0 * (4 * F * D * D + 4 * F * D * U + 2 * F * F * D) * B          # per layer launch (U = 2 D: 12 F D^2)
     per_launch = {
         "adam_untouched": dict(kernel="adam_untouched_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                                work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
         "layer_bwd": dict(kernel=os.environ.get("SATRANS_BWD8", "1") != "0" and "layer_bwd8_kernel" or "layer_bwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                           work=2.0 * fwd_flops / 1e12),
-        "layer_fwd": dict(kernel="layer_fwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
+        "layer_fwd": dict(kernel="layer_fwd_fused_kernel" if args.config != "c5" else "gen_gemm_kernel (general path: whole layer)", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                           work=fwd_flops / 1e12),
         "gather_fwd": dict(kernel="gather_rows_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                            work=B * F * (D * 4 + 4) / 1e9),                        # read bytes (only timed with SATRANS_FUSE_GATHER=0)
@@ -357,7 +414,7 @@ def main():
 
     # ---- the gather on its own: achieved HBM GB/s at the training batch and at the reference's prediction batch
     #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
-    gather = gather_microbench(eng, Xd, B, 19, 32) if not args.train_only else None
+    gather = gather_microbench(eng, Xd, B, F, D) if not args.train_only else None
 
     # ---- the evaluation forward alone (predict / evaluate path) at the reference's prediction batch --------------------------
     forward_only = None
@@ -440,27 +497,33 @@ def main():
     if do_cpu:
         t_cpu = time.time()
         n_need = 1 + 5 + 2 + args.cpu_steps + 5 + 2
-        Xc, yc = synth_batches(n_need * B, seed=7)
-        r = cpu_baseline(state_cpu, Xc, yc, B, args.lr, args.flag, timed=args.cpu_steps)
+        # bounded sample: the same step at a smaller batch where one CPU step of the full batch would take minutes (c5)
+        Bc = B if args.config != "c5" else min(B, 512)
+        timed_c = args.cpu_steps if args.config != "c5" else min(args.cpu_steps, 3)
+        Xc, yc = synth_batches(n_need * Bc, seed=7)
+        r = cpu_baseline(state_cpu, Xc, yc, Bc, args.lr, args.flag, timed=timed_c, timed_verbose=5 if args.config != "c5" else 2)
         cpu = {"value": round(r["value"], 1), "unit": "samples/s", "cores": r["threads"], "kind": "port",
                "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(),
                "value_verbose1": round(r["value_verbose1"], 1),
                "thread_sweep_s_per_step": r["sweep_s_per_step"],
-               "sample": f"median of {r['timed']} training steps of B={B} after 2 untimed ones at the best thread count of a "
-                         f"one-step sweep (dropout on, dense L2 + dense torch Adam over all 6.57 M rows; `value` = verbose=0, "
+               "sample": f"median of {r['timed']} training steps of B={Bc} after 2 untimed ones at the best thread count of a "
+                         f"one-step sweep (dropout on, dense L2 + dense torch Adam over all {model.embedding_arena.shape[0]:,} rows; `value` = verbose=0, "
                          f"`value_verbose1` = median of {r['timed_verbose']} steps with the per-step sklearn log_loss + "
                          f"roc_auc_score of fit(verbose=1), what reference main.py runs); {time.time() - t_cpu:.0f}s wall"}
 
     value = world * B * K / elapsed
     out = {
-        "metric": "training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)" + ("" if args.flag == "sota" else f" flag={args.flag}"),
+        "metric": ("training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)" if args.config == "aliccp" else
+                   f"training samples/sec ({args.config}-shaped, emb={D}, {L}L/{CFG['H']}H, meta_mode=QK)") +
+                  ("" if args.flag == "sota" else f" flag={args.flag}"),
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: AliCCP-shaped SATrans training step, 19 fields, 6,571,961 table rows "
-                               f"(841 MB fp32), {args.ids} ids, dropout on, dense-Adam+L2 semantics over all rows",
-                   "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": 32, "layers": 3, "heads": 4,
-                   "parallelism": f"dp{world}"},
+        "config": {"workload": f"{CFG['label']}, {model.embedding_arena.shape[0]:,} table rows "
+                               f"({model.embedding_arena.numel() * 4 / 1e6:,.0f} MB fp32), {args.ids} ids, dropout on, "
+                               f"dense-Adam+L2 semantics over all rows",
+                   "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": D, "layers": L, "heads": CFG["H"],
+                   "fields": F, "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
         "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
         "forward_only": forward_only, "forward_only_bf16": forward_bf16, "cpu_baseline": cpu,
