@@ -189,6 +189,48 @@ int satrans_layer_bwd_generic(const satrans_layer_desc* d, const float* dy, floa
                               float* g_tab_q, float* g_tab_k, void* stream);
 int satrans_set_generic_attention(int mode);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sibling users of the same kernels, for the reference's baselines that plug the attention stack in.
+ *
+ * SelfAttention_Layer (models/submodules.py:178-238; `usetrans` in star.py, mmoe.py, ple.py, sharedbottom.py, adasparse.py):
+ *     q,k,v = x W ; heads ; softmax(q k^T [/ sqrt(d)]) -> dropout -> @ v ; y = LayerNorm(relu(dropout(o) + x W_Res))
+ * x, y, dy, dx [B,F,D] in the caller's order; W_* [D,D] (y = x @ W); g_ln [2,D] (gamma row, beta row).  Gradients are
+ * ACCUMULATED (+=) in a fixed order; dx is written.  `saved` carries the forward's activations to the backward.
+ * flags: SATRANS_TRAIN (dropout on), SATRANS_NO_RES (use_res=False), SATRANS_NO_SCALING (scaling=False). */
+#define SATRANS_NO_SCALING 128
+#define SATRANS_NO_NORM 256
+typedef struct satrans_selfatt_desc {
+    int32_t B, F, D, H, flags, layer;
+    float drop_p;
+    uint32_t seed, step;
+    const float *x, *w_query, *w_key, *w_value, *w_res, *ln_g, *ln_b;
+} satrans_selfatt_desc;
+int64_t satrans_selfatt_saved_floats(const satrans_selfatt_desc* d);
+int64_t satrans_selfatt_scratch_floats(const satrans_selfatt_desc* d);
+int satrans_selfatt_fwd(const satrans_selfatt_desc* d, float* y, float* att, float* saved, void* stream);
+int satrans_selfatt_bwd(const satrans_selfatt_desc* d, const float* dy, float* dx, const float* saved, float* scratch,
+                        float* g_wq, float* g_wk, float* g_wv, float* g_wres, float* g_ln, void* stream);
+
+/* MetaNet over an embedding block = BaseModel.meta_transformation (models/basemodel.py:191-199 with MetaNet,
+ * models/submodules.py:64-103; `metatrans` in deepfm.py, dcn.py, ...):
+ *     y = [LayerNorm](dropout(relu(x W1[s]) W2[s]) + x)      s = scenario of the sample, generated row tab[s] = [W1 D*U | W2 U*D]
+ * order / seg from satrans_bucket_scenarios; flags: SATRANS_TRAIN, SATRANS_NO_NORM (MetaNet(use_norm=False)).
+ * g_tab [S, tab_stride] and g_ln [2,D] are ACCUMULATED; dx is written. */
+typedef struct satrans_metanet_desc {
+    int32_t B, F, D, U, S, flags, layer;
+    float drop_p;
+    uint32_t seed, step;
+    int64_t tab_stride;
+    const float* x;
+    const int32_t *order, *seg;
+    const float *tab, *ln_g, *ln_b;
+} satrans_metanet_desc;
+int64_t satrans_metanet_saved_floats(const satrans_metanet_desc* d);
+int64_t satrans_metanet_scratch_floats(const satrans_metanet_desc* d);
+int satrans_metanet_fwd(const satrans_metanet_desc* d, float* y, float* saved, void* stream);
+int satrans_metanet_bwd(const satrans_metanet_desc* d, const float* dy, float* dx, const float* saved, float* scratch,
+                        float* g_tab, float* g_ln, void* stream);
+
 /* Backward of one layer.  Recomputes the forward from d->x (same dropout counters), so nothing but
  * the layer input is kept between the passes.
  *   dy        [B,F,D] gradient of the layer output

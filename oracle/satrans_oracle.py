@@ -384,3 +384,44 @@ def dropout_masks(seed: int, step: int, B: int, Fn: int, D: int, H: int, L: int,
 def bce_sum(prob: Tensor, y: Tensor) -> Tensor:
     """F.binary_cross_entropy(reduction='sum') with torch's log clamp at -100."""
     return F.binary_cross_entropy(prob.reshape(-1), y.to(prob.dtype).reshape(-1), reduction="sum")
+
+
+# --------------------------------------------------------------------------------------
+# Sibling users of the same kernels (SURVEY.md §8 f-4); test infrastructure like everything above
+# --------------------------------------------------------------------------------------
+def selfattention_layer(P: Dict[str, Tensor], x: Tensor, head_num: int, use_res: bool = True, scaling: bool = True,
+                        drop: Optional[Dropper] = None) -> Tuple[Tensor, Tensor]:
+    """models/submodules.py:209-236 (SelfAttention_Layer.forward): q,k,v = x W; heads = contiguous chunks of D/H channels;
+    softmax(q k^T / sqrt(d)) -> dropout -> @ v; heads concatenated in order; dropout; += x W_Res; ReLU; LayerNorm(eps 1e-6).
+    -> (y [B,F,D], normalized_att_scores [H,B,F,F])"""
+    drop = drop or Dropper("off")
+    D = x.shape[-1]
+    d = D // head_num
+    q, k, v = x @ P["W_Query"], x @ P["W_Key"], x @ P["W_Value"]
+    split = lambda t: torch.stack(torch.split(t, d, dim=2))
+    qh, kh, vh = split(q), split(k), split(v)
+    s = torch.einsum('bnik,bnjk->bnij', qh, kh)
+    if scaling:
+        s = s / d ** 0.5
+    att = drop(torch.softmax(s, dim=-1), 0, "attn")
+    o = torch.cat(torch.split(torch.matmul(att, vh), 1), dim=-1).squeeze(0)
+    o = drop(o, 0, "out")
+    if use_res:
+        o = o + x @ P["W_Res"]
+    o = torch.relu(o)
+    return F.layer_norm(o, (D,), P["layer_norm.weight"], P["layer_norm.bias"], 1e-6), att
+
+
+def meta_transformation(P: Dict[str, Tensor], ids: Tensor, x: Tensor, units: List[int], use_norm: bool,
+                        drop: Optional[Dropper] = None) -> Tensor:
+    """models/basemodel.py:191-199 + MetaNet (models/submodules.py:77-103): per-sample generated weights
+    vec = Linear(relu(domain_embeddings[id])); y = [LN](dropout(relu(x @ W1) @ W2) + x)."""
+    drop = drop or Dropper("off")
+    vec = F.linear(torch.relu(P["domain_embeddings.weight"][ids.long()]), P["domain_map_dnn.weight"], P["domain_map_dnn.bias"])
+    D, U = units[0], units[1]
+    W1 = vec[:, :D * U].reshape(-1, D, U)
+    W2 = vec[:, D * U:D * U + U * units[2]].reshape(-1, U, units[2])
+    y = drop(torch.relu(x @ W1) @ W2, 0, "meta_q") + x
+    if use_norm:
+        y = F.layer_norm(y, (D,), P["ffn_layer_norm.weight"], P["ffn_layer_norm.bias"], 1e-6)
+    return y

@@ -4,6 +4,7 @@ from .inputs import DenseFeat, SparseFeat, VarLenSparseFeat, build_input_feature
 from .callbacks import History  # noqa: F401
 from .basemodel import BaseModel  # noqa: F401
 from .satrans import SATrans  # noqa: F401
+from .layers import MetaTransformation, SelfAttention_Layer  # noqa: F401
 
 __all__ = ["SATrans", "BaseModel", "SparseFeat", "DenseFeat", "VarLenSparseFeat", "get_feature_names",
-           "build_input_features", "History"]
+           "build_input_features", "History", "SelfAttention_Layer", "MetaTransformation"]

@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void gen_ln_fwd_kernel(const float* __restrict
                                                        float* __restrict__ t_out, float* __restrict__ y, bool y_orig,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int64_t Ntok, int F, const int32_t* __restrict__ order, GenDrop dc,
-                                                       bool relu) {
+                                                       bool relu, bool relu_post, bool norm) {
+    // relu_post (SelfAttention_Layer, submodules.py:230-235): t = drop(a) + res is SAVED, the norm sees relu(t);
+    // !norm (MetaNet(use_norm=False), submodules.py:100-102): y = t
     constexpr int D = 4 * LPT;
     const int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPT;
     const int c = (int)(threadIdx.x % LPT) * 4;
@@ -251,7 +253,12 @@ __global__ __launch_bounds__(256) void gen_ln_fwd_kernel(const float* __restrict
         if (dc.on) x = (kb >> e) & 1u ? x * dc.scale : 0.f;
         x += rs[e];
         v[e] = x;
-        sum += x;
+    }
+    if (live && t_out) *reinterpret_cast<float4*>(t_out + m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (relu_post) v[e] = fmaxf(v[e], 0.f);
+        sum += v[e];
     }
 #pragma unroll
     for (int o = 1; o < LPT; o <<= 1) sum += __shfl_xor(sum, o, 64);
@@ -263,9 +270,12 @@ __global__ __launch_bounds__(256) void gen_ln_fwd_kernel(const float* __restrict
     for (int o = 1; o < LPT; o <<= 1) q += __shfl_xor(q, o, 64);
     const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-6f);
     if (!live) return;
-    if (t_out) *reinterpret_cast<float4*>(t_out + m * D + c) = make_float4(v[0], v[1], v[2], v[3]);
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
     const int64_t dst = y_orig ? (int64_t)b * F + f : m;
+    if (!norm) {
+        *reinterpret_cast<float4*>(y + dst * D + c) = make_float4(v[0], v[1], v[2], v[3]);
+        return;
+    }
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
     *reinterpret_cast<float4*>(y + dst * D + c) = make_float4((v[0] - mean) * rstd * gm.x + bt.x, (v[1] - mean) * rstd * gm.y + bt.y,
                                                               (v[2] - mean) * rstd * gm.z + bt.z, (v[3] - mean) * rstd * gm.w + bt.w);
 }
@@ -278,14 +288,17 @@ __global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict
                                                        const float* __restrict__ a_pre, const float* __restrict__ gamma,
                                                        float* __restrict__ dt, float* __restrict__ dm, float* __restrict__ part,
                                                        int64_t Ntok, int F, const int32_t* __restrict__ order, GenDrop dc,
-                                                       bool relu, int tokens_per_block) {
+                                                       bool relu, int tokens_per_block, bool relu_post, bool norm) {
     constexpr int D = 4 * LPT, TPI = 256 / LPT;      // tokens per iteration
     __shared__ float red[2][TPI][D];
     const int sub = threadIdx.x / LPT, c = (int)(threadIdx.x % LPT) * 4;
     const int64_t t_lo = (int64_t)blockIdx.x * tokens_per_block, t_hi = min(Ntok, t_lo + tokens_per_block);
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-    const float4 gm4 = *reinterpret_cast<const float4*>(gamma + c);
-    const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+    float gm[4] = {1.f, 1.f, 1.f, 1.f};
+    if (norm) {
+        const float4 gm4 = *reinterpret_cast<const float4*>(gamma + c);
+        gm[0] = gm4.x; gm[1] = gm4.y; gm[2] = gm4.z; gm[3] = gm4.w;
+    }
     for (int64_t base = t_lo; base < t_hi; base += TPI) {
         const int64_t m = base + sub;
         const bool live = m < t_hi;
@@ -295,8 +308,14 @@ __global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict
         const int64_t src = g_orig ? (int64_t)b * F + f : mm;
         const float4 g4 = *reinterpret_cast<const float4*>(g + src * D + c);
         const float4 t4 = *reinterpret_cast<const float4*>(t + mm * D + c);
+        const float g4_raw[4] = {g4.x, g4.y, g4.z, g4.w};
         float gv[4] = {g4.x, g4.y, g4.z, g4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
         if (!live) { gv[0] = gv[1] = gv[2] = gv[3] = 0.f; }
+        bool pos_[4] = {true, true, true, true};            // relu_post: the norm saw relu(t); its gradient passes where t > 0
+        if (relu_post) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pos_[e] = tv[e] > 0.f; tv[e] = fmaxf(tv[e], 0.f); }
+        }
         float sum = (tv[0] + tv[1]) + (tv[2] + tv[3]);
 #pragma unroll
         for (int o = 1; o < LPT; o <<= 1) sum += __shfl_xor(sum, o, 64);
@@ -331,7 +350,8 @@ __global__ __launch_bounds__(256) void gen_ln_bwd_kernel(const float* __restrict
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                d_[e] = rstd * (gv[e] - m1 - zh[e] * m2);
+                d_[e] = norm ? rstd * (gv[e] - m1 - zh[e] * m2) : g4_raw[e];
+                if (!pos_[e]) d_[e] = 0.f;
                 float mk = 1.0f;
                 if (dc.on) mk = (kb >> e) & 1u ? dc.scale : 0.f;
                 if (relu && !(pre[e] > 0.f)) mk = 0.f;
@@ -358,7 +378,8 @@ template <int d>
 __global__ __launch_bounds__(256) void gen_attn_fwd_wave_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, float* __restrict__ o,
                                                               float2* __restrict__ st, float* __restrict__ att, int B, int F,
-                                                              int H, const int32_t* __restrict__ order, GenDrop dc) {
+                                                              int H, const int32_t* __restrict__ order, GenDrop dc,
+                                                              float inv_sqrt_d) {
     extern __shared__ __align__(16) float at_lds[];
     const int D = H * d, LD = D + 4;
     float* sk = at_lds;
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(256) void gen_attn_fwd_wave_kernel(const float* __r
     }
     __syncthreads();
     const int b = order[p];
-    const float sc_scale = kLog2e / sqrtf((float)d);
+    const float sc_scale = kLog2e * inv_sqrt_d;
     for (int task = threadIdx.x; task < H * F; task += blockDim.x) {
         const int h = task / F, i = task - h * F;
         f32x2 qi[d / 2];
@@ -441,7 +462,7 @@ __global__ __launch_bounds__(256) void gen_attn_fwd_wave_kernel(const float* __r
 __global__ __launch_bounds__(256) void gen_attn_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, float* __restrict__ o,
                                                               float2* __restrict__ st, int F, int H,
-                                                              const int32_t* __restrict__ order, GenDrop dc) {
+                                                              const int32_t* __restrict__ order, GenDrop dc, float inv_sqrt_d) {
     constexpr int d = 16;
     extern __shared__ __align__(16) float at_lds[];
     const int D = H * d, LD = D + 4;
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(256) void gen_attn_fwd_mfma_kernel(const float* __r
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     if (h >= H) return;
     const int b = order[p];
-    const float sc_scale = kLog2e / sqrtf((float)d);
+    const float sc_scale = kLog2e * inv_sqrt_d;
     const int JT = FP >> 4;
     const uint32_t skey = drop_sample_key(dc.key, (uint32_t)b);
     for (int it = 0; it < JT; ++it) {               // query tile: queries 16 it + n on the lanes
@@ -535,7 +556,8 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kernel(const float* __restri
                                                          const float* __restrict__ v, const float* __restrict__ o,
                                                          const float* __restrict__ go, const float2* __restrict__ st,
                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
-                                                         int F, int H, const int32_t* __restrict__ order, GenDrop dc) {
+                                                         int F, int H, const int32_t* __restrict__ order, GenDrop dc,
+                                                         float inv_sqrt_d) {
     extern __shared__ __align__(16) float at_lds[];
     const int D = H * d, LD = D + 4;
     float* sq = at_lds;
@@ -564,7 +586,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kernel(const float* __restri
         sst[task] = make_float4(s2.x, s2.y, dot_row<d>(gi, oi), 0.f);
     }
     __syncthreads();
-    const float inv_sqrt_d = 1.0f / sqrtf((float)d), sc_scale = inv_sqrt_d * kLog2e, scale = dc.scale;
+    const float sc_scale = inv_sqrt_d * kLog2e, scale = dc.scale;
     for (int task = threadIdx.x; task < H * F; task += blockDim.x) {
         const int h = task / F, i = task - h * F;
         const float* qb_ = sq + h * d;
@@ -717,18 +739,19 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
     }
 
 static int gen_ln_fwd(hipStream_t st, const satrans_layer_desc* d, const float* a, const float* res, float* t_out, float* y,
-                      bool y_orig, const float* gamma, const float* beta, int site, bool relu) {
+                      bool y_orig, const float* gamma, const float* beta, int site, bool relu, bool relu_post = false,
+                      bool norm = true) {
     const int64_t N = (int64_t)d->B * d->F;
     const GenDrop dc = gen_drop(d, site);
     GEN_LN_DISPATCH(d->D, (gen_ln_fwd_kernel<LPT><<<(unsigned)ceil_div(N * LPT, 256), 256, 0, st>>>(
-                              a, res, t_out, y, y_orig, gamma, beta, N, d->F, d->order, dc, relu)));
+                              a, res, t_out, y, y_orig, gamma, beta, N, d->F, d->order, dc, relu, relu_post, norm)));
     SATRANS_CHECK_LAUNCH("gen_ln_fwd_kernel");
     return SATRANS_OK;
 }
 
 static int gen_ln_bwd(hipStream_t st, const satrans_layer_desc* d, const GenLayout& L, float* scratch, const float* g, bool g_orig,
                       const float* t, const float* a_pre, const float* gamma, float* dt, float* dm, int site, bool relu,
-                      float* g_gamma_beta) {
+                      float* g_gamma_beta, bool relu_post = false, bool norm = true) {
     const int64_t N = (int64_t)d->B * d->F;
     const GenDrop dc = gen_drop(d, site);
     const int tpi = 256 / (d->D / 4);
@@ -736,12 +759,70 @@ static int gen_ln_bwd(hipStream_t st, const satrans_layer_desc* d, const GenLayo
     const int tpb = (int)(ceil_div(ceil_div(N, blocks), tpi) * tpi);
     float* part = scratch + L.ln_part;
     GEN_LN_DISPATCH(d->D, (gen_ln_bwd_kernel<LPT><<<(unsigned)blocks, 256, 0, st>>>(g, g_orig, t, a_pre, gamma, dt, dm, part, N,
-                                                                                   d->F, d->order, dc, relu, tpb)));
+                                                                                   d->F, d->order, dc, relu, tpb, relu_post, norm)));
     SATRANS_CHECK_LAUNCH("gen_ln_bwd_kernel");
-    if (g_gamma_beta) {
+    if (g_gamma_beta && norm) {
         gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * d->D, 32), 1), 256, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta, 0);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
+    return SATRANS_OK;
+}
+
+// attention forward / backward launches shared by the layer and by SelfAttention_Layer
+static int gen_attention_fwd(hipStream_t st, const satrans_layer_desc* d, const float* q, const float* k, const float* v, float* o,
+                             float2* stp, float* att, float inv_sqrt_d) {
+    const int B = d->B, F = d->F, D = d->D, H = d->H;
+    const GenDrop dc = gen_drop(d, kSiteAttn);
+    const int dd = D / H;
+    int mode = g_attn_override >= 0 ? g_attn_override : gen_attn_mode();
+    const bool can_mfma = dd == 16 && F <= 64 && H <= 4 && !att;
+    const bool mfma = mode == 2 ? can_mfma : (mode == 0 && can_mfma);
+    SATRANS_REQUIRE(mode != 2 || can_mfma, SATRANS_E_UNSUPPORTED, "generic attention: the MFMA arm needs d = 16, F <= 64, H <= 4");
+    if (mfma) {
+        const int FP = (F + 15) & ~15;
+        const size_t lds = sizeof(float) * 3 * FP * (D + 4);
+        static size_t attr = 0;
+        if (lds > attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)gen_attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention: LDS attribute: %s", hipGetErrorString(e));
+            attr = lds;
+        }
+        gen_attn_fwd_mfma_kernel<<<B, 256, lds, st>>>(q, k, v, o, stp, F, H, d->order, dc, inv_sqrt_d);
+        SATRANS_CHECK_LAUNCH("gen_attn_fwd_mfma_kernel");
+    } else {
+        const size_t lds = sizeof(float) * 2 * F * (D + 4);
+        static size_t attr8 = 0, attr16 = 0;
+        size_t& attr = dd == 8 ? attr8 : attr16;
+        if (lds > attr) {
+            hipError_t e = dd == 8 ? hipFuncSetAttribute((const void*)gen_attn_fwd_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                   : hipFuncSetAttribute((const void*)gen_attn_fwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention: LDS attribute: %s", hipGetErrorString(e));
+            attr = lds;
+        }
+        if (dd == 8) gen_attn_fwd_wave_kernel<8><<<B, 256, lds, st>>>(q, k, v, o, stp, att, B, F, H, d->order, dc, inv_sqrt_d);
+        else gen_attn_fwd_wave_kernel<16><<<B, 256, lds, st>>>(q, k, v, o, stp, att, B, F, H, d->order, dc, inv_sqrt_d);
+        SATRANS_CHECK_LAUNCH("gen_attn_fwd_wave_kernel");
+    }
+    return SATRANS_OK;
+}
+
+static int gen_attention_bwd(hipStream_t st, const satrans_layer_desc* d, const float* q, const float* k, const float* v,
+                             const float* o, const float* go, const float2* stp, float* dq, float* dk, float* dv, float inv_sqrt_d) {
+    const int B = d->B, F = d->F, D = d->D, H = d->H;
+    const GenDrop dc = gen_drop(d, kSiteAttn);
+    const int dd = D / H;
+    const size_t lds = sizeof(float) * (4 * (size_t)F * (D + 4) + 4 * (size_t)H * F);
+    static size_t attr8 = 0, attr16 = 0;
+    size_t& attr = dd == 8 ? attr8 : attr16;
+    if (lds > attr) {
+        hipError_t e = dd == 8 ? hipFuncSetAttribute((const void*)gen_attn_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipFuncSetAttribute((const void*)gen_attn_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention backward: LDS attribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    if (dd == 8) gen_attn_bwd_kernel<8><<<B, 256, lds, st>>>(q, k, v, o, go, stp, dq, dk, dv, F, H, d->order, dc, inv_sqrt_d);
+    else gen_attn_bwd_kernel<16><<<B, 256, lds, st>>>(q, k, v, o, go, stp, dq, dk, dv, F, H, d->order, dc, inv_sqrt_d);
+    SATRANS_CHECK_LAUNCH("gen_attn_bwd_kernel");
     return SATRANS_OK;
 }
 
@@ -807,40 +888,8 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
         if ((rc = metanet(k0, saved + L.hk, saved + L.mk, saved + L.tk, saved + L.k, d->tab_k, d->lnk_g, d->lnk_b, kSiteMetaK))) return rc;
         k = saved + L.k;
     }
-    {   // satrans.py:75-90
-        const GenDrop dc = gen_drop(d, kSiteAttn);
-        const int dd = D / H;
-        int mode = g_attn_override >= 0 ? g_attn_override : gen_attn_mode();
-        const bool can_mfma = dd == 16 && F <= 64 && H <= 4 && !att;
-        const bool mfma = mode == 2 ? can_mfma : (mode == 0 && can_mfma);
-        SATRANS_REQUIRE(mode != 2 || can_mfma, SATRANS_E_UNSUPPORTED, "generic attention: the MFMA arm needs d = 16, F <= 64, H <= 4");
-        float2* stp = reinterpret_cast<float2*>(saved + L.st);
-        if (mfma) {
-            const int FP = (F + 15) & ~15;
-            const size_t lds = sizeof(float) * 3 * FP * (D + 4);
-            static size_t attr = 0;
-            if (lds > attr) {
-                hipError_t e = hipFuncSetAttribute((const void*)gen_attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention: LDS attribute: %s", hipGetErrorString(e));
-                attr = lds;
-            }
-            gen_attn_fwd_mfma_kernel<<<B, 256, lds, st>>>(q, k, v, saved + L.o, stp, F, H, d->order, dc);
-            SATRANS_CHECK_LAUNCH("gen_attn_fwd_mfma_kernel");
-        } else {
-            const size_t lds = sizeof(float) * 2 * F * (D + 4);
-            static size_t attr8 = 0, attr16 = 0;
-            size_t& attr = dd == 8 ? attr8 : attr16;
-            if (lds > attr) {
-                hipError_t e = dd == 8 ? hipFuncSetAttribute((const void*)gen_attn_fwd_wave_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                       : hipFuncSetAttribute((const void*)gen_attn_fwd_wave_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention: LDS attribute: %s", hipGetErrorString(e));
-                attr = lds;
-            }
-            if (dd == 8) gen_attn_fwd_wave_kernel<8><<<B, 256, lds, st>>>(q, k, v, saved + L.o, stp, att, B, F, H, d->order, dc);
-            else gen_attn_fwd_wave_kernel<16><<<B, 256, lds, st>>>(q, k, v, saved + L.o, stp, att, B, F, H, d->order, dc);
-            SATRANS_CHECK_LAUNCH("gen_attn_fwd_wave_kernel");
-        }
-    }
+    if ((rc = gen_attention_fwd(st, d, q, k, v, saved + L.o, reinterpret_cast<float2*>(saved + L.st), att,   // satrans.py:75-90
+                                1.0f / sqrtf((float)(D / H))))) return rc;
     {   // satrans.py:91-99
         const float* A[1] = {saved + L.o};
         const float* Bw[1] = {d->w_out};
@@ -882,23 +931,8 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): memset: %s", hipGetErrorString(e));
     }
     // ---- attention --------------------------------------------------------------------------------------------------------------
-    {
-        const GenDrop dc = gen_drop(d, kSiteAttn);
-        const int dd = D / H;
-        const size_t lds = sizeof(float) * (4 * (size_t)F * (D + 4) + 4 * (size_t)H * F);
-        static size_t attr8 = 0, attr16 = 0;
-        size_t& attr = dd == 8 ? attr8 : attr16;
-        if (lds > attr) {
-            hipError_t e = dd == 8 ? hipFuncSetAttribute((const void*)gen_attn_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                   : hipFuncSetAttribute((const void*)gen_attn_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention backward: LDS attribute: %s", hipGetErrorString(e));
-            attr = lds;
-        }
-        const float2* stp = reinterpret_cast<const float2*>(saved + L.st);
-        if (dd == 8) gen_attn_bwd_kernel<8><<<B, 256, lds, st>>>(q, k, v, saved + L.o, go, stp, dq, dk, dv, F, H, d->order, dc);
-        else gen_attn_bwd_kernel<16><<<B, 256, lds, st>>>(q, k, v, saved + L.o, go, stp, dq, dk, dv, F, H, d->order, dc);
-        SATRANS_CHECK_LAUNCH("gen_attn_bwd_kernel");
-    }
+    if ((rc = gen_attention_bwd(st, d, q, k, v, saved + L.o, go, reinterpret_cast<const float2*>(saved + L.st), dq, dk, dv,
+                                1.0f / sqrtf((float)(D / H))))) return rc;
     // ---- MetaNet backward of one role: g (gradient of the role's output rows) becomes the gradient of z0 -------------------------
     auto metanet_bwd = [&](float* g, const float* z0, const float* h, const float* t, const float* tab, const float* gam,
                            float* g_ln_role, float* g_tab, int site) -> int {
@@ -936,6 +970,243 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
         }
     }
     gen_permute_out_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, dr, dx);
+    SATRANS_CHECK_LAUNCH("gen_permute_out_kernel");
+    return SATRANS_OK;
+}
+
+// =================================================================================================================================
+// Sibling users of the same kernels
+//   * SelfAttention_Layer (reference models/submodules.py:178-238; `usetrans` of star.py, mmoe.py, ple.py, sharedbottom.py,
+//     adasparse.py): q,k,v = x W ; multi-head attention ; y = LayerNorm(relu(drop(o) + x W_Res)) - no MetaNet, no out-linear
+//     (W_Out is a parameter the reference never uses), ReLU BEFORE the norm, a projected residual.
+//   * MetaNet over an embedding block = BaseModel.meta_transformation (models/basemodel.py:191-199; `metatrans` of deepfm.py,
+//     dcn.py, ...): y = [LayerNorm](drop(relu(x W1[s]) W2[s]) + x) with the scenario's generated weights.
+// =================================================================================================================================
+namespace satrans {
+
+__global__ void gen_iota_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+struct SelfAttLayout {
+    int64_t nd, order, q, k, v, o, r, t, st, saved_total, dt, dm, dq, dk, dv, part, ln_part, scratch_total;
+    int ln_blocks;
+};
+static SelfAttLayout selfatt_layout(const satrans_selfatt_desc* d) {
+    SelfAttLayout L;
+    const int64_t N = (int64_t)d->B * d->F;
+    L.nd = N * d->D;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
+    L.order = take(d->B); L.q = take(L.nd); L.k = take(L.nd); L.v = take(L.nd); L.o = take(L.nd); L.r = take(L.nd); L.t = take(L.nd);
+    L.st = take(2 * (int64_t)d->B * d->H * d->F);
+    L.saved_total = o;
+    o = 0;
+    L.dt = take(L.nd); L.dm = take(L.nd); L.dq = take(L.nd); L.dk = take(L.nd); L.dv = take(L.nd);
+    L.part = take((ceil_div(N, kTnRows) + 1) * (int64_t)d->D * d->D);
+    L.ln_blocks = (int)std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
+    L.ln_part = take((int64_t)L.ln_blocks * 2 * d->D);
+    L.scratch_total = o;
+    return L;
+}
+static bool selfatt_supported(const satrans_selfatt_desc* d) {
+    if (!d || d->B <= 0 || d->F <= 0 || d->H <= 0) return false;
+    if (!(d->D == 16 || d->D == 32 || d->D == 64 || d->D == 128) || d->D % d->H) return false;
+    const int dd = d->D / d->H;
+    return (dd == 8 || dd == 16) && (int64_t)4 * d->F * (d->D + 4) * 4 + (int64_t)d->H * d->F * 16 <= 150 * 1024;
+}
+// the pieces of a layer descriptor the shared helpers read
+static satrans_layer_desc as_layer(const satrans_selfatt_desc* d, const int32_t* order) {
+    satrans_layer_desc l;
+    memset(&l, 0, sizeof(l));
+    l.B = d->B; l.F = d->F; l.D = d->D; l.H = d->H; l.S = 1;
+    l.flags = d->flags & SATRANS_TRAIN;
+    l.drop_p = d->drop_p; l.seed = d->seed; l.step = d->step; l.layer = d->layer;
+    l.order = order;
+    return l;
+}
+
+}  // namespace satrans
+
+extern "C" int64_t satrans_selfatt_saved_floats(const satrans_selfatt_desc* d) {
+    return selfatt_supported(d) ? selfatt_layout(d).saved_total : -1;
+}
+extern "C" int64_t satrans_selfatt_scratch_floats(const satrans_selfatt_desc* d) {
+    return selfatt_supported(d) ? selfatt_layout(d).scratch_total : -1;
+}
+
+extern "C" int satrans_selfatt_fwd(const satrans_selfatt_desc* d, float* y, float* att, float* saved, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SATRANS_REQUIRE(selfatt_supported(d), SATRANS_E_UNSUPPORTED, "selfatt_fwd: shape not supported");
+    const bool use_res = !(d->flags & SATRANS_NO_RES);
+    SATRANS_REQUIRE(d->x && d->w_query && d->w_key && d->w_value && d->ln_g && d->ln_b && y && saved && (!use_res || d->w_res),
+                    SATRANS_E_BADARG, "selfatt_fwd: null pointer");
+    const SelfAttLayout L = selfatt_layout(d);
+    const int B = d->B, F = d->F, D = d->D, M = B * F;
+    int32_t* order = reinterpret_cast<int32_t*>(saved + L.order);
+    gen_iota_kernel<<<(unsigned)ceil_div(B, 256), 256, 0, st>>>(order, B);
+    SATRANS_CHECK_LAUNCH("gen_iota_kernel");
+    const satrans_layer_desc ld = as_layer(d, order);
+    int rc;
+    {
+        const float* A[3] = {d->x, d->x, d->x};
+        const float* Bw[3] = {d->w_query, d->w_key, d->w_value};
+        float* C[3] = {saved + L.q, saved + L.k, saved + L.v};
+        if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+    }
+    const float scale = (d->flags & SATRANS_NO_SCALING) ? 1.0f : 1.0f / sqrtf((float)(D / d->H));
+    if ((rc = gen_attention_fwd(st, &ld, saved + L.q, saved + L.k, saved + L.v, saved + L.o, reinterpret_cast<float2*>(saved + L.st),
+                                att, scale))) return rc;
+    if (use_res) {
+        const float* A[1] = {d->x};
+        const float* Bw[1] = {d->w_res};
+        float* C[1] = {saved + L.r};
+        if ((rc = gen_gemm<false, 0>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+    }
+    return gen_ln_fwd(st, &ld, saved + L.o, use_res ? saved + L.r : nullptr, saved + L.t, y, false, d->ln_g, d->ln_b, kSiteOut, false,
+                      true, true);
+}
+
+extern "C" int satrans_selfatt_bwd(const satrans_selfatt_desc* d, const float* dy, float* dx, const float* saved, float* scratch,
+                                   float* g_wq, float* g_wk, float* g_wv, float* g_wres, float* g_ln, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SATRANS_REQUIRE(selfatt_supported(d), SATRANS_E_UNSUPPORTED, "selfatt_bwd: shape not supported");
+    const bool use_res = !(d->flags & SATRANS_NO_RES);
+    SATRANS_REQUIRE(dy && dx && saved && scratch && g_wq && g_wk && g_wv && g_ln && (!use_res || g_wres), SATRANS_E_BADARG,
+                    "selfatt_bwd: null pointer");
+    const SelfAttLayout L = selfatt_layout(d);
+    const int B = d->B, F = d->F, D = d->D, M = B * F;
+    const int32_t* order = reinterpret_cast<const int32_t*>(saved + L.order);
+    const satrans_layer_desc ld = as_layer(d, order);
+    GenLayout GL;
+    memset(&GL, 0, sizeof(GL));
+    GL.ln_blocks = L.ln_blocks;
+    GL.ln_part = L.ln_part;
+    float *dt = scratch + L.dt, *dm = scratch + L.dm, *dq = scratch + L.dq, *dk = scratch + L.dk, *dv = scratch + L.dv,
+          *part = scratch + L.part;
+    int rc;
+    // y = LN(relu(t)), t = drop(o) + x W_Res: dt = gradient of t (zero where t <= 0), dm = dt * dropout mask = gradient of o
+    if ((rc = gen_ln_bwd(st, &ld, GL, scratch, dy, false, saved + L.t, nullptr, d->ln_g, dt, dm, kSiteOut, false, g_ln, true, true)))
+        return rc;
+    const float scale = (d->flags & SATRANS_NO_SCALING) ? 1.0f : 1.0f / sqrtf((float)(D / d->H));
+    if ((rc = gen_attention_bwd(st, &ld, saved + L.q, saved + L.k, saved + L.v, saved + L.o, dm,
+                                reinterpret_cast<const float2*>(saved + L.st), dq, dk, dv, scale))) return rc;
+    if ((rc = gen_gemm_tn(st, d->x, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
+    if ((rc = gen_gemm_tn(st, d->x, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
+    if ((rc = gen_gemm_tn(st, d->x, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+    if (use_res && (rc = gen_gemm_tn(st, d->x, dt, nullptr, 1, M, F, D, D, part, g_wres, 0))) return rc;
+    // dx = dq Wq^T + dk Wk^T + dv Wv^T (+ dt Wres^T)
+    const float* grads[4] = {dq, dk, dv, dt};
+    const float* ws[4] = {d->w_query, d->w_key, d->w_value, d->w_res};
+    for (int i = 0; i < (use_res ? 4 : 3); ++i) {
+        const float* A[1] = {grads[i]};
+        const float* Bw[1] = {ws[i]};
+        float* C[1] = {dx};
+        rc = i == 0 ? gen_gemm<true, 0>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0)
+                    : gen_gemm<true, 2>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0);
+        if (rc) return rc;
+    }
+    return SATRANS_OK;
+}
+
+// ---- MetaNet over an embedding block ----------------------------------------------------------------------------------------------
+namespace satrans {
+struct MetaLayout {
+    int64_t nd, nu, xs, h, m, t, saved_total, dt, dm, dh, part, ln_part, scratch_total;
+    int ln_blocks;
+};
+static MetaLayout metanet_layout(const satrans_metanet_desc* d) {
+    MetaLayout L;
+    const int64_t N = (int64_t)d->B * d->F;
+    L.nd = N * d->D;
+    L.nu = N * d->U;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += (n + 3) & ~(int64_t)3; return r; };
+    L.xs = take(L.nd); L.h = take(L.nu); L.m = take(L.nd); L.t = take(L.nd);
+    L.saved_total = o;
+    o = 0;
+    L.dt = take(L.nd); L.dm = take(L.nd); L.dh = take(L.nu);
+    L.part = take((int64_t)d->S * (ceil_div(N, kTnRows) + 1) * (int64_t)d->D * d->U);
+    L.ln_blocks = (int)std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
+    L.ln_part = take((int64_t)L.ln_blocks * 2 * d->D);
+    L.scratch_total = o;
+    return L;
+}
+static bool metanet_supported(const satrans_metanet_desc* d) {
+    if (!d || d->B <= 0 || d->F <= 0 || d->S <= 0) return false;
+    if (!(d->D == 16 || d->D == 32 || d->D == 64 || d->D == 128)) return false;
+    return d->U > 0 && d->U % 16 == 0 && d->U <= 128 && (int64_t)d->D * d->U <= 8192;
+}
+static satrans_layer_desc as_layer(const satrans_metanet_desc* d) {
+    satrans_layer_desc l;
+    memset(&l, 0, sizeof(l));
+    l.B = d->B; l.F = d->F; l.D = d->D; l.H = 1; l.U = d->U; l.S = d->S;
+    l.flags = d->flags & SATRANS_TRAIN;
+    l.drop_p = d->drop_p; l.seed = d->seed; l.step = d->step; l.layer = d->layer;
+    l.order = d->order; l.seg = d->seg; l.x = d->x; l.tab_stride = d->tab_stride;
+    return l;
+}
+}  // namespace satrans
+
+extern "C" int64_t satrans_metanet_saved_floats(const satrans_metanet_desc* d) {
+    return metanet_supported(d) ? metanet_layout(d).saved_total : -1;
+}
+extern "C" int64_t satrans_metanet_scratch_floats(const satrans_metanet_desc* d) {
+    return metanet_supported(d) ? metanet_layout(d).scratch_total : -1;
+}
+
+extern "C" int satrans_metanet_fwd(const satrans_metanet_desc* d, float* y, float* saved, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SATRANS_REQUIRE(metanet_supported(d), SATRANS_E_UNSUPPORTED, "metanet_fwd: shape not supported");
+    const bool norm = !(d->flags & SATRANS_NO_NORM);
+    SATRANS_REQUIRE(d->x && d->order && d->seg && d->tab && y && saved && (!norm || (d->ln_g && d->ln_b)), SATRANS_E_BADARG,
+                    "metanet_fwd: null pointer");
+    const MetaLayout L = metanet_layout(d);
+    const satrans_layer_desc ld = as_layer(d);
+    const int M = d->B * d->F, D = d->D, U = d->U;
+    gen_permute_in_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(ld, nullptr, saved + L.xs, true);
+    SATRANS_CHECK_LAUNCH("gen_permute_in_kernel");
+    int rc;
+    const float* A1[1] = {saved + L.xs};
+    const float* B1[1] = {d->tab};
+    float* C1[1] = {saved + L.h};
+    if ((rc = gen_gemm<false, 1>(st, 1, A1, B1, C1, d->seg, d->S, M, d->F, D, U, U, d->tab_stride))) return rc;
+    const float* A2[1] = {saved + L.h};
+    const float* B2[1] = {d->tab + (size_t)D * U};
+    float* C2[1] = {saved + L.m};
+    if ((rc = gen_gemm<false, 0>(st, 1, A2, B2, C2, d->seg, d->S, M, d->F, U, D, D, d->tab_stride))) return rc;
+    return gen_ln_fwd(st, &ld, saved + L.m, saved + L.xs, saved + L.t, y, true, d->ln_g, d->ln_b, kSiteMetaQ, false, false, norm);
+}
+
+extern "C" int satrans_metanet_bwd(const satrans_metanet_desc* d, const float* dy, float* dx, const float* saved, float* scratch,
+                                   float* g_tab, float* g_ln, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    SATRANS_REQUIRE(metanet_supported(d), SATRANS_E_UNSUPPORTED, "metanet_bwd: shape not supported");
+    const bool norm = !(d->flags & SATRANS_NO_NORM);
+    SATRANS_REQUIRE(dy && dx && saved && scratch && g_tab && (!norm || g_ln), SATRANS_E_BADARG, "metanet_bwd: null pointer");
+    const MetaLayout L = metanet_layout(d);
+    const satrans_layer_desc ld = as_layer(d);
+    const int M = d->B * d->F, D = d->D, U = d->U, S = d->S, F = d->F;
+    GenLayout GL;
+    memset(&GL, 0, sizeof(GL));
+    GL.ln_blocks = L.ln_blocks;
+    GL.ln_part = L.ln_part;
+    float *dt = scratch + L.dt, *dm = scratch + L.dm, *dh = scratch + L.dh, *part = scratch + L.part;
+    int rc;
+    if ((rc = gen_ln_bwd(st, &ld, GL, scratch, dy, true, saved + L.t, nullptr, d->ln_g, dt, dm, kSiteMetaQ, false, g_ln, false, norm)))
+        return rc;
+    if ((rc = gen_gemm_tn(st, saved + L.h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride))) return rc;
+    const float* A1[1] = {dm};
+    const float* B1[1] = {d->tab + (size_t)D * U};
+    float* C1[1] = {dh};
+    if ((rc = gen_gemm<true, 3>(st, 1, A1, B1, C1, d->seg, S, M, F, D, U, D, d->tab_stride, saved + L.h))) return rc;
+    if ((rc = gen_gemm_tn(st, saved + L.xs, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride))) return rc;
+    const float* A2[1] = {dh};
+    const float* B2[1] = {d->tab};
+    float* C2[1] = {dt};
+    if ((rc = gen_gemm<true, 2>(st, 1, A2, B2, C2, d->seg, S, M, F, U, D, U, d->tab_stride))) return rc;
+    gen_permute_out_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(ld, dt, dx);
     SATRANS_CHECK_LAUNCH("gen_permute_out_kernel");
     return SATRANS_OK;
 }

@@ -559,7 +559,8 @@ class PathEngine:
         tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
         self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready)
-        self._head(X, ws, y)
+        with self.phase("head"):
+            self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
             desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather)
@@ -592,7 +593,8 @@ class PathEngine:
                     self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
             cur = 1 - cur
         if modulated:
-            self.scenario_tables_backward(g_tabs)
+            with self.phase("scenario_bwd"):
+                self.scenario_tables_backward(g_tabs)
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
 
@@ -744,6 +746,11 @@ class PathEngine:
         if self.lazy:
             self._lazy_pending = True
         h_flat = self._hparams(0.0)
+        with self.phase("adam_flat"):
+            self._flat_step(h_flat, ws, st)
+
+    def _flat_step(self, h_flat, ws, st):
+        lib, m = self.lib, self.m
         N.check(lib.satrans_adam_flat_sum(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                           self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat),
                                           ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(),
@@ -771,13 +778,17 @@ class PathEngine:
         h = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
         st = self._stream()
         table = self._table(self.adam_t)
+        with self.phase("lazy_flush"):
+            self._flush_launches(m, h, st, table)
+        self._lazy_pending = False
+
+    def _flush_launches(self, m, h, st, table):
         N.check(self.lib.satrans_embed_lazy_flush(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
                                                   self.adam_v.data_ptr(), self.last_step.data_ptr(), self.total_rows,
                                                   self.D, self.adam_t, table.data_ptr(), C.byref(h), 0,
                                                   self._flush_reg.data_ptr(), st), "satrans_embed_lazy_flush")
         N.check(self.lib.satrans_sum_f64(self._flush_reg.data_ptr(), self._flush_reg.numel(), self.reg_sum.data_ptr(),
                                          1, st), "satrans_sum_f64")
-        self._lazy_pending = False
 
     # ------------------------------------------------------------------------------------------------
     # inspection for the parity tests: one forward+backward, gradients by state_dict key (dense tables)

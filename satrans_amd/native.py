@@ -41,6 +41,20 @@ class LayerDesc(C.Structure):
     ]
 
 
+class SelfAttDesc(C.Structure):
+    """Mirror of `satrans_selfatt_desc`."""
+    _fields_ = [("B", C.c_int32), ("F", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("flags", C.c_int32),
+                ("layer", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("step", C.c_uint32),
+                ("x", _vp), ("w_query", _vp), ("w_key", _vp), ("w_value", _vp), ("w_res", _vp), ("ln_g", _vp), ("ln_b", _vp)]
+
+
+class MetaNetDesc(C.Structure):
+    """Mirror of `satrans_metanet_desc`."""
+    _fields_ = [("B", C.c_int32), ("F", C.c_int32), ("D", C.c_int32), ("U", C.c_int32), ("S", C.c_int32), ("flags", C.c_int32),
+                ("layer", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("step", C.c_uint32),
+                ("tab_stride", C.c_int64), ("x", _vp), ("order", _vp), ("seg", _vp), ("tab", _vp), ("ln_g", _vp), ("ln_b", _vp)]
+
+
 class AdamHParams(C.Structure):
     """Mirror of `satrans_adam_hparams`."""
     _fields_ = [("lr_over_bc1", C.c_float), ("bc2_sqrt", C.c_float), ("beta1", C.c_float),
@@ -70,6 +84,14 @@ SIGNATURES = {
     "satrans_layer_bwd_generic": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, _vp]),
     "satrans_set_generic_attention": (C.c_int, [C.c_int]),
+"satrans_selfatt_saved_floats": (C.c_int64, [C.POINTER(SelfAttDesc)]),
+    "satrans_selfatt_scratch_floats": (C.c_int64, [C.POINTER(SelfAttDesc)]),
+    "satrans_selfatt_fwd": (C.c_int, [C.POINTER(SelfAttDesc), _vp, _vp, _vp, _vp]),
+    "satrans_selfatt_bwd": (C.c_int, [C.POINTER(SelfAttDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "satrans_metanet_saved_floats": (C.c_int64, [C.POINTER(MetaNetDesc)]),
+    "satrans_metanet_scratch_floats": (C.c_int64, [C.POINTER(MetaNetDesc)]),
+    "satrans_metanet_fwd": (C.c_int, [C.POINTER(MetaNetDesc), _vp, _vp, _vp]),
+    "satrans_metanet_bwd": (C.c_int, [C.POINTER(MetaNetDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "satrans_layer_bwd_slab_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
     "satrans_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp]),

@@ -8,7 +8,9 @@ import torch
 from oracle.satrans_oracle import PathSpec
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("sibling_"))
+SIBLING_SELFATT = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("sibling_selfatt"))
+SIBLING_METANET = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("sibling_metanet"))
 TRAIN_CASES = [c for c in ALL_CASES if c != "small_relu"]
 
 
