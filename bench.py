@@ -357,7 +357,7 @@ def main():
     per_launch = {
         "adam_untouched": dict(kernel="adam_untouched_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                                work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
-        "layer_bwd": dict(kernel=os.environ.get("SATRANS_BWD8", "1") != "0" and "layer_bwd8_kernel" or "layer_bwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
+        "layer_bwd": dict(kernel=os.environ.get("SATRANS_BWD8", "0") == "1" and "layer_bwd8_kernel" or "layer_bwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                           work=2.0 * fwd_flops / 1e12),
         "layer_fwd": dict(kernel="layer_fwd_fused_kernel" if args.config != "c5" else "gen_gemm_kernel (general path: whole layer)", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
                           work=fwd_flops / 1e12),

@@ -3,14 +3,17 @@
 // Reference: models/satrans.py:50-100 (layer), models/submodules.py:77-103 (MetaNet).  Same mathematics, inputs, outputs and
 // slab layout as layer_bwd_fused_kernel (layer_fused.hip); what differs is how the work sits on the CU:
 //
-//   * one workgroup of EIGHT waves per CU on tiles of up to 128 tokens (T samples, T*F <= 128), one copy of the weight
-//     images in LDS: two waves share every SIMD, so LDS / HBM latency and the VALU work of one wave hide behind the MFMAs
-//     of the other (the 4-wave kernel holds a full copy of every weight-gradient accumulator per wave - 128 registers -
-//     and is stuck at one wave per SIMD with every latency exposed);
-//   * the weight-gradient accumulators are SPLIT: of an (MT x NT)-tile gradient matrix every wave owns ONE 16x16 output
-//     tile (or one tile over a share of the token rows when there are fewer than eight tiles) and contracts it over the
-//     token rows of ALL waves: 24 accumulator registers per wave instead of 128.  The token-row operands of those products
-//     (h, dm, in0, dh, x, gq, gk, dv, du, o) are exchanged through the six row buffers in three rounds per tile;
+//   * one workgroup of EIGHT waves per CU = two HALVES of four waves that share one copy of the weight images in LDS but work
+//     on DIFFERENT tiles (up to 64 tokens each: T samples, T*F <= 64) with their own row buffers and their own barrier (an LDS
+//     counter: s_barrier would couple them).  Two waves share every SIMD and - because the halves drift apart - are usually
+//     in different phases: the MFMA-bound token phases of one half run underneath the VALU / LDS-bound attention phases of
+//     the other (the 4-wave kernel holds a full copy of every weight-gradient accumulator per wave - 128 registers - and is
+//     stuck at one wave per SIMD with every latency exposed; a first version of this kernel ran all eight waves through the
+//     phases in lockstep on 128-token tiles and was no faster: 290 us against 279 us per launch);
+//   * the weight-gradient accumulators are SPLIT inside a half: of an (MT x NT)-tile gradient matrix every wave owns one or two
+//     16x16 output tiles (or one tile over a share of the token rows when there are fewer than four tiles) and contracts them
+//     over the token rows of ALL four waves: 32 accumulator registers per wave instead of 128.  The token-row operands of those
+//     products (h, dm, in0, dh, x, gq, gk, dv, du, o) are exchanged through the half's six row buffers in three rounds per tile;
 //   * LayerNorm gamma / beta gradients are reduced over the 16 token lanes with DPP adds as they are produced and kept in
 //     8 registers (lane n of a 16-lane row holds vector n) instead of 48;
 //   * nothing F x F is cached: the softmax backward recomputes P_ij from q_i, k_j and the row statistics (max, 1/sum) of
@@ -19,7 +22,7 @@
 //     a barrier.  Pure VALU work instead of 35 KB of LDS per 64 tokens;
 //   * fixed summation orders everywhere (no float atomics): bitwise reproducible from run to run.
 //
-// Phases per tile (all eight waves; || = workgroup barrier):
+// Phases per tile (the four waves of a half; || = barrier of the half):
 //   A  token   forward chain x -> q0,k0,v -> MetaNet(q0), MetaNet(k0) -> q,k,v rows                                  ||
 //   B  task    attention forward: o_i, row statistics (max, 1/sum), dropout keep word                               ||
 //   C  token   Out_linear + residual + LayerNorm forward/backward -> dr, du rows, go rows, dot_i                    ||
@@ -32,7 +35,8 @@ namespace satrans {
 
 constexpr int kB8Waves = 8;
 constexpr int kB8Block = 64 * kB8Waves;
-constexpr int kB8Rows = 16 * kB8Waves;      // token rows of a workgroup tile
+constexpr int kHalfWaves = 4;
+constexpr int kB8Rows = 16 * kHalfWaves;    // token rows of a half's tile
 
 
 // Workgroup barrier for LDS hand-offs inside the tile loop.  __syncthreads() makes hipcc wait for EVERY outstanding memory
@@ -40,6 +44,18 @@ constexpr int kB8Rows = 16 * kB8Waves;      // token rows of a workgroup tile
 // meant to fly across the phases (next tile's sample index and input row, dy); only the LDS traffic has to be complete here.
 // Global memory is never used to pass data between waves inside the loop.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Barrier of ONE half (four waves) of the workgroup: a monotonic arrival counter in LDS.  Every wave adds one after its own LDS
+// traffic has completed, then polls until all four arrivals of this round are in (`round` counts this wave's barriers).  The
+// counter never wraps in practice (4 per barrier, a few thousand barriers per launch).  All four waves of a half execute the
+// same sequence of barriers by construction (the phases branch inside, never around, a barrier).
+__device__ __forceinline__ void half_barrier(unsigned* ctr, unsigned& round) {
+    round += kHalfWaves;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < round) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
@@ -83,34 +99,45 @@ __device__ __forceinline__ void layer_norm_bwd_c(float (&g)[KT_][4], const float
         for (int r = 0; r < 4; ++r) g[t][r] = rstd * (g[t][r] - m1 - zh[t][r] * m2);
 }
 
-// One wave's share of a weight-gradient product  dW[16 mt + i][16 nt + j] += sum_rows A[row][16 mt + i] * G[row][16 nt + j].
-// The MT x NT output tiles (TILES = 1, 2, 4 or 8) times KS = 8 / TILES shares of the 128 token rows make eight work items,
-// one per wave: wave w owns tile w % TILES over rows [(w / TILES) * 128 / KS, ...).  An operand wider than one row buffer
-// (the U-wide hidden rows) spans two buffers: its first NB* tiles in X0, the rest in X1.
+// One wave's share of a weight-gradient product  dW[16 mt + i][16 nt + j] += sum_rows A[row][16 mt + i] * G[row][16 nt + j]  over
+// the 64 token rows of its half.  The MT x NT output tiles (TILES = 1, 2, 4 or 8) are dealt to the four waves: with 8 tiles a
+// wave owns tiles w and w + 4 (SLOTS = 2), with 4 tiles one each; with fewer, KS = 4 / TILES waves share a tile and split the
+// rows.  An operand wider than one row buffer (the U-wide hidden rows) spans two buffers: its first NB* tiles in X0, the rest in X1.
+template <int MT, int NT>
+struct SplitShape {
+    static constexpr int TILES = MT * NT;
+    static_assert(TILES == 1 || TILES == 2 || TILES == 4 || TILES == 8, "tiles per gradient matrix");
+    static constexpr int SLOTS = TILES > kHalfWaves ? TILES / kHalfWaves : 1;
+    static constexpr int KS = TILES >= kHalfWaves ? 1 : kHalfWaves / TILES;
+    static constexpr int NK = (kB8Rows / 4) / KS;      // k-steps (4 token rows each) of one share
+};
 template <int MT, int NT, int NBA, int NBG, int LDX>
 __device__ __forceinline__ void wgrad_split(const float* A0, const float* A1, const float* G0, const float* G1, int wave, int n,
-                                            int g, f32x4& acc) {
-    constexpr int TILES = MT * NT;
-    static_assert(TILES == 1 || TILES == 2 || TILES == 4 || TILES == 8, "tiles per gradient matrix");
-    constexpr int KS = kB8Waves / TILES, NK = (kB8Rows / 4) / KS;       // k-steps (4 token rows each) of one share
-    const int tile = wave % TILES, kpart = wave / TILES;
-    const int mt = tile / NT, nt = tile - mt * NT;
-    // Which four token rows form a contraction step is free (both operands use the same rows): lane group g of step ks takes
-    // row 16 (ks / 4) + 4 g + ks % 4 of the share, so that the two groups of a 32-lane half read rows FOUR apart - with the
-    // row stride LDX = 4 mod 8 that is 16 banks apart, conflict-free (rows one apart collide on 12 of 16 banks)
-    const float* al = (mt < NBA ? A0 + 16 * mt : A1 + 16 * (mt - NBA)) + (kpart * NK * 4 + 4 * g) * LDX + n;
-    const float* gl = (nt < NBG ? G0 + 16 * nt : G1 + 16 * (nt - NBG)) + (kpart * NK * 4 + 4 * g) * LDX + n;
-    constexpr int CH = NK < 8 ? NK : 8;
+                                            int g, f32x4 (&acc)[SplitShape<MT, NT>::SLOTS]) {
+    using SS = SplitShape<MT, NT>;
+    constexpr int TILES = SS::TILES, NK = SS::NK;
 #pragma unroll
-    for (int k0 = 0; k0 < NK; k0 += CH) {
-        float av[CH], gv[CH];
+    for (int slot = 0; slot < SS::SLOTS; ++slot) {
+        const int tile = TILES >= kHalfWaves ? wave + kHalfWaves * slot : wave % TILES;
+        const int kpart = TILES >= kHalfWaves ? 0 : wave / TILES;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        // Which four token rows form a contraction step is free (both operands use the same rows): lane group g of step ks takes
+        // row 16 (ks / 4) + 4 g + ks % 4 of the share, so that the two groups of a 32-lane half read rows FOUR apart - with the
+        // row stride LDX = 4 mod 8 that is 16 banks apart, conflict-free (rows one apart collide on 12 of 16 banks)
+        const float* al = (mt < NBA ? A0 + 16 * mt : A1 + 16 * (mt - NBA)) + (kpart * NK * 4 + 4 * g) * LDX + n;
+        const float* gl = (nt < NBG ? G0 + 16 * nt : G1 + 16 * (nt - NBG)) + (kpart * NK * 4 + 4 * g) * LDX + n;
+        constexpr int CH = NK < 8 ? NK : 8;
 #pragma unroll
-        for (int ks = 0; ks < CH; ++ks) {
-            av[ks] = al[(16 * ((k0 + ks) >> 2) + ((k0 + ks) & 3)) * LDX];
-            gv[ks] = gl[(16 * ((k0 + ks) >> 2) + ((k0 + ks) & 3)) * LDX];
+        for (int k0 = 0; k0 < NK; k0 += CH) {
+            float av[CH], gv[CH];
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks) {
+                av[ks] = al[(16 * ((k0 + ks) >> 2) + ((k0 + ks) & 3)) * LDX];
+                gv[ks] = gl[(16 * ((k0 + ks) >> 2) + ((k0 + ks) & 3)) * LDX];
+            }
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks) acc[slot] = mfma4(av[ks], gv[ks], acc[slot]);
         }
-#pragma unroll
-        for (int ks = 0; ks < CH; ++ks) acc = mfma4(av[ks], gv[ks], acc);
     }
 }
 
@@ -124,10 +151,12 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
     static_assert(UT == 2 * KT, "the hidden rows span exactly two row buffers (U = 2 D)");
     static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
     static_assert(d == 8, "head dimension 8 (two lane groups of a token share a head)");
-    static_assert(H <= 4, "one attention task per thread: T * H * F <= 128 * H <= 512");
+    static_assert(H <= 4, "one attention task per thread of a half: T * H * F <= 64 * H <= 256");
     extern __shared__ __align__(16) float lds[];
     const int F = FT ? FT : a.F;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wave8 >> 2, wave = wave8 & 3;          // which half of the workgroup, wave inside the half
+    const int tid_h = (int)threadIdx.x & 255;               // thread inside the half
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
     const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
     const bool relu_out = a.flags & SATRANS_RELU_OUT, use_res = !(a.flags & SATRANS_NO_RES);
@@ -141,14 +170,17 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
     float* w2k = SAME ? w2q : take(U * LD);
     float* lnq_g = take(D); float* lnk_g = take(D); float* ln_g = take(D);
     float* lnq_b = take(D); float* lnk_b = take(D); float* ln_b = take(D);
-    float* sq = take(kB8Rows * LD);     // q            | F: exchange E0
-    float* sk = take(kB8Rows * LD);     // k  -> dk     | F: exchange E4
-    float* sv = take(kB8Rows * LD);     // v  -> dv     | F: exchange (after dWv)
-    float* so = take(kB8Rows * LD);     // o            | F: exchange E1
-    float* x1 = take(kB8Rows * LD);     // du -> dq     | F: exchange E3
-    float* x2 = take(kB8Rows * LD);     // go           | F: exchange E2
+    float* bufs = take(2 * 6 * kB8Rows * LD);          // six row buffers per half, back to back
+    float* sq = bufs + (size_t)half * 6 * kB8Rows * LD; // q            | F: exchange E0
+    float* sk = sq + kB8Rows * LD;                      // k  -> dk     | F: exchange E4
+    float* sv = sk + kB8Rows * LD;                      // v  -> dv     | F: exchange (after dWv)
+    float* so = sv + kB8Rows * LD;                      // o            | F: exchange E1
+    float* x1 = so + kB8Rows * LD;                      // du -> dq     | F: exchange E3
+    float* x2 = x1 + kB8Rows * LD;                      // go           | F: exchange E2
     const int ntask_max = Tsamp * H * F;
-    float4* st = (float4*)take(4 * ntask_max);        // per (sample, head, row): max, 1/sum, dot, keep word
+    float4* st = (float4*)take(2 * 4 * ntask_max) + (size_t)half * ntask_max;   // per (sample, head, row): max, 1/sum, dot, keep word
+    unsigned* hb_ctr = (unsigned*)take(4) + half;       // arrival counter of this half's barrier
+    unsigned hb_round = 0;
 
     const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
@@ -164,14 +196,15 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
         }
         // rows of padding tokens meet exact zeros in the token-contraction products: they must hold finite numbers from the
         // start (0 * NaN would poison an accumulator)
-        for (int i = threadIdx.x; i < 6 * kB8Rows * LD; i += blockDim.x) sq[i] = 0.f;
+        for (int i = threadIdx.x; i < 2 * 6 * kB8Rows * LD; i += blockDim.x) bufs[i] = 0.f;
     }
+    if (threadIdx.x < 2) (hb_ctr - half)[threadIdx.x] = 0u;
     __syncthreads();
 
     const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
     const int lt_d = n * LD + g4, lt_u = n * LU + g4;          // ... for a read by rows (chain_t): row n, column 4g
     // (sample, head, row) of this thread's attention task - the same in every tile
-    const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
+    const int t0_ls = tid_h / (H * F), t0_rem = tid_h - t0_ls * H * F;
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);
@@ -179,8 +212,13 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
 
     // ---- this wave's accumulators: one output tile (or tile share) of every gradient matrix; compact LN gradients ------
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc_wq = zero4, acc_wk = zero4, acc_wv = zero4, acc_wo = zero4;
-    f32x4 acc_w1q = zero4, acc_w2q = zero4, acc_w1k = zero4, acc_w2k = zero4;
+    constexpr int SP = SplitShape<KT, KT>::SLOTS, S1 = SplitShape<KT, UT>::SLOTS;
+    f32x4 acc_wq[SP], acc_wk[SP], acc_wv[SP], acc_wo[SP];
+    f32x4 acc_w1q[S1], acc_w2q[S1], acc_w1k[S1], acc_w2k[S1];
+#pragma unroll
+    for (int i = 0; i < SP; ++i) { acc_wq[i] = zero4; acc_wk[i] = zero4; acc_wv[i] = zero4; acc_wo[i] = zero4; }
+#pragma unroll
+    for (int i = 0; i < S1; ++i) { acc_w1q[i] = zero4; acc_w2q[i] = zero4; acc_w1k[i] = zero4; acc_w2k[i] = zero4; }
     float aln[KT][4];       // lane n: 0 = ln gamma, 1 = ln beta, 2 = lnq gamma, 3 = lnq beta, 4 = lnk gamma, 5 = lnk beta
 #pragma unroll
     for (int t = 0; t < KT; ++t)
@@ -194,16 +232,23 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
     constexpr int CSZ = 4 * D * D + 6 * D, TSZ = 4 * D * U;
     float* common = slabs + (size_t)blockIdx.x * CSZ;
     float* records = slabs + (size_t)gridDim.x * CSZ;
-    float* stage = sq;   // the six row buffers are contiguous
-    // combine the shares of one matrix (KS = 8 / TILES row shares per tile) through LDS in share order, write it out, clear
-    auto flush = [&](f32x4& acc, auto mtc, auto ntc, float* dst, bool live) {
+    float* stage = bufs;   // the twelve row buffers are contiguous
+    // combine the shares of one matrix - two halves x KS row shares per tile - through LDS in (half, share) order, write it out,
+    // clear the accumulators
+    auto flush = [&](auto& acc, auto mtc, auto ntc, float* dst, bool live) {
         constexpr int MT_ = decltype(mtc)::value, NT_ = decltype(ntc)::value;
-        constexpr int TILES = MT_ * NT_, KS = kB8Waves / TILES, ncols = 16 * NT_;
+        using SS = SplitShape<MT_, NT_>;
+        constexpr int TILES = SS::TILES, ncols = 16 * NT_, PARTS = 2 * SS::KS;
         if (live) {
-            const int tile = wave % TILES, kpart = wave / TILES;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(kpart * TILES + tile) * 256 + (g4 + r) * 16 + n] = acc[r];
-            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int slot = 0; slot < SS::SLOTS; ++slot) {
+                const int tile = TILES >= kHalfWaves ? wave + kHalfWaves * slot : wave % TILES;
+                const int kpart = TILES >= kHalfWaves ? 0 : wave / TILES;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stage[((half * SS::KS + kpart) * TILES + tile) * 256 + (g4 + r) * 16 + n] = acc[slot][r];
+                acc[slot] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < TILES * 256; e += kB8Block) {
@@ -213,7 +258,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             if (live) {
                 s = stage[e];
 #pragma unroll
-                for (int k = 1; k < KS; ++k) s += stage[k * TILES * 256 + e];
+                for (int k = 1; k < PARTS; ++k) s += stage[k * TILES * 256 + e];
             }
             dst[(16 * mt + rr) * ncols + 16 * nt + cc] = s;
         }
@@ -255,8 +300,13 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
           b_next = a.order[first_ + (valid_ ? ls_tok : 0)];
           load_frag<KT>(layer_x_row(a, b_next, valid_ ? f_tok : 0, F, D) + g4, x_next, valid_);
       };
-      fetch_tile(t0);
-      for (int tile = t0; tile < t1; ++tile) {
+#ifdef SATRANS_ONE_HALF      // diagnostic build: half 0 takes every tile, half 1 idles (how long does ONE wave per SIMD take?)
+      const int t_first = half == 0 ? t0 : t1, t_step = 1;
+#else
+      const int t_first = t0 + half, t_step = 2;
+#endif
+      if (t_first < t1) fetch_tile(t_first);
+      for (int tile = t_first; tile < t1; tile += t_step) {    // the halves take alternate tiles of the workgroup's range
         const int first = lo + tile * Tsamp;
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F;
@@ -265,8 +315,8 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
         const int b = b_next;
         const size_t grow = ((size_t)b * F + f) * D + g4;       // this lane's row of x / dy / dx
         const int ntask = nS * H * F;
-        const bool task_ok = (int)threadIdx.x < ntask;
-        const int task = task_ok ? (int)threadIdx.x : 0;
+        const bool task_ok = tid_h < ntask;
+        const int task = task_ok ? tid_h : 0;
         const int tls = task_ok ? t0_ls : 0, th = task_ok ? t0_h : 0, ti = task_ok ? t0_i : 0;
 
         // token-wise state that lives from phase A to phase F
@@ -356,7 +406,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             store_frag<KT>(sk + my, k);
             store_frag<KT>(sv + my, v);
         }
-        lds_barrier();
+        half_barrier(hb_ctr, hb_round);
         STAMP(1);
 
         // ================= phase B: attention forward: o_i, row statistics, dropout keep word ===============================
@@ -409,7 +459,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             st[task] = make_float4(mx, inv, 0.f, __uint_as_float(keep));
             store_row<d>(so + (tls * F + ti) * LD + th * d, oacc, inv);
         }
-        lds_barrier();
+        half_barrier(hb_ctr, hb_round);
         STAMP(2);
 
         // ================= phase C: output block forward + backward ======================================================
@@ -458,7 +508,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 }
             }
         }
-        lds_barrier();
+        half_barrier(hb_ctr, hb_round);
         STAMP(3);
 
         // ================= phase D: dWo; softmax backward, row pass and column pass of every task =========================
@@ -528,14 +578,14 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 }
             }
         }
-        lds_barrier();
+        half_barrier(hb_ctr, hb_round);
         STAMP(4);
         if (task_ok) {      // every q, k, v, go row has been read (and du, o by the dWo product)
             store_row<d>(x1 + (tls * F + ti) * LD + th * d, dq, 1.0f);
             store_row<d>(sk + (tls * F + ti) * LD + th * d, dk, 1.0f);
             store_row<d>(sv + (tls * F + ti) * LD + th * d, dv, 1.0f);
         }
-        lds_barrier();
+        half_barrier(hb_ctr, hb_round);
         STAMP(5);
 
         // ================= phase F: MetaNet and projection backward, dx; split weight gradients in three rounds ============
@@ -610,11 +660,11 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 store_wide(so, x2, hq);
                 store_frag<KT>(x1 + my, dm);
             }
-            lds_barrier();
+            half_barrier(hb_ctr, hb_round);
             STAMP(6);
             wgrad_split<KT, KT, KT, KT, LD>(sq, sq, sv, sv, wave, n, g, acc_wv);                 // dWv[i][o] += x^T dv
             if (meta_q) wgrad_split<UT, KT, KT, KT, LD>(so, x2, x1, x1, wave, n, g, acc_w2q);   // dW2[u][o] += hq^T dm
-            lds_barrier();
+            half_barrier(hb_ctr, hb_round);
             STAMP(7);
             // ---- round 2: {q0, dhq} -> dW1 (Q role) ; {hk, dmk} -> dW2 (K role) ---------------------------------------------
             float dhk[UT][4];
@@ -628,14 +678,14 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 store_wide(x1, sv, hk);
                 store_frag<KT>(sk + my, dm);
             }
-            lds_barrier();
+            half_barrier(hb_ctr, hb_round);
             STAMP(8);
             if (meta_q) wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1q);   // dW1[i][u] += q0^T dhq
             if (meta_k) {
                 if constexpr (SAME) wgrad_split<UT, KT, KT, KT, LD>(x1, sv, sk, sk, wave, n, g, acc_w2q);
                 else wgrad_split<UT, KT, KT, KT, LD>(x1, sv, sk, sk, wave, n, g, acc_w2k);
             }
-            lds_barrier();
+            half_barrier(hb_ctr, hb_round);
             STAMP(9);
             // ---- round 3: {k0, dhk} -> dW1 (K role) ; {x, gq, gk} -> dWq, dWk -------------------------------------------------
             if (meta_k) {
@@ -645,8 +695,8 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
             store_frag<KT>(x1 + my, x);
             store_frag<KT>(sv + my, gq);
             store_frag<KT>(sk + my, gk);
-            if (tile + 1 < t1) fetch_tile(tile + 1);
-            lds_barrier();
+            if (tile + t_step < t1) fetch_tile(tile + t_step);
+            half_barrier(hb_ctr, hb_round);
             STAMP(10);
             if (meta_k) {
                 if constexpr (SAME) wgrad_split<KT, UT, KT, KT, LD>(sq, sq, so, x2, wave, n, g, acc_w1q);
@@ -668,9 +718,10 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
             if (valid) store_frag<KT>(dx + grow, dr);
         }
-        lds_barrier();
+        half_barrier(hb_ctr, hb_round);
         STAMP(11);
       }
+      __syncthreads();      // both halves are through with this scenario's tiles (and with the row buffers the flush stages in)
       // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
       // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the part of a role only
       // when that role is active, so the sums go to the Q part when Q is modulated, else to the K part
@@ -695,7 +746,7 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (n < 6) stage[(wave * 6 + n) * D + 16 * t + g4 + r] = aln[t][r];
+            if (n < 6) stage[(wave8 * 6 + n) * D + 16 * t + g4 + r] = aln[t][r];
     __syncthreads();
     for (int e = threadIdx.x; e < 6 * D; e += kB8Block) {
         float s = stage[e];
@@ -708,8 +759,8 @@ __global__ __launch_bounds__(kB8Block) void layer_bwd8_kernel(satrans_layer_desc
 static int64_t bwd8_lds_floats(int T, int F, int D, int U, int H, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
-    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 6 * (int64_t)kB8Rows * LD +
-           r4(4 * (int64_t)T * H * F) + 64;
+    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 2 * 6 * (int64_t)kB8Rows * LD +
+           r4(2 * 4 * (int64_t)T * H * F) + 64;
 }
 
 struct Bwd8Plan {
