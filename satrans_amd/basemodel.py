@@ -325,6 +325,9 @@ class BaseModel(nn.Module):
             x = [x[name] for name in self.feature_index]
         cols = [np.asarray(a) for a in x]
         cols = [c.reshape(-1, 1) if c.ndim == 1 else c for c in cols]
+        if any(np.issubdtype(c.dtype, np.integer) and c.size and int(c.max()) >= (1 << 24) for c in cols) and \
+                any(not np.issubdtype(c.dtype, np.integer) for c in cols):
+            cols = [c.astype(np.float64) for c in cols]                  # ids beyond 2**24 next to float columns: exact in fp64
         return np.concatenate(cols, axis=-1)
 
     def _to_device_matrix(self, packed: np.ndarray) -> torch.Tensor:
@@ -333,16 +336,31 @@ class BaseModel(nn.Module):
         reference silently gathers the wrong row there): the matrix then travels as int64 and the kernels read the ids
         as integers (`SATRANS_ID_I64`).  Dense features next to such a vocabulary would need a separate float block,
         which no reference dataset calls for."""
+        ids, dense_block = self._host_matrices(packed)
+        ids_d = torch.from_numpy(ids).to(self.device)
+        if dense_block is None:
+            return ids_d
+        from .inputs import PackedInput
+        return PackedInput(ids_d, torch.from_numpy(dense_block).to(self.device))
+
+    def _host_matrices(self, packed: np.ndarray):
+        """-> (ids matrix, dense block or None) on the host: fp32 in the reference's layout while every vocabulary is below
+        2**24, else int64 ids plus - when the model has DenseFeat columns - their float block (inputs.PackedInput)."""
         sparse, dense, _ = split_columns(self.dnn_feature_columns)
         if max(c.vocabulary_size for c in sparse) >= (1 << 24):
+            if not np.issubdtype(packed.dtype, np.integer) and packed.dtype == np.float32 and np.abs(packed).max() >= (1 << 24):
+                raise ValueError("ids of 2**24 and above arrived as float32: they are already rounded; pass integers")
+            block = None
             if dense:
-                raise NotImplementedError("vocabularies of 2**24 rows or more together with DenseFeat columns")
-            if not np.issubdtype(packed.dtype, np.integer):
-                if np.abs(packed).max() >= (1 << 24) and packed.dtype == np.float32:
-                    raise ValueError("ids of 2**24 and above arrived as float32: they are already rounded; pass integers")
-                packed = packed.astype(np.int64)
-            return torch.from_numpy(np.ascontiguousarray(packed, dtype=np.int64)).to(self.device)
-        return torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float32)).to(self.device)
+                cols = []
+                for c in dense:
+                    lo, hi = self.feature_index[c.name]
+                    cols += list(range(lo, hi))
+                block = np.ascontiguousarray(packed[:, cols], dtype=np.float32)
+                packed = packed.copy()
+                packed[:, cols] = 0                                      # (unused as ids; keeps the cast below finite)
+            return np.ascontiguousarray(packed.astype(np.int64)), block
+        return np.ascontiguousarray(packed, dtype=np.float32), None
 
     # ------------------------------------------------------------------------------------------
     # fit / evaluate / predict
@@ -376,8 +394,18 @@ class BaseModel(nn.Module):
         steps_per_epoch = (sample_num - 1) // batch_size + 1
         steps_to_valid = steps_per_epoch // valid_cnt_per_epoch + 1
 
-        data = self._to_device_matrix(packed)                 # whole training set resident in HBM
-        labels = torch.from_numpy(y).to(self.device)
+        # Small datasets are uploaded once and stay resident in HBM; large ones (or SATRANS_STREAM_INPUT=1 / model.stream_input
+        # = True) stay on the host and are streamed in double-buffered batches (satrans_amd/pipeline.py).
+        import os as _os
+        stream = getattr(self, "stream_input", None)
+        if stream is None:
+            stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or packed.nbytes > (8 << 30)
+        data = labels = None
+        if stream:
+            host_ids, host_dense = self._host_matrices(packed)
+        else:
+            data = self._to_device_matrix(packed)             # whole training set resident in HBM
+            labels = torch.from_numpy(y).to(self.device)
         self.train()
 
         # SATRANS_HOST_METRICS=1: per-step train metrics through sklearn on host copies, as the reference does
@@ -398,6 +426,11 @@ class BaseModel(nn.Module):
             train_result: Dict[str, list] = {}
             engine.reset_epoch_sums()
             order = self._epoch_order(sample_num, shuffle)
+            feeder = None
+            if stream:
+                from .pipeline import HostBatchFeeder
+                feeder = iter(HostBatchFeeder(host_ids, y, batch_size, self.device,
+                                              order.cpu().numpy() if order is not None else None, host_dense))
             iterator = range(steps_per_epoch)
             bar = None
             if verbose == 1:
@@ -407,7 +440,9 @@ class BaseModel(nn.Module):
             step_num = 0
             for step in iterator:
                 lo, hi = step * batch_size, min(sample_num, (step + 1) * batch_size)
-                if order is None:
+                if feeder is not None:
+                    xb, yb = next(feeder)
+                elif order is None:
                     xb, yb = data[lo:hi], labels[lo:hi]
                 else:
                     idx = order[lo:hi]
@@ -523,11 +558,23 @@ class BaseModel(nn.Module):
         was_training = self.training
         self.eval()
         packed = x if isinstance(x, np.ndarray) and x.ndim == 2 and not isinstance(x, (dict, list)) else self._pack(x)
-        data = self._to_device_matrix(packed)
-        out = torch.empty((data.shape[0], 1), dtype=torch.float32, device=self.device)
-        for lo in range(0, data.shape[0], batch_size):
-            hi = min(data.shape[0], lo + batch_size)
-            out[lo:hi] = engine.forward(data[lo:hi], training=False)
+        import os as _os
+        stream = getattr(self, "stream_input", None)
+        if stream is None:
+            stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or packed.nbytes > (8 << 30)
+        out = torch.empty((packed.shape[0], 1), dtype=torch.float32, device=self.device)
+        if stream:                                      # host-resident, double-buffered (satrans_amd/pipeline.py)
+            from .pipeline import HostBatchFeeder
+            host_ids, host_dense = self._host_matrices(packed)
+            lo = 0
+            for xb, _ in HostBatchFeeder(host_ids, None, batch_size, self.device, None, host_dense):
+                out[lo:lo + len(xb)] = engine.forward(xb, training=False)
+                lo += len(xb)
+        else:
+            data = self._to_device_matrix(packed)
+            for lo in range(0, data.shape[0], batch_size):
+                hi = min(data.shape[0], lo + batch_size)
+                out[lo:hi] = engine.forward(data[lo:hi], training=False)
         engine.raise_if_bad_ids()
         if was_training:
             self.train()

@@ -375,7 +375,18 @@ class PathEngine:
         return tabs[0, 0], tabs[0, 0]
 
     # ------------------------------------------------------------------------------------------------
-    def _prepare_input(self, X: torch.Tensor):
+    def _prepare_input(self, X):
+        from .inputs import PackedInput
+        self._dense_override = None
+        if isinstance(X, PackedInput):            # integer ids + a separate float block for the dense features
+            if self.n_dense:
+                dn = X.dense
+                if dn.dtype != torch.float32 or not dn.is_contiguous():
+                    dn = dn.float().contiguous()
+                if dn.shape[1] != self.n_dense:
+                    raise ValueError(f"expected {self.n_dense} dense columns, got {dn.shape[1]}")
+                self._dense_override = dn
+            X = X.ids
         N.require_gpu(X, "SATrans.forward input")
         if X.dim() != 2 or X.shape[1] < self.n_cols:
             raise ValueError(f"expected X of shape [B, {self.n_cols}], got {tuple(X.shape)}")
@@ -383,8 +394,8 @@ class PathEngine:
             X = X.float()
         if not X.is_contiguous():
             X = X.contiguous()
-        if X.dtype != torch.float32 and self.n_dense:
-            raise NotImplementedError("integer id matrix together with dense features")
+        if X.dtype != torch.float32 and self.n_dense and self._dense_override is None:
+            raise NotImplementedError("integer id matrix together with dense features: pass inputs.PackedInput(ids, dense)")
         return X
 
     def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False):
@@ -426,14 +437,19 @@ class PathEngine:
         m = self.m
         dense_ptr = X.data_ptr() if self.n_dense else None
         dcols = self.dense_cols.data_ptr() if self.n_dense else None
+        dstride = X.stride(0)
+        if self.n_dense and getattr(self, "_dense_override", None) is not None:
+            if getattr(self, "_dense_iota", None) is None:
+                self._dense_iota = torch.arange(self.n_dense, dtype=torch.int32, device=self.dev)
+            dense_ptr, dcols, dstride = self._dense_override.data_ptr(), self._dense_iota.data_ptr(), self._dense_override.stride(0)
         if y is None:
-            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, X.stride(0), dcols, self.n_dense, B,
+            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, dstride, dcols, self.n_dense, B,
                                      self.F * self.D, m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr(),
                                      ws["prob"].data_ptr(), ws["logit"].data_ptr(), None, None, None, None, None, None,
                                      st), "satrans_head")
         else:
             gw, gb = self._grad_view("dnn_linear.weight"), self._grad_view("dnn_linear.bias")
-            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, X.stride(0), dcols, self.n_dense, B,
+            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, dstride, dcols, self.n_dense, B,
                                      self.F * self.D, m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr(),
                                      ws["prob"].data_ptr(), ws["logit"].data_ptr(), y.data_ptr(),
                                      self.loss_sum.data_ptr(), ws["dact"][0].data_ptr(), gw.data_ptr(), gb.data_ptr(),

@@ -140,3 +140,22 @@ def split_columns(feature_columns):
     dense = [c for c in cols if isinstance(c, DenseFeat)]
     varlen = [c for c in cols if isinstance(c, VarLenSparseFeat)]
     return sparse, dense, varlen
+
+
+class PackedInput:
+    """Ids and dense features of a batch as TWO device matrices: `ids` [N, C] integer (every feature_index column, the dense
+    ones unused) and `dense` [N, n_dense] float32.  Used when a vocabulary does not survive the reference's fp32 id matrix
+    (2**24 rows and more, models/meta_basemodel.py:311) AND the model has DenseFeat columns; slices like a tensor."""
+
+    def __init__(self, ids, dense):
+        self.ids, self.dense = ids, dense
+        self.shape = ids.shape
+
+    def __getitem__(self, s):
+        return PackedInput(self.ids[s], self.dense[s])
+
+    def index_select(self, dim, idx):
+        return PackedInput(self.ids.index_select(dim, idx), self.dense.index_select(dim, idx))
+
+    def __len__(self):
+        return self.ids.shape[0]

@@ -519,6 +519,78 @@ def test_bf16_forward_stays_within_bf16_rounding_of_the_reference(name):
     print(f"[bf16] {name}: logit max-abs-err vs reference {err:.3e}, vs fp32 kernels {float((lb - l32).abs().max()):.3e}")
 
 
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
+def test_streamed_input_pipeline_equals_the_resident_dataset(name, tmp_path):
+    """fit / predict with the dataset kept on the host and streamed in double-buffered pinned batches (satrans_amd/pipeline.py;
+    here from memory-mapped .npy columns, the loader for datasets that should not sit in HBM) against the resident-dataset
+    path: same History, same predictions, same parameters, bit for bit - and both on the reference's golden History."""
+    from satrans_amd.pipeline import load_npy_columns
+    c = Case(name)
+    names = c.meta["feature_names"]
+    x = {n: c.z[f"fit/x/{n}"] for n in names}
+    y, B = c.z["fit/y"], int(c.z["fit/batch_size"])
+    for n in names:
+        np.save(tmp_path / f"{n}.npy", x[n])
+    x_mm = load_npy_columns(str(tmp_path), names)
+    assert all(isinstance(v, np.memmap) for v in x_mm.values())
+    res = {}
+    for stream in (False, True):
+        model = build_model(c, DEV)
+        for mod in model.modules():
+            pass
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy",
+                      metrics=["binary_crossentropy", "auc"])
+        model.stream_input = stream
+        model._require_engine().drop_p = 0.0                    # the reference's fit was recorded with every dropout p = 0
+        hist = model.fit(x=dict(x_mm if stream else x), y=y, batch_size=B, epochs=2, verbose=0, shuffle=False)
+        pred = model.predict(dict(x_mm if stream else x), batch_size=2 * B)
+        res[stream] = (hist.history["loss"], pred, sd_to_cpu(model))
+    assert res[True][0] == res[False][0]
+    assert np.array_equal(res[True][1], res[False][1])
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+    np.testing.assert_allclose(res[True][0], c.z["fit/loss"], rtol=2e-5)
+    # shuffled epochs draw the same permutation either way
+    out = []
+    for stream in (False, True):
+        model = build_model(c, DEV)
+        model.compile("adam", "binary_crossentropy")
+        model.stream_input = stream
+        torch.manual_seed(5)
+        out.append(model.fit(x=dict(x), y=y, batch_size=B, epochs=1, verbose=0, shuffle=True).history["loss"])
+    assert out[0] == out[1]
+
+
+def test_integer_ids_with_dense_features_travel_as_a_packed_input():
+    """A vocabulary of 2**24 rows and more next to a DenseFeat: ids as int64, dense features as their own float block
+    (inputs.PackedInput) - resident and streamed - must gather exactly the rows the ids name and use the dense values."""
+    from satrans_amd import DenseFeat, SATrans, SparseFeat
+    big = (1 << 24) + 1000
+    cols = [SparseFeat("a", big, 16), SparseFeat("b", 50, 16), SparseFeat("dom", 4, 16), DenseFeat("price", 1)]
+    model = SATrans(cols, cols, ["dom"], [3], att_layer_num=0, domain_att_layer_num=1, att_head_num=2, use_linear=False,
+                    use_dnn=False, meta_mode="QK", meta_dnn_hidden_units=(32, 16), seed=3, device=DEV, flag="sota")
+    rng = np.random.RandomState(0)
+    N = 300
+    x = {"a": np.concatenate([[big - 1, (1 << 24) + 1, (1 << 24) + 3], rng.randint(0, big, size=N - 3)]).astype(np.int64),
+         "b": rng.randint(0, 50, size=N).astype(np.int64), "dom": rng.randint(1, 4, size=N).astype(np.int64),
+         "price": rng.rand(N).astype(np.float32)}
+    with torch.no_grad():
+        model.dnn_linear.weight[0, -1] = 3.0                    # make the dense feature matter
+    preds = {}
+    for stream in (False, True):
+        model.stream_input = stream
+        preds[stream] = model.predict(dict(x), batch_size=128)
+    assert np.array_equal(preds[True], preds[False])
+    eng = model._engine
+    rows = eng._ws[N % 128 or 128]["rows"].cpu().numpy()
+    # the last batch's recorded arena rows of field "a" are exactly id + table offset
+    off = model._table_rows["a"][0]
+    last = x["a"][-(N % 128 or 128):]
+    assert np.array_equal(rows[:, 0], (last + off).astype(np.int32))
+    x2 = dict(x, price=np.zeros(N, dtype=np.float32))
+    assert not np.array_equal(model.predict(x2, batch_size=128), preds[False])
+
+
 def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
     """satrans_amd/device_metrics.py on device tensors (sort + searchsorted on the GPU) against sklearn on host copies - ties
     and saturated probabilities included - and `evaluate_domains`, the test report of reference main.py:353-374."""

@@ -146,3 +146,33 @@ def test_device_metrics_equal_sklearn():
             assert per[i] == pytest.approx(roc_auc_score(y[dom == i], p64[dom == i]), rel=1e-12, abs=1e-15)
         want = torch.nn.functional.binary_cross_entropy(torch.tensor(p64), torch.tensor(y).double()).item()
         assert loss == pytest.approx(want, rel=1e-12)
+
+
+def test_host_batch_feeder_yields_every_row_once_in_order(tmp_path):
+    """satrans_amd/pipeline.py on the CPU device (no pinning, same staging logic): batches of a memory-mapped column set, in
+    order and along a permutation, with a ragged last batch, an integer id matrix and a dense block."""
+    from satrans_amd.inputs import PackedInput
+    from satrans_amd.pipeline import HostBatchFeeder, load_npy_columns
+    rng = np.random.RandomState(1)
+    N, C = 1003, 5
+    cols = {f"c{i}": rng.randint(0, 1 << 30, size=N).astype(np.int64) for i in range(C)}
+    for k, v in cols.items():
+        np.save(tmp_path / f"{k}.npy", v)
+    mm = load_npy_columns(str(tmp_path), list(cols))
+    ids = np.stack([mm[k] for k in cols], axis=1)
+    y = rng.rand(N).astype(np.float32)
+    dense = rng.rand(N, 2).astype(np.float32)
+    for order in (None, rng.permutation(N)):
+        got_x, got_y, got_d = [], [], []
+        feeder = HostBatchFeeder(ids, y, 128, "cpu", order, dense)
+        assert len(feeder) == 8
+        for xb, yb in feeder:
+            assert isinstance(xb, PackedInput) and xb.ids.dtype == torch.int64
+            got_x.append(xb.ids.clone()); got_d.append(xb.dense.clone()); got_y.append(yb.clone())
+        idx = np.arange(N) if order is None else order
+        assert torch.equal(torch.cat(got_x), torch.from_numpy(ids[idx]))
+        assert torch.equal(torch.cat(got_y), torch.from_numpy(y[idx]))
+        assert torch.equal(torch.cat(got_d), torch.from_numpy(dense[idx]))
+    with pytest.raises(ImportError):
+        from satrans_amd.pipeline import load_h5_columns
+        load_h5_columns("/nonexistent.h5", "ctr_train", ["101"])
