@@ -260,6 +260,27 @@ int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, f
 int satrans_head(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols, int n_dense,
                  int B, int FD, const float* w, const float* bias, float* prob, float* logit, const float* y,
                  double* loss_sum, float* da, float* g_w, float* g_b, float* scratch, void* stream);
+
+/* The same with the loss of `compile(loss=...)` (models/meta_basemodel.py:642-653, all reduction='sum' in fit):
+ * SATRANS_LOSS_BCE binary_cross_entropy, SATRANS_LOSS_MSE F.mse_loss, SATRANS_LOSS_MAE F.l1_loss on the probability. */
+#define SATRANS_LOSS_BCE 0
+#define SATRANS_LOSS_MSE 1
+#define SATRANS_LOSS_MAE 2
+int satrans_head_loss(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols, int n_dense, int B,
+                      int FD, const float* w, const float* bias, float* prob, float* logit, const float* y, double* loss_sum,
+                      float* da, float* g_w, float* g_b, float* scratch, int loss_kind, void* stream);
+
+/* Dense elementwise steps of the optimizers `compile` accepts besides Adam (models/meta_basemodel.py:612-640: torch.optim.SGD
+ * lr 0.01, Adagrad lr 0.01 eps 1e-10, RMSprop lr 0.01 alpha 0.99 eps 1e-8), over n floats with the dense gradient g:
+ *   SATRANS_OPT_SGD      p -= lr g
+ *   SATRANS_OPT_ADAGRAD  s += g^2 ; p -= lr g / (sqrt(s) + eps)
+ *   SATRANS_OPT_RMSPROP  s = alpha s + (1 - alpha) g^2 ; p -= lr g / (sqrt(s) + eps)
+ * Used with the dense table gradient of satrans_embed_grad_dense (every row: gathered rows + 2 l2 p), i.e. the reference's
+ * dense semantics as one sweep over the tables per step; Adam has the lazy-exact kernels above instead. */
+#define SATRANS_OPT_SGD 1
+#define SATRANS_OPT_ADAGRAD 2
+#define SATRANS_OPT_RMSPROP 3
+int satrans_optim_flat(int kind, float* p, const float* g, float* state, int64_t n, float lr, float alpha, float eps, void* stream);
 int64_t satrans_head_scratch_floats(int B, int FD, int n_dense);
 
 /* ------------------------------------------------------------------------------------------------

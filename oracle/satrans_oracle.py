@@ -298,16 +298,28 @@ class OracleTrainer:
     exactly as in the reference (grad is None)."""
 
     def __init__(self, P: Dict[str, Tensor], spec: PathSpec, lr: float,
-                 betas=(0.9, 0.999), eps: float = 1e-8):
+                 betas=(0.9, 0.999), eps: float = 1e-8, optimizer: str = "adam", loss: str = "binary_crossentropy"):
         self.spec = spec
         self.leaves = make_leaves(P)
+        self.loss = loss
         uniq = list({id(t): t for t in self.leaves.values()}.values())
-        self.optim = torch.optim.Adam(uniq, lr=lr, betas=betas, eps=eps)
+        # the optimizers models/meta_basemodel.py:612-640 resolves, with torch's own arithmetic
+        if optimizer == "adam":
+            self.optim = torch.optim.Adam(uniq, lr=lr, betas=betas, eps=eps)
+        elif optimizer == "sgd":
+            self.optim = torch.optim.SGD(uniq, lr=lr)
+        elif optimizer == "adagrad":
+            self.optim = torch.optim.Adagrad(uniq, lr=lr)
+        elif optimizer == "rmsprop":
+            self.optim = torch.optim.RMSprop(uniq, lr=lr)
+        else:
+            raise ValueError(optimizer)
 
     def step(self, X: Tensor, y: Tensor, drop: Optional[Dropper] = None, return_prob: bool = False):
         prob, _ = forward(self.leaves, X, self.spec, drop)
         self.optim.zero_grad()
-        bce = F.binary_cross_entropy(prob.squeeze(-1), y.to(prob.dtype).reshape(-1), reduction="sum")
+        fn = {"binary_crossentropy": F.binary_cross_entropy, "mse": F.mse_loss, "mae": F.l1_loss}[self.loss]
+        bce = fn(prob.squeeze(-1), y.to(prob.dtype).reshape(-1), reduction="sum")       # models/meta_basemodel.py:317,642-653
         reg = regularization_loss(self.leaves, self.spec)
         (bce + reg.sum()).backward()
         self.optim.step()

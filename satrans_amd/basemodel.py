@@ -254,7 +254,7 @@ class BaseModel(nn.Module):
         `param_groups` take effect at the next step, as they do for torch.optim.Adam).  Steps that are still postponed
         (lazy-exact form) belong to the old values and are applied first."""
         opt = getattr(self, "optim", None)
-        if isinstance(opt, torch.optim.Adam):
+        if isinstance(opt, torch.optim.Optimizer):
             new = self._read_optimizer(opt)
             if new != self._adam_cfg:
                 self._flush_engine()
@@ -276,28 +276,48 @@ class BaseModel(nn.Module):
 
     @staticmethod
     def _read_optimizer(optimizer):
+        """-> dict(kind, lr, ...).  Strings as the reference resolves them (models/meta_basemodel.py:612-640: "sgd" lr 0.01,
+        "adam" lr 0.001, "adagrad" lr 0.01, "rmsprop"), or the matching torch.optim instance (its hyper-parameters are read,
+        the step itself runs as HIP kernels).  Adam has the lazy-exact table kernels; the others take one dense elementwise
+        sweep over the tables per step (reference semantics: dense gradients, every row moves)."""
         if isinstance(optimizer, str):
-            if optimizer == "adam":
-                return dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
-            if optimizer in ("sgd", "adagrad", "rmsprop"):
-                raise NotImplementedError(
-                    f"optimizer '{optimizer}': only Adam (the reference's choice, main.py:343) has a HIP step")
-            raise NotImplementedError(optimizer)
+            table = {"adam": dict(kind="adam", lr=1e-3, betas=(0.9, 0.999), eps=1e-8),
+                     "sgd": dict(kind="sgd", lr=0.01),
+                     "adagrad": dict(kind="adagrad", lr=0.01, eps=1e-10),
+                     "rmsprop": dict(kind="rmsprop", lr=0.01, alpha=0.99, eps=1e-8)}
+            if optimizer not in table:
+                raise NotImplementedError(optimizer)
+            return table[optimizer]
+        if len(getattr(optimizer, "param_groups", [0])) != 1:
+            raise NotImplementedError("optimizers with several parameter groups")
+        g = optimizer.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("maximize", False):
+            raise NotImplementedError("weight_decay / maximize")
         if isinstance(optimizer, torch.optim.Adam):
-            if len(optimizer.param_groups) != 1:
-                raise NotImplementedError("Adam with several parameter groups")
-            g = optimizer.param_groups[0]
-            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
-                raise NotImplementedError("Adam with weight_decay / amsgrad / maximize")
-            return dict(lr=float(g["lr"]), betas=tuple(float(b) for b in g["betas"]), eps=float(g["eps"]))
-        raise NotImplementedError(f"optimizer {type(optimizer).__name__}: only torch.optim.Adam has a HIP step")
+            if g.get("amsgrad", False):
+                raise NotImplementedError("Adam with amsgrad")
+            return dict(kind="adam", lr=float(g["lr"]), betas=tuple(float(b) for b in g["betas"]), eps=float(g["eps"]))
+        if isinstance(optimizer, torch.optim.SGD):
+            if g.get("momentum", 0) != 0 or g.get("nesterov", False) or g.get("dampening", 0) != 0:
+                raise NotImplementedError("SGD with momentum / nesterov / dampening")
+            return dict(kind="sgd", lr=float(g["lr"]))
+        if isinstance(optimizer, torch.optim.Adagrad):
+            if g.get("lr_decay", 0) != 0 or g.get("initial_accumulator_value", 0) != 0:
+                raise NotImplementedError("Adagrad with lr_decay / initial_accumulator_value")
+            return dict(kind="adagrad", lr=float(g["lr"]), eps=float(g["eps"]))
+        if isinstance(optimizer, torch.optim.RMSprop):
+            if g.get("momentum", 0) != 0 or g.get("centered", False):
+                raise NotImplementedError("RMSprop with momentum / centered")
+            return dict(kind="rmsprop", lr=float(g["lr"]), alpha=float(g["alpha"]), eps=float(g["eps"]))
+        raise NotImplementedError(f"optimizer {type(optimizer).__name__}: Adam, SGD, Adagrad and RMSprop have HIP steps")
 
     @staticmethod
     def _get_loss_func(loss):
+        """"binary_crossentropy" / "mse" / "mae" (models/meta_basemodel.py:642-653; summed over the batch in fit)."""
         if loss is None or loss == "binary_crossentropy":
             return "binary_crossentropy"
         if loss in ("mse", "mae"):
-            raise NotImplementedError(f"loss '{loss}': the fused head computes binary cross-entropy only")
+            return loss
         raise NotImplementedError(str(loss))
 
     def _get_metrics(self, metrics, set_eps=False):

@@ -970,3 +970,35 @@ extern "C" int satrans_embed_lazy_mark(const int32_t* sorted_rows, int64_t n, in
     SATRANS_CHECK_LAUNCH("mark_last_kernel");
     return SATRANS_OK;
 }
+
+
+// ---- the other optimizers of compile(): dense elementwise steps (see include/satrans_hip.h) ---------------------------------------
+namespace satrans {
+__global__ void optim_flat_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ st, int64_t n,
+                                  float lr, float alpha, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    float pi = p[i];
+    if (kind == SATRANS_OPT_SGD) {
+        pi = __fadd_rn(pi, __fmul_rn(-lr, gi));                                   // p.add_(g, alpha=-lr)
+    } else {
+        float s = st[i];
+        if (kind == SATRANS_OPT_ADAGRAD) s = fmaf(gi, gi, s);                      // state_sum.addcmul_(g, g, value=1)
+        else s = fmaf(__fmul_rn(1.0f - alpha, gi), gi, __fmul_rn(s, alpha));       // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
+        st[i] = s;
+        const float denom = __fadd_rn(__fsqrt_rn(s), eps);                         // std = sqrt(.) + eps
+        pi = __fadd_rn(pi, __fmul_rn(-lr, __fdiv_rn(gi, denom)));                 // p.addcdiv_(g, std, value=-lr)
+    }
+    p[i] = pi;
+}
+}  // namespace satrans
+
+extern "C" int satrans_optim_flat(int kind, float* p, const float* g, float* state, int64_t n, float lr, float alpha, float eps,
+                                  void* stream_) {
+    SATRANS_REQUIRE(kind >= SATRANS_OPT_SGD && kind <= SATRANS_OPT_RMSPROP, SATRANS_E_BADARG, "optim_flat: kind %d", kind);
+    SATRANS_REQUIRE(p && g && n > 0 && (kind == SATRANS_OPT_SGD || state), SATRANS_E_BADARG, "optim_flat: bad arguments");
+    satrans::optim_flat_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream_>>>(kind, p, g, state, n, lr, alpha, eps);
+    SATRANS_CHECK_LAUNCH("optim_flat_kernel");
+    return SATRANS_OK;
+}

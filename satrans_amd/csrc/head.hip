@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kHeadBlock) void head_kernel(const float* __restric
                                                         int n_dense, int B, int FD, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ prob,
                                                         float* __restrict__ logit, const float* __restrict__ y,
-                                                        float* __restrict__ da, float* __restrict__ partial) {
+                                                        float* __restrict__ da, float* __restrict__ partial, int loss_kind) {
     __shared__ float s_dlogit[kSamplesPerBlock];
     __shared__ float s_loss[kSamplesPerBlock];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,12 +51,20 @@ __global__ __launch_bounds__(kHeadBlock) void head_kernel(const float* __restric
             if (logit) logit[b] = z;
             if (y) {
                 const float t = y[b];
-                // torch.nn.functional.binary_cross_entropy clamps both logs at -100
-                const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
-                s_loss[ls] = -(t * lp + (1.0f - t) * lq);
-                // BCE backward (grad * (p - t) / max(p(1-p), 1e-12)) chained with sigmoid backward (* p(1-p))
                 const float pq = (1.0f - p) * p;
-                s_dlogit[ls] = (p - t) / fmaxf(pq, 1e-12f) * pq;
+                if (loss_kind == SATRANS_LOSS_MSE) {            // F.mse_loss(reduction='sum'): (p - t)^2, d/dp = 2 (p - t)
+                    s_loss[ls] = (p - t) * (p - t);
+                    s_dlogit[ls] = 2.0f * (p - t) * pq;
+                } else if (loss_kind == SATRANS_LOSS_MAE) {     // F.l1_loss(reduction='sum'): |p - t|, d/dp = sign(p - t)
+                    s_loss[ls] = fabsf(p - t);
+                    s_dlogit[ls] = (p > t ? 1.0f : (p < t ? -1.0f : 0.0f)) * pq;
+                } else {
+                    // torch.nn.functional.binary_cross_entropy clamps both logs at -100
+                    const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
+                    s_loss[ls] = -(t * lp + (1.0f - t) * lq);
+                    // BCE backward (grad * (p - t) / max(p(1-p), 1e-12)) chained with sigmoid backward (* p(1-p))
+                    s_dlogit[ls] = (p - t) / fmaxf(pq, 1e-12f) * pq;
+                }
             }
         }
     }
@@ -135,18 +143,32 @@ extern "C" int64_t satrans_head_scratch_floats(int B, int FD, int n_dense) {
     return ceil_div(B, kSamplesPerBlock) * (int64_t)(FD + n_dense + 2);
 }
 
+extern "C" int satrans_head_loss(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols,
+                                 int n_dense, int B, int FD, const float* w, const float* bias, float* prob, float* logit,
+                                 const float* y, double* loss_sum, float* da, float* g_w, float* g_b, float* scratch,
+                                 int loss_kind, void* stream_);
+
 extern "C" int satrans_head(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols,
                             int n_dense, int B, int FD, const float* w, const float* bias, float* prob, float* logit,
                             const float* y, double* loss_sum, float* da, float* g_w, float* g_b, float* scratch,
                             void* stream_) {
+    return satrans_head_loss(a, dense, dense_stride, dense_cols, n_dense, B, FD, w, bias, prob, logit, y, loss_sum, da, g_w, g_b,
+                             scratch, SATRANS_LOSS_BCE, stream_);
+}
+
+extern "C" int satrans_head_loss(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols,
+                                 int n_dense, int B, int FD, const float* w, const float* bias, float* prob, float* logit,
+                                 const float* y, double* loss_sum, float* da, float* g_w, float* g_b, float* scratch,
+                                 int loss_kind, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(a && w && bias && prob, SATRANS_E_BADARG, "head: null pointer");
     SATRANS_REQUIRE(B > 0 && FD > 0 && (FD % 4) == 0 && n_dense >= 0, SATRANS_E_BADARG, "head: bad sizes B=%d FD=%d", B, FD);
     SATRANS_REQUIRE(n_dense == 0 || (dense && dense_cols), SATRANS_E_BADARG, "head: dense columns without a float matrix");
+    SATRANS_REQUIRE(loss_kind >= SATRANS_LOSS_BCE && loss_kind <= SATRANS_LOSS_MAE, SATRANS_E_BADARG, "head: loss kind %d", loss_kind);
     if (y) SATRANS_REQUIRE(loss_sum && da && g_w && g_b && scratch, SATRANS_E_BADARG, "head: training outputs missing");
     const int nblk = (int)ceil_div(B, kSamplesPerBlock);
     head_kernel<<<nblk, kHeadBlock, 0, stream>>>(a, dense, dense_stride, dense_cols, n_dense, B, FD, w, bias, prob, logit,
-                                                  y, da, scratch);
+                                                  y, da, scratch, loss_kind);
     SATRANS_CHECK_LAUNCH("head_kernel");
     if (y) {
         const int ncol = FD + n_dense;

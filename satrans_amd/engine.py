@@ -449,11 +449,12 @@ class PathEngine:
                                      st), "satrans_head")
         else:
             gw, gb = self._grad_view("dnn_linear.weight"), self._grad_view("dnn_linear.bias")
-            N.check(lib.satrans_head(ws["acts"][self.L].data_ptr(), dense_ptr, dstride, dcols, self.n_dense, B,
-                                     self.F * self.D, m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr(),
-                                     ws["prob"].data_ptr(), ws["logit"].data_ptr(), y.data_ptr(),
-                                     self.loss_sum.data_ptr(), ws["dact"][0].data_ptr(), gw.data_ptr(), gb.data_ptr(),
-                                     ws["head_scratch"].data_ptr(), st), "satrans_head")
+            kind = {"binary_crossentropy": 0, "mse": 1, "mae": 2}[getattr(m, "loss_func", "binary_crossentropy")]
+            N.check(lib.satrans_head_loss(ws["acts"][self.L].data_ptr(), dense_ptr, dstride, dcols, self.n_dense, B,
+                                          self.F * self.D, m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr(),
+                                          ws["prob"].data_ptr(), ws["logit"].data_ptr(), y.data_ptr(),
+                                          self.loss_sum.data_ptr(), ws["dact"][0].data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                          ws["head_scratch"].data_ptr(), kind, st), "satrans_head_loss")
 
     def forward(self, X: torch.Tensor, training: bool = False, capture_attention: bool = False) -> torch.Tensor:
         self.flush_lazy()
@@ -627,7 +628,9 @@ class PathEngine:
         y = y.reshape(-1).to(torch.float32).contiguous()
         B = X.shape[0]
         self._ensure_train_state()
-        self.m._refresh_adam_cfg()                    # lr schedulers / edited param_groups take effect at this step
+        cfg = self.m._refresh_adam_cfg()              # lr schedulers / edited param_groups take effect at this step
+        if cfg.get("kind", "adam") != "adam":
+            return self._train_step_dense(X, y, cfg)
         world = parallel.world_size()
         exch = parallel.exchange_enabled()            # several ranks (or one rank made to run its collectives: tests)
         ws = self.train_workspace(B, world, exch)
@@ -764,6 +767,42 @@ class PathEngine:
         h_flat = self._hparams(0.0)
         with self.phase("adam_flat"):
             self._flat_step(h_flat, ws, st)
+
+    def _train_step_dense(self, X, y, cfg):
+        """One step of SGD / Adagrad / RMSprop with the reference's dense semantics (models/meta_basemodel.py:612-640): the
+        gradient of EVERY table row (gathered rows + 2 l2 p) is materialised once and one elementwise kernel steps the tables,
+        another the remaining parameters.  One sweep over the tables per step - these optimizers are accepted for API parity,
+        the Adam path (reference main.py:343) is the tuned one."""
+        from . import parallel
+        if parallel.exchange_enabled():
+            raise NotImplementedError("data-parallel training with optimizers other than Adam")
+        B = X.shape[0]
+        ws = self.train_workspace(B, 1, False)
+        lib, m, D, st = self.lib, self.m, self.D, self._stream()
+        l2 = float(m.l2_reg_embedding)
+        if l2 > 0:                                    # the step's regulariser term of the logged loss (pre-update weights)
+            self.reg_sum += l2 * torch.sum(torch.square(m.embedding_arena.double()))
+        gemb = self.backward(X, y, ws)
+        n_rows = B * self.F
+        N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
+                                       ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
+                                       ws["iota"].data_ptr(), st), "satrans_embed_sort")
+        if getattr(self, "_g_arena", None) is None:
+            self._g_arena = torch.empty_like(m.embedding_arena)
+            self._opt_state_arena = torch.zeros_like(m.embedding_arena)
+            self._opt_state_flat = torch.zeros_like(m.flat_params)
+        self._g_arena.zero_()
+        N.check(lib.satrans_embed_grad_dense(m.embedding_arena.data_ptr(), ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(),
+                                             n_rows, gemb.data_ptr(), self.total_rows, D, l2, self._g_arena.data_ptr(), st),
+                "satrans_embed_grad_dense")
+        kind = {"sgd": 1, "adagrad": 2, "rmsprop": 3}[cfg["kind"]]
+        lr, alpha, eps = float(cfg["lr"]), float(cfg.get("alpha", 0.0)), float(cfg.get("eps", 0.0))
+        N.check(lib.satrans_optim_flat(kind, m.embedding_arena.data_ptr(), self._g_arena.data_ptr(),
+                                       self._opt_state_arena.data_ptr(), m.embedding_arena.numel(), lr, alpha, eps, st),
+                "satrans_optim_flat")
+        N.check(lib.satrans_optim_flat(kind, m.flat_params.data_ptr(), self.flat_g.data_ptr(), self._opt_state_flat.data_ptr(),
+                                       m.flat_params.numel(), lr, alpha, eps, st), "satrans_optim_flat")
+        self.adam_t += 1
 
     def _flat_step(self, h_flat, ws, st):
         lib, m = self.lib, self.m

@@ -98,6 +98,9 @@ SIGNATURES = {
     "satrans_head_scratch_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "satrans_head": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp]),
+"satrans_head_loss": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "satrans_optim_flat": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, _vp]),
     "satrans_adam_flat": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamHParams), _vp]),
     "satrans_adam_flat_sum": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(AdamHParams), _vp, C.c_int64, _vp, _vp]),
     "satrans_embed_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),

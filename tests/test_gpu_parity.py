@@ -591,6 +591,42 @@ def test_integer_ids_with_dense_features_travel_as_a_packed_input():
     assert not np.array_equal(model.predict(x2, batch_size=128), preds[False])
 
 
+@pytest.mark.parametrize("opt,loss", [("sgd", "binary_crossentropy"), ("adagrad", "mse"), ("rmsprop", "mae"), ("adam", "mse")])
+def test_other_optimizers_and_losses_of_compile(opt, loss):
+    """compile() accepts what the reference's does (models/meta_basemodel.py:612-653): sgd / adagrad / rmsprop next to adam,
+    mse / mae next to binary_crossentropy.  Three steps against torch's own optimizers on the oracle's dense gradients."""
+    c = Case("small_qkv")
+    model = build_model(c, DEV)
+    model.compile(opt, loss)
+    model.eval()
+    eng = model._require_engine()
+    lr = model._adam_cfg["lr"]
+    X, y = c.X.to(DEV), c.y.to(DEV)
+    tr = O.OracleTrainer(c.tensors("param"), c.spec(), lr=lr, optimizer=opt, loss=loss)
+    eng.reset_epoch_sums()
+    loss_ref = reg_ref = 0.0
+    for _ in range(3):
+        eng.train_step(X, y)
+        a, b = tr.step(c.X, c.y)
+        loss_ref, reg_ref = loss_ref + a, reg_ref + b
+    got_loss, got_reg = eng.epoch_sums()
+    assert got_loss == pytest.approx(loss_ref, rel=2e-5)
+    assert got_reg == pytest.approx(reg_ref, rel=2e-5)
+    got, want = sd_to_cpu(model), tr.state()
+    init = c.tensors("param")
+    for k, w in want.items():
+        moved = float((w - init[k]).abs().max())
+        if moved == 0.0:
+            assert torch.equal(got[k], w), k
+            continue
+        err = (got[k] - w).abs().flatten().double()
+        if opt == "sgd":                     # well-conditioned: every element
+            assert float(err.max()) <= 2e-4 * moved + 1e-9, (k, float(err.max()), moved)
+        else:                                # g / sqrt(state): ill-conditioned where the gradient is ~0 (see the Adam tests)
+            assert float(err.median()) <= 2e-3 * lr * 3, (k, float(err.median()))
+            assert float(err.max()) <= 2.0 * lr * 3 + 1e-6, (k, float(err.max()))
+
+
 def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
     """satrans_amd/device_metrics.py on device tensors (sort + searchsorted on the GPU) against sklearn on host copies - ties
     and saturated probabilities included - and `evaluate_domains`, the test report of reference main.py:353-374."""
