@@ -772,6 +772,47 @@ def test_fit_predict_at_baseline_config_scale():
     assert set(ev) == {"binary_crossentropy", "auc"}
 
 
+def test_public_api_on_full_size_aliccp_tables_against_the_oracle():
+    """BASELINE configs[1] with the FULL-SIZE tables (6,571,961 rows, 841 MB) through the public API: `fit` for two steps of
+    1,024 samples (dropout off, as in the golden fit cases), then `predict` - against the CPU oracle taking the same two dense
+    steps over every table row (torch.optim.Adam + dense L2, ~2 s per step on the host) from the same seeded parameters:
+    logged loss, and predictions on fresh rows through both trained models.  (The 50,000-row test above caps the tables.)"""
+    import bench
+    B = 1024
+    X, y = bench.synth_batches(3 * B, 17)
+    model = bench.build_model("cpu", 0.005)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    by_ptr = {}
+    for k, v in model.state_dict().items():                      # keep the reference's aliasing (K_/V_ share Q_'s tensors)
+        state[k] = by_ptr.setdefault(v.data_ptr(), state[k])
+    model.to(DEV)
+    model.device = DEV
+    model._require_engine().drop_p = 0.0
+    x = {f: X[:2 * B, i] for i, f in enumerate(bench.ALICCP_FIELDS)}
+    hist = model.fit(x=x, y=y[:2 * B], batch_size=B, epochs=1, verbose=0, shuffle=False)
+    tr = O.OracleTrainer(state, bench.oracle_spec(), lr=0.005)
+    total = 0.0
+    for i in range(2):
+        bce, reg = tr.step(torch.from_numpy(X[i * B:(i + 1) * B]), torch.from_numpy(y[i * B:(i + 1) * B]))
+        total += bce + reg
+    assert hist.history["loss"][0] == pytest.approx(total / (2 * B), rel=2e-5)
+    x_new = {f: X[2 * B:, i] for i, f in enumerate(bench.ALICCP_FIELDS)}
+    pred = model.predict(x_new, B)
+    p_ref, _ = O.forward(tr.state(), torch.from_numpy(X[2 * B:]), bench.oracle_spec())
+    # two Adam steps move every weight by ~lr; elements with near-zero gradients may differ by a step between any two fp32
+    # implementations (see the Adam tests), which shows up as ~1e-4 on a probability
+    np.testing.assert_allclose(pred, p_ref.numpy().astype(np.float64), rtol=0, atol=2e-3)
+    assert float(np.abs(pred - p_ref.numpy()).mean()) < 2e-4
+    # and the untouched rows took their regulariser-only steps (|g| = 2 l2 |p| ~ 2e-9 against eps = 1e-8: ~0.07 lr per step)
+    sd = sd_to_cpu(model)
+    name = "embedding_dict.205.weight"                           # 4.3 M rows, 2,048 of them gathered
+    moved = (sd[name] - state[name]).abs()
+    ref_moved = (tr.state()[name] - state[name]).abs()
+    assert float((moved - ref_moved).abs().max()) < 2 * 0.005 + 1e-6
+    assert float((moved - ref_moved).abs().median()) < 1e-6
+    assert float(moved.median()) > 1e-4
+
+
 def test_lazy_adam_is_bitwise_the_streaming_adam():
     """The lazy-exact optimizer path (postponed regulariser-only steps, replayed before a row is gathered and by the
     flush) must leave EXACTLY the tables, moments and epoch sums of the every-step streaming kernel."""
