@@ -254,11 +254,26 @@ def main():
     if args.config != "aliccp" and args.lr == 0.005:
         args.lr = CFG["lr"]
 
+    # C libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line version banner there): keep the real
+    # stdout for the ONE JSON line and send everything else to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    force_exchange = os.environ.get("SATRANS_FORCE_EXCHANGE", "0") == "1"
+    import torch.distributed as dist
+    if world == 1 and force_exchange:
+        # diagnostic: a ONE-rank nccl group + the step's multi-rank branch (every collective an identity through RCCL): what
+        # the exchange code path itself costs on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # SATRANS_BENCH_SHARE_GPU=1 (diagnostic): all ranks on cuda:0 over gloo, to exercise the multi-rank step on a
         # one-GPU box; its numbers are not a scaling measurement
@@ -533,8 +548,9 @@ def main():
         "forward_only": forward_only, "forward_only_bf16": forward_bf16, "cpu_baseline": cpu,
         "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "collectives": collectives,
     }
-    print(json.dumps(out))
-    if world > 1:
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
