@@ -370,6 +370,13 @@ int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_t* last, in
                              void* stream);
 int satrans_embed_lazy_mark(const int32_t* sorted_rows, int64_t n, int32_t* last, int t, void* stream);
 
+/* Diagnostic behind the replay's arithmetic.  Replay and flush run four elements per lane on the packed fp32 pipe with the
+ * square root and the division written out as correctly rounded fma sequences (embed_adam.hip); this call counts the results
+ * that differ from the IEEE operations: mode 0 = square root over the floats with bit patterns [first, first + count),
+ * restricted to the operand range of the packed path; mode 1 = division over `count` pseudo-random pairs (seed `first`) of that
+ * range.  *mismatches is HOST memory.  Used by tests/test_gpu_parity.py (every float of the range for mode 0). */
+int satrans_debug_check_packed_math(int mode, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream);
+
 /* Dense materialisation of the embedding gradient (debug / parity tests only):
  * g_arena [total_rows, D] += scatter of gemb by rows (position order), + 2*l2*p when l2 != 0. */
 int satrans_embed_grad_dense(const float* arena, const int32_t* sorted_rows, const int32_t* src, int64_t n,

@@ -470,32 +470,131 @@ __host__ inline LazyK make_lazyk(const satrans_adam_hparams& h) {
     return k;
 }
 
-// one element per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s) as fp32, 1 / (double)fp32(sqrt(1 - beta2^s))) as doubles
-__device__ __forceinline__ double replay_element(float& p, float& m, float& v, int from, int to,
-                                                 const double2* __restrict__ table, const LazyK& k) {
+// ---- packed arithmetic of the replay ---------------------------------------------------------------------------------------
+// The replay and the flush are bound by VALU issue (one dependent Adam step per element and pending step, ~50 instructions
+// with hipcc's IEEE sqrtf and division).  They run four elements per lane as two float2 pairs on the packed fp32 pipe
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction), with the square root and the division
+// written out as hipcc's own correctly rounded sequences WITHOUT their range scaling:
+//   sqrt: r = rsq(x); s = x r; h = r/2; e = fma(-h, s, 1/2); h = fma(h, e, h); s = fma(s, e, s); s = fma(fma(-s, s, x), h, s)
+//   a/b : r = rcp(b); r = fma(fma(-b, r, 1), r, r); q = a r; q = fma(fma(-b, q, a), r, q); q = fma(fma(-b, q, a), r, q)
+// The scaling steps (v_div_scale / v_div_fixup, the 2^32 pre-scale of sqrt) only matter when a residual fma would leave the
+// exactly representable range; a pair takes the packed path when every operand is inside kPkV / kPkA below, where all
+// residuals are exact, and the scalar IEEE path of adam_core otherwise (zero, tiny, huge, NaN).  Both produce the correctly
+// rounded result, so the tables stay bit-identical to the streaming kernel: `satrans_debug_check_packed_math` compares the
+// sqrt with the fp32 rounding of the fp64 square root over EVERY float of the packed range and the division with the rounded
+// fp64 quotient over as many pairs as asked (and adam_core's sqrtf / __fdiv_rn with the same references)
+// (tests/test_gpu_parity.py), and test_lazy_adam_is_bitwise_the_streaming_adam stays the end-to-end gate.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ f32x2 pk_set(float x) { return f32x2{x, x}; }
+
+constexpr float kPkVLo = 0x1p-100f, kPkVHi = 0x1p64f;   // exp_avg_sq operands of the packed sqrt
+constexpr float kPkALo = 0x1p-80f, kPkAHi = 0x1p40f;    // |step_size * exp_avg| operands of the packed division
+constexpr float kPkEpsLo = 0x1p-30f;                    // eps below this: denominators may leave the exact range, scalar kernels only
+
+__device__ __forceinline__ f32x2 pk_sqrt_rn(f32x2 x) {
+    const f32x2 r = {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    f32x2 s = pk_mul(x, r);
+    f32x2 h = pk_mul(r, pk_set(0.5f));
+    const f32x2 e = pk_fma(-h, s, pk_set(0.5f));
+    h = pk_fma(h, e, h);
+    s = pk_fma(s, e, s);
+    const f32x2 d = pk_fma(-s, s, x);
+    return pk_fma(d, h, s);
+}
+
+__device__ __forceinline__ f32x2 pk_div_rn(f32x2 a, f32x2 b) {
+    f32x2 r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    const f32x2 e = pk_fma(-b, r, pk_set(1.0f));
+    r = pk_fma(e, r, r);
+    f32x2 q = pk_mul(a, r);
+    f32x2 d = pk_fma(-b, q, a);
+    q = pk_fma(d, r, q);
+    d = pk_fma(-b, q, a);
+    return pk_fma(d, r, q);
+}
+
+// sqrt(v) / bc2_sqrt + eps of adam_core for one element (the division by the per-step constant, see there)
+__device__ __forceinline__ float denom_of(float root, double rbc2, float eps) {
+    return __fadd_rn((float)__dmul_rn((double)root, rbc2), eps);
+}
+
+// One regulariser-only Adam step of four elements; bit for bit four calls of adam_core with g = 0 + 2*l2*p.
+__device__ __forceinline__ void adam_step4(f32x2 (&p)[2], f32x2 (&m)[2], f32x2 (&v)[2], f32x2 (&sq)[2], float neg_step,
+                                           double rbc2, const LazyK& k) {
+    f32x2 a[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        sq[u] = pk_fma(p[u], p[u], sq[u]);
+        const f32x2 g = pk_add(pk_set(0.f), pk_mul(pk_set(k.l2x2), p[u]));
+        m[u] = pk_fma(pk_set(k.w1), pk_sub(g, m[u]), m[u]);
+        v[u] = pk_fma(pk_mul(pk_set(k.w2), g), g, pk_mul(v[u], pk_set(k.beta2)));
+        a[u] = pk_mul(pk_set(neg_step), m[u]);
+    }
+    const float vmin = fminf(__builtin_fminf(__builtin_fminf(v[0].x, v[0].y), v[1].x), v[1].y);
+    const float vmax = fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0].x, v[0].y), v[1].x), v[1].y);
+    const float amin = fminf(__builtin_fminf(__builtin_fminf(fabsf(a[0].x), fabsf(a[0].y)), fabsf(a[1].x)), fabsf(a[1].y));
+    const float amax = fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(a[0].x), fabsf(a[0].y)), fabsf(a[1].x)), fabsf(a[1].y));
+    // NaNs drop out of min / max, and a NaN operand gives NaN on either path
+    const bool packed = vmin >= kPkVLo && vmax <= kPkVHi && amin >= kPkALo && amax <= kPkAHi && k.eps >= kPkEpsLo;
+    if (packed) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x2 root = pk_sqrt_rn(v[u]);
+            const f32x2 den = {denom_of(root.x, rbc2, k.eps), denom_of(root.y, rbc2, k.eps)};
+            p[u] = pk_add(p[u], pk_div_rn(a[u], den));
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            p[u].x = __fadd_rn(p[u].x, __fdiv_rn(a[u].x, denom_of(sqrtf(v[u].x), rbc2, k.eps)));
+            p[u].y = __fadd_rn(p[u].y, __fdiv_rn(a[u].y, denom_of(sqrtf(v[u].y), rbc2, k.eps)));
+        }
+    }
+}
+
+// four elements per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s) as fp32, 1 / (double)fp32(sqrt(1 - beta2^s))) as doubles
+__device__ __forceinline__ double replay_element4(float4& P4, float4& M4, float4& V4, int from, int to,
+                                                  const double2* __restrict__ table, const LazyK& k) {
     // sum of p^2 over the replayed steps in fp32 (<= a few thousand terms of one element: relative error ~1e-7 x steps,
     // far inside the fp32 reduction the reference itself uses), converted to double once; the sums over elements,
     // blocks and steps stay in double
-    float sq = 0.f;
+    f32x2 p[2] = {{P4.x, P4.y}, {P4.z, P4.w}}, m[2] = {{M4.x, M4.y}, {M4.z, M4.w}}, v[2] = {{V4.x, V4.y}, {V4.z, V4.w}};
+    f32x2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int s = from + 1; s <= to; ++s) {
         const double2 hp = table[s];
-        sq = fmaf(p, p, sq);
-        // gradient of a row that was not gathered: 0 + 2*l2*p, the same expression the streaming kernel evaluates
-        const float g = __fadd_rn(0.f, __fmul_rn(k.l2x2, p));
-        adam_core(p, m, v, g, -(float)hp.x, hp.y, k.w1, k.beta2, k.w2, k.eps);
+        adam_step4(p, m, v, sq, -(float)hp.x, hp.y, k);
     }
-    return (double)k.l2 * (double)sq;
+    P4 = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
+    M4 = make_float4(m[0].x, m[0].y, m[1].x, m[1].y);
+    V4 = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    return (double)k.l2 * (((double)sq[0].x + (double)sq[0].y) + ((double)sq[1].x + (double)sq[1].y));
 }
 
-// replay for the rows of one batch: one group of D lanes per sorted position, run heads only
+// replay for the rows of one batch: one group of D/4 lanes per sorted position, run heads only.  `slots` partial sums are
+// written (the workspace is sized for one per 256 elements): this grid's one per block, zeros in the rest.
 template <int D>
-__global__ __launch_bounds__(256) void lazy_replay_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+__global__ __launch_bounds__(256) void lazy_replay_kernel(float4* __restrict__ P, float4* __restrict__ M, float4* __restrict__ V,
                                                          int32_t* __restrict__ last, const int32_t* __restrict__ sorted_rows,
                                                          int64_t n, int target, const double2* __restrict__ table, LazyK k,
-                                                         double* __restrict__ reg_partials) {
+                                                         double* __restrict__ reg_partials, int64_t slots) {
+    constexpr int LR = D / 4;
     __shared__ double s_red[256];
-    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D;
-    const int c = threadIdx.x % D;
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LR;
+    const int c = threadIdx.x % LR;
     double reg = 0.0;
     if (j < n) {
         const int32_t row = sorted_rows[j];
@@ -503,9 +602,9 @@ __global__ __launch_bounds__(256) void lazy_replay_kernel(float* __restrict__ P,
         if (head) {
             const int from = last[row];
             if (from < target) {
-                const int64_t at = (int64_t)row * D + c;
-                float p = P[at], m = M[at], v = V[at];
-                reg = replay_element(p, m, v, from, target, table, k);
+                const int64_t at = (int64_t)row * LR + c;
+                float4 p = P[at], m = M[at], v = V[at];
+                reg = replay_element4(p, m, v, from, target, table, k);
                 P[at] = p; M[at] = m; V[at] = v;
             }
         }
@@ -517,33 +616,71 @@ __global__ __launch_bounds__(256) void lazy_replay_kernel(float* __restrict__ P,
         if ((j == 0 || sorted_rows[j - 1] != row) && last[row] < target) last[row] = target;
     }
     const double total = block_sum(reg, s_red);
-    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+    if (threadIdx.x == 0) {
+        reg_partials[blockIdx.x] = total;
+        for (int64_t t = (int64_t)blockIdx.x + gridDim.x; t < slots; t += gridDim.x) reg_partials[t] = 0.0;
+    }
 }
 
 // replay for every row of the arena
 template <int D>
-__global__ __launch_bounds__(256) void lazy_flush_kernel(float* __restrict__ P, float* __restrict__ M, float* __restrict__ V,
+__global__ __launch_bounds__(256) void lazy_flush_kernel(float4* __restrict__ P, float4* __restrict__ M, float4* __restrict__ V,
                                                         int32_t* __restrict__ last, int64_t total_rows, int target,
                                                         const double2* __restrict__ table, LazyK k,
                                                         double* __restrict__ reg_partials) {
+    constexpr int LR = D / 4;
     __shared__ double s_red[256];
     double reg = 0.0;
-    const int64_t groups_per_pass = (int64_t)gridDim.x * 256 / D;
-    const int c = threadIdx.x % D;
-    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D; row < total_rows; row += groups_per_pass) {
+    const int64_t groups_per_pass = (int64_t)gridDim.x * 256 / LR;
+    const int c = threadIdx.x % LR;
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LR; row < total_rows; row += groups_per_pass) {
         const int from = last[row];
         if (from < target) {
-            const int64_t at = row * D + c;
-            float p = P[at], m = M[at], v = V[at];
-            reg += replay_element(p, m, v, from, target, table, k);
+            const int64_t at = row * LR + c;
+            float4 p = P[at], m = M[at], v = V[at];
+            reg += replay_element4(p, m, v, from, target, table, k);
             P[at] = p; M[at] = m; V[at] = v;
         }
     }
     __syncthreads();    // all reads of last[] in this block are done; blocks own disjoint rows
-    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / D; row < total_rows; row += groups_per_pass)
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LR; row < total_rows; row += groups_per_pass)
         if (c == 0 && last[row] < target) last[row] = target;
     const double total = block_sum(reg, s_red);
     if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+}
+
+// Diagnostic behind the packed arithmetic: mode 0 compares pk_sqrt_rn with RN32(sqrt in fp64) on the floats whose bit patterns are
+// [first, first + count) (the caller walks the whole packed range), mode 1 compares pk_div_rn with RN32(fp64 quotient) on `count`
+// pseudo-random (a, b) pairs drawn from seed `first` with a in +-[2^-80, 2^40], b in [2^-30, 2^38]; mismatches are counted.
+__global__ void packed_math_check_kernel(int mode, uint64_t first, uint64_t count, unsigned long long* __restrict__ bad) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (mode == 0) {
+            const float x = __uint_as_float((uint32_t)(first + i));
+            if (!(x >= kPkVLo && x <= kPkVHi)) continue;
+            const f32x2 r = pk_sqrt_rn(f32x2{x, x});
+            const float want = (float)sqrt((double)x);       // correctly rounded: 53 >= 2*24 + 2 bits make the double rounding innocuous
+            mine += __float_as_uint(sqrtf(x)) != __float_as_uint(want);   // ... and hipcc's own fp32 sqrt (adam_core's) agrees
+            mine += (__float_as_uint(r.x) != __float_as_uint(want)) + (__float_as_uint(r.y) != __float_as_uint(want));
+        } else {
+            // splitmix64 of the pair index: mantissas uniform, exponents uniform over the packed range
+            uint64_t z = (first + i) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            uint64_t w = (z + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+            w ^= w >> 29;
+            const uint32_t ea = 127 - 80 + (uint32_t)((w >> 8) % 120u);        // 2^-80 .. 2^39
+            const uint32_t eb = 127 - 30 + (uint32_t)((w >> 20) % 68u);        // 2^-30 .. 2^37
+            const float a = __uint_as_float(((uint32_t)(w & 1u) << 31) | (ea << 23) | (uint32_t)(z & 0x7FFFFFu));
+            const float b = __uint_as_float((eb << 23) | (uint32_t)((z >> 23) & 0x7FFFFFu));
+            const f32x2 q = pk_div_rn(f32x2{a, -a}, f32x2{b, b});
+            const float want = (float)((double)a / (double)b);   // correctly rounded for the same reason
+            mine += __float_as_uint(__fdiv_rn(a, b)) != __float_as_uint(want);
+            mine += (__float_as_uint(q.x) != __float_as_uint(want)) + (__float_as_uint(q.y) != __float_as_uint(-want));
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
 }
 
 __global__ void mark_last_kernel(const int32_t* __restrict__ sorted_rows, int64_t n, int32_t* __restrict__ last, int t) {
@@ -940,9 +1077,12 @@ extern "C" int satrans_embed_lazy_replay(float* arena, float* m, float* v, int32
                     "embed_lazy_replay: null pointer");
     SATRANS_REQUIRE(n > 0 && target >= 0, SATRANS_E_BADARG, "embed_lazy_replay: n=%lld target=%d", (long long)n, target);
     const LazyK k = make_lazyk(*h);
-    const int64_t blocks = ceil_div(n * D, 256);
-    DISPATCH_D(D, (lazy_replay_kernel<DD><<<(unsigned)blocks, 256, 0, stream>>>(arena, m, v, last, sorted_rows, n, target,
-                                                                                (const double2*)table, k, reg_partials)));
+    SATRANS_REQUIRE(D % 4 == 0, SATRANS_E_UNSUPPORTED, "embed_lazy_replay: embedding_dim %d is not a multiple of 4", D);
+    const int64_t slots = ceil_div(n * D, 256);
+    const int64_t blocks = ceil_div(n * (D / 4), 256);
+    DISPATCH_D(D, (lazy_replay_kernel<DD><<<(unsigned)blocks, 256, 0, stream>>>((float4*)arena, (float4*)m, (float4*)v, last,
+                                                                                sorted_rows, n, target, (const double2*)table, k,
+                                                                                reg_partials, slots)));
     SATRANS_CHECK_LAUNCH("lazy_replay_kernel");
     return SATRANS_OK;
 }
@@ -956,9 +1096,27 @@ extern "C" int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_
     SATRANS_REQUIRE(arena && m && v && last && table && h && reg_partials, SATRANS_E_BADARG, "embed_lazy_flush: null pointer");
     const LazyK k = make_lazyk(*h);
     double* reg = reg_partials + ceil_div(n * D, 256);
-    DISPATCH_D(D, (lazy_flush_kernel<DD><<<kFlushBlocks, 256, 0, stream>>>(arena, m, v, last, total_rows, target,
-                                                                          (const double2*)table, k, reg)));
+    DISPATCH_D(D, (lazy_flush_kernel<DD><<<kFlushBlocks, 256, 0, stream>>>((float4*)arena, (float4*)m, (float4*)v, last, total_rows,
+                                                                          target, (const double2*)table, k, reg)));
     SATRANS_CHECK_LAUNCH("lazy_flush_kernel");
+    return SATRANS_OK;
+}
+
+// Diagnostic: mismatches of the replay's packed sqrt (mode 0, bit patterns [first, first + count)) or division (mode 1, `count`
+// pairs from seed `first`) against the IEEE operations; *mismatches (host) receives the count.
+extern "C" int satrans_debug_check_packed_math(int mode, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE((mode == 0 || mode == 1) && mismatches, SATRANS_E_BADARG, "check_packed_math: bad arguments");
+    unsigned long long* dev = nullptr;
+    SATRANS_REQUIRE(hipMalloc(&dev, sizeof(unsigned long long)) == hipSuccess, SATRANS_E_LAUNCH, "check_packed_math: hipMalloc");
+    (void)hipMemsetAsync(dev, 0, sizeof(unsigned long long), stream);
+    packed_math_check_kernel<<<4096, 256, 0, stream>>>(mode, first, count, dev);
+    unsigned long long host = 0;
+    const hipError_t e = hipMemcpyAsync(&host, dev, sizeof(host), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(dev);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "check_packed_math: %s", hipGetErrorString(e));
+    *mismatches = host;
     return SATRANS_OK;
 }
 
@@ -987,7 +1145,7 @@ __global__ void optim_flat_kernel(int kind, float* __restrict__ p, const float* 
         if (kind == SATRANS_OPT_ADAGRAD) s = fmaf(gi, gi, s);                      // state_sum.addcmul_(g, g, value=1)
         else s = fmaf(__fmul_rn(1.0f - alpha, gi), gi, __fmul_rn(s, alpha));       // square_avg.mul_(alpha).addcmul_(g, g, value=1-alpha)
         st[i] = s;
-        const float denom = __fadd_rn(__fsqrt_rn(s), eps);                         // std = sqrt(.) + eps
+        const float denom = __fadd_rn(sqrtf(s), eps);                         // std = sqrt(.) + eps
         pi = __fadd_rn(pi, __fmul_rn(-lr, __fdiv_rn(gi, denom)));                 // p.addcdiv_(g, std, value=-lr)
     }
     p[i] = pi;

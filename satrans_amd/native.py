@@ -131,6 +131,7 @@ SIGNATURES = {
     "satrans_embed_lazy_flush": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, C.POINTER(AdamHParams),
                                            C.c_int64, _vp, _vp]),
     "satrans_embed_lazy_mark": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp]),
+    "satrans_debug_check_packed_math": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), _vp]),
     "satrans_embed_grad_dense": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_float, _vp, _vp]),
     "satrans_sum_f64": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp]),
 }

@@ -844,6 +844,97 @@ def test_lazy_adam_is_bitwise_the_streaming_adam():
     assert reg_l == pytest.approx(reg_d, rel=1e-6)      # lazy sums p^2 per element in fp32 before going to double
 
 
+def test_packed_replay_arithmetic_is_the_ieee_arithmetic():
+    """The replay / flush kernels run their square root and division as packed fma sequences (embed_adam.hip).  They must be
+    the correctly rounded operations: the square root is compared with the fp32 rounding of the fp64 square root (correct, as
+    53 >= 2*24 + 2) on EVERY float of the packed operand range [2^-100, 2^64], the division with the rounded fp64 quotient on
+    2^33 pseudo-random pairs of its range (both signs); the scalar sqrtf / division of the streaming kernel are held against the
+    same references in the same pass."""
+    import ctypes as C
+    from satrans_amd import native as N
+    lib = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bad = C.c_uint64(123)
+    lo = int(np.float32(2.0 ** -100).view(np.uint32))
+    hi = int(np.float32(2.0 ** 64).view(np.uint32))
+    N.check(lib.satrans_debug_check_packed_math(0, lo - 1000, hi - lo + 2000, C.byref(bad), st), "packed sqrt")
+    assert bad.value == 0, f"{bad.value} square roots are not correctly rounded"
+    for seed in (0, 1 << 40):
+        N.check(lib.satrans_debug_check_packed_math(1, seed, 1 << 32, C.byref(bad), st), "packed division")
+        assert bad.value == 0, f"{bad.value} quotients are not correctly rounded"
+
+
+@pytest.mark.parametrize("D", [16, 32, 64])
+def test_lazy_flush_equals_streaming_steps_on_edge_values(D):
+    """Kernel level: K regulariser-only steps through the streaming kernel (one launch per step) and one flush (and one
+    replay of a row list) must leave identical bits - on ordinary table values and on the values that take the scalar path
+    of the packed replay (zeros, subnormals, 1e-30, 1e20, negative zero) mixed into the same lanes."""
+    import ctypes as C
+    import math
+    from satrans_amd import native as N
+    lib = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(17 + D)
+    R, K = 4099, 13
+    lr, b1, b2, eps, l2 = 0.005, 0.9, 0.999, 1e-8, 1e-5
+    P = torch.randn(R, D, generator=g) * 1e-4
+    M = torch.randn(R, D, generator=g) * 1e-9
+    V = torch.rand(R, D, generator=g) * 1e-17
+    odd = torch.tensor([0.0, -0.0, 1e-45, 3e-39, 1e-30, -1e-30, 1e20, -3e18, 1.0, 1e-12], dtype=torch.float32)
+    pick = torch.randint(0, odd.numel(), (R, D), generator=g)
+    where = torch.rand(R, D, generator=g) < 0.05
+    P = torch.where(where, odd[pick], P)
+    M = torch.where(torch.rand(R, D, generator=g) < 0.03, torch.zeros(()), M)
+    V = torch.where(torch.rand(R, D, generator=g) < 0.03, odd[pick].abs() ** 2, V)
+    V = torch.where(torch.isfinite(V), V, torch.full((), 1e30))
+    f32 = lambda x: float(np.float32(x))
+    table = torch.tensor([(0.0, 1.0)] + [(f32(lr / (1.0 - b1 ** s)), 1.0 / f32(math.sqrt(1.0 - b2 ** s))) for s in range(1, K + 1)],
+                         dtype=torch.float64, device=DEV)
+
+    def hp(t):
+        h = N.AdamHParams()
+        h.lr_over_bc1, h.bc2_sqrt = lr / (1 - b1 ** t), math.sqrt(1 - b2 ** t)
+        h.beta1, h.beta2, h.eps, h.l2 = b1, b2, eps, l2
+        return h
+
+    Ps, Ms, Vs = (x.clone().to(DEV) for x in (P, M, V))
+    touched = torch.zeros((R + 31) // 32, dtype=torch.int32, device=DEV)
+    regs = torch.zeros(int(lib.satrans_embed_reg_partials(R, 64, D)), dtype=torch.float64, device=DEV)
+    for t in range(1, K + 1):
+        N.check(lib.satrans_embed_adam_untouched(Ps.data_ptr(), Ms.data_ptr(), Vs.data_ptr(), 0, R, D, touched.data_ptr(),
+                                                 C.byref(hp(t)), regs.data_ptr(), 0, st), "untouched")
+    # flush: everything from step 0 to K in one launch
+    Pf, Mf, Vf = (x.clone().to(DEV) for x in (P, M, V))
+    last = torch.zeros(R, dtype=torch.int32, device=DEV)
+    n = 64
+    regl = torch.zeros(int(lib.satrans_embed_lazy_reg_partials(n, D)), dtype=torch.float64, device=DEV)
+    N.check(lib.satrans_embed_lazy_flush(Pf.data_ptr(), Mf.data_ptr(), Vf.data_ptr(), last.data_ptr(), R, D, K, table.data_ptr(),
+                                         C.byref(hp(K)), n, regl.data_ptr(), st), "flush")
+    assert int(last.min()) == K
+    for a, b, what in ((Pf, Ps, "p"), (Mf, Ms, "m"), (Vf, Vs, "v")):
+        same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same.all()), f"{what}: {int((~same).sum())} elements differ between flush and streaming steps"
+    # replay of a sorted row list with duplicates, in two stages (0 -> 5 for some rows, then everything listed -> K)
+    Pr, Mr, Vr = (x.clone().to(DEV) for x in (P, M, V))
+    last = torch.zeros(R, dtype=torch.int32, device=DEV)
+    rows1 = torch.sort(torch.randint(0, R, (1000,), generator=g).to(torch.int32)).values.to(DEV)
+    rows2 = torch.sort(torch.randint(0, R, (3000,), generator=g).to(torch.int32)).values.to(DEV)
+    for rows, target in ((rows1, 5), (rows2, K)):
+        regr = torch.full((int(lib.satrans_embed_lazy_reg_partials(rows.numel(), D)),), 7.0, dtype=torch.float64, device=DEV)
+        N.check(lib.satrans_embed_lazy_replay(Pr.data_ptr(), Mr.data_ptr(), Vr.data_ptr(), last.data_ptr(), D, rows.data_ptr(),
+                                              rows.numel(), target, table.data_ptr(), C.byref(hp(target)), regr.data_ptr(), st),
+                "replay")
+        slots = (rows.numel() * D + 255) // 256
+        assert not bool((regr[:slots] == 7.0).any()), "every partial-sum slot of the replay must be written"
+    done = (last == K).cpu()
+    assert int(done.sum()) == int(torch.unique(rows2).numel())
+    for a, b, what in ((Pr, Ps, "p"), (Mr, Ms, "m"), (Vr, Vs, "v")):
+        same = (a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same[done.to(DEV)].all()), f"{what}: replayed rows differ from the streaming steps"
+    untouched_rows = (last == 0).cpu()
+    assert torch.equal(Pr.cpu()[untouched_rows], P[untouched_rows])
+
+
 def _dp_worker(rank, world, port, name, steps, out_dir, small_rows):
     """One data-parallel rank of the engine; both ranks share cuda:0 and talk over gloo (host-staged), which runs
     exactly the code path of an RCCL job: ids all-gathered before the forward, gradient rows after the backward."""
