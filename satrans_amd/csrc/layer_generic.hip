@@ -18,7 +18,6 @@
 
 namespace satrans {
 
-constexpr int kGM = 128, kGN = 64, kGK = 16;      // GEMM workgroup tile
 constexpr int kTnRows = 512;                        // token rows per workgroup of a weight-gradient product (2048: 1.4x slower)
 
 struct GemmBatch {      // blockIdx.z selects one of up to three products that share shapes (q0 / k0 / v)
@@ -30,152 +29,210 @@ struct GemmBatch {      // blockIdx.z selects one of up to three products that s
 // C[m][n] (op)= sum_k A[m][k] B(k, n) over the rows of one segment.  Segment s = rows [seg[s] F, seg[s+1] F) and takes
 // B + s * b_seg_stride (seg == nullptr: one segment of M rows).  TRANSB: B(k, n) = B[n * ldb + k], else B[k * ldb + n].
 // EPI: 0 store, 1 relu then store, 2 C += acc, 3 store where mask[m][n] > 0 else 0 (relu backward).
-template <bool TRANSB, int EPI>
-__global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32_t* __restrict__ seg, int M, int F, int K, int N,
-                                                     int lda, int ldb, int ldc, int64_t b_seg_stride,
-                                                     const float* __restrict__ mask) {
-    __shared__ float As[kGK][kGM + 16];
-    __shared__ float Bs[kGK][kGN + 16];
+// K, N multiples of 16, <= 128; A and C are dense token-row buffers (lda = K, ldc = N).
+//
+// HBM-bound by shape (K <= 128: ~40 MAC per float moved), so the kernel is built around the row traffic: no LDS for the token
+// rows at all.  The product is computed TRANSPOSED, C^T = B^T A^T: the MFMA's first operand is a B^T fragment from LDS (the
+// weights of the segment, staged once per workgroup), the second is A^T - lane (m, g) supplies A[m][16 j + 4 g + i], which
+// is component i of ONE 16-byte load per 16 k - and the accumulator tile then holds C[m][16 jn + 4 g + r], four consecutive
+// columns of one row per lane: 16-byte loads and 16-byte stores straight between HBM and the MFMA operands, the next row
+// group's loads in flight under the current group's MFMAs.  The k order of the contraction is permuted the same way on both
+// operands (k = 16 j + 4 g + i), which a sum does not see.
+// B^T in LDS as [g][n][j][i] planes (plane stride a multiple of 256 B, row stride an ODD number of 16-byte slots): the
+// 16 lanes of a ds_read_b128 service group hold 16 different n, i.e. 16 different slots - conflict-free.
+constexpr int kG2Rows = 512;     // token rows per workgroup (4 waves x 8 groups of 16)
+
+__host__ __device__ inline int g2_row_slots(int K) { return (K >> 4) | 1; }
+__host__ __device__ inline int g2_plane_floats(int K, int N) { return ((N * g2_row_slots(K) * 4 + 63) / 64) * 64; }
+
+template <bool TRANSB, int EPI, int KJ>       // KJ = K / 16
+__global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32_t* __restrict__ seg, int M, int F, int N,
+                                                     int ldb, int64_t b_seg_stride, const float* __restrict__ mask) {
+    extern __shared__ __align__(16) float g2_lds[];
+    constexpr int K = KJ * 16;
     const int s = blockIdx.y;
-    const int n_tiles = (N + kGN - 1) / kGN;
-    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
     const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
-    const int64_t row0 = r_lo + (int64_t)mt * kGM;
+    const int64_t row0 = r_lo + (int64_t)blockIdx.x * kG2Rows;
     if (row0 >= r_hi) return;
-    const int n0 = nt * kGN;
     const float* __restrict__ A = gb.A[blockIdx.z];
     const float* __restrict__ B = gb.B[blockIdx.z] + (size_t)s * b_seg_stride;
     float* __restrict__ C = gb.C[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    f32x4 acc[2][4];
+    const int RS = g2_row_slots(K) * 4, PL = g2_plane_floats(K, N);
+    // stage B^T: element (k, nn) -> plane (k >> 2) & 3, row nn, position 4 (k >> 4) + (k & 3)
+    for (int e = tid; e < K * N; e += 256) {
+        int k, nn;
+        if (TRANSB) { nn = e / K; k = e - nn * K; } else { k = e / N; nn = e - k * N; }
+        const float v = TRANSB ? B[(size_t)nn * ldb + k] : B[(size_t)k * ldb + nn];
+        g2_lds[((k >> 2) & 3) * PL + nn * RS + 4 * (k >> 4) + (k & 3)] = v;
+    }
+    __syncthreads();
+    const float* bt = g2_lds + g * PL + n * RS;
+    const int NT = N >> 4;
+    float4 a[KJ], an[KJ];
+    auto load_rows = [&](int64_t g0, float4 (&dst)[KJ]) {
+        const int64_t row = g0 + n;
+        if (row < r_hi) {
+            const float4* src = reinterpret_cast<const float4*>(A + row * K + 4 * g);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < KJ; ++j) dst[j] = src[4 * j];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += kGK) {
-        {   // A tile: 128 rows x 16 k, transposed into As[k][row]
-            const int r = tid >> 2, kq = (tid & 3) * 4;
+            for (int j = 0; j < KJ; ++j) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int64_t wave_row0 = row0 + 16 * wave;
+    const int64_t tile_hi = min(r_hi, row0 + kG2Rows);
+    if (wave_row0 < tile_hi) load_rows(wave_row0, a);
+    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 64) {
+        const bool more = g0 + 64 < tile_hi;
+        if (more) load_rows(g0 + 64, an);
+        const int64_t row = g0 + n;
+        for (int jn = 0; jn < NT; ++jn) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = bt + 16 * jn * RS;
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int64_t row = row0 + r + 64 * pass;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < r_hi) v = *reinterpret_cast<const float4*>(A + row * lda + k0 + kq);
-                As[kq][r + 64 * pass] = v.x; As[kq + 1][r + 64 * pass] = v.y;
-                As[kq + 2][r + 64 * pass] = v.z; As[kq + 3][r + 64 * pass] = v.w;
+            for (int j = 0; j < KJ; ++j) {
+                const float4 b = *reinterpret_cast<const float4*>(bp + 4 * j);
+                acc = mfma4(b.x, a[j].x, acc);
+                acc = mfma4(b.y, a[j].y, acc);
+                acc = mfma4(b.z, a[j].z, acc);
+                acc = mfma4(b.w, a[j].w, acc);
+            }
+            if (row < r_hi) {
+                float4* dst = reinterpret_cast<float4*>(C + row * N + 16 * jn + 4 * g);
+                float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (EPI == 1) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                if (EPI == 2) {
+                    const float4 o = *dst;
+                    v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+                }
+                if (EPI == 3) {
+                    const float4 mk = *reinterpret_cast<const float4*>(mask + row * N + 16 * jn + 4 * g);
+                    v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f, mk.w > 0.f ? v.w : 0.f);
+                }
+                *dst = v;
             }
         }
-        if constexpr (!TRANSB) {
-            const int k = tid >> 4, n4 = (tid & 15) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + n4 < N) v = *reinterpret_cast<const float4*>(B + (size_t)(k0 + k) * ldb + n0 + n4);
-            *reinterpret_cast<float4*>(&Bs[k][n4]) = v;
-        } else {
-            const int nn = tid >> 2, kq = (tid & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + nn < N) v = *reinterpret_cast<const float4*>(B + (size_t)(n0 + nn) * ldb + k0 + kq);
-            Bs[kq][nn] = v.x; Bs[kq + 1][nn] = v.y; Bs[kq + 2][nn] = v.z; Bs[kq + 3][nn] = v.w;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) a[j] = an[j];
         }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[4 * ks + g][32 * wave + 16 * i + n];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[4 * ks + g][16 * j + n];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
     }
+}
+
+// partial[(s * chunks + c)][k][n] = sum over the token rows of chunk c of segment s of A[m][k] G[m][n]   (K, N multiples of 16,
+// KA = ceil(K / 64) and NA = ceil(N / 64) 64-column blocks, KA * NA <= 2).  Chunks beyond a segment's rows write nothing.
+//
+// Token rows straight from HBM into the MFMA operands: lane (c, g) loads the 16 bytes A[m = 4 step + g][4 c .. 4 c + 3] (the 16
+// lanes of a g cover one 256-byte row: fully coalesced), and component i of that load is the first operand of the output
+// tile whose 16 rows are k = 4 c' + i (c' = 0..15) - a row PERMUTATION of dW that the store undoes; the same for G and the
+// columns.  16 KA NA MFMAs per two or three 16-byte loads, no LDS on the operand path, the next step's loads issued before
+// the current step's MFMAs.  The four waves of a workgroup own a quarter of the chunk's rows each and add their tiles into
+// one LDS image in wave order (fixed order => bitwise reproducible), which is written out coalesced.
+template <int KA, int NA>
+__global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ G,
+                                                        const int32_t* __restrict__ seg, int M, int F, int K, int N, int lda,
+                                                        float* __restrict__ partial) {
+    extern __shared__ __align__(16) float tn_lds[];      // [K][N]
+    const int s = blockIdx.y, cidx = blockIdx.x, chunks = gridDim.x;
+    const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
+    const int64_t c_lo = r_lo + (int64_t)cidx * kTnRows, c_hi = min(r_hi, c_lo + kTnRows);
+    if (c_lo >= r_hi) return;          // the reducer reads only the chunks a segment uses
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    f32x4 acc[4 * KA][4 * NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4 * KA; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4 * NA; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kWaveRows = kTnRows / 4;
+    const int64_t w_lo = c_lo + (int64_t)wave * kWaveRows, w_hi = min(c_hi, w_lo + kWaveRows);
+    bool ka_ok[KA], na_ok[NA];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 32 * wave + 16 * i + 4 * g + r;
-                const int col = n0 + 16 * j + n;
-                if (row < r_hi && col < N) {
-                    float v = acc[i][j][r];
-                    float* dst = C + row * ldc + col;
-                    if (EPI == 1) v = fmaxf(v, 0.f);
-                    if (EPI == 2) v += *dst;
-                    if (EPI == 3) v = mask[row * ldc + col] > 0.f ? v : 0.f;
-                    *dst = v;
+    for (int u = 0; u < KA; ++u) ka_ok[u] = 64 * u + 4 * c < K;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) na_ok[u] = 64 * u + 4 * c < N;
+    auto load = [&](int64_t m0, float4 (&av)[KA], float4 (&gv)[NA]) {
+        const int64_t m = m0 + g;
+        const bool in = m < w_hi;
+#pragma unroll
+        for (int u = 0; u < KA; ++u)
+            av[u] = in && ka_ok[u] ? *reinterpret_cast<const float4*>(A + m * lda + 64 * u + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+            gv[u] = in && na_ok[u] ? *reinterpret_cast<const float4*>(G + m * N + 64 * u + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // two steps of loads in flight under the MFMAs of the current one (a step is 16 KA NA MFMAs = 0.2 - 0.4 us, the HBM latency
+    // under load is above that)
+    float4 av[3][KA], gv[3][NA];
+    load(w_lo, av[0], gv[0]);
+    load(w_lo + 4, av[1], gv[1]);
+    for (int64_t m0 = w_lo; m0 < w_hi; m0 += 12) {
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            if (m0 + 4 * ph < w_hi) {           // wave-uniform
+                load(m0 + 4 * ph + 8, av[(ph + 2) % 3], gv[(ph + 2) % 3]);
+#pragma unroll
+                for (int u = 0; u < KA; ++u) {
+                    const float ac[4] = {av[ph][u].x, av[ph][u].y, av[ph][u].z, av[ph][u].w};
+#pragma unroll
+                    for (int w = 0; w < NA; ++w) {
+                        const float gc[4] = {gv[ph][w].x, gv[ph][w].y, gv[ph][w].z, gv[ph][w].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[4 * u + i][4 * w + j] = mfma4(ac[i], gc[j], acc[4 * u + i][4 * w + j]);
+                    }
                 }
             }
-}
-
-// partial[(s * chunks + c)][k][n] = sum over the token rows of chunk c of segment s of A[m][k] G[m][n]   (K, N <= 128,
-// multiples of 16, K * N <= 8192).  Every (s, c) writes its partial (zeros when the chunk holds no row).
-__global__ __launch_bounds__(256) void gen_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ G,
-                                                        const int32_t* __restrict__ seg, int M, int F, int K, int N,
-                                                        float* __restrict__ partial) {
-    extern __shared__ __align__(16) float tn_lds[];
-    const int LA = K + 16, LG = N + 16;
-    float* As = tn_lds;                  // [32][LA]
-    float* Gs = tn_lds + 32 * LA;        // [32][LG]
-    const int s = blockIdx.y, c = blockIdx.x, chunks = gridDim.x;
-    const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
-    const int64_t c_lo = r_lo + (int64_t)c * kTnRows, c_hi = min(r_hi, c_lo + kTnRows);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
-    const int NT = N >> 4, tiles = (K >> 4) * NT;
-    f32x4 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ka4 = K >> 2, kg4 = N >> 2;
-    for (int64_t m0 = c_lo; m0 < c_hi; m0 += 32) {
-        for (int i = tid; i < 32 * ka4; i += 256) {
-            const int r = i / ka4, q = (i - r * ka4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < c_hi) v = *reinterpret_cast<const float4*>(A + (m0 + r) * K + q);
-            *reinterpret_cast<float4*>(As + r * LA + q) = v;
         }
-        for (int i = tid; i < 32 * kg4; i += 256) {
-            const int r = i / kg4, q = (i - r * kg4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < c_hi) v = *reinterpret_cast<const float4*>(G + (m0 + r) * N + q);
-            *reinterpret_cast<float4*>(Gs + r * LG + q) = v;
-        }
-        __syncthreads();
+    }
+    // tile (u, i) x (w, j): accumulator register r of lane (c, g) is dW[k = 64 u + 4 (4 g + r) + i][n = 64 w + 4 c + j]
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-        for (int slot = 0; slot < 8; ++slot) {
-            const int t = wave + 4 * slot;
-            if (t < tiles) {
-                const int kt = t / NT, nt = t - kt * NT;
+            for (int u = 0; u < KA; ++u)
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    acc[slot] = mfma4(As[(4 * ks + g) * LA + 16 * kt + n], Gs[(4 * ks + g) * LG + 16 * nt + n], acc[slot]);
-            }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 64 * u + 4 * (4 * g + r) + i;
+#pragma unroll
+                        for (int w = 0; w < NA; ++w) {
+                            const int nn = 64 * w + 4 * c;
+                            if (k < K && nn < N) {
+                                float4* dst = reinterpret_cast<float4*>(tn_lds + k * N + nn);
+                                float4 v = make_float4(acc[4 * u + i][4 * w][r], acc[4 * u + i][4 * w + 1][r],
+                                                       acc[4 * u + i][4 * w + 2][r], acc[4 * u + i][4 * w + 3][r]);
+                                if (turn > 0) {
+                                    const float4 o = *dst;
+                                    v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                                }
+                                *dst = v;
+                            }
+                        }
+                    }
         }
         __syncthreads();
     }
-    float* out = partial + ((size_t)s * chunks + c) * K * N;
-#pragma unroll
-    for (int slot = 0; slot < 8; ++slot) {
-        const int t = wave + 4 * slot;
-        if (t < tiles) {
-            const int kt = t / NT, nt = t - kt * NT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(16 * kt + 4 * g + r) * N + 16 * nt + n] = acc[slot][r];
-        }
-    }
+    float4* out = reinterpret_cast<float4*>(partial + ((size_t)s * chunks + cidx) * K * N);
+    for (int e = tid; e < (K * N) >> 2; e += 256) out[e] = reinterpret_cast<const float4*>(tn_lds)[e];
 }
 
-// dst[s * dst_seg_stride + e] += sum_c partial[(s * chunks + c)][e]; S segments (grid.y).  Blocks of 32 elements x 8 groups:
+// dst[s * dst_seg_stride + e] += sum_c partial[(s * chunks + c)][e] over the chunks segment s uses; S segments (grid.y).  Blocks of 32 elements x 8 groups:
 // every group adds its contiguous share of the chunks in chunk order, the 8 group sums are combined in group order (fixed
 // order => bitwise reproducible, and 8 x more parallel than one thread per element)
 __global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restrict__ partial, int chunks, int count,
-                                                          float* __restrict__ dst, int64_t dst_seg_stride) {
+                                                          float* __restrict__ dst, int64_t dst_seg_stride,
+                                                          const int32_t* __restrict__ seg, int F, int chunk_rows) {
     __shared__ float s_part[8][32];
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + lane;
     const int s = blockIdx.y;
-    const int share = (chunks + 7) / 8;
-    const int c0 = grp * share, c1 = min(chunks, c0 + share);
+    // a segment fills only its first ceil(rows / chunk_rows) partials; the rest were never written
+    const int used = seg ? (int)(((int64_t)(seg[s + 1] - seg[s]) * F + chunk_rows - 1) / chunk_rows) : chunks;
+    const int share = (used + 7) / 8;
+    const int c0 = grp * share, c1 = min(used, c0 + share);
     float t = 0.f;
     if (e < count) {
         const float* p = partial + (size_t)s * chunks * count + e;
@@ -640,6 +697,148 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_kernel(const float* __restri
     }
 }
 
+// ---- attention backward on the matrix pipe (d = 16, F <= 64, H <= 4): one workgroup per sample, one wave per head, the scores
+// TRANSPOSED as in the forward kernel.  Per tile of 16 queries (query i on the lane's column n):
+//   S^T  = K Q^T and dP^T = V G^T          lane (i, g), register r of tile jt <-> key j = 16 jt + 4 g + r
+//   P = exp2(s - max_i) / sum_i from the forward's row statistics, keep bits regenerated, dot_i = go_i . o_i:
+//   dS^T = P (keep dP scale - dot_i) / sqrt(d),  Pm^T = keep P scale                              - all in registers
+//   dQ^T = K^T dS^T: the accumulator tiles ARE the second operand (contraction over the register index j)
+//   dK^T += Q^T dS, dV^T += G^T Pm contract over the QUERIES, which sit on the lanes: the two tiles go through a wave-private
+//   LDS scratch (written by rows j, read back 16 bytes along i) - 32 ds_write_b32 + 8 ds_read_b128 per query tile.
+// Every output tile is transposed (lane = token, 4 consecutive features in its registers): 16-byte stores.
+__global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ o,
+                                                              const float* __restrict__ go, const float2* __restrict__ st,
+                                                              float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                              int F, int H, const int32_t* __restrict__ order, GenDrop dc,
+                                                              float inv_sqrt_d) {
+    constexpr int d = 16;
+    extern __shared__ __align__(16) float at_lds[];
+    const int D = H * d, LD = D + 4;
+    const int FP = (F + 15) & ~15, JT = FP >> 4;
+    const int PL = FP * 4 + 4;                       // scratch plane (one per 4 queries of a tile): [key j][query & 3]
+    float* sq = at_lds;
+    float* sk = sq + FP * LD;
+    float* sv = sk + FP * LD;
+    float* sg = sv + FP * LD;
+    float4* sst = reinterpret_cast<float4*>(sg + FP * LD);          // [H][FP]: max, 1/sum, dot, -
+    float* scr = reinterpret_cast<float*>(sst + H * FP);            // [4 waves][2][4 PL]
+    const int p = blockIdx.x;
+    const int64_t base = (int64_t)p * F * D;
+    for (int i = threadIdx.x; i < FP * (D >> 2); i += blockDim.x) {
+        const int r = i / (D >> 2), c = (i - r * (D >> 2)) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a, gg = a;
+        if (r < F) {
+            a = *reinterpret_cast<const float4*>(q + base + r * D + c);
+            b = *reinterpret_cast<const float4*>(k + base + r * D + c);
+            cc = *reinterpret_cast<const float4*>(v + base + r * D + c);
+            gg = *reinterpret_cast<const float4*>(go + base + r * D + c);
+        }
+        *reinterpret_cast<float4*>(sq + r * LD + c) = a;
+        *reinterpret_cast<float4*>(sk + r * LD + c) = b;
+        *reinterpret_cast<float4*>(sv + r * LD + c) = cc;
+        *reinterpret_cast<float4*>(sg + r * LD + c) = gg;
+    }
+    __syncthreads();
+    for (int task = threadIdx.x; task < H * FP; task += blockDim.x) {
+        const int h = task / FP, i = task - h * FP;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);     // padding queries: P = exp2(0 - 0) * 0 = 0
+        if (i < F) {
+            f32x2 gi[d / 2], oi[d / 2];
+            load_row<d>(sg + i * LD + h * d, gi);
+            load_row<d>(o + base + (int64_t)i * D + h * d, oi);
+            const float2 s2 = st[((size_t)p * H + h) * F + i];
+            s4 = make_float4(s2.x, s2.y, dot_row<d>(gi, oi), 0.f);
+        }
+        sst[task] = s4;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    if (h >= H) return;
+    const int b = order[p];
+    const float sc_scale = kLog2e * inv_sqrt_d;
+    const uint32_t skey = drop_sample_key(dc.key, (uint32_t)b);
+    float* sds = scr + (size_t)h * 8 * PL;            // dS^T of the current query tile
+    float* spm = sds + 4 * PL;                        // Pm^T
+    const float* qh = sq + h * d;
+    const float* kh = sk + h * d;
+    const float* vh = sv + h * d;
+    const float* gh = sg + h * d;
+    f32x4 dkt[4], dvt[4];                             // dK^T / dV^T[e = 4 g + r][key j = 16 jt + n]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) { dkt[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int it = 0; it < JT; ++it) {
+        const int i = 16 * it + n;
+        const float4 s4 = sst[h * FP + i];
+        float qb[4], gb[4];                           // second operands: Q^T / G^T[e = 4 ks + g][i]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qb[ks] = qh[i * LD + 4 * ks + g]; gb[ks] = gh[i * LD + 4 * ks + g]; }
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            s[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (jt < JT) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s[jt] = mfma4(kh[(16 * jt + n) * LD + 4 * ks + g], qb[ks], s[jt]);
+                    dp[jt] = mfma4(vh[(16 * jt + n) * LD + 4 * ks + g], gb[ks], dp[jt]);
+                }
+            }
+        }
+        const uint32_t block0 = drop_attn_elem(h, F, i < F ? i : 0, 0) >> 2;
+        f32x4 dqt = f32x4{0.f, 0.f, 0.f, 0.f};       // dQ^T[e = 4 g + r][i]
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt < JT) {
+                const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(4 * jt + g), dc.thresh) : 0xFu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * g + r;
+                    const float pr = j < F ? __builtin_amdgcn_exp2f(s[jt][r] * sc_scale - s4.x) * s4.y : 0.f;
+                    const bool kp = (kb >> r) & 1u;
+                    const float dpm = kp ? dp[jt][r] * dc.scale : 0.f;
+                    const float ds = pr * (dpm - s4.z) * inv_sqrt_d;
+                    const float pm = kp ? pr * dc.scale : 0.f;
+                    s[jt][r] = ds;
+                    sds[(n >> 2) * PL + j * 4 + (n & 3)] = ds;
+                    spm[(n >> 2) * PL + j * 4 + (n & 3)] = pm;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)           // contraction over keys j = 16 jt + 4 g + r: first operand K[j][e = n]
+                    dqt = mfma4(kh[(16 * jt + 4 * g + r) * LD + n], s[jt][r], dqt);
+            }
+        }
+        if (i < F)
+            *reinterpret_cast<float4*>(dq + base + (int64_t)i * D + h * d + 4 * g) = make_float4(dqt[0], dqt[1], dqt[2], dqt[3]);
+        __builtin_amdgcn_wave_barrier();
+        // contraction over the tile's queries i = 16 it + 4 g + r: first operand Q / G[i][e = n], second dS^T / Pm^T[key 16 jt + n][i]
+        float qa[4], ga[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { qa[r] = qh[(16 * it + 4 * g + r) * LD + n]; ga[r] = gh[(16 * it + 4 * g + r) * LD + n]; }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt < JT) {
+                const float4 dsv = *reinterpret_cast<const float4*>(sds + g * PL + (16 * jt + n) * 4);
+                const float4 pmv = *reinterpret_cast<const float4*>(spm + g * PL + (16 * jt + n) * 4);
+                dkt[jt] = mfma4(qa[0], dsv.x, dkt[jt]); dkt[jt] = mfma4(qa[1], dsv.y, dkt[jt]);
+                dkt[jt] = mfma4(qa[2], dsv.z, dkt[jt]); dkt[jt] = mfma4(qa[3], dsv.w, dkt[jt]);
+                dvt[jt] = mfma4(ga[0], pmv.x, dvt[jt]); dvt[jt] = mfma4(ga[1], pmv.y, dvt[jt]);
+                dvt[jt] = mfma4(ga[2], pmv.z, dvt[jt]); dvt[jt] = mfma4(ga[3], pmv.w, dvt[jt]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const int j = 16 * jt + n;
+        if (jt < JT && j < F) {
+            *reinterpret_cast<float4*>(dk + base + (int64_t)j * D + h * d + 4 * g) = make_float4(dkt[jt][0], dkt[jt][1], dkt[jt][2], dkt[jt][3]);
+            *reinterpret_cast<float4*>(dv + base + (int64_t)j * D + h * d + 4 * g) = make_float4(dvt[jt][0], dvt[jt][1], dvt[jt][2], dvt[jt][3]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -709,9 +908,25 @@ static int gen_gemm(hipStream_t st, int batch, const float* const* A, const floa
                     int S, int M, int F, int K, int N, int ldb, int64_t b_seg_stride, const float* mask = nullptr) {
     GemmBatch gb;
     for (int i = 0; i < 3; ++i) { gb.A[i] = A[i < batch ? i : 0]; gb.B[i] = Bm[i < batch ? i : 0]; gb.C[i] = C[i < batch ? i : 0]; }
-    const int n_tiles = (int)ceil_div(N, kGN);
-    const dim3 grid((unsigned)(ceil_div(M, kGM) * n_tiles), (unsigned)(seg ? S : 1), (unsigned)batch);
-    gen_gemm_kernel<TRANSB, EPI><<<grid, 256, 0, st>>>(gb, seg, M, F, K, N, K, ldb, N, b_seg_stride, mask);
+    SATRANS_REQUIRE(K % 16 == 0 && N % 16 == 0 && K >= 16 && K <= 128 && N >= 16 && N <= 128, SATRANS_E_UNSUPPORTED,
+                    "general-path product %d x %d: K and N must be multiples of 16 up to 128", K, N);
+    const dim3 grid((unsigned)ceil_div(M, kG2Rows), (unsigned)(seg ? S : 1), (unsigned)batch);
+    const size_t lds = sizeof(float) * 4 * (size_t)g2_plane_floats(K, N);
+#define GEN_GEMM_CASE(KJ_)                                                                                                \
+    case KJ_: {                                                                                                           \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)gen_gemm_kernel<TRANSB, EPI, KJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                        \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        gen_gemm_kernel<TRANSB, EPI, KJ_><<<grid, 256, lds, st>>>(gb, seg, M, F, N, ldb, b_seg_stride, mask);              \
+    } break;
+    switch (K >> 4) {
+        GEN_GEMM_CASE(1) GEN_GEMM_CASE(2) GEN_GEMM_CASE(3) GEN_GEMM_CASE(4) GEN_GEMM_CASE(5) GEN_GEMM_CASE(6) GEN_GEMM_CASE(7)
+        GEN_GEMM_CASE(8)
+    }
+#undef GEN_GEMM_CASE
     SATRANS_CHECK_LAUNCH("gen_gemm_kernel");
     return SATRANS_OK;
 }
@@ -721,12 +936,24 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
                        float* partial, float* dst, int64_t dst_seg_stride) {
     const int segs = seg ? S : 1;
     const int chunks = (int)ceil_div(M, kTnRows);
-    const size_t lds = sizeof(float) * 32 * ((size_t)K + 16 + N + 16);
-    gen_gemm_tn_kernel<<<dim3((unsigned)chunks, (unsigned)segs), 256, lds, st>>>(A, G, seg, M, F, K, N, partial);
-    SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel");
-    gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)K * N, 32), (unsigned)segs), 256, 0, st>>>(partial, chunks, K * N, dst,
-                                                                                                     dst_seg_stride);
-    SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
+    SATRANS_REQUIRE(K % 16 == 0 && N % 16 == 0 && K >= 16 && N >= 16 && K <= 128 && N <= 128, SATRANS_E_UNSUPPORTED,
+                    "general-path weight gradient %d x %d: K and N must be multiples of 16 up to 128", K, N);
+    const dim3 grid((unsigned)chunks, (unsigned)segs);
+    // both above 64 (64 accumulator tiles): two passes over 64-row halves of dW, i.e. over column halves of A
+    const int passes = K > 64 && N > 64 ? 2 : 1;
+    for (int h = 0; h < passes; ++h) {
+        const int Kp = passes == 1 ? K : (h == 0 ? 64 : K - 64);
+        const float* Ap = A + 64 * h;
+        float* dp = dst + (size_t)64 * h * N;
+        const size_t lds = sizeof(float) * (size_t)Kp * N;
+        if (Kp <= 64 && N <= 64) gen_gemm_tn_kernel<1, 1><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
+        else if (Kp <= 64) gen_gemm_tn_kernel<1, 2><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
+        else gen_gemm_tn_kernel<2, 1><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
+        SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel");
+        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)Kp * N, 32), (unsigned)segs), 256, 0, st>>>(partial, chunks, Kp * N, dp,
+                                                                                                          dst_seg_stride, seg, F, kTnRows);
+        SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
+    }
     return SATRANS_OK;
 }
 
@@ -762,7 +989,7 @@ static int gen_ln_bwd(hipStream_t st, const satrans_layer_desc* d, const GenLayo
                                                                                    d->F, d->order, dc, relu, tpb, relu_post, norm)));
     SATRANS_CHECK_LAUNCH("gen_ln_bwd_kernel");
     if (g_gamma_beta && norm) {
-        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * d->D, 32), 1), 256, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta, 0);
+        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * d->D, 32), 1), 256, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta, 0, nullptr, 0, 1);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
     return SATRANS_OK;
@@ -811,6 +1038,22 @@ static int gen_attention_bwd(hipStream_t st, const satrans_layer_desc* d, const 
     const int B = d->B, F = d->F, D = d->D, H = d->H;
     const GenDrop dc = gen_drop(d, kSiteAttn);
     const int dd = D / H;
+    const int mode = g_attn_override >= 0 ? g_attn_override : gen_attn_mode();
+    const bool can_mfma = dd == 16 && F <= 64 && H <= 4;
+    SATRANS_REQUIRE(mode != 2 || can_mfma, SATRANS_E_UNSUPPORTED, "generic attention backward: the MFMA arm needs d = 16, F <= 64, H <= 4");
+    if (can_mfma && mode != 1) {
+        const int FP = (F + 15) & ~15;
+        const size_t lds_m = sizeof(float) * (4 * (size_t)FP * (D + 4) + 4 * (size_t)H * FP + 4 * 8 * ((size_t)FP * 4 + 4));
+        static size_t attr_m = 0;
+        if (lds_m > attr_m) {
+            hipError_t e = hipFuncSetAttribute((const void*)gen_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "generic attention backward: LDS attribute: %s", hipGetErrorString(e));
+            attr_m = lds_m;
+        }
+        gen_attn_bwd_mfma_kernel<<<B, 256, lds_m, st>>>(q, k, v, o, go, stp, dq, dk, dv, F, H, d->order, dc, inv_sqrt_d);
+        SATRANS_CHECK_LAUNCH("gen_attn_bwd_mfma_kernel");
+        return SATRANS_OK;
+    }
     const size_t lds = sizeof(float) * (4 * (size_t)F * (D + 4) + 4 * (size_t)H * F);
     static size_t attr8 = 0, attr16 = 0;
     size_t& attr = dd == 8 ? attr8 : attr16;

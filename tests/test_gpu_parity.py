@@ -720,15 +720,19 @@ def test_general_path_attention_arms_agree():
     the MFMA-vs-wavefront ablation - must give the same layer outputs to rounding, with and without dropout."""
     from satrans_amd import native as N
     c = Case("small_d64_u128")
-    outs = {}
+    outs, grads = {}, {}
     for mode in (1, 2):
         N.check(N.lib().satrans_set_generic_attention(mode), "set_generic_attention")
         try:
             model = build_model(c, DEV)
+            model.compile("adam", "binary_crossentropy")
             for train in (False, True):
                 model.train(train)
                 model(c.X.to(DEV))
                 outs[(mode, train)] = [a.clone() for a in model._engine.layer_outputs(c.X.shape[0])[1:]]
+                eng = model._require_engine()
+                eng.drop_step = 40          # the same masks in both arms
+                grads[(mode, train)] = {k: g.clone() for k, g in eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))[2].items()}
             assert model._engine._ws[c.X.shape[0]]["generic"]
         finally:
             N.check(N.lib().satrans_set_generic_attention(-1), "set_generic_attention")
@@ -736,6 +740,12 @@ def test_general_path_attention_arms_agree():
         for a, b in zip(outs[(1, train)], outs[(2, train)]):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-6)
     assert not torch.equal(outs[(1, True)][0], outs[(1, False)][0])
+    # ... and the two backward arms (one lane per row / transposed MFMA tiles with the dK, dV contraction through LDS)
+    for train in (False, True):
+        for k, g in grads[(1, train)].items():
+            scale = max(1e-6, float(g.abs().max()))
+            np.testing.assert_allclose(grads[(2, train)][k].cpu().numpy(), g.cpu().numpy(), rtol=0, atol=5e-5 * scale + 5e-9,
+                                       err_msg=f"{k} train={train}")
 
 
 def test_fit_predict_at_baseline_config_scale():
