@@ -342,7 +342,27 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 // -------------------------------------------------------------------------------------------------------------------
 // SAME: Q and K roles share one generated-weight table (no 'pos' flag).  TR: transposed copies of every weight image live in LDS
 // too (conflict-free reads for the backward products); without them those products read the forward images by rows (chain_t).
-template <int D, int U, int H, bool SAME, bool TR>
+// The key / query loops of the attention phases in chunks of four: with the field count as a template constant (FT) the chunks are
+// unrolled - constant addresses, no bounds arithmetic, no branches - with a scheduling barrier after each, so that the loads of
+// later chunks are not hoisted over earlier ones (that costs the registers the token state needs: 77 spilled VGPRs); FT = 0
+// keeps the rolled loop over a.F.
+// (measured per loop with -Rpass-analysis: unrolling the exp / P V loop of phase B is what spills - 56 VGPRs on its own - so that
+// one stays rolled; the other four unroll spill-free)
+#ifndef SATRANS_UB1
+#define SATRANS_UB1 1
+#define SATRANS_UB2 0
+#define SATRANS_UD1 1
+#define SATRANS_UD2 1
+#define SATRANS_UE 1
+#endif
+#define ATTN_CHUNKS(VAR, BODY, UNROLL)                                                                          \
+    if constexpr (FT != 0 && (UNROLL)) {                                                                                  \
+        _Pragma("unroll") for (int VAR = 0; VAR < FT; VAR += 4) { BODY(VAR); __builtin_amdgcn_sched_barrier(0); } \
+    } else {                                                                                                    \
+        _Pragma("unroll 1") for (int VAR = 0; VAR < F; VAR += 4) BODY(VAR);                                      \
+    }
+
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0>      // FT: the field count as a constant (0 = a.F)
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     static_assert(HB <= 2 && UT == HB * NB, "MetaNet hidden width must be D/.. or 2*D for the fused backward");
     static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
     extern __shared__ __align__(16) float lds[];
-    const int F = a.F;
+    const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
     const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
@@ -639,7 +659,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             float* prow = sP + (size_t)task * F;
             const float sc_scale = inv_sqrt_d * kLog2e;
             float mx = -INFINITY;
-            for (int j0 = 0; j0 < F; j0 += 4) {
+            auto chunk1 = [&](const int j0) {
                 f32x2 kr[4][d / 2];
                 float sc[4];
 #pragma unroll
@@ -652,7 +672,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) prow[j0 + u] = sc[u];
-            }
+            };
+            ATTN_CHUNKS(j0, chunk1, SATRANS_UB1);
             f32x2 oacc[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
@@ -660,7 +681,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
             const uint32_t block0 = drop_attn_elem(h, F, i, 0) >> 2;
-            for (int j0 = 0; j0 < F; j0 += 4) {
+            auto chunk2 = [&](const int j0) {
                 f32x2 vr[4][d / 2];
                 float ex[4];
                 const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(j0 >> 2), dc.thresh) : 0xFu;
@@ -686,7 +707,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) prow[j0 + u] = ex[u];
-            }
+            };
+            ATTN_CHUNKS(j0, chunk2, SATRANS_UB2);
             const float inv = 1.0f / sum;
             st_inv[task] = inv;
             st_keep[task] = keep;
@@ -757,7 +779,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
             float dot = 0.f;
-            for (int j0 = 0; j0 < F; j0 += 4) {
+            auto chunk3 = [&](const int j0) {
                 f32x2 vr[4][d / 2];
                 float pj[4], dp[4];
 #pragma unroll
@@ -777,11 +799,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) drow[j0 + u] = dp[u];
-            }
+            };
+            ATTN_CHUNKS(j0, chunk3, SATRANS_UD1);
             f32x2 dq[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) dq[e] = f32x2{0.f, 0.f};
-            for (int j0 = 0; j0 < F; j0 += 4) {
+            auto chunk4 = [&](const int j0) {
                 f32x2 kr[4][d / 2];
                 float pj[4], ds[4];
 #pragma unroll
@@ -802,7 +825,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) { drow[j0 + u] = ds[u]; prow[j0 + u] = pj[u]; }
-            }
+            };
+            ATTN_CHUNKS(j0, chunk4, SATRANS_UD2);
             store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
         }
         __syncthreads();
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* gbase = so + (size_t)(tls * F) * LD + h * d;
             const float* dcol = sDS + (size_t)((tls * H + h) * F) * F + j;
             const float* pcol = sP + (size_t)((tls * H + h) * F) * F + j;
-            for (int i0 = 0; i0 < F; i0 += 4) {
+            auto chunk5 = [&](const int i0) {
                 f32x2 qr[4][d / 2], gr[4][d / 2];
                 float ds[4], pm[4];
 #pragma unroll
@@ -841,7 +865,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     axpy_row<d>(real ? ds[u] : 0.f, qr[u], dk);
                     axpy_row<d>(real ? pm[u] : 0.f, gr[u], dv);
                 }
-            }
+            };
+            ATTN_CHUNKS(i0, chunk5, SATRANS_UE);
             store_row<d>(sk + (size_t)(tls * F + j) * LD + h * d, dk, 1.0f);
             store_row<d>(sv + (size_t)(tls * F + j) * LD + h * d, dv, 1.0f);
         }
@@ -1207,17 +1232,17 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     return true;
 }
 
-template <int D, int U, int H, bool SAME, bool TR>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
                       hipStream_t stream) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME, TR><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1288,7 +1313,12 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
         rc = satrans_layer_bwd8_launch(d, dy, dx, slabs, &p.T, &p.G, stream_);
     } else {
     SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");
-    if (d->D == 32) rc = same ? (p.tr ? launch_bwd<32, 64, 4, true, true>(d, p, dy, dx, slabs, stream)
+    static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
+    // the AliCCP field count as a compile-time constant: -11 % (0.868 -> 0.777 ms over three layers).  The same for the 16
+    // fields of the Alimama `sota-pos` shape (separate Q / K tables) spills 34 VGPRs and gains nothing: not instantiated.
+    if (d->D == 32 && same && !p.tr && d->F == 19 && f_const)
+        rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
+    else if (d->D == 32) rc = same ? (p.tr ? launch_bwd<32, 64, 4, true, true>(d, p, dy, dx, slabs, stream)
                                       : launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream))
                               : launch_bwd<32, 64, 4, false, false>(d, p, dy, dx, slabs, stream);
     else rc = same ? launch_bwd<16, 32, 2, true, false>(d, p, dy, dx, slabs, stream)
