@@ -176,8 +176,9 @@ int satrans_layer_fwd_bf16(const satrans_layer_desc* d, float* y, void* stream);
  * attention launches over token rows kept in HBM in scenario-sorted order.  The forward SAVES its activations in `saved`
  * (satrans_layer_generic_saved_floats floats, one buffer per layer between forward and backward); the backward reads them and
  * uses `scratch` (satrans_layer_generic_scratch_floats floats, shared by all layers).  Arguments otherwise as
- * satrans_layer_fwd / satrans_layer_bwd (gradients ACCUMULATED in a fixed order; x_rows honoured).  Supported: no gate /
- * bilinear, D in {16,32,64,128}, head dimension 8 or 16, U a multiple of 16 with D*U <= 8192.
+ * satrans_layer_fwd / satrans_layer_bwd (gradients ACCUMULATED in a fixed order; x_rows honoured).  Supported: D in
+ * {16,32,64,128}, head dimension 8 or 16, U a multiple of 16 with D*U <= 8192; SATRANS_GATE or SATRANS_BILINEAR (not both):
+ * the generated row is applied to q0 / k0 by an elementwise / per-head kernel, its gradient taken from the segment's z^T g.
  * satrans_set_generic_attention: attention arm of the forward - 0 automatic, 1 one lane per query row ("wavefront"),
  * 2 MFMA (F <= 64, head dimension 16), -1 back to SATRANS_GENERIC_ATTN / automatic. */
 int satrans_layer_generic_supported(const satrans_layer_desc* d);

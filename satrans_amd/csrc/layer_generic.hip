@@ -271,6 +271,55 @@ __global__ void gen_permute_out_kernel(satrans_layer_desc a, const float* __rest
     *reinterpret_cast<float4*>(dst + ((size_t)a.order[p] * a.F + f) * a.D + c) = *reinterpret_cast<const float4*>(src + m * a.D + c);
 }
 
+// ---- flags `gate` and `bilinear` (satrans.py:61-64,68-69,79-81): the scenario's generated row modulates q0 / k0 directly ----------
+// gate:     out[t][c] = z[t][c] * vec_s[c] * 2            (vec = the row, length D)
+// bilinear: out[t][h d + e2] = sum_e z[t][h d + e] M_s[h][e][e2]   (M = the row viewed as [H][d][d]; queries only)
+// TRANSPOSE = the backward of the same map with respect to z (gate: identical; bilinear: M^T).  Rows are scenario-sorted: the
+// scenario of token row t is the segment that holds sample position t / F (S is small: linear scan).
+template <bool BILINEAR, bool TRANSPOSE>
+__global__ void gen_modulate_kernel(const float* __restrict__ z, const float* __restrict__ tab, int64_t tab_stride,
+                                    const int32_t* __restrict__ seg, int S, int F, int D, int dh, float* __restrict__ out, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const int64_t t = i / D;
+    const int c = (int)(i - t * D);
+    const int pos = (int)(t / F);
+    int s = 0;
+    while (s + 1 < S && seg[s + 1] <= pos) ++s;
+    const float* row = tab + (size_t)s * tab_stride;
+    if (!BILINEAR) {
+        out[i] = z[i] * row[c] * 2.0f;
+    } else {
+        const int h = c / dh, e_ = c - h * dh;
+        const float* zr = z + t * D + h * dh;
+        float acc = 0.f;
+        for (int e = 0; e < dh; ++e)
+            acc = fmaf(zr[e], TRANSPOSE ? row[(h * dh + e_) * dh + e] : row[(h * dh + e) * dh + e_], acc);
+        out[i] = acc;
+    }
+}
+
+// gradient of the generated rows from full[s][D][D] = z^T g of the segment (a weight-gradient product): gate takes twice the
+// diagonal, bilinear the H diagonal d x d blocks
+template <bool BILINEAR>
+__global__ void gen_modulate_extract_kernel(const float* __restrict__ full, int S, int D, int dh, float* __restrict__ g_tab,
+                                            int64_t tab_stride) {
+    const int len = BILINEAR ? D * dh : D;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * len) return;
+    const int s = i / len, e_ = i - s * len;
+    const float* f = full + (size_t)s * D * D;
+    float v;
+    if (!BILINEAR) {
+        v = 2.0f * f[e_ * D + e_];
+    } else {
+        const int h = e_ / (dh * dh), rem = e_ - h * dh * dh;
+        const int e = rem / dh, e2 = rem - e * dh;
+        v = f[(h * dh + e) * D + h * dh + e2];
+    }
+    g_tab[(size_t)s * tab_stride + e_] += v;
+}
+
 struct GenDrop {
     bool on;
     float scale;
@@ -847,7 +896,7 @@ struct GenLayout {          // offsets in floats; nd = B F D, nu = B F U
     // saved by the forward, read by the backward
     int64_t xs, q0, k0, v, hq, hk, mq, mk, tq, tk, q, k, o, u, to, st, saved_total;
     // scratch
-    int64_t dr, du, go, dq, dk, dv, dt, dm, dh, part, part_floats, ln_part, ln_blocks, scratch_total;
+    int64_t dr, du, go, dq, dk, dv, dt, dm, dh, part, part_floats, ln_part, ln_blocks, modfull, scratch_total;
 };
 
 static int gen_attn_mode() {      // 0 = automatic (MFMA forward where it is built), 1 = wavefront, 2 = MFMA
@@ -877,17 +926,18 @@ static GenLayout gen_layout(const satrans_layer_desc* d) {
     L.part = take(L.part_floats);
     L.ln_blocks = std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
     L.ln_part = take(L.ln_blocks * 2 * d->D);
+    L.modfull = take((d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) ? (int64_t)d->S * d->D * d->D : 0);   // gate / bilinear: z^T g per scenario
     L.scratch_total = o;
     return L;
 }
 
 static bool gen_supported(const satrans_layer_desc* d) {
-    if (!d || (d->flags & (SATRANS_GATE | SATRANS_BILINEAR))) return false;
+    if (!d || ((d->flags & SATRANS_GATE) && (d->flags & SATRANS_BILINEAR))) return false;
     const int D = d->D, H = d->H;
     if (!(D == 16 || D == 32 || D == 64 || D == 128) || D % H) return false;
     const int dd = D / H;
     if (dd != 8 && dd != 16) return false;
-    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
+    const bool meta = (d->flags & (SATRANS_META_Q | SATRANS_META_K)) && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR));
     if (meta && (d->U % 16 || d->U > 128 || (int64_t)D * d->U > 8192)) return false;
     if (D > 128 || d->F > 256) return false;
     if ((int64_t)4 * d->F * (D + 4) * 4 + (int64_t)H * d->F * 16 > 150 * 1024) return false;   // attention backward LDS
@@ -1123,6 +1173,24 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
     };
     const float* q = q0;
     const float* k = k0;
+    const bool gate = d->flags & SATRANS_GATE, bil = d->flags & SATRANS_BILINEAR;
+    const unsigned mod_blocks = (unsigned)ceil_div((int64_t)M * D, 256);
+    if (gate || bil) {      // satrans.py:61-64,68-69,79-81: the generated row applied directly (bilinear: queries only)
+        if (bil) {
+            gen_modulate_kernel<true, false><<<mod_blocks, 256, 0, st>>>(q0, d->tab_q, d->tab_stride, d->seg, S, F, D, D / H, saved + L.q, M);
+            q = saved + L.q;
+        } else {
+            if (meta_q) {
+                gen_modulate_kernel<false, false><<<mod_blocks, 256, 0, st>>>(q0, d->tab_q, d->tab_stride, d->seg, S, F, D, D / H, saved + L.q, M);
+                q = saved + L.q;
+            }
+            if (meta_k) {
+                gen_modulate_kernel<false, false><<<mod_blocks, 256, 0, st>>>(k0, d->tab_k, d->tab_stride, d->seg, S, F, D, D / H, saved + L.k, M);
+                k = saved + L.k;
+            }
+        }
+        SATRANS_CHECK_LAUNCH("gen_modulate_kernel");
+    } else {
     if (meta_q) {
         if ((rc = metanet(q0, saved + L.hq, saved + L.mq, saved + L.tq, saved + L.q, d->tab_q, d->lnq_g, d->lnq_b, kSiteMetaQ))) return rc;
         q = saved + L.q;
@@ -1130,6 +1198,7 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
     if (meta_k) {
         if ((rc = metanet(k0, saved + L.hk, saved + L.mk, saved + L.tk, saved + L.k, d->tab_k, d->lnk_g, d->lnk_b, kSiteMetaK))) return rc;
         k = saved + L.k;
+    }
     }
     if ((rc = gen_attention_fwd(st, d, q, k, v, saved + L.o, reinterpret_cast<float2*>(saved + L.st), att,   // satrans.py:75-90
                                 1.0f / sqrtf((float)(D / H))))) return rc;
@@ -1155,8 +1224,10 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     const bool meta_q = d->flags & SATRANS_META_Q, meta_k = d->flags & SATRANS_META_K;
     const bool relu = d->flags & SATRANS_RELU_OUT, use_res = !(d->flags & SATRANS_NO_RES);
     const float *xs = saved + L.xs, *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
-    const float* q = meta_q ? saved + L.q : q0;
-    const float* k = meta_k ? saved + L.k : k0;
+    const bool gate = d->flags & SATRANS_GATE, bil = d->flags & SATRANS_BILINEAR;
+    const bool q_mod = bil || meta_q, k_mod = !bil && meta_k;
+    const float* q = q_mod ? saved + L.q : q0;
+    const float* k = k_mod ? saved + L.k : k0;
     float *dr = scratch + L.dr, *du = scratch + L.du, *go = scratch + L.go, *dq = scratch + L.dq, *dk = scratch + L.dk,
           *dv = scratch + L.dv, *dt = scratch + L.dt, *dm = scratch + L.dm, *dh = scratch + L.dh, *part = scratch + L.part;
     int rc;
@@ -1196,8 +1267,35 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): copy: %s", hipGetErrorString(e));
         return SATRANS_OK;
     };
+    // ---- gate / bilinear backward of one role: d row from the segment's z0^T g (diagonal / diagonal blocks), g <- gradient of z0 -----
+    auto modulate_bwd = [&](float* g, const float* z0, const float* tab, float* g_tab) -> int {
+        SATRANS_REQUIRE(g_tab, SATRANS_E_BADARG, "layer_bwd(generic): null gradient of the generated rows");
+        float* full = scratch + L.modfull;
+        hipError_t e = hipMemsetAsync(full, 0, sizeof(float) * (size_t)S * D * D, st);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): memset: %s", hipGetErrorString(e));
+        int r = gen_gemm_tn(st, z0, g, d->seg, S, M, F, D, D, part, full, (int64_t)D * D);
+        if (r) return r;
+        const int len = bil ? D * (D / H) : D;
+        const unsigned eb = (unsigned)ceil_div((int64_t)S * len, 256), mb = (unsigned)ceil_div((int64_t)M * D, 256);
+        if (bil) {
+            gen_modulate_extract_kernel<true><<<eb, 256, 0, st>>>(full, S, D, D / H, g_tab, d->tab_stride);
+            gen_modulate_kernel<true, true><<<mb, 256, 0, st>>>(g, tab, d->tab_stride, d->seg, S, F, D, D / H, dt, M);
+        } else {
+            gen_modulate_extract_kernel<false><<<eb, 256, 0, st>>>(full, S, D, D / H, g_tab, d->tab_stride);
+            gen_modulate_kernel<false, true><<<mb, 256, 0, st>>>(g, tab, d->tab_stride, d->seg, S, F, D, D / H, dt, M);
+        }
+        SATRANS_CHECK_LAUNCH("gen_modulate_kernel(backward)");
+        e = hipMemcpyAsync(g, dt, sizeof(float) * (size_t)L.nd, hipMemcpyDeviceToDevice, st);
+        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): copy: %s", hipGetErrorString(e));
+        return SATRANS_OK;
+    };
+    if (gate || bil) {
+        if (q_mod && (rc = modulate_bwd(dq, q0, d->tab_q, g_tab_q))) return rc;
+        if (k_mod && (rc = modulate_bwd(dk, k0, d->tab_k, g_tab_k))) return rc;
+    } else {
     if (meta_q && (rc = metanet_bwd(dq, q0, saved + L.hq, saved + L.tq, d->tab_q, d->lnq_g, g_lnq, g_tab_q, kSiteMetaQ))) return rc;
     if (meta_k && (rc = metanet_bwd(dk, k0, saved + L.hk, saved + L.tk, d->tab_k, d->lnk_g, g_lnk, g_tab_k, kSiteMetaK))) return rc;
+    }
     // ---- projections: dW{q,k,v}[i][o] += x^T g ;  dx = dr + gq Wq^T + gk Wk^T + gv Wv^T ---------------------------------------------
     if ((rc = gen_gemm_tn(st, xs, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
     if ((rc = gen_gemm_tn(st, xs, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;

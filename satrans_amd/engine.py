@@ -218,7 +218,10 @@ class PathEngine:
         fits = int(self.lib.satrans_layer_bwd_slab_floats(C.byref(probe))) >= 0
         can = bool(self.lib.satrans_layer_generic_supported(C.byref(probe)))
         import os
-        ws["generic"] = can and (os.environ.get("SATRANS_GENERIC", "0") == "1" or not fits)
+        # `gate` / `bilinear` have no fused kernels: the general path (HBM-rate products) instead of the LDS kernels, whose
+        # backward is an order of magnitude slower (SATRANS_GENERIC=0 keeps the LDS kernels, for the comparison)
+        choice = os.environ.get("SATRANS_GENERIC")
+        ws["generic"] = can and (choice == "1" or not fits or (choice is None and (self.gate or self.bilinear)))
         if ws["generic"]:
             n = int(self.lib.satrans_layer_generic_saved_floats(C.byref(probe)))
             ws["gen_saved"] = [torch.empty(n, **f32)]

@@ -669,7 +669,7 @@ def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
 
 
 @pytest.mark.parametrize("name", ["small_d64_u128", "aliccp_sota", "alimama_sota_pos", "small_qkv", "small_k", "small_none",
-                                  "small_pos_dense", "small_relu", "small_multidomain"])
+                                  "small_pos_dense", "small_relu", "small_multidomain", "small_gate", "small_bilinear"])
 def test_general_layer_path_matches_golden_and_the_oracle(monkeypatch, name):
     """csrc/layer_generic.hip (grouped f32-MFMA GEMMs + LayerNorm + attention launches over token rows in HBM; the path of
     BASELINE configs[4]-class shapes), forced also on shapes the fused kernels cover: forward and every gradient against
@@ -712,6 +712,30 @@ def test_general_layer_path_matches_golden_and_the_oracle(monkeypatch, name):
                 scale = max(1e-6, float(g.abs().max()))
                 np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9,
                                            err_msg=f"{k} B={B} train={train}")
+
+
+@pytest.mark.parametrize("name", ["small_gate", "small_bilinear"])
+def test_gate_and_bilinear_on_the_lds_kernels(monkeypatch, name):
+    """`gate` / `bilinear` run on the general path by default; the LDS-resident kernels (csrc/layer_lds.hip) still serve them
+    with SATRANS_GENERIC=0 and must keep matching the reference's golden outputs and gradients."""
+    monkeypatch.setenv("SATRANS_GENERIC", "0")
+    c = Case(name)
+    model = build_model(c, DEV)
+    model.compile("adam", "binary_crossentropy")
+    model.eval()
+    model(c.X.to(DEV))
+    eng = model._engine
+    assert not eng._ws[c.X.shape[0]]["generic"]
+    want = c.arrays("out")
+    acts = eng.layer_outputs(c.X.shape[0])
+    for l in range(c.meta["L"]):
+        np.testing.assert_allclose(acts[l + 1].cpu().numpy(), want[f"layer{l}"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(eng.last_logit().cpu().numpy(), want["logit"], rtol=0, atol=LOGIT_ATOL)
+    bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+    assert bce == pytest.approx(float(c.z["train/bce"]), rel=2e-6)
+    for k, g in c.arrays("grad").items():
+        scale = max(1e-6, float(np.abs(g).max()))
+        np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
 
 
 def test_general_path_attention_arms_agree():
