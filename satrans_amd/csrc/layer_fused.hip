@@ -66,14 +66,17 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     const float* w2k_l = W.w2k + g4 * LD + wl;
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);   // scores * (1/sqrt d): within 1 ulp of the reference's true division
-    const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
+    // Work split by SAMPLES, not by tiles: workgroup w owns the sorted sample positions [B w / G, B (w+1) / G) and walks its share
+    // of a scenario in tiles of Tsamp samples plus a remainder.  The token phases are bound by the MFMA pipe that the waves of
+    // a SIMD share, so an iteration costs what its busiest SIMD holds: 8192 samples in tiles of ten are 3.2 tiles per
+    // workgroup, i.e. four full iterations for a fifth of the chip while the rest idles; 10 + 10 + 10 + 2 samples everywhere
+    // is three full iterations and one with a single wave per SIMD.
+    const int p0 = (int)((int64_t)a.B * blockIdx.x / gridDim.x), p1 = (int)((int64_t)a.B * (blockIdx.x + 1) / gridDim.x);
 
-    int pre = 0;
-    for (int scen = 0; scen < a.S && pre < wr.g1; ++scen) {
-      const int nt_s = tiles_of(a.seg, scen, Tsamp);
-      const int t0 = max(wr.g0, pre) - pre, t1 = min(wr.g1, pre + nt_s) - pre;
-      pre += nt_s;
-      if (t0 >= t1) continue;
+    STAMP_DECL          // (SATRANS_STAMPS builds: slots 9-12 = staging / phase 1 / phase 2 / phase 3 of this kernel)
+    for (int scen = 0; scen < a.S; ++scen) {
+      const int lo = max(a.seg[scen], p0), hi = min(a.seg[scen + 1], p1);
+      if (lo >= hi) continue;
       // ---- this scenario's generated MetaNet weights (the previous tile loop ended on a barrier) ------------------
       if (meta_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
@@ -86,12 +89,11 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
           stage_image(row + D * U, W.w2k, U, D, LD, false);
       }
       __syncthreads();
-      const int lo = a.seg[scen], hi = a.seg[scen + 1];
-      for (int tile = t0; tile < t1; ++tile) {
-        const int first = lo + tile * Tsamp;
+      for (int first = lo; first < hi; first += Tsamp) {
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
 
+        STAMP(9);
         // ---- phase 1: projections + MetaNet per 16-token tile, all in registers --------------------------
         for (int tt = wave; tt < ntt; tt += WAVES) {
             const int tok = 16 * tt + n;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
         }
         __syncthreads();
 
+        STAMP(10);
         // ---- phase 2: attention, one lane per (sample, head, query row)  (satrans.py:75-90) -------------------
         if (F <= 4 * kRowChunks) {
           // One pass over the keys: the score row stays in registers (chunks of four keys, guarded by the uniform F),
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
         }
         __syncthreads();
 
+        STAMP(11);
         // ---- phase 3: Out_linear, dropout, residual, LayerNorm per 16-token tile (satrans.py:91-99) ------------
         for (int tt = wave; tt < ntt; tt += WAVES) {
             const int tok = 16 * tt + n;
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             }
         }
         __syncthreads();
+        STAMP(12);
       }
     }
 }
@@ -1181,7 +1186,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
     }
-    const int64_t tiles = ceil_div(d->B, best) + d->S;                 // upper bound of the tile list
+    const int64_t tiles = ceil_div(d->B, best);                        // (the kernel splits the batch by samples)
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
     layer_fwd_fused_kernel<D, U, H, WAVES><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);

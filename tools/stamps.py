@@ -60,3 +60,9 @@ tot = sum(vals)
 # slot k holds the time BEFORE stamp k: 0 = scenario staging/loop top, 1 = phase A, ... 6 = phase F, 7 = record flush, 8 = prologue
 for n, v in zip(names, vals):
     print(f"{n:26s} {v / tot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
+# the forward kernel's slots (three launches per step, two steps)
+fnames = ["fwd staging / loop top", "fwd 1 projections + MetaNet", "fwd 2 attention", "fwd 3 out block"]
+fvals = [buf[i] for i in range(9, 13)]
+ftot = sum(fvals) or 1
+for n, v in zip(fnames, fvals):
+    print(f"{n:26s} {v / ftot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
