@@ -28,7 +28,8 @@ struct GemmBatch {      // blockIdx.z selects one of up to three products that s
 
 // C[m][n] (op)= sum_k A[m][k] B(k, n) over the rows of one segment.  Segment s = rows [seg[s] F, seg[s+1] F) and takes
 // B + s * b_seg_stride (seg == nullptr: one segment of M rows).  TRANSB: B(k, n) = B[n * ldb + k], else B[k * ldb + n].
-// EPI: 0 store, 1 relu then store, 2 C += acc, 3 store where mask[m][n] > 0 else 0 (relu backward).
+// EPI: 0 store, 1 relu then store, 2 C += acc (C = mask + acc when a mask pointer is given), 3 store where mask[m][n] > 0
+// else 0 (relu backward).
 // K, N multiples of 16, <= 128; A and C are dense token-row buffers (lda = K, ldc = N).
 //
 // HBM-bound by shape (K <= 128: ~40 MAC per float moved), so the kernel is built around the row traffic: no LDS for the token
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32
                 float4* dst = reinterpret_cast<float4*>(C + row * N + 16 * jn + 4 * g);
                 float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
                 if (EPI == 1) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                if (EPI == 2) {
-                    const float4 o = *dst;
+                if (EPI == 2) {      // the addend is C itself, or `mask` when given (C = mask + acc: saves a copy of the rows)
+                    const float4 o = mask ? *reinterpret_cast<const float4*>(mask + row * N + 16 * jn + 4 * g) : *dst;
                     v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
                 }
                 if (EPI == 3) {
@@ -1261,11 +1262,8 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
         if ((r = gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride))) return r;
         const float* A2[1] = {dh};
         const float* B2[1] = {tab};
-        float* C2[1] = {dt};
-        if ((r = gen_gemm<true, 2>(st, 1, A2, B2, C2, d->seg, S, M, F, U, D, U, d->tab_stride))) return r;
-        hipError_t e = hipMemcpyAsync(g, dt, sizeof(float) * (size_t)L.nd, hipMemcpyDeviceToDevice, st);
-        SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(generic): copy: %s", hipGetErrorString(e));
-        return SATRANS_OK;
+        float* C2[1] = {g};                  // g <- dt + dh W1^T
+        return gen_gemm<true, 2>(st, 1, A2, B2, C2, d->seg, S, M, F, U, D, U, d->tab_stride, dt);
     };
     // ---- gate / bilinear backward of one role: d row from the segment's z0^T g (diagonal / diagonal blocks), g <- gradient of z0 -----
     auto modulate_bwd = [&](float* g, const float* z0, const float* tab, float* g_tab) -> int {
