@@ -122,6 +122,82 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32
     }
 }
 
+// C[m][n] = (addend ? addend[m][n] : 0) + sum over the NSRC sources i of sum_k A_i[m][k] W_i[n][k]   (gradient of the rows through
+// NSRC projections that read the same input: dx = dr + gq Wq^T + gk Wk^T + gv Wv^T in ONE pass - the sources are read once,
+// the sum is written once, where three accumulating products read and write the sum three times).  Same operand scheme as
+// gen_gemm_kernel (transposed product, 16-byte loads and stores, B^T planes in LDS, next row group's loads in flight); K = N = D.
+template <int KJ, int NSRC>
+__global__ __launch_bounds__(256) void gen_gemm_sum_kernel(GemmBatch gb, int nsrc_unused, int M, const float* __restrict__ addend,
+                                                         float* __restrict__ C) {
+    extern __shared__ __align__(16) float g2_lds[];
+    constexpr int K = KJ * 16, N = K;
+    const int64_t row0 = (int64_t)blockIdx.x * kG2Rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int RS = g2_row_slots(K) * 4, PL = g2_plane_floats(K, N);
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        const float* __restrict__ B = gb.B[i];
+        float* img = g2_lds + (size_t)i * 4 * PL;
+        for (int e = tid; e < K * N; e += 256) {           // B(k, nn) = W[nn][k]
+            const int nn = e / K, k = e - nn * K;
+            img[((k >> 2) & 3) * PL + nn * RS + 4 * (k >> 4) + (k & 3)] = B[(size_t)nn * K + k];
+        }
+    }
+    __syncthreads();
+    float4 a[NSRC][KJ], an[NSRC][KJ];
+    auto load_rows = [&](int64_t g0, float4 (&dst)[NSRC][KJ]) {
+        const int64_t row = g0 + n;
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) {
+            if (row < M) {
+                const float4* src = reinterpret_cast<const float4*>(gb.A[i] + row * K + 4 * g);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) dst[i][j] = src[4 * j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) dst[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    const int64_t wave_row0 = row0 + 16 * wave;
+    const int64_t tile_hi = min((int64_t)M, row0 + kG2Rows);
+    if (wave_row0 < tile_hi) load_rows(wave_row0, a);
+    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 64) {
+        const bool more = g0 + 64 < tile_hi;
+        if (more) load_rows(g0 + 64, an);
+        const int64_t row = g0 + n;
+        for (int jn = 0; jn < KJ; ++jn) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) {
+                const float* bp = g2_lds + (size_t)i * 4 * PL + g * PL + (16 * jn + n) * RS;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const float4 b = *reinterpret_cast<const float4*>(bp + 4 * j);
+                    acc = mfma4(b.x, a[i][j].x, acc);
+                    acc = mfma4(b.y, a[i][j].y, acc);
+                    acc = mfma4(b.z, a[i][j].z, acc);
+                    acc = mfma4(b.w, a[i][j].w, acc);
+                }
+            }
+            if (row < M) {
+                float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (addend) {
+                    const float4 o = *reinterpret_cast<const float4*>(addend + row * N + 16 * jn + 4 * g);
+                    v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+                }
+                *reinterpret_cast<float4*>(C + row * N + 16 * jn + 4 * g) = v;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i)
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) a[i][j] = an[i][j];
+        }
+    }
+}
+
 // partial[(s * chunks + c)][k][n] = sum over the token rows of chunk c of segment s of A[m][k] G[m][n]   (K, N multiples of 16,
 // KA = ceil(K / 64) and NA = ceil(N / 64) 64-column blocks, KA * NA <= 2).  Chunks beyond a segment's rows write nothing.
 //
@@ -1008,6 +1084,37 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
     return SATRANS_OK;
 }
 
+// C = (addend) + sum_i A_i W_i^T for nsrc = 3 or 4 sources with square [D, D] weights (see gen_gemm_sum_kernel)
+static int gen_gemm_sum(hipStream_t st, int nsrc, const float* const* A, const float* const* W, int M, int D, const float* addend,
+                        float* C) {
+    SATRANS_REQUIRE((nsrc == 3 || nsrc == 4) && (D == 16 || D == 32 || D == 64), SATRANS_E_UNSUPPORTED,
+                    "general-path summed product: %d sources, D = %d", nsrc, D);
+    GemmBatch gb;
+    for (int i = 0; i < 3; ++i) { gb.A[i] = A[i]; gb.B[i] = W[i]; gb.C[i] = C; }
+    const dim3 grid((unsigned)ceil_div(M, kG2Rows));
+    const size_t lds = sizeof(float) * 3 * 4 * (size_t)g2_plane_floats(D, D);
+#define GEN_SUM_CASE(KJ_)                                                                                                      \
+    case KJ_: {                                                                                                               \
+        static bool attr_set = false;                                                                                         \
+        if (!attr_set) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)gen_gemm_sum_kernel<KJ_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      160 * 1024);                                                                            \
+            attr_set = true;                                                                                                  \
+        }                                                                                                                     \
+        gen_gemm_sum_kernel<KJ_, 3><<<grid, 256, lds, st>>>(gb, 3, M, addend, C);                                              \
+    } break;
+    switch (D >> 4) { GEN_SUM_CASE(1) GEN_SUM_CASE(2) GEN_SUM_CASE(4) }
+#undef GEN_SUM_CASE
+    SATRANS_CHECK_LAUNCH("gen_gemm_sum_kernel");
+    if (nsrc == 4) {        // the fourth source (SelfAttention_Layer's residual projection) as one accumulating product
+        const float* A4[1] = {A[3]};
+        const float* B4[1] = {W[3]};
+        float* C4[1] = {C};
+        return gen_gemm<true, 2>(st, 1, A4, B4, C4, nullptr, 1, M, 1, D, D, D, 0);
+    }
+    return SATRANS_OK;
+}
+
 #define GEN_LN_DISPATCH(D, CALL)                                   \
     switch ((D) / 4) {                                             \
         case 4: { constexpr int LPT = 4; CALL; } break;            \
@@ -1301,11 +1408,15 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     {
         const float* grads[3] = {dq, dk, dv};
         const float* ws[3] = {d->w_query, d->w_key, d->w_value};
-        for (int i = 0; i < 3; ++i) {
-            const float* A[1] = {grads[i]};
-            const float* Bw[1] = {ws[i]};
-            float* C[1] = {dr};
-            if ((rc = gen_gemm<true, 2>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+        if (D <= 64) {
+            if ((rc = gen_gemm_sum(st, 3, grads, ws, M, D, dr, dr))) return rc;
+        } else {
+            for (int i = 0; i < 3; ++i) {
+                const float* A[1] = {grads[i]};
+                const float* Bw[1] = {ws[i]};
+                float* C[1] = {dr};
+                if ((rc = gen_gemm<true, 2>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+            }
         }
     }
     gen_permute_out_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, dr, dx);
@@ -1438,6 +1549,7 @@ extern "C" int satrans_selfatt_bwd(const satrans_selfatt_desc* d, const float* d
     // dx = dq Wq^T + dk Wk^T + dv Wv^T (+ dt Wres^T)
     const float* grads[4] = {dq, dk, dv, dt};
     const float* ws[4] = {d->w_query, d->w_key, d->w_value, d->w_res};
+    if (D <= 64) return gen_gemm_sum(st, use_res ? 4 : 3, grads, ws, M, D, nullptr, dx);
     for (int i = 0; i < (use_res ? 4 : 3); ++i) {
         const float* A[1] = {grads[i]};
         const float* Bw[1] = {ws[i]};
