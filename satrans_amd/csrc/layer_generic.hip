@@ -207,11 +207,14 @@ __global__ __launch_bounds__(256) void gen_gemm_sum_kernel(GemmBatch gb, int nsr
 // columns.  16 KA NA MFMAs per two or three 16-byte loads, no LDS on the operand path, the next step's loads issued before
 // the current step's MFMAs.  The four waves of a workgroup own a quarter of the chunk's rows each and add their tiles into
 // one LDS image in wave order (fixed order => bitwise reproducible), which is written out coalesced.
-template <int KA, int NA>
-__global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ G,
+// FAN: the NA column blocks are NA separate gradient tensors G, G1, G2 of width N <= 64 that share A (dWq, dWk, dWv = x^T gq, x^T gk,
+// x^T gv: x is read once); the partial of a chunk is then [NA][K][N].
+template <int KA, int NA, bool FAN = false>
+__global__ __launch_bounds__(256, KA * NA >= 3 ? 1 : 2) void gen_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ G,
                                                         const int32_t* __restrict__ seg, int M, int F, int K, int N, int lda,
-                                                        float* __restrict__ partial) {
-    extern __shared__ __align__(16) float tn_lds[];      // [K][N]
+                                                        float* __restrict__ partial, const float* __restrict__ G1 = nullptr,
+                                                        const float* __restrict__ G2 = nullptr) {
+    extern __shared__ __align__(16) float tn_lds[];      // [K][N]  (FAN: [NA][K][N])
     const int s = blockIdx.y, cidx = blockIdx.x, chunks = gridDim.x;
     const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
     const int64_t c_lo = r_lo + (int64_t)cidx * kTnRows, c_hi = min(r_hi, c_lo + kTnRows);
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < KA; ++u) ka_ok[u] = 64 * u + 4 * c < K;
 #pragma unroll
-    for (int u = 0; u < NA; ++u) na_ok[u] = 64 * u + 4 * c < N;
+    for (int u = 0; u < NA; ++u) na_ok[u] = (FAN ? 0 : 64 * u) + 4 * c < N;
+    const float* Gp[3] = {G, G1, G2};
     auto load = [&](int64_t m0, float4 (&av)[KA], float4 (&gv)[NA]) {
         const int64_t m = m0 + g;
         const bool in = m < w_hi;
@@ -237,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __rest
             av[u] = in && ka_ok[u] ? *reinterpret_cast<const float4*>(A + m * lda + 64 * u + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < NA; ++u)
-            gv[u] = in && na_ok[u] ? *reinterpret_cast<const float4*>(G + m * N + 64 * u + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gv[u] = in && na_ok[u] ? *reinterpret_cast<const float4*>((FAN ? Gp[u < 3 ? u : 0] : G) + m * N + (FAN ? 0 : 64 * u) + 4 * c)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     // two steps of loads in flight under the MFMAs of the current one (a step is 16 KA NA MFMAs = 0.2 - 0.4 us, the HBM latency
     // under load is above that)
@@ -276,9 +281,9 @@ __global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __rest
                         const int k = 64 * u + 4 * (4 * g + r) + i;
 #pragma unroll
                         for (int w = 0; w < NA; ++w) {
-                            const int nn = 64 * w + 4 * c;
+                            const int nn = (FAN ? 0 : 64 * w) + 4 * c;
                             if (k < K && nn < N) {
-                                float4* dst = reinterpret_cast<float4*>(tn_lds + k * N + nn);
+                                float4* dst = reinterpret_cast<float4*>(tn_lds + (FAN ? w * K * N : 0) + k * N + nn);
                                 float4 v = make_float4(acc[4 * u + i][4 * w][r], acc[4 * u + i][4 * w + 1][r],
                                                        acc[4 * u + i][4 * w + 2][r], acc[4 * u + i][4 * w + 3][r]);
                                 if (turn > 0) {
@@ -292,8 +297,9 @@ __global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __rest
         }
         __syncthreads();
     }
-    float4* out = reinterpret_cast<float4*>(partial + ((size_t)s * chunks + cidx) * K * N);
-    for (int e = tid; e < (K * N) >> 2; e += 256) out[e] = reinterpret_cast<const float4*>(tn_lds)[e];
+    const int psz = (FAN ? NA : 1) * K * N;
+    float4* out = reinterpret_cast<float4*>(partial + ((size_t)s * chunks + cidx) * psz);
+    for (int e = tid; e < psz >> 2; e += 256) out[e] = reinterpret_cast<const float4*>(tn_lds)[e];
 }
 
 // dst[s * dst_seg_stride + e] += sum_c partial[(s * chunks + c)][e] over the chunks segment s uses; S segments (grid.y).  Blocks of 32 elements x 8 groups:
@@ -301,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void gen_gemm_tn_kernel(const float* __rest
 // order => bitwise reproducible, and 8 x more parallel than one thread per element)
 __global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restrict__ partial, int chunks, int count,
                                                           float* __restrict__ dst, int64_t dst_seg_stride,
-                                                          const int32_t* __restrict__ seg, int F, int chunk_rows) {
+                                                          const int32_t* __restrict__ seg, int F, int chunk_rows,
+                                                          int chunk_stride = 0) {      // floats between chunks (0: count)
     __shared__ float s_part[8][32];
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + lane;
@@ -312,9 +319,10 @@ __global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restr
     const int c0 = grp * share, c1 = min(used, c0 + share);
     float t = 0.f;
     if (e < count) {
-        const float* p = partial + (size_t)s * chunks * count + e;
+        const int stride = chunk_stride ? chunk_stride : count;
+        const float* p = partial + (size_t)s * chunks * stride + e;
 #pragma unroll 4
-        for (int c = c0; c < c1; ++c) t += p[(size_t)c * count];
+        for (int c = c0; c < c1; ++c) t += p[(size_t)c * stride];
     }
     s_part[grp][lane] = t;
     __syncthreads();
@@ -999,7 +1007,9 @@ static GenLayout gen_layout(const satrans_layer_desc* d) {
     L.dr = take(L.nd); L.du = take(L.nd); L.go = take(L.nd); L.dq = take(L.nd); L.dk = take(L.nd); L.dv = take(L.nd);
     L.dt = take(L.nd); L.dm = take(L.nd); L.dh = take(L.nu);
     const int64_t chunks = ceil_div(N, kTnRows) + d->S;
-    L.part_floats = (int64_t)d->S * chunks * std::max<int64_t>((int64_t)d->D * std::max(d->U, d->D), 1);
+    // per chunk: one [K][N] partial of the largest product, or the three [D][D] partials of the fan product (dWq, dWk, dWv)
+    L.part_floats = std::max<int64_t>((int64_t)d->S * chunks * std::max<int64_t>((int64_t)d->D * std::max(d->U, d->D), 1),
+                                      chunks * 3 * (int64_t)d->D * d->D);
     L.part = take(L.part_floats);
     L.ln_blocks = std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
     L.ln_part = take(L.ln_blocks * 2 * d->D);
@@ -1079,6 +1089,21 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
         SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel");
         gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)Kp * N, 32), (unsigned)segs), 256, 0, st>>>(partial, chunks, Kp * N, dp,
                                                                                                           dst_seg_stride, seg, F, kTnRows);
+        SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
+    }
+    return SATRANS_OK;
+}
+
+// dst_i += A^T G_i for three gradient tensors of width N = K = D <= 64 over the same rows A (see gen_gemm_tn_kernel, FAN)
+static int gen_gemm_tn_fan(hipStream_t st, const float* A, const float* const* G, int M, int D, float* partial, float* const* dst) {
+    SATRANS_REQUIRE(D % 16 == 0 && D >= 16 && D <= 64, SATRANS_E_UNSUPPORTED, "general-path fan weight gradient: D = %d", D);
+    const int chunks = (int)ceil_div(M, kTnRows);
+    const size_t lds = sizeof(float) * 3 * (size_t)D * D;
+    gen_gemm_tn_kernel<1, 3, true><<<dim3((unsigned)chunks, 1), 256, lds, st>>>(A, G[0], nullptr, M, 1, D, D, D, partial, G[1], G[2]);
+    SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel(fan)");
+    for (int w = 0; w < 3; ++w) {
+        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)D * D, 32), 1), 256, 0, st>>>(partial + (size_t)w * D * D, chunks, D * D,
+                                                                                             dst[w], 0, nullptr, 1, kTnRows, 3 * D * D);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
     return SATRANS_OK;
@@ -1264,7 +1289,7 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
         const float* A[3] = {xs, xs, xs};
         const float* Bw[3] = {d->w_query, d->w_key, d->w_value};
         float* C[3] = {q0, k0, v};
-        if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+                if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
     }
     auto metanet = [&](const float* z0, float* h, float* m, float* t, float* out, const float* tab, const float* gam,
                        const float* bet, int site) -> int {      // submodules.py:77-103
@@ -1402,9 +1427,15 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     if (meta_k && (rc = metanet_bwd(dk, k0, saved + L.hk, saved + L.tk, d->tab_k, d->lnk_g, g_lnk, g_tab_k, kSiteMetaK))) return rc;
     }
     // ---- projections: dW{q,k,v}[i][o] += x^T g ;  dx = dr + gq Wq^T + gk Wk^T + gv Wv^T ---------------------------------------------
-    if ((rc = gen_gemm_tn(st, xs, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
-    if ((rc = gen_gemm_tn(st, xs, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
-    if ((rc = gen_gemm_tn(st, xs, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+    if (D <= 64) {
+        const float* gs[3] = {dq, dk, dv};
+        float* dsts[3] = {g_wq, g_wk, g_wv};
+        if ((rc = gen_gemm_tn_fan(st, xs, gs, M, D, part, dsts))) return rc;
+    } else {
+        if ((rc = gen_gemm_tn(st, xs, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
+        if ((rc = gen_gemm_tn(st, xs, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
+        if ((rc = gen_gemm_tn(st, xs, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+    }
     {
         const float* grads[3] = {dq, dk, dv};
         const float* ws[3] = {d->w_query, d->w_key, d->w_value};
@@ -1454,7 +1485,7 @@ static SelfAttLayout selfatt_layout(const satrans_selfatt_desc* d) {
     L.saved_total = o;
     o = 0;
     L.dt = take(L.nd); L.dm = take(L.nd); L.dq = take(L.nd); L.dk = take(L.nd); L.dv = take(L.nd);
-    L.part = take((ceil_div(N, kTnRows) + 1) * (int64_t)d->D * d->D);
+    L.part = take((ceil_div(N, kTnRows) + 1) * 3 * (int64_t)d->D * d->D);      // (three [D][D] partials per chunk: gen_gemm_tn_fan)
     L.ln_blocks = (int)std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
     L.ln_part = take((int64_t)L.ln_blocks * 2 * d->D);
     L.scratch_total = o;
@@ -1503,7 +1534,7 @@ extern "C" int satrans_selfatt_fwd(const satrans_selfatt_desc* d, float* y, floa
         const float* A[3] = {d->x, d->x, d->x};
         const float* Bw[3] = {d->w_query, d->w_key, d->w_value};
         float* C[3] = {saved + L.q, saved + L.k, saved + L.v};
-        if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
+                if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
     }
     const float scale = (d->flags & SATRANS_NO_SCALING) ? 1.0f : 1.0f / sqrtf((float)(D / d->H));
     if ((rc = gen_attention_fwd(st, &ld, saved + L.q, saved + L.k, saved + L.v, saved + L.o, reinterpret_cast<float2*>(saved + L.st),
@@ -1542,9 +1573,15 @@ extern "C" int satrans_selfatt_bwd(const satrans_selfatt_desc* d, const float* d
     const float scale = (d->flags & SATRANS_NO_SCALING) ? 1.0f : 1.0f / sqrtf((float)(D / d->H));
     if ((rc = gen_attention_bwd(st, &ld, saved + L.q, saved + L.k, saved + L.v, saved + L.o, dm,
                                 reinterpret_cast<const float2*>(saved + L.st), dq, dk, dv, scale))) return rc;
-    if ((rc = gen_gemm_tn(st, d->x, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
-    if ((rc = gen_gemm_tn(st, d->x, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
-    if ((rc = gen_gemm_tn(st, d->x, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+    if (D <= 64) {
+        const float* gs[3] = {dq, dk, dv};
+        float* dsts[3] = {g_wq, g_wk, g_wv};
+        if ((rc = gen_gemm_tn_fan(st, d->x, gs, M, D, part, dsts))) return rc;
+    } else {
+        if ((rc = gen_gemm_tn(st, d->x, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
+        if ((rc = gen_gemm_tn(st, d->x, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
+        if ((rc = gen_gemm_tn(st, d->x, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+    }
     if (use_res && (rc = gen_gemm_tn(st, d->x, dt, nullptr, 1, M, F, D, D, part, g_wres, 0))) return rc;
     // dx = dq Wq^T + dk Wk^T + dv Wv^T (+ dt Wres^T)
     const float* grads[4] = {dq, dk, dv, dt};
