@@ -411,6 +411,143 @@ struct GenDrop {
     uint32_t thresh, key;
 };
 
+// ---- MetaNet forward in one pass (submodules.py:77-103): h = relu(z W1[s]), m = h W2[s], t = drop(m) + z, y = LayerNorm(t) -----------
+// Operand scheme of gen_gemm_kernel, chained: the accumulator tile of the first product - lane (token, g) holds h[token][16 ju + 4 g
+// .. + 3] - is, as it stands, the second operand of the contraction over u in the second product (the same k permutation
+// 16 j + 4 g + i on both sides), and the tiles of m meet the z fragments the lane loaded at the start (the residual) column for
+// column; a token's row is spread over the four lanes g, so the LayerNorm statistics are two cross-lane adds.  Read z once,
+// write h and t (the backward needs them) and y: 670 MB at the configs[4] shape where the three separate launches move 1.6 GB.
+// W1^T and W2^T planes of the scenario in LDS.  norm == false: y = t (MetaNet(use_norm=False)).
+template <int KJ, int UJ>       // D = 16 KJ, U = 16 UJ
+__global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tab, int64_t tab_stride,
+                                                            const int32_t* __restrict__ seg, int M, int F, float* __restrict__ hbuf,
+                                                            float* __restrict__ tbuf, float* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const int32_t* __restrict__ order, GenDrop dc, bool norm) {
+    extern __shared__ __align__(16) float g2_lds[];
+    constexpr int D = KJ * 16, U = UJ * 16;
+    const int s = blockIdx.y;
+    const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
+    const int64_t row0 = r_lo + (int64_t)blockIdx.x * kG2Rows;
+    if (row0 >= r_hi) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int RS1 = g2_row_slots(D) * 4, PL1 = g2_plane_floats(D, U);      // W1^T: K = D, N = U
+    const int RS2 = g2_row_slots(U) * 4, PL2 = g2_plane_floats(U, D);      // W2^T: K = U, N = D
+    float* img1 = g2_lds;
+    float* img2 = g2_lds + 4 * PL1;
+    const float* __restrict__ W1 = tab + (size_t)s * tab_stride;            // [D][U]
+    const float* __restrict__ W2 = W1 + (size_t)D * U;                      // [U][D]
+    for (int e = tid; e < D * U; e += 256) {
+        const int k = e / U, nn = e - k * U;
+        img1[((k >> 2) & 3) * PL1 + nn * RS1 + 4 * (k >> 4) + (k & 3)] = W1[e];
+    }
+    for (int e = tid; e < U * D; e += 256) {
+        const int k = e / D, nn = e - k * D;
+        img2[((k >> 2) & 3) * PL2 + nn * RS2 + 4 * (k >> 4) + (k & 3)] = W2[e];
+    }
+    __syncthreads();
+    const float* b1 = img1 + g * PL1 + n * RS1;
+    const float* b2 = img2 + g * PL2 + n * RS2;
+    float4 a[KJ], an[KJ];
+    auto load_rows = [&](int64_t g0, float4 (&dst)[KJ]) {
+        const int64_t row = g0 + n;
+        if (row < r_hi) {
+            const float4* src = reinterpret_cast<const float4*>(z + row * D + 4 * g);
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) dst[j] = src[4 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int64_t wave_row0 = row0 + 16 * wave;
+    const int64_t tile_hi = min(r_hi, row0 + kG2Rows);
+    if (wave_row0 < tile_hi) load_rows(wave_row0, a);
+    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 64) {
+        const bool more = g0 + 64 < tile_hi;
+        if (more) load_rows(g0 + 64, an);
+        const int64_t row = g0 + n;
+        const bool live = row < r_hi;
+        float4 h[UJ];
+#pragma unroll
+        for (int ju = 0; ju < UJ; ++ju) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = b1 + 16 * ju * RS1;
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const float4 b = *reinterpret_cast<const float4*>(bp + 4 * j);
+                acc = mfma4(b.x, a[j].x, acc);
+                acc = mfma4(b.y, a[j].y, acc);
+                acc = mfma4(b.z, a[j].z, acc);
+                acc = mfma4(b.w, a[j].w, acc);
+            }
+            h[ju] = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+            if (live && hbuf) *reinterpret_cast<float4*>(hbuf + row * U + 16 * ju + 4 * g) = h[ju];
+            __builtin_amdgcn_sched_barrier(0);      // the fragment reads of later tiles stay behind this tile (registers)
+        }
+        // token (sample position, field) of this lane's row and its dropout key
+        const int64_t rr = live ? row : r_lo;
+        const int pos = (int)(rr / F), f = (int)(rr - (int64_t)pos * F);
+        const uint32_t skey = dc.on ? drop_sample_key(dc.key, (uint32_t)order[pos]) : 0u;
+        float v[KJ][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = b2 + 16 * jn * RS2;
+#pragma unroll
+            for (int ju = 0; ju < UJ; ++ju) {
+                const float4 b = *reinterpret_cast<const float4*>(bp + 4 * ju);
+                acc = mfma4(b.x, h[ju].x, acc);
+                acc = mfma4(b.y, h[ju].y, acc);
+                acc = mfma4(b.z, h[ju].z, acc);
+                acc = mfma4(b.w, h[ju].w, acc);
+            }
+            const int c = 16 * jn + 4 * g;
+            const uint32_t kb = dc.on ? drop_keep4(skey, (uint32_t)(f * D + c) >> 2, dc.thresh) : 0xFu;
+            const float zr[4] = {a[jn].x, a[jn].y, a[jn].z, a[jn].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[e];
+                if (dc.on) x = (kb >> e) & 1u ? x * dc.scale : 0.f;
+                x += zr[e];
+                v[jn][e] = x;
+                sum += x;
+            }
+            if (live && tbuf) *reinterpret_cast<float4*>(tbuf + row * D + c) = make_float4(v[jn][0], v[jn][1], v[jn][2], v[jn][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q = fmaf(v[jn][e] - mean, v[jn][e] - mean, q);
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-6f);
+        if (live) {
+#pragma unroll
+            for (int jn = 0; jn < KJ; ++jn) {
+                const int c = 16 * jn + 4 * g;
+                float4 o = make_float4(v[jn][0], v[jn][1], v[jn][2], v[jn][3]);
+                if (norm) {
+                    const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+                    o = make_float4((o.x - mean) * rstd * gm.x + bt.x, (o.y - mean) * rstd * gm.y + bt.y,
+                                    (o.z - mean) * rstd * gm.z + bt.z, (o.w - mean) * rstd * gm.w + bt.w);
+                }
+                *reinterpret_cast<float4*>(y + row * D + c) = o;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) a[j] = an[j];
+        }
+    }
+}
+
 // t = drop(relu?(a)) + res ; y = LayerNorm(t) * gamma + beta       (submodules.py:96-101, satrans.py:91-99)
 // LPT = D / 4 lanes per token.  y goes to the caller's sample order when `y_orig` is set.
 template <int LPT>
@@ -1140,6 +1277,36 @@ static int gen_gemm_sum(hipStream_t st, int nsrc, const float* const* A, const f
     return SATRANS_OK;
 }
 
+// the fused MetaNet forward where it is built: (D, U) in {(64, 128), (32, 64), (16, 32), (64, 16)}, planes of both weights <= 80 KB
+static bool gen_metanet_fused_ok(int D, int U) {
+    return (D == 64 && U == 128) || (D == 32 && U == 64) || (D == 16 && U == 32) || (D == 64 && U == 16);
+}
+static int gen_metanet_fused_fwd(hipStream_t st, const satrans_layer_desc* d, const float* z0, const float* tab, float* h, float* t,
+                                 float* out, const float* gam, const float* bet, int site, bool norm) {
+    const int M = d->B * d->F, D = d->D, U = d->U;
+    const GenDrop dc = gen_drop(d, site);
+    const dim3 grid((unsigned)ceil_div(M, kG2Rows), (unsigned)(d->seg ? d->S : 1));
+    const size_t lds = sizeof(float) * 4 * ((size_t)g2_plane_floats(D, U) + (size_t)g2_plane_floats(U, D));
+#define GEN_MN_CASE(KJ_, UJ_)                                                                                                   \
+    {                                                                                                                            \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)gen_metanet_fwd_kernel<KJ_, UJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                               \
+            attr_set = true;                                                                                                     \
+        }                                                                                                                        \
+        gen_metanet_fwd_kernel<KJ_, UJ_><<<grid, 256, lds, st>>>(z0, tab, d->tab_stride, d->seg, M, d->F, h, t, out, gam, bet,     \
+                                                               d->order, dc, norm);                                             \
+    }
+    if (D == 64 && U == 128) GEN_MN_CASE(4, 8)
+    else if (D == 32 && U == 64) GEN_MN_CASE(2, 4)
+    else if (D == 16 && U == 32) GEN_MN_CASE(1, 2)
+    else GEN_MN_CASE(4, 1)
+#undef GEN_MN_CASE
+    SATRANS_CHECK_LAUNCH("gen_metanet_fwd_kernel");
+    return SATRANS_OK;
+}
+
 #define GEN_LN_DISPATCH(D, CALL)                                   \
     switch ((D) / 4) {                                             \
         case 4: { constexpr int LPT = 4; CALL; } break;            \
@@ -1291,8 +1458,11 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
         float* C[3] = {q0, k0, v};
                 if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
     }
+    static const bool fuse_metanet = !(getenv("SATRANS_GENERIC_FUSED_METANET") && atoi(getenv("SATRANS_GENERIC_FUSED_METANET")) == 0);
     auto metanet = [&](const float* z0, float* h, float* m, float* t, float* out, const float* tab, const float* gam,
                        const float* bet, int site) -> int {      // submodules.py:77-103
+        if (fuse_metanet && gen_metanet_fused_ok(D, U))          // one pass: h and t saved for the backward, m never materialised
+            return gen_metanet_fused_fwd(st, d, z0, tab, h, t, out, gam, bet, site, true);
         const float* A1[1] = {z0};
         const float* B1[1] = {tab};
         float* C1[1] = {h};

@@ -768,7 +768,7 @@ def test_general_path_attention_arms_agree():
     for train in (False, True):
         for k, g in grads[(1, train)].items():
             scale = max(1e-6, float(g.abs().max()))
-            np.testing.assert_allclose(grads[(2, train)][k].cpu().numpy(), g.cpu().numpy(), rtol=0, atol=5e-5 * scale + 5e-9,
+            np.testing.assert_allclose(grads[(2, train)][k].cpu().numpy(), g.cpu().numpy(), rtol=0, atol=1e-4 * scale + 1e-8,
                                        err_msg=f"{k} train={train}")
 
 
