@@ -548,6 +548,174 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __
     }
 }
 
+// ---- MetaNet backward, the data-gradient chain in one pass: LayerNorm backward -> dm = mask(dt) -> dh = (dm W2^T) [h > 0] ->
+// dz = dt + dh W1^T, with the same chaining as the forward kernel (dm tiles are the second operand of the contraction over D, dh
+// tiles of the contraction over U).  dm and dh are written out because the weight-gradient products (dW2 = h^T dm, dW1 = z^T dh)
+// read them; g is overwritten with dz.  Reads g, t, h once (536 MB at the configs[4] shape), writes dm, dh, dz (536 MB) where the
+// three separate launches move 1.74 GB.  LayerNorm gamma / beta gradient partials per workgroup into `part` ([gridDim.x * S][2 D],
+// every workgroup writes its slot - zeros when it holds no row), summed in a fixed order by gen_tn_reduce_kernel.
+template <int KJ, int UJ>
+__global__ __launch_bounds__(256, 2) void gen_metanet_bwd_kernel(float* __restrict__ g, const float* __restrict__ t,
+                                                               const float* __restrict__ hbuf, const float* __restrict__ tab,
+                                                               int64_t tab_stride, const int32_t* __restrict__ seg, int M, int F,
+                                                               float* __restrict__ dm_out, float* __restrict__ dh_out,
+                                                               const float* __restrict__ gamma, float* __restrict__ part,
+                                                               const int32_t* __restrict__ order, GenDrop dc) {
+    extern __shared__ __align__(16) float g2_lds[];
+    constexpr int D = KJ * 16, U = UJ * 16;
+    const int s = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g_ = lane >> 4;
+    float* my_part = part + ((size_t)s * gridDim.x + blockIdx.x) * 2 * D;
+    const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
+    const int64_t row0 = r_lo + (int64_t)blockIdx.x * kG2Rows;
+    if (row0 >= r_hi) {
+        for (int i = tid; i < 2 * D; i += 256) my_part[i] = 0.f;
+        return;
+    }
+    const int RS2 = g2_row_slots(D) * 4, PL2 = g2_plane_floats(D, U);      // dh = dm W2^T: K = D, N = U, B(k = o, n = u) = W2[u][o]
+    const int RS1 = g2_row_slots(U) * 4, PL1 = g2_plane_floats(U, D);      // dz = dh W1^T: K = U, N = D, B(k = u, n = i) = W1[i][u]
+    float* img2 = g2_lds;
+    float* img1 = g2_lds + 4 * PL2;
+    const float* __restrict__ W1 = tab + (size_t)s * tab_stride;            // [D][U]
+    const float* __restrict__ W2 = W1 + (size_t)D * U;                      // [U][D]
+    for (int e = tid; e < U * D; e += 256) {
+        const int nn = e / D, k = e - nn * D;                               // W2[u = nn][o = k]
+        img2[((k >> 2) & 3) * PL2 + nn * RS2 + 4 * (k >> 4) + (k & 3)] = W2[e];
+    }
+    for (int e = tid; e < D * U; e += 256) {
+        const int nn = e / U, k = e - nn * U;                               // W1[i = nn][u = k]
+        img1[((k >> 2) & 3) * PL1 + nn * RS1 + 4 * (k >> 4) + (k & 3)] = W1[e];
+    }
+    __syncthreads();
+    const float* b2 = img2 + g_ * PL2 + n * RS2;
+    const float* b1 = img1 + g_ * PL1 + n * RS1;
+    float gmv[KJ][4];
+#pragma unroll
+    for (int jn = 0; jn < KJ; ++jn) {
+        const float4 gm4 = *reinterpret_cast<const float4*>(gamma + 16 * jn + 4 * g_);
+        gmv[jn][0] = gm4.x; gmv[jn][1] = gm4.y; gmv[jn][2] = gm4.z; gmv[jn][3] = gm4.w;
+    }
+    float ag[KJ][4], ab[KJ][4];
+#pragma unroll
+    for (int jn = 0; jn < KJ; ++jn)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[jn][e] = 0.f; ab[jn][e] = 0.f; }
+    const int64_t wave_row0 = row0 + 16 * wave;
+    const int64_t tile_hi = min(r_hi, row0 + kG2Rows);
+    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 64) {
+        const int64_t row = g0 + n;
+        const bool live = row < r_hi;
+        const int64_t rr = live ? row : r_lo;
+        float gv[KJ][4], zh[KJ][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn) {
+            const int c = 16 * jn + 4 * g_;
+            const float4 g4 = *reinterpret_cast<const float4*>(g + rr * D + c);
+            const float4 t4 = *reinterpret_cast<const float4*>(t + rr * D + c);
+            gv[jn][0] = live ? g4.x : 0.f; gv[jn][1] = live ? g4.y : 0.f; gv[jn][2] = live ? g4.z : 0.f; gv[jn][3] = live ? g4.w : 0.f;
+            zh[jn][0] = t4.x; zh[jn][1] = t4.y; zh[jn][2] = t4.z; zh[jn][3] = t4.w;
+            sum += (t4.x + t4.y) + (t4.z + t4.w);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q = fmaf(zh[jn][e] - mean, zh[jn][e] - mean, q);
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-6f);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                zh[jn][e] = (zh[jn][e] - mean) * rstd;
+                ag[jn][e] = fmaf(gv[jn][e], zh[jn][e], ag[jn][e]);
+                ab[jn][e] += gv[jn][e];
+                gv[jn][e] *= gmv[jn][e];
+                m1 += gv[jn][e];
+                m2 = fmaf(gv[jn][e], zh[jn][e], m2);
+            }
+        m1 += __shfl_xor(m1, 16, 64); m1 += __shfl_xor(m1, 32, 64);
+        m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
+        m1 *= (1.0f / D);
+        m2 *= (1.0f / D);
+        const int pos = (int)(rr / F), f = (int)(rr - (int64_t)pos * F);
+        const uint32_t skey = dc.on ? drop_sample_key(dc.key, (uint32_t)order[pos]) : 0u;
+        float4 dmt[KJ];                    // dm tiles: second operand of dh = dm W2^T; gv becomes dt
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn) {
+            const int c = 16 * jn + 4 * g_;
+            const uint32_t kb = dc.on ? drop_keep4(skey, (uint32_t)(f * D + c) >> 2, dc.thresh) : 0xFu;
+            float dmv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d_ = rstd * (gv[jn][e] - m1 - zh[jn][e] * m2);
+                gv[jn][e] = d_;
+                dmv[e] = dc.on ? ((kb >> e) & 1u ? d_ * dc.scale : 0.f) : d_;
+            }
+            dmt[jn] = make_float4(dmv[0], dmv[1], dmv[2], dmv[3]);
+            if (live) *reinterpret_cast<float4*>(dm_out + row * D + c) = dmt[jn];
+        }
+        float4 dh[UJ];
+#pragma unroll
+        for (int ju = 0; ju < UJ; ++ju) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = b2 + 16 * ju * RS2;
+#pragma unroll
+            for (int jn = 0; jn < KJ; ++jn) {
+                const float4 b = *reinterpret_cast<const float4*>(bp + 4 * jn);
+                acc = mfma4(b.x, dmt[jn].x, acc);
+                acc = mfma4(b.y, dmt[jn].y, acc);
+                acc = mfma4(b.z, dmt[jn].z, acc);
+                acc = mfma4(b.w, dmt[jn].w, acc);
+            }
+            const float4 hv = *reinterpret_cast<const float4*>(hbuf + rr * U + 16 * ju + 4 * g_);
+            dh[ju] = make_float4(hv.x > 0.f ? acc[0] : 0.f, hv.y > 0.f ? acc[1] : 0.f, hv.z > 0.f ? acc[2] : 0.f, hv.w > 0.f ? acc[3] : 0.f);
+            if (live) *reinterpret_cast<float4*>(dh_out + row * U + 16 * ju + 4 * g_) = dh[ju];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = b1 + 16 * jn * RS1;
+#pragma unroll
+            for (int ju = 0; ju < UJ; ++ju) {
+                const float4 b = *reinterpret_cast<const float4*>(bp + 4 * ju);
+                acc = mfma4(b.x, dh[ju].x, acc);
+                acc = mfma4(b.y, dh[ju].y, acc);
+                acc = mfma4(b.z, dh[ju].z, acc);
+                acc = mfma4(b.w, dh[ju].w, acc);
+            }
+            if (live)
+                *reinterpret_cast<float4*>(g + row * D + 16 * jn + 4 * g_) =
+                    make_float4(acc[0] + gv[jn][0], acc[1] + gv[jn][1], acc[2] + gv[jn][2], acc[3] + gv[jn][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // gamma / beta partials of this workgroup: column c of the 16 token lanes x 4 waves, summed in a fixed order
+    __syncthreads();                                   // (the weight images are dead: the LDS is reused)
+    float* red = g2_lds;                               // [2][64 rows = wave * 16 + n][D]
+#pragma unroll
+    for (int jn = 0; jn < KJ; ++jn)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(size_t)(wave * 16 + n) * D + 16 * jn + 4 * g_ + e] = ag[jn][e];
+            red[(size_t)(64 + wave * 16 + n) * D + 16 * jn + 4 * g_ + e] = ab[jn][e];
+        }
+    __syncthreads();
+    for (int i = tid; i < 2 * D; i += 256) {
+        const int which = i / D, col = i - which * D;
+        float s_ = 0.f;
+        for (int k = 0; k < 64; ++k) s_ += red[(size_t)(which * 64 + k) * D + col];
+        my_part[i] = s_;
+    }
+}
+
 // t = drop(relu?(a)) + res ; y = LayerNorm(t) * gamma + beta       (submodules.py:96-101, satrans.py:91-99)
 // LPT = D / 4 lanes per token.  y goes to the caller's sample order when `y_orig` is set.
 template <int LPT>
@@ -1118,7 +1286,7 @@ struct GenLayout {          // offsets in floats; nd = B F D, nu = B F U
     // saved by the forward, read by the backward
     int64_t xs, q0, k0, v, hq, hk, mq, mk, tq, tk, q, k, o, u, to, st, saved_total;
     // scratch
-    int64_t dr, du, go, dq, dk, dv, dt, dm, dh, part, part_floats, ln_part, ln_blocks, modfull, scratch_total;
+    int64_t dr, du, go, dq, dk, dv, dt, dm, dh, part, part_floats, ln_part, ln_blocks, modfull, mn_part, mn_slots, scratch_total;
 };
 
 static int gen_attn_mode() {      // 0 = automatic (MFMA forward where it is built), 1 = wavefront, 2 = MFMA
@@ -1151,6 +1319,8 @@ static GenLayout gen_layout(const satrans_layer_desc* d) {
     L.ln_blocks = std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
     L.ln_part = take(L.ln_blocks * 2 * d->D);
     L.modfull = take((d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) ? (int64_t)d->S * d->D * d->D : 0);   // gate / bilinear: z^T g per scenario
+    L.mn_slots = ceil_div(N, kG2Rows) * std::max(d->S, 1);                 // gamma / beta partials of the fused MetaNet backward
+    L.mn_part = take(L.mn_slots * 2 * d->D);
     L.scratch_total = o;
     return L;
 }
@@ -1304,6 +1474,32 @@ static int gen_metanet_fused_fwd(hipStream_t st, const satrans_layer_desc* d, co
     else GEN_MN_CASE(4, 1)
 #undef GEN_MN_CASE
     SATRANS_CHECK_LAUNCH("gen_metanet_fwd_kernel");
+    return SATRANS_OK;
+}
+
+static int gen_metanet_fused_bwd(hipStream_t st, const satrans_layer_desc* d, float* g, const float* t, const float* h, const float* tab,
+                                 float* dm, float* dh, const float* gam, float* part, int site) {
+    const int M = d->B * d->F, D = d->D, U = d->U;
+    const GenDrop dc = gen_drop(d, site);
+    const dim3 grid((unsigned)ceil_div(M, kG2Rows), (unsigned)(d->seg ? d->S : 1));
+    const size_t lds = sizeof(float) * std::max<size_t>(4 * ((size_t)g2_plane_floats(D, U) + (size_t)g2_plane_floats(U, D)), 2 * 64 * (size_t)D);
+#define GEN_MNB_CASE(KJ_, UJ_)                                                                                                  \
+    {                                                                                                                            \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)gen_metanet_bwd_kernel<KJ_, UJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                               \
+            attr_set = true;                                                                                                     \
+        }                                                                                                                        \
+        gen_metanet_bwd_kernel<KJ_, UJ_><<<grid, 256, lds, st>>>(g, t, h, tab, d->tab_stride, d->seg, M, d->F, dm, dh, gam, part,  \
+                                                               d->order, dc);                                                   \
+    }
+    if (D == 64 && U == 128) GEN_MNB_CASE(4, 8)
+    else if (D == 32 && U == 64) GEN_MNB_CASE(2, 4)
+    else if (D == 16 && U == 32) GEN_MNB_CASE(1, 2)
+    else GEN_MNB_CASE(4, 1)
+#undef GEN_MNB_CASE
+    SATRANS_CHECK_LAUNCH("gen_metanet_bwd_kernel");
     return SATRANS_OK;
 }
 
@@ -1553,6 +1749,20 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     // ---- MetaNet backward of one role: g (gradient of the role's output rows) becomes the gradient of z0 -------------------------
     auto metanet_bwd = [&](float* g, const float* z0, const float* h, const float* t, const float* tab, const float* gam,
                            float* g_ln_role, float* g_tab, int site) -> int {
+        static const bool fuse = !(getenv("SATRANS_GENERIC_FUSED_METANET") && atoi(getenv("SATRANS_GENERIC_FUSED_METANET")) == 0);
+        if (fuse && gen_metanet_fused_ok(D, U)) {
+            // data gradients in one pass (g <- dz0; dm, dh written for the two weight-gradient products), then dW2, dW1
+            float* mn_part = scratch + L.mn_part;
+            int r = gen_metanet_fused_bwd(st, d, g, t, h, tab, dm, dh, gam, mn_part, site);
+            if (r) return r;
+            if (g_ln_role) {
+                gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * D, 32), 1), 256, 0, st>>>(mn_part, (int)L.mn_slots, 2 * D, g_ln_role, 0,
+                                                                                           nullptr, 0, 1);
+                SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
+            }
+            if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride))) return r;
+            return gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride);
+        }
         int r = gen_ln_bwd(st, d, L, scratch, g, false, t, nullptr, gam, dt, dm, site, false, g_ln_role);
         if (r) return r;
         // dW2[u][o] += h^T dm ;  dh = (dm W2^T) * [h > 0] ;  dW1[i][u] += z0^T dh ;  dz0 = dt + dh W1^T
