@@ -334,6 +334,35 @@ __global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restr
     }
 }
 
+// dst[e] += sum over the USED slots of part[(s * gridx + c)][e] (segment s uses its first ceil(rows_s / chunk_rows) slots), count <= 256
+// values per slot: 32 columns x 8 groups per block, group g takes the used slots with (running index) % 8 == g in order, the eight
+// group sums are combined in group order - fixed order, and the empty slots of the (row tile, segment) grid are never read.
+__global__ __launch_bounds__(256) void gen_slot_reduce_kernel(const float* __restrict__ part, int gridx, int S,
+                                                            const int32_t* __restrict__ seg, int F, int chunk_rows, int count,
+                                                            float* __restrict__ dst) {
+    __shared__ float s_part[8][32];
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + lane;
+    float t = 0.f;
+    int running = 0;
+    for (int s = 0; s < S; ++s) {
+        const int used = (int)(((int64_t)(seg[s + 1] - seg[s]) * F + chunk_rows - 1) / chunk_rows);
+        if (e < count) {
+            const float* p = part + (size_t)s * gridx * count + e;
+            for (int c = (grp - running % 8 + 8) % 8; c < used; c += 8) t += p[(size_t)c * count];
+        }
+        running += used;
+    }
+    s_part[grp][lane] = t;
+    __syncthreads();
+    if (grp == 0 && e < count) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += s_part[k][lane];
+        dst[e] += r;
+    }
+}
+
 // rows in scenario-sorted order <- the layer input in the caller's order (or the arena rows of the fused gather), and back
 __global__ void gen_permute_in_kernel(satrans_layer_desc a, const float* __restrict__ src, float* __restrict__ dst, bool is_x) {
     const int q4 = a.D >> 2;
@@ -608,6 +637,9 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_bwd_kernel(float* __restri
         const int64_t rr = live ? row : r_lo;
         float gv[KJ][4], zh[KJ][4];
         float sum = 0.f;
+        float4 hv[UJ];                    // the relu mask rows: requested now, used after the LayerNorm arithmetic
+#pragma unroll
+        for (int ju = 0; ju < UJ; ++ju) hv[ju] = *reinterpret_cast<const float4*>(hbuf + rr * U + 16 * ju + 4 * g_);
 #pragma unroll
         for (int jn = 0; jn < KJ; ++jn) {
             const int c = 16 * jn + 4 * g_;
@@ -674,8 +706,8 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_bwd_kernel(float* __restri
                 acc = mfma4(b.z, dmt[jn].z, acc);
                 acc = mfma4(b.w, dmt[jn].w, acc);
             }
-            const float4 hv = *reinterpret_cast<const float4*>(hbuf + rr * U + 16 * ju + 4 * g_);
-            dh[ju] = make_float4(hv.x > 0.f ? acc[0] : 0.f, hv.y > 0.f ? acc[1] : 0.f, hv.z > 0.f ? acc[2] : 0.f, hv.w > 0.f ? acc[3] : 0.f);
+            dh[ju] = make_float4(hv[ju].x > 0.f ? acc[0] : 0.f, hv[ju].y > 0.f ? acc[1] : 0.f, hv[ju].z > 0.f ? acc[2] : 0.f,
+                                 hv[ju].w > 0.f ? acc[3] : 0.f);
             if (live) *reinterpret_cast<float4*>(dh_out + row * U + 16 * ju + 4 * g_) = dh[ju];
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1756,9 +1788,9 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
             int r = gen_metanet_fused_bwd(st, d, g, t, h, tab, dm, dh, gam, mn_part, site);
             if (r) return r;
             if (g_ln_role) {
-                gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * D, 32), 1), 256, 0, st>>>(mn_part, (int)L.mn_slots, 2 * D, g_ln_role, 0,
-                                                                                           nullptr, 0, 1);
-                SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
+                gen_slot_reduce_kernel<<<(unsigned)ceil_div(2 * D, 32), 256, 0, st>>>(mn_part, (int)ceil_div(M, kG2Rows), S, d->seg, F,
+                                                                                    kG2Rows, 2 * D, g_ln_role);
+                SATRANS_CHECK_LAUNCH("gen_slot_reduce_kernel");
             }
             if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride))) return r;
             return gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride);
