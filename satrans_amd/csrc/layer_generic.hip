@@ -46,6 +46,28 @@ constexpr int kG2Rows = 512;     // token rows per workgroup (4 waves x 8 groups
 __host__ __device__ inline int g2_row_slots(int K) { return (K >> 4) | 1; }
 __host__ __device__ inline int g2_plane_floats(int K, int N) { return ((N * g2_row_slots(K) * 4 + 63) / 64) * 64; }
 
+// Stage B^T as planes: element (k, nn) -> plane (k >> 2) & 3, row nn, position 4 (k >> 4) + (k & 3).  16-byte global loads; when k
+// is the contiguous index of the source (KCONTIG: B(k, nn) = B[nn * ldb + k]) the four values are one 16-byte LDS write too.
+template <bool KCONTIG>
+__device__ __forceinline__ void g2_stage(const float* __restrict__ B, int K, int N, int ldb, float* __restrict__ img, int RS, int PL) {
+    if (KCONTIG) {
+        const int kq = K >> 2;
+        for (int e = threadIdx.x; e < N * kq; e += blockDim.x) {
+            const int nn = e / kq, k = (e - nn * kq) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(B + (size_t)nn * ldb + k);
+            *reinterpret_cast<float4*>(img + ((k >> 2) & 3) * PL + nn * RS + 4 * (k >> 4)) = v;
+        }
+    } else {
+        const int nq = N >> 2;
+        for (int e = threadIdx.x; e < K * nq; e += blockDim.x) {
+            const int k = e / nq, nn = (e - k * nq) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(B + (size_t)k * ldb + nn);
+            float* dst = img + ((k >> 2) & 3) * PL + nn * RS + 4 * (k >> 4) + (k & 3);
+            dst[0] = v.x; dst[RS] = v.y; dst[2 * RS] = v.z; dst[3 * RS] = v.w;
+        }
+    }
+}
+
 template <bool TRANSB, int EPI, int KJ>       // KJ = K / 16
 __global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32_t* __restrict__ seg, int M, int F, int N,
                                                      int ldb, int64_t b_seg_stride, const float* __restrict__ mask) {
@@ -60,13 +82,7 @@ __global__ __launch_bounds__(256) void gen_gemm_kernel(GemmBatch gb, const int32
     float* __restrict__ C = gb.C[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     const int RS = g2_row_slots(K) * 4, PL = g2_plane_floats(K, N);
-    // stage B^T: element (k, nn) -> plane (k >> 2) & 3, row nn, position 4 (k >> 4) + (k & 3)
-    for (int e = tid; e < K * N; e += 256) {
-        int k, nn;
-        if (TRANSB) { nn = e / K; k = e - nn * K; } else { k = e / N; nn = e - k * N; }
-        const float v = TRANSB ? B[(size_t)nn * ldb + k] : B[(size_t)k * ldb + nn];
-        g2_lds[((k >> 2) & 3) * PL + nn * RS + 4 * (k >> 4) + (k & 3)] = v;
-    }
+    g2_stage<TRANSB>(B, K, N, ldb, g2_lds, RS, PL);
     __syncthreads();
     const float* bt = g2_lds + g * PL + n * RS;
     const int NT = N >> 4;
@@ -136,12 +152,7 @@ __global__ __launch_bounds__(256) void gen_gemm_sum_kernel(GemmBatch gb, int nsr
     const int RS = g2_row_slots(K) * 4, PL = g2_plane_floats(K, N);
 #pragma unroll
     for (int i = 0; i < NSRC; ++i) {
-        const float* __restrict__ B = gb.B[i];
-        float* img = g2_lds + (size_t)i * 4 * PL;
-        for (int e = tid; e < K * N; e += 256) {           // B(k, nn) = W[nn][k]
-            const int nn = e / K, k = e - nn * K;
-            img[((k >> 2) & 3) * PL + nn * RS + 4 * (k >> 4) + (k & 3)] = B[(size_t)nn * K + k];
-        }
+        g2_stage<true>(gb.B[i], K, N, K, g2_lds + (size_t)i * 4 * PL, RS, PL);           // B(k, nn) = W[nn][k]
     }
     __syncthreads();
     float4 a[NSRC][KJ], an[NSRC][KJ];
@@ -466,14 +477,8 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __
     float* img2 = g2_lds + 4 * PL1;
     const float* __restrict__ W1 = tab + (size_t)s * tab_stride;            // [D][U]
     const float* __restrict__ W2 = W1 + (size_t)D * U;                      // [U][D]
-    for (int e = tid; e < D * U; e += 256) {
-        const int k = e / U, nn = e - k * U;
-        img1[((k >> 2) & 3) * PL1 + nn * RS1 + 4 * (k >> 4) + (k & 3)] = W1[e];
-    }
-    for (int e = tid; e < U * D; e += 256) {
-        const int k = e / D, nn = e - k * D;
-        img2[((k >> 2) & 3) * PL2 + nn * RS2 + 4 * (k >> 4) + (k & 3)] = W2[e];
-    }
+    g2_stage<false>(W1, D, U, U, img1, RS1, PL1);          // B(k = i, nn = u) = W1[i][u]
+    g2_stage<false>(W2, U, D, D, img2, RS2, PL2);          // B(k = u, nn = o) = W2[u][o]
     __syncthreads();
     const float* b1 = img1 + g * PL1 + n * RS1;
     const float* b2 = img2 + g * PL2 + n * RS2;
@@ -607,14 +612,8 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_bwd_kernel(float* __restri
     float* img1 = g2_lds + 4 * PL2;
     const float* __restrict__ W1 = tab + (size_t)s * tab_stride;            // [D][U]
     const float* __restrict__ W2 = W1 + (size_t)D * U;                      // [U][D]
-    for (int e = tid; e < U * D; e += 256) {
-        const int nn = e / D, k = e - nn * D;                               // W2[u = nn][o = k]
-        img2[((k >> 2) & 3) * PL2 + nn * RS2 + 4 * (k >> 4) + (k & 3)] = W2[e];
-    }
-    for (int e = tid; e < D * U; e += 256) {
-        const int nn = e / U, k = e - nn * U;                               // W1[i = nn][u = k]
-        img1[((k >> 2) & 3) * PL1 + nn * RS1 + 4 * (k >> 4) + (k & 3)] = W1[e];
-    }
+    g2_stage<true>(W2, D, U, D, img2, RS2, PL2);           // B(k = o, nn = u) = W2[u][o]
+    g2_stage<true>(W1, U, D, U, img1, RS1, PL1);           // B(k = u, nn = i) = W1[i][u]
     __syncthreads();
     const float* b2 = img2 + g_ * PL2 + n * RS2;
     const float* b1 = img1 + g_ * PL1 + n * RS1;
