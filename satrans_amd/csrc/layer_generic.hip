@@ -458,8 +458,8 @@ struct GenDrop {
 // column; a token's row is spread over the four lanes g, so the LayerNorm statistics are two cross-lane adds.  Read z once,
 // write h and t (the backward needs them) and y: 670 MB at the configs[4] shape where the three separate launches move 1.6 GB.
 // W1^T and W2^T planes of the scenario in LDS.  norm == false: y = t (MetaNet(use_norm=False)).
-template <int KJ, int UJ>       // D = 16 KJ, U = 16 UJ
-__global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tab, int64_t tab_stride,
+template <int KJ, int UJ, int WV>       // D = 16 KJ, U = 16 UJ, WV waves per workgroup (128 WV token rows)
+__global__ __launch_bounds__(64 * WV, WV == 8 ? 4 : 2) void gen_metanet_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tab, int64_t tab_stride,
                                                             const int32_t* __restrict__ seg, int M, int F, float* __restrict__ hbuf,
                                                             float* __restrict__ tbuf, float* __restrict__ y,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __
     constexpr int D = KJ * 16, U = UJ * 16;
     const int s = blockIdx.y;
     const int64_t r_lo = seg ? (int64_t)seg[s] * F : 0, r_hi = seg ? (int64_t)seg[s + 1] * F : M;
-    const int64_t row0 = r_lo + (int64_t)blockIdx.x * kG2Rows;
+    constexpr int ROWS = 128 * WV;
+    const int64_t row0 = r_lo + (int64_t)blockIdx.x * ROWS;
     if (row0 >= r_hi) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
     const int RS1 = g2_row_slots(D) * 4, PL1 = g2_plane_floats(D, U);      // W1^T: K = D, N = U
@@ -495,13 +496,18 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __
         }
     };
     const int64_t wave_row0 = row0 + 16 * wave;
-    const int64_t tile_hi = min(r_hi, row0 + kG2Rows);
+    const int64_t tile_hi = min(r_hi, row0 + ROWS);
     if (wave_row0 < tile_hi) load_rows(wave_row0, a);
-    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 64) {
-        const bool more = g0 + 64 < tile_hi;
-        if (more) load_rows(g0 + 64, an);
+    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 16 * WV) {
         const int64_t row = g0 + n;
         const bool live = row < r_hi;
+        // token (sample position, field) of this lane's row and its dropout key: the sample id is loaded BEFORE the next group's
+        // rows are requested, so that waiting for it does not wait for them (loads return in order)
+        const int64_t rr = live ? row : r_lo;
+        const int pos = (int)(rr / F), f = (int)(rr - (int64_t)pos * F);
+        const uint32_t skey = dc.on ? drop_sample_key(dc.key, (uint32_t)order[pos]) : 0u;
+        const bool more = g0 + 16 * WV < tile_hi;
+        if (more) load_rows(g0 + 16 * WV, an);
         float4 h[UJ];
 #pragma unroll
         for (int ju = 0; ju < UJ; ++ju) {
@@ -519,10 +525,6 @@ __global__ __launch_bounds__(256, 2) void gen_metanet_fwd_kernel(const float* __
             if (live && hbuf) *reinterpret_cast<float4*>(hbuf + row * U + 16 * ju + 4 * g) = h[ju];
             __builtin_amdgcn_sched_barrier(0);      // the fragment reads of later tiles stay behind this tile (registers)
         }
-        // token (sample position, field) of this lane's row and its dropout key
-        const int64_t rr = live ? row : r_lo;
-        const int pos = (int)(rr / F), f = (int)(rr - (int64_t)pos * F);
-        const uint32_t skey = dc.on ? drop_sample_key(dc.key, (uint32_t)order[pos]) : 0u;
         float v[KJ][4];
         float sum = 0.f;
 #pragma unroll
@@ -1486,18 +1488,28 @@ static int gen_metanet_fused_fwd(hipStream_t st, const satrans_layer_desc* d, co
                                  float* out, const float* gam, const float* bet, int site, bool norm) {
     const int M = d->B * d->F, D = d->D, U = d->U;
     const GenDrop dc = gen_drop(d, site);
-    const dim3 grid((unsigned)ceil_div(M, kG2Rows), (unsigned)(d->seg ? d->S : 1));
+    // 4 waves per workgroup (two workgroups = two waves per SIMD under the 78 KB of weight planes): 264 us per launch at the
+    // configs[4] shape; 8 waves (four per SIMD, SATRANS_MN_WAVES=8) 290 us - more waves do not help, the kernel is bound by issue
+    static const int wv = getenv("SATRANS_MN_WAVES") ? atoi(getenv("SATRANS_MN_WAVES")) : 4;
+    const int rows = 128 * (wv == 8 ? 8 : 4);
+    const dim3 grid((unsigned)ceil_div(M, rows), (unsigned)(d->seg ? d->S : 1));
     const size_t lds = sizeof(float) * 4 * ((size_t)g2_plane_floats(D, U) + (size_t)g2_plane_floats(U, D));
 #define GEN_MN_CASE(KJ_, UJ_)                                                                                                   \
     {                                                                                                                            \
         static bool attr_set = false;                                                                                            \
         if (!attr_set) {                                                                                                         \
-            (void)hipFuncSetAttribute((const void*)gen_metanet_fwd_kernel<KJ_, UJ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)gen_metanet_fwd_kernel<KJ_, UJ_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                               \
+            (void)hipFuncSetAttribute((const void*)gen_metanet_fwd_kernel<KJ_, UJ_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                               \
             attr_set = true;                                                                                                     \
         }                                                                                                                        \
-        gen_metanet_fwd_kernel<KJ_, UJ_><<<grid, 256, lds, st>>>(z0, tab, d->tab_stride, d->seg, M, d->F, h, t, out, gam, bet,     \
-                                                               d->order, dc, norm);                                             \
+        if (wv == 8)                                                                                                             \
+            gen_metanet_fwd_kernel<KJ_, UJ_, 8><<<grid, 512, lds, st>>>(z0, tab, d->tab_stride, d->seg, M, d->F, h, t, out, gam, bet, \
+                                                                      d->order, dc, norm);                                      \
+        else                                                                                                                     \
+            gen_metanet_fwd_kernel<KJ_, UJ_, 4><<<grid, 256, lds, st>>>(z0, tab, d->tab_stride, d->seg, M, d->F, h, t, out, gam, bet, \
+                                                                      d->order, dc, norm);                                      \
     }
     if (D == 64 && U == 128) GEN_MN_CASE(4, 8)
     else if (D == 32 && U == 64) GEN_MN_CASE(2, 4)
