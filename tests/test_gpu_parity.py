@@ -669,7 +669,8 @@ def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
 
 
 @pytest.mark.parametrize("name", ["small_d64_u128", "aliccp_sota", "alimama_sota_pos", "small_qkv", "small_k", "small_none",
-                                  "small_pos_dense", "small_relu", "small_multidomain", "small_gate", "small_bilinear"])
+                                  "small_pos_dense", "small_relu", "small_multidomain", "small_gate", "small_bilinear", "small_d64",
+                                  "small_onlyemb"])
 def test_general_layer_path_matches_golden_and_the_oracle(monkeypatch, name):
     """csrc/layer_generic.hip (grouped f32-MFMA GEMMs + LayerNorm + attention launches over token rows in HBM; the path of
     BASELINE configs[4]-class shapes), forced also on shapes the fused kernels cover: forward and every gradient against
