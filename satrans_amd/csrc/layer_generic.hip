@@ -1192,24 +1192,23 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __r
     float* sq = at_lds;
     float* sk = sq + FP * LD;
     float* sv = sk + FP * LD;
-    float* sg = sv + FP * LD;
-    float4* sst = reinterpret_cast<float4*>(sg + FP * LD);          // [H][FP]: max, 1/sum, dot, -
-    float* scr = reinterpret_cast<float*>(sst + H * FP);            // [4 waves][2][4 PL]
+    float4* sst = reinterpret_cast<float4*>(sv + FP * LD);          // [H][FP]: max, 1/sum, dot, -
+    float* scr = reinterpret_cast<float*>(sst + H * FP);            // [4 waves][4 PL]: dS^T, then Pm^T of the current query tile
+    // (the go rows are read from global memory where they are needed - 8 scalar loads per lane and query tile, L1 / L2 hits
+    // between the heads' waves - and the two transposed tiles share one scratch: 73 KB instead of 107 KB, two workgroups per CU)
     const int p = blockIdx.x;
     const int64_t base = (int64_t)p * F * D;
     for (int i = threadIdx.x; i < FP * (D >> 2); i += blockDim.x) {
         const int r = i / (D >> 2), c = (i - r * (D >> 2)) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a, gg = a;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a;
         if (r < F) {
             a = *reinterpret_cast<const float4*>(q + base + r * D + c);
             b = *reinterpret_cast<const float4*>(k + base + r * D + c);
             cc = *reinterpret_cast<const float4*>(v + base + r * D + c);
-            gg = *reinterpret_cast<const float4*>(go + base + r * D + c);
         }
         *reinterpret_cast<float4*>(sq + r * LD + c) = a;
         *reinterpret_cast<float4*>(sk + r * LD + c) = b;
         *reinterpret_cast<float4*>(sv + r * LD + c) = cc;
-        *reinterpret_cast<float4*>(sg + r * LD + c) = gg;
     }
     __syncthreads();
     for (int task = threadIdx.x; task < H * FP; task += blockDim.x) {
@@ -1217,7 +1216,7 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __r
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);     // padding queries: P = exp2(0 - 0) * 0 = 0
         if (i < F) {
             f32x2 gi[d / 2], oi[d / 2];
-            load_row<d>(sg + i * LD + h * d, gi);
+            load_row<d>(go + base + (int64_t)i * D + h * d, gi);
             load_row<d>(o + base + (int64_t)i * D + h * d, oi);
             const float2 s2 = st[((size_t)p * H + h) * F + i];
             s4 = make_float4(s2.x, s2.y, dot_row<d>(gi, oi), 0.f);
@@ -1230,12 +1229,11 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __r
     const int b = order[p];
     const float sc_scale = kLog2e * inv_sqrt_d;
     const uint32_t skey = drop_sample_key(dc.key, (uint32_t)b);
-    float* sds = scr + (size_t)h * 8 * PL;            // dS^T of the current query tile
-    float* spm = sds + 4 * PL;                        // Pm^T
+    float* sds = scr + (size_t)h * 4 * PL;            // dS^T of the current query tile, then Pm^T
     const float* qh = sq + h * d;
     const float* kh = sk + h * d;
     const float* vh = sv + h * d;
-    const float* gh = sg + h * d;
+    const float* gg_ = go + base + h * d;             // go rows of this head in global memory
     f32x4 dkt[4], dvt[4];                             // dK^T / dV^T[e = 4 g + r][key j = 16 jt + n]
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) { dkt[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1244,8 +1242,8 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __r
         const float4 s4 = sst[h * FP + i];
         float qb[4], gb[4];                           // second operands: Q^T / G^T[e = 4 ks + g][i]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { qb[ks] = qh[i * LD + 4 * ks + g]; gb[ks] = gh[i * LD + 4 * ks + g]; }
-        f32x4 s[4], dp[4];
+        for (int ks = 0; ks < 4; ++ks) { qb[ks] = qh[i * LD + 4 * ks + g]; gb[ks] = i < F ? gg_[(int64_t)i * D + 4 * ks + g] : 0.f; }
+        f32x4 s[4], dp[4];                         // scores -> dS^T ; dP^T -> Pm^T
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             s[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1273,8 +1271,8 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __r
                     const float ds = pr * (dpm - s4.z) * inv_sqrt_d;
                     const float pm = kp ? pr * dc.scale : 0.f;
                     s[jt][r] = ds;
+                    dp[jt][r] = pm;
                     sds[(n >> 2) * PL + j * 4 + (n & 3)] = ds;
-                    spm[(n >> 2) * PL + j * 4 + (n & 3)] = pm;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)           // contraction over keys j = 16 jt + 4 g + r: first operand K[j][e = n]
@@ -1287,14 +1285,32 @@ __global__ __launch_bounds__(256) void gen_attn_bwd_mfma_kernel(const float* __r
         // contraction over the tile's queries i = 16 it + 4 g + r: first operand Q / G[i][e = n], second dS^T / Pm^T[key 16 jt + n][i]
         float qa[4], ga[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { qa[r] = qh[(16 * it + 4 * g + r) * LD + n]; ga[r] = gh[(16 * it + 4 * g + r) * LD + n]; }
+        for (int r = 0; r < 4; ++r) {
+            const int ir = 16 * it + 4 * g + r;
+            qa[r] = qh[ir * LD + n];
+            ga[r] = ir < F ? gg_[(int64_t)ir * D + n] : 0.f;
+        }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             if (jt < JT) {
                 const float4 dsv = *reinterpret_cast<const float4*>(sds + g * PL + (16 * jt + n) * 4);
-                const float4 pmv = *reinterpret_cast<const float4*>(spm + g * PL + (16 * jt + n) * 4);
                 dkt[jt] = mfma4(qa[0], dsv.x, dkt[jt]); dkt[jt] = mfma4(qa[1], dsv.y, dkt[jt]);
                 dkt[jt] = mfma4(qa[2], dsv.z, dkt[jt]); dkt[jt] = mfma4(qa[3], dsv.w, dkt[jt]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the same scratch again for Pm^T
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            if (jt < JT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sds[(n >> 2) * PL + (16 * jt + 4 * g + r) * 4 + (n & 3)] = dp[jt][r];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            if (jt < JT) {
+                const float4 pmv = *reinterpret_cast<const float4*>(sds + g * PL + (16 * jt + n) * 4);
                 dvt[jt] = mfma4(ga[0], pmv.x, dvt[jt]); dvt[jt] = mfma4(ga[1], pmv.y, dvt[jt]);
                 dvt[jt] = mfma4(ga[2], pmv.z, dvt[jt]); dvt[jt] = mfma4(ga[3], pmv.w, dvt[jt]);
             }
@@ -1632,7 +1648,7 @@ static int gen_attention_bwd(hipStream_t st, const satrans_layer_desc* d, const 
     SATRANS_REQUIRE(mode != 2 || can_mfma, SATRANS_E_UNSUPPORTED, "generic attention backward: the MFMA arm needs d = 16, F <= 64, H <= 4");
     if (can_mfma && mode != 1) {
         const int FP = (F + 15) & ~15;
-        const size_t lds_m = sizeof(float) * (4 * (size_t)FP * (D + 4) + 4 * (size_t)H * FP + 4 * 8 * ((size_t)FP * 4 + 4));
+        const size_t lds_m = sizeof(float) * (3 * (size_t)FP * (D + 4) + 4 * (size_t)H * FP + 4 * 4 * ((size_t)FP * 4 + 4));
         static size_t attr_m = 0;
         if (lds_m > attr_m) {
             hipError_t e = hipFuncSetAttribute((const void*)gen_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
