@@ -346,12 +346,13 @@ __global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restr
 }
 
 // dst[e] += sum over the USED slots of part[(s * gridx + c)][e] (segment s uses its first ceil(rows_s / chunk_rows) slots), count <= 256
-// values per slot: 32 columns x 8 groups per block, group g takes the used slots with (running index) % 8 == g in order, the eight
+// values per slot: 32 columns x 32 groups per block, group g takes the used slots with (running index) % 32 == g in order, the
 // group sums are combined in group order - fixed order, and the empty slots of the (row tile, segment) grid are never read.
-__global__ __launch_bounds__(256) void gen_slot_reduce_kernel(const float* __restrict__ part, int gridx, int S,
+__global__ __launch_bounds__(1024) void gen_slot_reduce_kernel(const float* __restrict__ part, int gridx, int S,
                                                             const int32_t* __restrict__ seg, int F, int chunk_rows, int count,
                                                             float* __restrict__ dst) {
-    __shared__ float s_part[8][32];
+    constexpr int G = 32;                 // groups of 32 columns: 1024 threads
+    __shared__ float s_part[G][32];
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + lane;
     float t = 0.f;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void gen_slot_reduce_kernel(const float* __res
         const int used = (int)(((int64_t)(seg[s + 1] - seg[s]) * F + chunk_rows - 1) / chunk_rows);
         if (e < count) {
             const float* p = part + (size_t)s * gridx * count + e;
-            for (int c = (grp - running % 8 + 8) % 8; c < used; c += 8) t += p[(size_t)c * count];
+            for (int c = (grp - running % G + G) % G; c < used; c += G) t += p[(size_t)c * count];
         }
         running += used;
     }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void gen_slot_reduce_kernel(const float* __res
     if (grp == 0 && e < count) {
         float r = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r += s_part[k][lane];
+        for (int k = 0; k < G; ++k) r += s_part[k][lane];
         dst[e] += r;
     }
 }
@@ -1815,7 +1816,7 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
             int r = gen_metanet_fused_bwd(st, d, g, t, h, tab, dm, dh, gam, mn_part, site);
             if (r) return r;
             if (g_ln_role) {
-                gen_slot_reduce_kernel<<<(unsigned)ceil_div(2 * D, 32), 256, 0, st>>>(mn_part, (int)ceil_div(M, kG2Rows), S, d->seg, F,
+                gen_slot_reduce_kernel<<<(unsigned)ceil_div(2 * D, 32), 1024, 0, st>>>(mn_part, (int)ceil_div(M, kG2Rows), S, d->seg, F,
                                                                                     kG2Rows, 2 * D, g_ln_role);
                 SATRANS_CHECK_LAUNCH("gen_slot_reduce_kernel");
             }
