@@ -37,6 +37,7 @@ def run(N, steps=12, warmup=4, B=8192):
         others = [rows_o[i].contiguous() for i in range(steps + warmup)]
     state = {"i": 0}
     parallel.world_size = lambda: N
+    parallel.exchange_enabled = lambda: N > 1          # the step's multi-rank branch, fed by the stand-ins below
     parallel.gather_rows = lambda rows: torch.cat([rows.reshape(-1), others[state["i"]]]) if N > 1 else rows.reshape(-1)
     parallel.gather_grad_rows_async = lambda g: ((g.reshape(-1, g.shape[-1]).repeat(N, 1) if N > 1 else g.reshape(-1, g.shape[-1])), None)
     parallel.all_reduce_flat = lambda flat: None
