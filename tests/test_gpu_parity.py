@@ -1213,3 +1213,55 @@ def test_ragged_batches_gradients_match_the_oracle(name, B):
         # softmax terms) are ~1e-5 and carry ~1e-9 of fp32 cancellation noise in ANY fp32 evaluation: absolute floor 5e-9
         scale = max(1e-6, float(g.abs().max()))
         np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("D,H,U,F", [(128, 8, 64, 9), (64, 8, 32, 33), (32, 2, 64, 70), (64, 4, 48, 24), (16, 1, 16, 5)])
+def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U, F):
+    """Shapes no recorded case holds and no fused kernel covers - embedding_dim 128 (weight-gradient products in two passes,
+    per-product dx), head dimension 8 with more than 32 fields (wavefront attention arms), more than 64 fields at head dimension
+    16 (MFMA arms not applicable), a MetaNet width that is not a power of two - through the public API against the oracle:
+    logits and every gradient, evaluation mode and training mode with replayed dropout masks, on a ragged batch."""
+    from satrans_amd import SATrans, SparseFeat
+    monkeypatch.setenv("SATRANS_GENERIC", "1")             # (small batches of these shapes would otherwise go to the LDS kernels)
+    rng = np.random.RandomState(D + F)
+    fields = [f"f{i}" for i in range(F)]
+    vocab = {f: int(rng.randint(5, 60)) for f in fields}
+    vocab[fields[0]] = 4                                   # the scenario column: ids 1..3
+    cols = [SparseFeat(f, vocabulary_size=vocab[f] + 1, embedding_dim=D) for f in fields]
+    torch.manual_seed(3)
+    model = SATrans(cols, cols, [fields[0]], [3], att_layer_num=0, domain_att_layer_num=2, att_head_num=H, use_linear=False,
+                    use_dnn=False, meta_mode='QK', meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag='sota')
+    with torch.no_grad():                                  # weights far enough from zero for every gradient to matter
+        for k, p in model.named_parameters():
+            if "embedding" in k:
+                p.mul_(300.0)
+    sd = model.state_dict()
+    state, by_ptr = {}, {}
+    for k, v in sd.items():                                # keep the reference's aliasing (K_meta_mlp is Q_meta_mlp without 'pos')
+        state[k] = by_ptr.setdefault(v.data_ptr(), v.detach().clone())
+    B = 21
+    X = np.stack([rng.randint(1 if f == fields[0] else 0, vocab[f], size=B) for f in fields], axis=1).astype(np.float32)
+    y = (rng.rand(B) < 0.4).astype(np.float32)
+    spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(fields)], dense=[], domain_cols=[0], embedding_dim=D, head_num=H,
+                      layer_num=2, flag='sota', meta_mode='QK', meta_units=[D, U, D])
+    Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    model.to(DEV); model.device = DEV
+    model.compile("adam", "binary_crossentropy")
+    for train in (False, True):
+        model.train(train)
+        eng = model._require_engine()
+        bce, reg, grads = eng.loss_and_grads(Xt.to(DEV), yt.to(DEV))
+        assert eng._ws[B]["generic"], "the general path was not selected"
+        drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, F, D, H, 2, 0.1)) if train else None
+        bce_ref, reg_ref, g_ref = O.loss_and_grads(state, Xt, yt, spec, drop)
+        if not train:
+            model(Xt.to(DEV))
+            _, logit_ref = O.forward(state, Xt, spec)
+            np.testing.assert_allclose(eng.last_logit().cpu().numpy().reshape(-1), logit_ref.numpy().reshape(-1), rtol=0,
+                                       atol=2e-5 * max(1.0, float(logit_ref.abs().max())))
+        assert bce == pytest.approx(bce_ref, rel=1e-5)
+        for k, g in g_ref.items():
+            if k in grads:
+                scale = max(1e-6, float(g.abs().max()))
+                np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=2e-4 * scale + 1e-8,
+                                           err_msg=f"{k} train={train}")

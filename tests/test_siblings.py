@@ -111,3 +111,41 @@ def test_meta_transformation_on_the_gpu_matches_reference(name):
     for k, g in G.items():
         if k != "x":
             close(grads[k].cpu().numpy(), g, 5e-5, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,U", [(16, 16), (16, 48), (32, 32), (32, 128), (64, 16), (64, 96), (64, 128), (128, 16), (128, 64)])
+@pytest.mark.parametrize("use_norm", [True, False])
+def test_meta_transformation_shape_sweep_against_the_oracle(D, U, use_norm):
+    """The general-path products behind MetaTransformation (register-direct MFMA products for every K / 16, N / 16 in 1..8,
+    weight-gradient products of the 1x1, 1x2 and 2x1 block forms) on shapes no golden case holds: forward and every gradient
+    against the oracle's meta_transformation - itself pinned to the reference by the recorded vectors above - on a ragged
+    batch with uneven, partly empty scenario segments."""
+    from satrans_amd import MetaTransformation
+    g = torch.Generator().manual_seed(1000 + 7 * D + U)
+    S, B, F = 5, 37, 11
+    mod = MetaTransformation(D, S - 1, (D, U, D), use_norm=use_norm)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.ndim > 1 else 0.1))
+        if use_norm:
+            mod.ffn_layer_norm.weight.copy_(1.0 + 0.2 * torch.randn(D, generator=g))
+    P = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    ids = torch.tensor([0, 1, 3, 3, 1, 0, 3] * 6)[:B]                     # scenario 2 and 4 stay empty
+    x = torch.randn(B, F, D, generator=g)
+    w = torch.randn(B, F, D, generator=g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    y_ref = O.meta_transformation(leaves, ids, xr, [D, U, D], use_norm)
+    (y_ref * w).sum().backward()
+    mod.to("cuda:0")
+    mod.eval()
+    xg = x.to("cuda:0").requires_grad_(True)
+    y = mod(ids.to("cuda:0"), xg)
+    close(y.detach().cpu().numpy(), y_ref.detach().numpy(), 2e-5, "y")
+    (y * w.to("cuda:0")).sum().backward()
+    close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-4, "grad x")
+    for k, p in mod.named_parameters():
+        want = leaves[k].grad
+        assert want is not None, k
+        close(p.grad.cpu().numpy(), want.numpy(), 1e-4, k)
