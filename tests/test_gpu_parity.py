@@ -1215,14 +1215,8 @@ def test_ragged_batches_gradients_match_the_oracle(name, B):
         np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9, err_msg=k)
 
 
-@pytest.mark.parametrize("D,H,U,F", [(128, 8, 64, 9), (64, 8, 32, 33), (32, 2, 64, 70), (64, 4, 48, 24), (16, 1, 16, 5)])
-def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U, F):
-    """Shapes no recorded case holds and no fused kernel covers - embedding_dim 128 (weight-gradient products in two passes,
-    per-product dx), head dimension 8 with more than 32 fields (wavefront attention arms), more than 64 fields at head dimension
-    16 (MFMA arms not applicable), a MetaNet width that is not a power of two - through the public API against the oracle:
-    logits and every gradient, evaluation mode and training mode with replayed dropout masks, on a ragged batch."""
+def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21):
     from satrans_amd import SATrans, SparseFeat
-    monkeypatch.setenv("SATRANS_GENERIC", "1")             # (small batches of these shapes would otherwise go to the LDS kernels)
     rng = np.random.RandomState(D + F)
     fields = [f"f{i}" for i in range(F)]
     vocab = {f: int(rng.randint(5, 60)) for f in fields}
@@ -1239,7 +1233,6 @@ def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U
     state, by_ptr = {}, {}
     for k, v in sd.items():                                # keep the reference's aliasing (K_meta_mlp is Q_meta_mlp without 'pos')
         state[k] = by_ptr.setdefault(v.data_ptr(), v.detach().clone())
-    B = 21
     X = np.stack([rng.randint(1 if f == fields[0] else 0, vocab[f], size=B) for f in fields], axis=1).astype(np.float32)
     y = (rng.rand(B) < 0.4).astype(np.float32)
     spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(fields)], dense=[], domain_cols=[0], embedding_dim=D, head_num=H,
@@ -1251,7 +1244,7 @@ def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U
         model.train(train)
         eng = model._require_engine()
         bce, reg, grads = eng.loss_and_grads(Xt.to(DEV), yt.to(DEV))
-        assert eng._ws[B]["generic"], "the general path was not selected"
+        assert bool(eng._ws[B]["generic"]) == generic, "unexpected layer path"
         drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, F, D, H, 2, 0.1)) if train else None
         bce_ref, reg_ref, g_ref = O.loss_and_grads(state, Xt, yt, spec, drop)
         if not train:
@@ -1265,3 +1258,21 @@ def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U
                 scale = max(1e-6, float(g.abs().max()))
                 np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=2e-4 * scale + 1e-8,
                                            err_msg=f"{k} train={train}")
+
+
+@pytest.mark.parametrize("D,H,U,F", [(128, 8, 64, 9), (64, 8, 32, 33), (32, 2, 64, 70), (64, 4, 48, 24), (16, 1, 16, 5)])
+def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U, F):
+    """Shapes no recorded case holds and no fused kernel covers - embedding_dim 128 (weight-gradient products in two passes,
+    per-product dx), head dimension 8 with more than 32 fields (wavefront attention arms), more than 64 fields at head dimension
+    16 (MFMA arms not applicable), a MetaNet width that is not a power of two - through the public API against the oracle:
+    logits and every gradient, evaluation mode and training mode with replayed dropout masks, on a ragged batch."""
+    monkeypatch.setenv("SATRANS_GENERIC", "1")             # (small batches of these shapes would otherwise go to the LDS kernels)
+    _synthetic_shape_against_oracle(D, H, U, F, generic=True)
+
+
+@pytest.mark.parametrize("F,B", [(3, 50), (7, 21), (13, 64), (20, 21), (25, 33), (32, 21)])
+def test_fused_kernels_on_field_counts_without_a_golden_case(F, B):
+    """The fused kernels at the AliCCP dimensions (D = 32, 4 heads, hidden 64) for field counts no recorded case has: the tile
+    geometry (samples per tile 64 / F: 21 ... 2), the task-to-lane maps of the attention phases and the generic (runtime field
+    count) backward instantiation, against the oracle in evaluation and training mode."""
+    _synthetic_shape_against_oracle(32, 4, 64, F, generic=False, B=B)
