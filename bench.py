@@ -314,6 +314,9 @@ def main():
 
     for i in range(W):
         step(i)
+    # the postponed row updates of the WARM-UP steps belong to the warm-up: bring every row up to date before the clock starts, so
+    # that the flush inside the timed region replays exactly the K timed steps (it used to pay for W + K)
+    eng.flush_lazy()
     # per-phase HIP events are recorded on every 4th step of the timed region: ~40 event records per step cost
     # ~0.4 ms/step (measured 2.13 vs 1.69 ms/step), which would distort the very number being reported
     timers = {} if not args.no_phase_timing else None
