@@ -319,6 +319,12 @@ int64_t satrans_embed_sort_workspace_bytes(int64_t n, int64_t total_rows);
 int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32_t* sorted_rows,
                        int32_t* src, uint32_t* touched, void* workspace, int64_t workspace_bytes,
                        const int32_t* positions, void* stream);
+/* The same sort for the rows of one batch, rows [B, F] (position = b*F + f), when every field has a table of its own: one launch,
+ * one workgroup per field sorting in LDS.  seg_field / seg_lo / seg_rows are HOST arrays of F entries: the fields in arena order
+ * with the first arena row and the row count of their tables (pairwise disjoint, ascending).  B <= 8192, F <= 64, otherwise
+ * SATRANS_E_UNSUPPORTED.  Output identical to satrans_embed_sort's. */
+int satrans_embed_sort_fields(const int32_t* rows, int B, int F, const int32_t* seg_field, const int32_t* seg_lo,
+                              const int32_t* seg_rows, int32_t* sorted_rows, int32_t* src, void* stream);
 int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D);
 /* last / t: optional (lazy form): last[row] = t for every row stepped */
 int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,

@@ -17,6 +17,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -131,6 +132,14 @@ class PathEngine:
         # B * F_small positions are the small-table ones.
         self.small_rows = int(m._arena_small_rows)
         self.F_small = sum(1 for lo, _ in spans if lo < self.small_rows)
+        # one-launch sort of a batch's rows, one workgroup per field (csrc/embed_adam.hip: satrans_embed_sort_fields): possible when
+        # every field has a table of its own; the fields in arena order with the first row and the row count of their tables
+        by_lo = sorted(range(len(spans)), key=lambda f: spans[f][0])
+        own = all(spans[by_lo[k]][0] >= spans[by_lo[k - 1]][1] for k in range(1, len(by_lo))) and len(spans) <= 64
+        self._sort_fields = None
+        if own and os.environ.get("SATRANS_SORT_FIELDS", "1") != "0":
+            Arr = C.c_int32 * len(spans)
+            self._sort_fields = (Arr(*by_lo), Arr(*[spans[f][0] for f in by_lo]), Arr(*[spans[f][1] - spans[f][0] for f in by_lo]))
 
         self._ws: Dict[int, dict] = {}
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -147,7 +156,6 @@ class PathEngine:
         # optional per-phase timing with HIP events recorded on the launch stream (bench.py): name -> [(start, end)]
         self.timers: Optional[Dict[str, list]] = None
         # run the streaming Adam of untouched rows on a side stream under the layer kernels (SATRANS_OVERLAP=0: serial)
-        import os
         self.overlap = os.environ.get("SATRANS_OVERLAP", "1") != "0"
         self._side = None
         # Lazy-exact dense Adam (default): the regulariser-only steps of rows that are not gathered are postponed and
@@ -217,7 +225,6 @@ class PathEngine:
         probe = self._layer_desc(ws, 0, B, None, None, False)
         fits = int(self.lib.satrans_layer_bwd_slab_floats(C.byref(probe))) >= 0
         can = bool(self.lib.satrans_layer_generic_supported(C.byref(probe)))
-        import os
         # `gate` / `bilinear` have no fused kernels: the general path (HBM-rate products) instead of the LDS kernels, whose
         # backward is an order of magnitude slower (SATRANS_GENERIC=0 keeps the LDS kernels, for the comparison)
         choice = os.environ.get("SATRANS_GENERIC")
@@ -651,6 +658,11 @@ class PathEngine:
         arena, am, av = m.embedding_arena.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
 
         def sort(rows, n, out_rows, out_src, touched):
+            if self._sort_fields is not None and touched is None and n == B * self.F and B <= 8192:
+                f_, lo_, n_ = self._sort_fields       # this batch's [B, F] rows: one workgroup per field, one launch
+                N.check(lib.satrans_embed_sort_fields(rows.data_ptr(), B, self.F, f_, lo_, n_, out_rows.data_ptr(),
+                                                      out_src.data_ptr(), self._stream()), "satrans_embed_sort_fields")
+                return
             N.check(lib.satrans_embed_sort(rows.data_ptr(), n, self.total_rows, out_rows.data_ptr(), out_src.data_ptr(),
                                            touched, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
                                            ws["iota"].data_ptr(), self._stream()),

@@ -1276,3 +1276,37 @@ def test_fused_kernels_on_field_counts_without_a_golden_case(F, B):
     geometry (samples per tile 64 / F: 21 ... 2), the task-to-lane maps of the attention phases and the generic (runtime field
     count) backward instantiation, against the oracle in evaluation and training mode."""
     _synthetic_shape_against_oracle(32, 4, 64, F, generic=False, B=B)
+
+
+@pytest.mark.parametrize("B", [1, 37, 1024, 3000, 8192])
+def test_per_field_sort_equals_the_device_wide_sort(B):
+    """satrans_embed_sort_fields (one workgroup per field, LDS radix sort) against satrans_embed_sort and torch's stable sort on
+    batches of [B, F] arena rows with heavy duplication, tables of very different sizes and fields out of arena order."""
+    import ctypes as C
+    from satrans_amd import native as N
+    lib = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(B)
+    sizes = [3, 70000, 17, 1 << 20, 5000, 2, 300000, 64]               # rows of each field's table
+    order = [2, 0, 5, 7, 4, 1, 6, 3]                                   # arena order of the fields
+    F = len(sizes)
+    lo = [0] * F
+    off = 0
+    for f in order:
+        lo[f] = off
+        off += sizes[f]
+    total = off
+    ids = torch.stack([torch.randint(0, min(sizes[f], 50 if f % 2 else sizes[f]), (B,), generator=g) for f in range(F)], dim=1)
+    rows = (ids + torch.tensor(lo)[None, :]).to(torch.int32).contiguous().to(DEV)
+    n = B * F
+    want_rows, want_src = torch.sort(rows.reshape(-1).cpu(), stable=True)
+    Arr = C.c_int32 * F
+    out_r, out_s = torch.empty(n, dtype=torch.int32, device=DEV), torch.empty(n, dtype=torch.int32, device=DEV)
+    N.check(lib.satrans_embed_sort_fields(rows.data_ptr(), B, F, Arr(*order), Arr(*[lo[f] for f in order]),
+                                          Arr(*[sizes[f] for f in order]), out_r.data_ptr(), out_s.data_ptr(), st), "sort_fields")
+    assert torch.equal(out_r.cpu(), want_rows) and torch.equal(out_s.cpu().long(), want_src)
+    ws = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n, total)), dtype=torch.uint8, device=DEV)
+    ref_r, ref_s = torch.empty_like(out_r), torch.empty_like(out_s)
+    N.check(lib.satrans_embed_sort(rows.data_ptr(), n, total, ref_r.data_ptr(), ref_s.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                   None, st), "sort")
+    assert torch.equal(out_r, ref_r) and torch.equal(out_s, ref_s)
