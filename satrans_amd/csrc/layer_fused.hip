@@ -1050,12 +1050,14 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 //   records [G+S][TSZ] TSZ = 4*D*U       : [w1q|w2q|w1k|w2k] of (workgroup w, scenario s) at index w + s
 // -------------------------------------------------------------------------------------------------------------------
 // One launch per layer.  Blocks [0, common_blocks): the scenario-independent part; the others: the generated-weight records.
-// Both use blocks of 32 elements x 8 groups of workgroups: every group adds its contiguous share of the workgroup range in
-// index order, the 8 group sums are then combined in group order (fixed order => bitwise reproducible).
+// Both use blocks of 32 elements x kRG = 32 groups of workgroups: every group adds its contiguous share of the workgroup range in
+// index order, the group sums are then combined in group order (fixed order => bitwise reproducible).  (8 groups: 32 dependent
+// rounds of loads per thread, 12 us per launch for 4 MB; 32 groups: 8 rounds.)
+constexpr int kRG = 32;
 __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ common, int G, int D, int flags, int block,
                                                     float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
                                                     float* g_lnq, float* g_lnk) {
-    __shared__ float s_a[8][32], s_b[8][32];
+    __shared__ float s_a[kRG][32], s_b[kRG][32];
     const int CSZ = 4 * D * D + 6 * D, DD = D * D;
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = block * 32 + lane;
@@ -1064,7 +1066,7 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
     const bool shared = mq && mk && g_lnq == g_lnk;
     const int r = e - 4 * DD;
     const bool second = shared && r >= 2 * D && r < 4 * D;       // this thread also needs the K-role element e + 2D
-    const int share = (G + 7) / 8;
+    const int share = (G + kRG - 1) / kRG;
     const int lo = grp * share, hi = min(G, lo + share);
     float acc = 0.f, acc2 = 0.f;
     if (e < CSZ) {
@@ -1079,7 +1081,7 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
     __syncthreads();
     if (grp != 0 || e >= CSZ) return;
     float t = 0.f, t2 = 0.f;
-    for (int k = 0; k < 8; ++k) { t += s_a[k][lane]; t2 += s_b[k][lane]; }
+    for (int k = 0; k < kRG; ++k) { t += s_a[k][lane]; t2 += s_b[k][lane]; }
     if (e < DD) { g_wq[e] += t; return; }
     if (e < 2 * DD) { g_wk[e - DD] += t; return; }
     if (e < 3 * DD) { g_wv[e - 2 * DD] += t; return; }
@@ -1096,7 +1098,7 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
 __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ records, const int32_t* __restrict__ seg,
                                                      int S, int T, int G, int D, int U, int flags, int64_t tab_stride,
                                                      float* g_tab_q, float* g_tab_k, int block, int s) {
-    __shared__ float s_q[8][32], s_k[8][32];
+    __shared__ float s_q[kRG][32], s_k[kRG][32];
     const int half = 2 * D * U;                                  // one role: [W1 D*U | W2 U*D] = the generated row layout
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = block * 32 + lane;
@@ -1110,7 +1112,7 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
     if (nt == 0) return;
     const int per = (total + G - 1) / G;
     const int w_lo = pre / per, w_hi = (pre + nt - 1) / per;
-    const int share = (w_hi - w_lo + 8) / 8;
+    const int share = (w_hi - w_lo + kRG) / kRG;
     const int a = w_lo + grp * share, b = min(w_hi + 1, a + share);
     const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
     float aq = 0.f, ak = 0.f;
@@ -1127,7 +1129,7 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
     __syncthreads();
     if (grp != 0 || e >= half) return;
     aq = 0.f; ak = 0.f;
-    for (int k = 0; k < 8; ++k) { aq += s_q[k][lane]; ak += s_k[k][lane]; }
+    for (int k = 0; k < kRG; ++k) { aq += s_q[k][lane]; ak += s_k[k][lane]; }
     if (mq && mk && g_tab_q == g_tab_k) {
         g_tab_q[(size_t)s * tab_stride + e] += aq + ak;
     } else {
@@ -1136,7 +1138,7 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
     }
 }
 
-__global__ __launch_bounds__(256) void fused_reduce_kernel(const float* __restrict__ common, const float* __restrict__ records,
+__global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __restrict__ common, const float* __restrict__ records,
                                                          const int32_t* __restrict__ seg, int S, int T, int G, int D, int U,
                                                          int flags, int64_t tab_stride, int common_blocks, int record_blocks,
                                                          float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
@@ -1334,7 +1336,7 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     float* records = slabs + (size_t)p.G * CSZ;
     const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
     const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(2 * D * U, 32);
-    fused_reduce_kernel<<<(unsigned)(common_blocks + (meta ? record_blocks * d->S : 0)), 256, 0, stream>>>(
+    fused_reduce_kernel<<<(unsigned)(common_blocks + (meta ? record_blocks * d->S : 0)), 32 * kRG, 0, stream>>>(
         slabs, records, d->seg, d->S, p.T, p.G, D, U, d->flags, d->tab_stride, common_blocks, record_blocks, g_wq, g_wk, g_wv,
         g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
     SATRANS_CHECK_LAUNCH("fused_reduce_kernel");

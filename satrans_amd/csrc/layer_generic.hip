@@ -313,20 +313,21 @@ __global__ __launch_bounds__(256, KA * NA >= 3 ? 1 : 2) void gen_gemm_tn_kernel(
     for (int e = tid; e < psz >> 2; e += 256) out[e] = reinterpret_cast<const float4*>(tn_lds)[e];
 }
 
-// dst[s * dst_seg_stride + e] += sum_c partial[(s * chunks + c)][e] over the chunks segment s uses; S segments (grid.y).  Blocks of 32 elements x 8 groups:
-// every group adds its contiguous share of the chunks in chunk order, the 8 group sums are combined in group order (fixed
-// order => bitwise reproducible, and 8 x more parallel than one thread per element)
-__global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restrict__ partial, int chunks, int count,
+// dst[s * dst_seg_stride + e] += sum_c partial[(s * chunks + c)][e] over the chunks segment s uses; S segments (grid.y).  Blocks of 32 elements x 32 groups:
+// every group adds its contiguous share of the chunks in chunk order, the group sums are combined in group order (fixed
+// order => bitwise reproducible)
+__global__ __launch_bounds__(1024) void gen_tn_reduce_kernel(const float* __restrict__ partial, int chunks, int count,
                                                           float* __restrict__ dst, int64_t dst_seg_stride,
                                                           const int32_t* __restrict__ seg, int F, int chunk_rows,
                                                           int chunk_stride = 0) {      // floats between chunks (0: count)
-    __shared__ float s_part[8][32];
+    constexpr int G = 32;                 // groups: 1024 threads (8 groups: four times as many dependent rounds of loads)
+    __shared__ float s_part[G][32];
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + lane;
     const int s = blockIdx.y;
     // a segment fills only its first ceil(rows / chunk_rows) partials; the rest were never written
     const int used = seg ? (int)(((int64_t)(seg[s + 1] - seg[s]) * F + chunk_rows - 1) / chunk_rows) : chunks;
-    const int share = (used + 7) / 8;
+    const int share = (used + G - 1) / G;
     const int c0 = grp * share, c1 = min(used, c0 + share);
     float t = 0.f;
     if (e < count) {
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void gen_tn_reduce_kernel(const float* __restr
     if (grp == 0 && e < count) {
         float r = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r += s_part[k][lane];
+        for (int k = 0; k < G; ++k) r += s_part[k][lane];
         dst[(size_t)s * dst_seg_stride + e] += r;
     }
 }
@@ -1444,7 +1445,7 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
         else if (Kp <= 64) gen_gemm_tn_kernel<1, 2><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
         else gen_gemm_tn_kernel<2, 1><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
         SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel");
-        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)Kp * N, 32), (unsigned)segs), 256, 0, st>>>(partial, chunks, Kp * N, dp,
+        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)Kp * N, 32), (unsigned)segs), 1024, 0, st>>>(partial, chunks, Kp * N, dp,
                                                                                                           dst_seg_stride, seg, F, kTnRows);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
@@ -1459,7 +1460,7 @@ static int gen_gemm_tn_fan(hipStream_t st, const float* A, const float* const* G
     gen_gemm_tn_kernel<1, 3, true><<<dim3((unsigned)chunks, 1), 256, lds, st>>>(A, G[0], nullptr, M, 1, D, D, D, partial, G[1], G[2]);
     SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel(fan)");
     for (int w = 0; w < 3; ++w) {
-        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)D * D, 32), 1), 256, 0, st>>>(partial + (size_t)w * D * D, chunks, D * D,
+        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)D * D, 32), 1), 1024, 0, st>>>(partial + (size_t)w * D * D, chunks, D * D,
                                                                                              dst[w], 0, nullptr, 1, kTnRows, 3 * D * D);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
@@ -1595,7 +1596,7 @@ static int gen_ln_bwd(hipStream_t st, const satrans_layer_desc* d, const GenLayo
                                                                                    d->F, d->order, dc, relu, tpb, relu_post, norm)));
     SATRANS_CHECK_LAUNCH("gen_ln_bwd_kernel");
     if (g_gamma_beta && norm) {
-        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * d->D, 32), 1), 256, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta, 0, nullptr, 0, 1);
+        gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * d->D, 32), 1), 1024, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta, 0, nullptr, 0, 1);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
     return SATRANS_OK;
