@@ -53,20 +53,22 @@ def make_config(name, table_rows=None):
                     label="BASELINE configs[3]: Alimama-shaped SATrans training step, 15 sparse + 1 dense field, flag sota-pos "
                           "(column maxima are public-dataset magnitudes, an assumption)")
     if name == "c5":
-        total = int(table_rows or 20_000_000)
+        total = int(table_rows or 100_000_000)                  # configs[4]: a 100 M-row embedding table
         per = max(8, total // 63)
         maxima = {f: per - 2 for f in C5_FIELDS[:-1]}
         maxima['dom'] = 3
         return dict(name=name, fields=C5_FIELDS, maxima=maxima, dense=[], domain='dom', dom_lo=1, n_domains=3, D=64, H=4, L=6,
                     units=(128, 64), flag='sota', lr=0.005, int_ids=True,
-                    label=f"BASELINE configs[4]: synthetic stress, 64 int64 fields, embedding_dim 64, 6 layers, MetaNet hidden 128, "
-                          f"{per * 63 + 5:,} table rows (configs[4] names 100 M rows = 25.6 GB + 51 GB of Adam state; scaled so that "
-                          f"the tables initialise on the host within the lease - pass --table-rows 100000000 for the full size)")
+                    scaled=total < 100_000_000,
+                    label="BASELINE configs[4]: synthetic stress, 64 int64 fields, embedding_dim 64, 6 layers, MetaNet hidden 128" +
+                          (f" - SCALED: {per * 63 + 5:,} table rows instead of the 100 M configs[4] names" if total < 100_000_000 else
+                           " (25.6 GB of tables + 51 GB of Adam moments resident in HBM)"))
     raise ValueError(name)
 
 
 CFG = make_config("aliccp")
 
+PMC_SUMMARY = "r03_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
 
@@ -242,7 +244,12 @@ def main():
     ap.add_argument("--config", choices=["aliccp", "alimama", "c5"], default="aliccp",
                     help="aliccp = BASELINE configs[1] (the headline metric), alimama = configs[3] (15 sparse + 1 dense, sota-pos), "
                          "c5 = configs[4] (64 int64 fields, embedding_dim 64, 6 layers)")
-    ap.add_argument("--table-rows", type=int, default=None, help="c5: total embedding rows (default 20 M; configs[4] names 100 M)")
+    ap.add_argument("--table-rows", type=int, default=None,
+                    help="c5: total embedding rows (default: the 100 M configs[4] names; smaller values are labelled SCALED)")
+    ap.add_argument("--sustained-steps", type=int, default=None,
+                    help="steps of the sustained leg (default 2000 over 200 distinct batches; c5: 120 over 30; 0 = skip)")
+    ap.add_argument("--fit-batches", type=int, default=None,
+                    help="batches of the fit()-level leg (default 200; c5: 0 = skipped; 0 = skip)")
     ap.add_argument("--flag", default=None, help="SATrans flag (reference main.py --flag); 'sota-pos' = the positional variant")
     ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
                     help="id distribution of the synthetic batches (uniform = HBM worst case, the reported configuration)")
@@ -292,12 +299,19 @@ def main():
     t_build = time.time()
     model = build_model("cpu", args.lr, args.flag)                                 # seeded init on CPU, as the reference
     do_cpu = world == 1 and args.cpu_steps > 0 and not args.train_only
-    state_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()} if do_cpu else None
+    # CPU leg of configs[4]: the oracle's dense step needs ~5 table-sized host buffers (parameters, gradient, two Adam moments,
+    # regulariser graph) - 128 GB at 100 M rows.  Its bounded sample therefore runs the same step on 2 M-row tables (said so in
+    # `cpu_baseline.sample`); its per-sample cost is dominated by the table sweeps, so this FLATTERS the CPU.
+    cpu_cfg = make_config("c5", 2_000_000) if (do_cpu and args.config == "c5" and CFG["maxima"]["f0"] > 40_000) else None
+    cpu_src = build_model("cpu", args.lr, args.flag, cfg=cpu_cfg) if cpu_cfg else model
+    state_cpu = {k: v.detach().clone() for k, v in cpu_src.state_dict().items()} if do_cpu else None
     if do_cpu:                                                                     # keep the reference's aliasing
-        sd = model.state_dict()
+        sd = cpu_src.state_dict()
         by_ptr = {}
         for k, v in sd.items():
             state_cpu[k] = by_ptr.setdefault(v.data_ptr(), state_cpu[k])
+    n_cpu_rows = cpu_src.embedding_arena.shape[0]
+    del cpu_src
     model.to(device)
     model.device = device
     eng = model._require_engine()
@@ -362,6 +376,55 @@ def main():
         eng.timers = None
         eng.overlap = True
 
+    # ---- sustained leg (single rank): thousands of steps over hundreds of DISTINCT batches, flush inside - long enough for a
+    #      5-second utilisation sampler to see, and the steady state of a real epoch (the 20-step headline pays one flush per
+    #      20 steps; an epoch pays one per thousands) -------------------------------------------------------------------------
+    sustained = None
+    n_sus = args.sustained_steps if args.sustained_steps is not None else (2000 if args.config != "c5" else 120)
+    if world == 1 and n_sus > 0 and not args.train_only:
+        n_distinct = max(1, min(200 if args.config != "c5" else 30, n_sus))
+        Xs, ys = synth_batches(n_distinct * B, seed=4242, ids=args.ids)
+        Xsd, ysd = torch.from_numpy(Xs).to(device), torch.from_numpy(ys).to(device)
+        eng.timers = None
+        for i in range(3):
+            eng.train_step(Xsd[i * B:(i + 1) * B], ysd[i * B:(i + 1) * B])
+        eng.flush_lazy()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_sus):
+            j = i % n_distinct
+            eng.train_step(Xsd[j * B:(j + 1) * B], ysd[j * B:(j + 1) * B])
+        eng.flush_lazy()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        sustained = {"steps": n_sus, "distinct_batches": n_distinct, "ms_per_step": round(dt / n_sus * 1e3, 4),
+                     "samples_per_s": round(n_sus * B / dt, 1), "wall_s": round(dt, 2),
+                     "note": "same step as `value`, lazy flush inside the timed region, one rank"}
+        del Xsd, ysd
+
+    # ---- fit()-level leg: the public API as reference main.py drives it (dict of columns, verbose=1 with its per-step
+    #      binary_crossentropy + auc, shuffle=True), everything fit does per epoch included (upload, shuffle index_select,
+    #      device metrics, History) ------------------------------------------------------------------------------------------------
+    fit_leg = None
+    n_fit = args.fit_batches if args.fit_batches is not None else (200 if args.config != "c5" else 0)
+    if world == 1 and n_fit > 0 and not args.train_only:
+        try:
+            Xf, yf = synth_batches(n_fit * B, seed=777, ids=args.ids)
+            names = list(CFG["fields"]) + list(CFG["dense"])
+            xf = {f: (Xf[:, i].astype(np.int64) if i < len(CFG["fields"]) else Xf[:, i]) for i, f in enumerate(names)}
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hist = model.fit(x=xf, y=yf, batch_size=B, epochs=1, verbose=1, shuffle=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            fit_leg = {"rows": int(n_fit * B), "batch_size": B, "wall_s": round(dt, 3), "samples_per_s": round(n_fit * B / dt, 1),
+                       "epoch_loss": float(hist.history["loss"][-1]) if hist.history.get("loss") else None,
+                       "note": "model.fit(x=dict, y, batch_size, epochs=1, verbose=1, shuffle=True): host packing + upload of "
+                               "the epoch's rows, per-epoch shuffle, per-step train metrics (binary_crossentropy, auc), History"}
+            model.train()
+        except Exception as ex:
+            print(f"[bench] fit leg skipped: {ex}", file=sys.stderr)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -372,13 +435,18 @@ def main():
     total_rows = model.embedding_arena.shape[0]
     uniq = int(torch.unique(eng._ws[B]["rows"]).numel()) if B in eng._ws else 0
     fwd_flops = 2.0 * (4 * F * D * D + 4 * F * D * U + 2 * F * F * D) * B          # per layer launch (U = 2 D: 12 F D^2)
+    # which kernels a "layer_fwd" / "layer_bwd" phase of THIS configuration consists of: one fused kernel (+ its reduction
+    # launch) on the fused path; on the general path (configs[4], gate / bilinear) a phase is a chain of ~25 / ~45 launches
+    # of the gen_* families, so the phase's rate is a whole-layer rate and no single kernel's counters describe it
+    generic = bool(eng._ws.get(B, {}).get("generic"))
+    one_kernel = not generic
+    fwd_kernel = "layer_fwd_fused_kernel" if one_kernel else "general path, whole layer forward (~25 gen_* launches)"
+    bwd_kernel = eng.bwd_kernel_name() if one_kernel else "general path, whole layer backward (~45 gen_* launches)"
     per_launch = {
         "adam_untouched": dict(kernel="adam_untouched_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                                work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
-        "layer_bwd": dict(kernel=os.environ.get("SATRANS_BWD8", "0") == "1" and "layer_bwd8_kernel" or "layer_bwd_fused_kernel", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
-                          work=2.0 * fwd_flops / 1e12),
-        "layer_fwd": dict(kernel="layer_fwd_fused_kernel" if args.config != "c5" else "gen_gemm_kernel (general path: whole layer)", bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS,
-                          work=fwd_flops / 1e12),
+        "layer_bwd": dict(kernel=bwd_kernel, bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=2.0 * fwd_flops / 1e12),
+        "layer_fwd": dict(kernel=fwd_kernel, bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=fwd_flops / 1e12),
         "gather_fwd": dict(kernel="gather_rows_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                            work=B * F * (D * 4 + 4) / 1e9),                        # read bytes (only timed with SATRANS_FUSE_GATHER=0)
     }
@@ -417,19 +485,25 @@ def main():
 
     # HBM bytes per launch of that kernel from the PMC passes under profiles/ (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE
     # in separate passes of `bench.py --train-only`, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The
-    # summary records the sha256 of the library it profiled: a summary of another build is reported as stale, not as traffic.
-    if roofline:
+    # summary records the hash of the kernel SOURCES it profiled and the bench configuration: a summary of other sources or
+    # of another configuration is reported as such, never as this run's traffic; a phase made of many kernels has none.
+    if roofline and not one_kernel:
+        roofline["traffic_source"] = "none: the phase is a chain of launches (general path); see profiles/ for per-kernel stats"
+    elif roofline:
         try:
-            import hashlib
-            sha = hashlib.sha256(open(os.path.join(ROOT, "satrans_amd", "libsatrans_hip.so"), "rb").read()).hexdigest()
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            from satrans_amd import native as _native
+            sha = _native.source_hash()
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
             rec = next(v for k, v in pmc.items() if k.startswith(roofline["kernel"]))
-            if pmc.get("_lib_sha256") == sha:
-                roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
-                roofline["traffic_source"] = "profiles/r02_pmc_summary.json (rocprofv3 --pmc of this build, bytes per launch)"
+            if pmc.get("_source_sha256") != sha:
+                roofline["traffic_source"] = (f"stale: profiles/{PMC_SUMMARY} was taken on other kernel sources "
+                                              f"({str(pmc.get('_source_sha256'))[:12]} vs {sha[:12]})")
+            elif pmc.get("_config") != args.config or args.flag != CFG["flag"]:
+                roofline["traffic_source"] = f"none: profiles/{PMC_SUMMARY} is of config {pmc.get('_config')!r}, default flag"
             else:
-                roofline["traffic_source"] = ("stale: profiles/r02_pmc_summary.json was taken on another build "
-                                              f"({str(pmc.get('_lib_sha256'))[:12]} vs {sha[:12]})")
+                roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
+                roofline["traffic_source"] = (f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc of these kernel sources, bytes per "
+                                              f"launch: 2 x FETCH_SIZE + WRITE_SIZE)")
         except (OSError, StopIteration, KeyError):
             pass
 
@@ -521,21 +595,21 @@ def main():
         # bounded sample: the same step at a smaller batch where one CPU step of the full batch would take minutes (c5)
         Bc = B if args.config != "c5" else min(B, 512)
         timed_c = args.cpu_steps if args.config != "c5" else min(args.cpu_steps, 3)
-        Xc, yc = synth_batches(n_need * Bc, seed=7)
+        Xc, yc = synth_batches(n_need * Bc, seed=7, cfg=cpu_cfg)
         r = cpu_baseline(state_cpu, Xc, yc, Bc, args.lr, args.flag, timed=timed_c, timed_verbose=5 if args.config != "c5" else 2)
         cpu = {"value": round(r["value"], 1), "unit": "samples/s", "cores": r["threads"], "kind": "port",
                "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(),
                "value_verbose1": round(r["value_verbose1"], 1),
                "thread_sweep_s_per_step": r["sweep_s_per_step"],
                "sample": f"median of {r['timed']} training steps of B={Bc} after 2 untimed ones at the best thread count of a "
-                         f"one-step sweep (dropout on, dense L2 + dense torch Adam over all {model.embedding_arena.shape[0]:,} rows; `value` = verbose=0, "
+                         f"one-step sweep (dropout on, dense L2 + dense torch Adam over all {n_cpu_rows:,} rows; `value` = verbose=0, "
                          f"`value_verbose1` = median of {r['timed_verbose']} steps with the per-step sklearn log_loss + "
                          f"roc_auc_score of fit(verbose=1), what reference main.py runs); {time.time() - t_cpu:.0f}s wall"}
 
     value = world * B * K / elapsed
     out = {
         "metric": ("training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)" if args.config == "aliccp" else
-                   f"training samples/sec ({args.config}-shaped, emb={D}, {L}L/{CFG['H']}H, meta_mode=QK)") +
+                   f"training samples/sec ({args.config}-shaped{' SCALED tables' if CFG.get('scaled') else ''}, emb={D}, {L}L/{CFG['H']}H, meta_mode=QK)") +
                   ("" if args.flag == "sota" else f" flag={args.flag}"),
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -546,6 +620,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": D, "layers": L, "heads": CFG["H"],
                    "fields": F, "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
+        "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
+        "fit_samples_per_s": fit_leg["samples_per_s"] if fit_leg else None, "fit": fit_leg,
         "phase_sum_ms_per_step": round(phase_sum, 4), "phase_sum_frac_of_step": round(phase_sum / (elapsed / K * 1e3), 4),
         "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
         "forward_only": forward_only, "forward_only_bf16": forward_bf16, "cpu_baseline": cpu,

@@ -214,34 +214,45 @@ class BaseModel(nn.Module):
         else:
             eng.flush_lazy()
             raw = eng.optimizer_state()
-        out = {"step": int(raw["adam_t"]), "drop_step": int(raw["drop_step"]), "state": {}}
+        kind = raw.get("kind", "adam")
+        out = {"kind": kind, "step": int(raw["adam_t"]), "drop_step": int(raw["drop_step"]), "state": {}}
+        # torch's own state keys: Adam `exp_avg` / `exp_avg_sq`, Adagrad `sum`, RMSprop `square_avg`, plain SGD none
+        fields = {"adam": (("exp_avg", "adam_m", "flat_m"), ("exp_avg_sq", "adam_v", "flat_v")),
+                  "adagrad": (("sum", "acc_arena", "acc_flat"),), "rmsprop": (("square_avg", "acc_arena", "acc_flat"),),
+                  "sgd": ()}[kind]
         for name, (off, rows) in self._table_rows.items():
             out["state"][f"embedding_dict.{name}.weight"] = {
-                "exp_avg": raw["adam_m"][off:off + rows].detach().cpu().clone(),
-                "exp_avg_sq": raw["adam_v"][off:off + rows].detach().cpu().clone()}
+                key: raw[arena][off:off + rows].detach().cpu().clone() for key, arena, _ in fields}
         for name, p in self._trainable_flat().items():
             off, cnt = self._flat_slices[name]
-            out["state"][name] = {"exp_avg": raw["flat_m"][off:off + cnt].view(p.shape).detach().cpu().clone(),
-                                  "exp_avg_sq": raw["flat_v"][off:off + cnt].view(p.shape).detach().cpu().clone()}
+            out["state"][name] = {key: raw[flat][off:off + cnt].view(p.shape).detach().cpu().clone()
+                                  for key, _, flat in fields}
         return out
 
     def load_optimizer_state_dict(self, sd: dict) -> None:
-        """Inverse of `optimizer_state_dict` (call after `load_state_dict`, on the device the run continues on)."""
+        """Inverse of `optimizer_state_dict` (call after `load_state_dict` and `compile`, on the device the run continues on)."""
         if not sd:
             return
         dev = self.embedding_arena.device
-        raw = {"adam_t": int(sd["step"]), "drop_step": int(sd.get("drop_step", 0)),
-               "adam_m": torch.zeros_like(self.embedding_arena), "adam_v": torch.zeros_like(self.embedding_arena),
-               "flat_m": torch.zeros_like(self.flat_params), "flat_v": torch.zeros_like(self.flat_params)}
+        kind = sd.get("kind", "adam")
+        fields = {"adam": (("exp_avg", "adam_m", "flat_m"), ("exp_avg_sq", "adam_v", "flat_v")),
+                  "adagrad": (("sum", "acc_arena", "acc_flat"),), "rmsprop": (("square_avg", "acc_arena", "acc_flat"),),
+                  "sgd": (("", "acc_arena", "acc_flat"),)}[kind]
+        raw = {"kind": kind, "adam_t": int(sd["step"]), "drop_step": int(sd.get("drop_step", 0))}
+        for _, arena, flat in fields:
+            raw[arena] = torch.zeros_like(self.embedding_arena)
+            raw[flat] = torch.zeros_like(self.flat_params)
         for name, (off, rows) in self._table_rows.items():
             st = sd["state"][f"embedding_dict.{name}.weight"]
-            raw["adam_m"][off:off + rows] = st["exp_avg"].to(dev)
-            raw["adam_v"][off:off + rows] = st["exp_avg_sq"].to(dev)
+            for key, arena, _ in fields:
+                if key:
+                    raw[arena][off:off + rows] = st[key].to(dev)
         for name, p in self._trainable_flat().items():
             off, cnt = self._flat_slices[name]
             st = sd["state"][name]
-            raw["flat_m"][off:off + cnt] = st["exp_avg"].to(dev).reshape(-1)
-            raw["flat_v"][off:off + cnt] = st["exp_avg_sq"].to(dev).reshape(-1)
+            for key, _, flat in fields:
+                if key:
+                    raw[flat][off:off + cnt] = st[key].to(dev).reshape(-1)
         eng = getattr(self, "_engine", None)
         if eng is not None:
             eng.flush_lazy()

@@ -247,34 +247,39 @@ class PathEngine:
         n_s = B * self.F_small                       # sorted positions [0, n_s): small tables; [n_s, n_loc): large tables
         n_big = (n_loc - n_s) * world                # large-table positions of ALL ranks
         n_max = max(n_loc, n_big)
-        ws["dact"] = [torch.empty(B, F, D, **f32) for _ in range(2)]
-        ws["head_scratch"] = torch.empty(int(lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
-        desc = self._layer_desc(ws, 0, B, None, None, True)
-        if ws["generic"]:
-            n = int(lib.satrans_layer_generic_saved_floats(C.byref(desc)))
-            ws["gen_saved"] = ws["gen_saved"] + [torch.empty(n, **f32) for _ in range(self.L - 1)]
-            ws["gen_scratch"] = torch.empty(int(lib.satrans_layer_generic_scratch_floats(C.byref(desc))), **f32)
-            ws["slabs"] = torch.empty(1, **f32)
-        else:
-            ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
-        ws["sorted_rows"] = torch.empty(n_loc, **i32)           # this rank's rows, sorted, and their source positions
-        ws["src"] = torch.empty(n_loc, **i32)
-        if exchange:
+        if "dact" not in ws:                                    # independent of the rank count: allocated once
+            ws["dact"] = [torch.empty(B, F, D, **f32) for _ in range(2)]
+            ws["head_scratch"] = torch.empty(int(lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
+            desc = self._layer_desc(ws, 0, B, None, None, True)
+            if ws["generic"]:
+                n = int(lib.satrans_layer_generic_saved_floats(C.byref(desc)))
+                while len(ws["gen_saved"]) < self.L:            # one per layer
+                    ws["gen_saved"].append(torch.empty(n, **f32))
+                ws["gen_scratch"] = torch.empty(int(lib.satrans_layer_generic_scratch_floats(C.byref(desc))), **f32)
+                ws["slabs"] = torch.empty(1, **f32)
+            else:
+                ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
+            ws["sorted_rows"] = torch.empty(n_loc, **i32)       # this rank's rows, sorted, and their source positions
+            ws["src"] = torch.empty(n_loc, **i32)
+            ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
+            ws["reg_unused"] = torch.zeros(int(lib.satrans_embed_reg_partials(self.total_rows, max(n_s, 1), D)), **f64)
+            ws["reg_rows"] = torch.zeros(max(1, int(lib.satrans_embed_adam_rows_partials(max(self.small_rows, 1), D))), **f64)
+        if exchange and ws.get("_exch_n_big", -1) != n_big:
             ws["g_sorted"] = torch.empty(max(n_big, 1), **i32)  # every rank's large-table rows, sorted
             ws["g_src"] = torch.empty(max(n_big, 1), **i32)
             ws["packed"] = torch.empty(max(n_loc - n_s, 1), D, **f32)
-        ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
-        ws["iota"] = torch.arange(n_max, **i32)                 # positions for the (row, position) sorts, written once
-        ws["sort_ws"] = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n_max, self.total_rows)),
-                                    dtype=torch.uint8, device=dev)
-        ws["partial_ws"] = torch.empty(int(lib.satrans_embed_partial_ws_floats(n_max, D)), **f32)
-        # [untouched | touched-row kernels | replay of this rank's rows]: one fixed-order sum per step covers all three
-        n_reg = int(lib.satrans_embed_reg_partials(self.total_rows, n_max, D))
-        ws["reg_partials"] = torch.zeros(n_reg + (n_loc * D + 255) // 256, **f64)
-        ws["replay_reg"] = ws["reg_partials"][n_reg:]
-        ws["reg_unused"] = torch.zeros(int(lib.satrans_embed_reg_partials(self.total_rows, max(n_s, 1), D)), **f64)
-        ws["reg_rows"] = torch.zeros(max(1, int(lib.satrans_embed_adam_rows_partials(max(self.small_rows, 1), D))), **f64)
-        ws["replay_reg_g"] = torch.zeros((max(n_big, 1) * D + 255) // 256, **f64)
+            ws["replay_reg_g"] = torch.zeros((max(n_big, 1) * D + 255) // 256, **f64)
+            ws["_exch_n_big"] = n_big
+        if ws.get("_train_n_max", -1) != n_max:                 # sized by the longest (row, position) list of the step
+            ws["iota"] = torch.arange(n_max, **i32)             # positions for the (row, position) sorts, written once
+            ws["sort_ws"] = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n_max, self.total_rows)),
+                                        dtype=torch.uint8, device=dev)
+            ws["partial_ws"] = torch.empty(int(lib.satrans_embed_partial_ws_floats(n_max, D)), **f32)
+            # [untouched | touched-row kernels | replay of this rank's rows]: one fixed-order sum per step covers all three
+            n_reg = int(lib.satrans_embed_reg_partials(self.total_rows, n_max, D))
+            ws["reg_partials"] = torch.zeros(n_reg + (n_loc * D + 255) // 256, **f64)
+            ws["replay_reg"] = ws["reg_partials"][n_reg:]
+            ws["_train_n_max"] = n_max
         ws[key] = True
         return ws
 
@@ -360,7 +365,10 @@ class PathEngine:
         d.x_rows = None
         if fuse and l == 0:
             # gather fused into the first layer: token (b, f) is read straight from the embedding arena through the row
-            # numbers the rows-only gather launch left in ws["rows"]; [B,F,D] is never written nor read back
+            # numbers the rows-only gather launch left in ws["rows"]; [B,F,D] is never written nor read back.
+            # (An out-of-range id - an IndexError in the reference - is recorded as the first row of the field's table and
+            # flagged in `status`; the fused layer reads that row where the standalone gather writes zeros.  Either way the
+            # batch is invalid and raise_if_bad_ids() raises before any result is handed to the caller.)
             d.x, d.x_rows = self.m.embedding_arena.data_ptr(), ws["rows"].data_ptr()
         d.sid, d.order, d.seg = ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr()
         d.w_query, d.w_key, d.w_value = lay.W_Query.data_ptr(), lay.W_Key.data_ptr(), lay.W_Value.data_ptr()
@@ -378,6 +386,10 @@ class PathEngine:
             d.tab_q = d.tab_k = ws["sid"].data_ptr()
             d.tab_stride = 2 * self.D * self.U
         return d
+
+    def bwd_kernel_name(self) -> str:
+        """Name of the fused backward kernel this process launches (profiles and bench.py's roofline line match on it)."""
+        return "layer_bwd8_kernel" if os.environ.get("SATRANS_BWD8", "0") == "1" else "layer_bwd_fused_kernel"
 
     def _layer_tables(self, tabs, l):
         if self.pos:
@@ -428,6 +440,7 @@ class PathEngine:
                                                None if fuse else ws["acts"][0].data_ptr(), ws["rows"].data_ptr(),
                                                self.status.data_ptr(), st), "satrans_gather_fwd")
         self._last_X = X
+        self._stepped_since_forward = False
         for l in range(self.L):
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse)
             att = att_list[l].data_ptr() if att_list is not None else None
@@ -497,6 +510,12 @@ class PathEngine:
         gather fused into the first layer `att_input` was never materialised: the standalone gather kernel writes it now."""
         ws = self._ws[B]
         if ws.get("acts0_of") is None:
+            if getattr(self, "_stepped_since_forward", False):
+                # the gather was fused into layer 0 and the optimizer has since moved the rows it read: a re-gather would
+                # NOT be the input that forward saw
+                raise RuntimeError("layer_outputs() after train_step(): att_input was never materialised (gather fused into "
+                                   "the first layer) and the tables have been updated since; call forward() / "
+                                   "loss_and_grads() first, or set SATRANS_FUSE_GATHER=0")
             X = self._last_X
             N.check(self.lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
                                                 self.cols.data_ptr(), X.data_ptr(), N.id_dtype_of(X), X.stride(0), B, self.F,
@@ -513,6 +532,9 @@ class PathEngine:
     # ------------------------------------------------------------------------------------------------
     # training
     # ------------------------------------------------------------------------------------------------
+    def _opt_kind(self) -> str:
+        return (getattr(self.m, "_adam_cfg", None) or {}).get("kind", "adam")
+
     def _ensure_train_state(self):
         m = self.m
         if self.flat_g is None:
@@ -523,36 +545,59 @@ class PathEngine:
             self.g_small = self.flat_g[n_flat:n_flat + self.small_rows * self.D].view(self.small_rows, self.D)
             self.g_exchange = self.flat_g[:n_flat + self.small_rows * self.D]      # what data-parallel ranks all-reduce
             self._g_tabs_flat = self.flat_g[n_flat + self.small_rows * self.D:]    # gradient of the generated-weight table
-            self.flat_m = torch.zeros_like(m.flat_params)
-            self.flat_v = torch.zeros_like(m.flat_params)
-            self.adam_m = torch.zeros_like(m.embedding_arena)
-            self.adam_v = torch.zeros_like(m.embedding_arena)
-            self.last_step = torch.zeros(self.total_rows, dtype=torch.int32, device=self.dev)
-            self._flush_reg = torch.zeros(4096, dtype=torch.float64, device=self.dev)
             # expose gradients the torch way: param.grad is a view into the flat gradient buffer
             for name, p in m._trainable_flat().items():
                 off, cnt = m._flat_slices[name]
                 p.grad = self.flat_g[off:off + cnt].view(p.shape)
+        # optimizer state of the kind compile() chose: Adam's two moment arenas (+ the lazy form's per-row step), or ONE
+        # accumulator arena for Adagrad (`sum`) / RMSprop (`square_avg`); plain SGD keeps none.  Allocated on first use of
+        # that kind only: at configs[4] an arena is 25.6 GB.
+        if self._opt_kind() == "adam":
+            if self.adam_m is None:
+                self.flat_m = torch.zeros_like(m.flat_params)
+                self.flat_v = torch.zeros_like(m.flat_params)
+                self.adam_m = torch.zeros_like(m.embedding_arena)
+                self.adam_v = torch.zeros_like(m.embedding_arena)
+                self.last_step = torch.zeros(self.total_rows, dtype=torch.int32, device=self.dev)
+                self._flush_reg = torch.zeros(4096, dtype=torch.float64, device=self.dev)
+        elif getattr(self, "_g_arena", None) is None:
+            self._g_arena = torch.empty_like(m.embedding_arena)
+            self._opt_state_arena = torch.zeros_like(m.embedding_arena)
+            self._opt_state_flat = torch.zeros_like(m.flat_params)
 
     def _grad_view(self, name: str) -> torch.Tensor:
         off, cnt = self.m._flat_slices[name]
         return self.flat_g[off:off + cnt]
 
     def optimizer_state(self) -> dict:
-        """Everything a new engine needs to continue this run (call flush_lazy() first: every row is then at adam_t)."""
+        """Everything a new engine needs to continue this run (call flush_lazy() first: every row is then at adam_t).
+        `kind` names the optimizer the state belongs to: "adam" carries the two moment arenas, "adagrad" / "rmsprop" their
+        one accumulator (`acc_arena`, `acc_flat`), "sgd" only the step counters."""
         self._ensure_train_state()
-        return dict(adam_t=self.adam_t, drop_step=self.drop_step, adam_m=self.adam_m, adam_v=self.adam_v,
-                    flat_m=self.flat_m, flat_v=self.flat_v)
+        kind = self._opt_kind()
+        st = dict(kind=kind, adam_t=self.adam_t, drop_step=self.drop_step)
+        if kind == "adam":
+            st.update(adam_m=self.adam_m, adam_v=self.adam_v, flat_m=self.flat_m, flat_v=self.flat_v)
+        else:
+            st.update(acc_arena=self._opt_state_arena, acc_flat=self._opt_state_flat)
+        return st
 
     def load_optimizer_state(self, st: dict) -> None:
+        kind = st.get("kind", "adam")
+        if kind != self._opt_kind():
+            raise ValueError(f"optimizer state of kind {kind!r} loaded into a model compiled with {self._opt_kind()!r}")
         self._ensure_train_state()
         self.adam_t = int(st["adam_t"])
         self.drop_step = int(st["drop_step"])
-        self.adam_m.copy_(st["adam_m"].to(self.dev))
-        self.adam_v.copy_(st["adam_v"].to(self.dev))
-        self.flat_m.copy_(st["flat_m"].to(self.dev))
-        self.flat_v.copy_(st["flat_v"].to(self.dev))
-        self.last_step.fill_(self.adam_t)            # the state was taken after a flush: every row is current
+        if kind == "adam":
+            self.adam_m.copy_(st["adam_m"].to(self.dev))
+            self.adam_v.copy_(st["adam_v"].to(self.dev))
+            self.flat_m.copy_(st["flat_m"].to(self.dev))
+            self.flat_v.copy_(st["flat_v"].to(self.dev))
+            self.last_step.fill_(self.adam_t)            # the state was taken after a flush: every row is current
+        else:
+            self._opt_state_arena.copy_(st["acc_arena"].to(self.dev))
+            self._opt_state_flat.copy_(st["acc_flat"].to(self.dev))
         self._lazy_pending = False
 
     def reset_epoch_sums(self):
@@ -657,9 +702,11 @@ class PathEngine:
         l2 = m.l2_reg_embedding
         arena, am, av = m.embedding_arena.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
 
-        def sort(rows, n, out_rows, out_src, touched):
-            if self._sort_fields is not None and touched is None and n == B * self.F and B <= 8192:
-                f_, lo_, n_ = self._sort_fields       # this batch's [B, F] rows: one workgroup per field, one launch
+        def sort(rows, n, out_rows, out_src, touched, per_field=False):
+            # per_field: `rows` is THIS batch's [B, F] row matrix (column f inside field f's table) - the only input the
+            # one-workgroup-per-field kernel may see; the rank-major concatenation of the exchange is not one
+            if per_field and self._sort_fields is not None and touched is None and n == B * self.F and B <= 8192:
+                f_, lo_, n_ = self._sort_fields       # one workgroup per field, one launch
                 N.check(lib.satrans_embed_sort_fields(rows.data_ptr(), B, self.F, f_, lo_, n_, out_rows.data_ptr(),
                                                       out_src.data_ptr(), self._stream()), "satrans_embed_sort_fields")
                 return
@@ -683,7 +730,7 @@ class PathEngine:
                                        N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
                                        self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
         with self.phase("embed_sort"):
-            sort(ws["rows"], n_loc, ws["sorted_rows"], ws["src"], None)
+            sort(ws["rows"], n_loc, ws["sorted_rows"], ws["src"], None, per_field=True)
         self.adam_t += 1
         h_emb = self._hparams(l2)
         # ---- 2. lazy form: replay the postponed steps of exactly these rows up to t-1, so that the gather reads current
@@ -779,6 +826,7 @@ class PathEngine:
                         "satrans_embed_adam_touched")
         if self.lazy:
             self._lazy_pending = True
+        self._stepped_since_forward = True
         h_flat = self._hparams(0.0)
         with self.phase("adam_flat"):
             self._flat_step(h_flat, ws, st)
@@ -802,10 +850,6 @@ class PathEngine:
         N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
                                        ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
                                        ws["iota"].data_ptr(), st), "satrans_embed_sort")
-        if getattr(self, "_g_arena", None) is None:
-            self._g_arena = torch.empty_like(m.embedding_arena)
-            self._opt_state_arena = torch.zeros_like(m.embedding_arena)
-            self._opt_state_flat = torch.zeros_like(m.flat_params)
         self._g_arena.zero_()
         N.check(lib.satrans_embed_grad_dense(m.embedding_arena.data_ptr(), ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(),
                                              n_rows, gemb.data_ptr(), self.total_rows, D, l2, self._g_arena.data_ptr(), st),

@@ -61,7 +61,7 @@ class AdamHParams(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("l2", C.c_float)]
 
 
-# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+# name -> (restype, argtypes); tests/test_host_cpu.py::test_library_exports_every_declared_symbol checks this table against the header
 SIGNATURES = {
     "satrans_last_error": (C.c_char_p, []),
     "satrans_abi_version": (C.c_int, []),
@@ -153,6 +153,21 @@ def build(force: bool = False) -> str:
             os.remove(os.path.join(_HERE, "csrc", "build", f))
     subprocess.run(["bash", script], check=True)
     return LIB_PATH
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, csrc/*.h, include/*.h; names and bytes, sorted).
+    Profiles under profiles/ record it, so a counter summary can be matched to the code it was taken on - the hash of the
+    .so would differ between two builds of identical sources."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".hip", ".h"))]
+    files += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    for path in sorted(files, key=os.path.basename):
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
 
 
 def lib() -> C.CDLL:

@@ -1,6 +1,6 @@
 """Helper process of tests/test_gpu_parity.py::test_rccl_single_rank_exchange_is_bitwise_the_local_step.
 
-    python tests/rccl_one_rank.py nccl|plain <case> <steps> <out.pt>
+    python tests/rccl_one_rank.py nccl|plain <case> <steps> <out.pt> <port> [small_table_rows]
 
 `nccl`: initialises a ONE-rank process group on the nccl backend (= RCCL) BEFORE anything touches the GPU, sets
 SATRANS_FORCE_EXCHANGE=1 so that the training step runs its multi-rank branch, and trains `steps` steps (dropout on).
@@ -16,7 +16,9 @@ sys.path.insert(0, ROOT)
 def main():
     mode, name, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     os.environ["SATRANS_SPLIT_TABLES"] = "1"
-    os.environ["SATRANS_SMALL_TABLE_ROWS"] = "20"          # golden tables: some small, some large
+    # 20: some golden tables small, some large; 0: every table "large", so the rank-major list of the exchange has exactly
+    # B * F entries - the length of this rank's own [B, F] row matrix (it must NOT take the per-field sort)
+    os.environ["SATRANS_SMALL_TABLE_ROWS"] = sys.argv[6] if len(sys.argv) > 6 else "20"
     import torch
     import torch.distributed as dist
     if mode == "nccl":

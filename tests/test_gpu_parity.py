@@ -156,15 +156,18 @@ def test_adam_trajectory_step_by_step_against_the_oracle(name):
             assert float(delta.max()) <= 2.0 * lr + 1e-6, (step, k)
 
 
-def test_optimizer_state_survives_a_device_move_and_a_resume():
-    """`.to()` in the middle of training keeps the Adam state (torch.optim.Adam's state follows its parameters), and
-    optimizer_state_dict()/load_optimizer_state_dict() resume a run: both continue bit for bit like an uninterrupted run."""
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "rmsprop", "sgd"])
+def test_optimizer_state_survives_a_device_move_and_a_resume(opt):
+    """`.to()` in the middle of training keeps the optimizer state (torch's optimizer state follows its parameters), and
+    optimizer_state_dict()/load_optimizer_state_dict() resume a run: both continue bit for bit like an uninterrupted run.
+    Adam's moments, Adagrad's `sum` and RMSprop's `square_avg` alike (the accumulators of the non-Adam
+    optimizers used to be dropped)."""
     c = Case("small_qkv")
     X, y = c.X.to(DEV), c.y.to(DEV)
 
     def fresh():
         m = build_model(c, DEV)
-        m.compile(torch.optim.Adam(m.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        m.compile(torch.optim.Adam(m.parameters(), lr=c.meta["lr"]) if opt == "adam" else opt, "binary_crossentropy")
         m.train()
         return m
 
@@ -187,10 +190,15 @@ def test_optimizer_state_survives_a_device_move_and_a_resume():
     first = fresh()
     for _ in range(2):
         first._require_engine().train_step(X, y)
-    params, opt = sd_to_cpu(first), first.optimizer_state_dict()
+    params, opt_sd = sd_to_cpu(first), first.optimizer_state_dict()
+    assert opt_sd["kind"] == opt and opt_sd["step"] == 2
+    key = {"adam": "exp_avg_sq", "adagrad": "sum", "rmsprop": "square_avg", "sgd": None}[opt]
+    if key is not None:                         # the accumulators are really there (not a zero-filled stand-in)
+        assert float(opt_sd["state"]["dnn_linear.weight"][key].abs().max()) > 0
+        assert any(float(v[key].abs().max()) > 0 for k, v in opt_sd["state"].items() if k.startswith("embedding_dict."))
     resumed = fresh()
     resumed.load_state_dict(params)
-    resumed.load_optimizer_state_dict(opt)
+    resumed.load_optimizer_state_dict(opt_sd)
     for _ in range(2):
         resumed._require_engine().train_step(X, y)
     got = sd_to_cpu(resumed)
@@ -848,6 +856,85 @@ def test_public_api_on_full_size_aliccp_tables_against_the_oracle():
     assert float(moved.median()) > 1e-4
 
 
+def test_teacher_forced_step_at_the_baseline_batch_on_full_size_tables():
+    """The optimizer at BASELINE configs[1] scale, pinned tightly: full-size tables (6,571,961 rows),
+    B = 8,192.  Two free-running GPU steps first (so that the moments are non-trivial and the lazy form has postponed steps
+    in flight), then the oracle - torch.optim.Adam over EVERY row with the dense L2 term, reference main.py:343 +
+    meta_basemodel.py:577-593 - takes over the GPU's parameters and both moments bit for bit and both take ONE step on a
+    fresh batch.  Moments element by element at 1e-4 / 2e-4 of the tensor's largest element, for gathered and for
+    not-gathered rows of every table separately (the latter move by the regulariser-only gradient 2 l2 p: they are what the
+    lazy replay / flush produces); parameters wherever Adam's quotient is well-conditioned."""
+    import bench
+    B, lr = 8192, 0.005
+    X, y = bench.synth_batches(3 * B, 23)
+    model = bench.build_model("cpu", lr)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    by_ptr = {}
+    for k, v in model.state_dict().items():                      # keep the reference's aliasing
+        state[k] = by_ptr.setdefault(v.data_ptr(), state[k])
+    model.to(DEV)
+    model.device = DEV
+    model.eval()                                                 # dropout off: the oracle replays no masks here
+    eng = model._require_engine()
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    for i in range(2):
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    assert eng.lazy and eng._lazy_pending
+    sd, opt = sd_to_cpu(model), model.optimizer_state_dict()     # (flushes the postponed steps)
+    assert opt["step"] == 2
+    tr = O.OracleTrainer(state, bench.oracle_spec(), lr=lr)
+    for k, leaf in tr.leaves.items():
+        leaf.data.copy_(sd[k])
+        st = opt["state"].get(k)
+        if st is not None:
+            tr.optim.state[leaf] = dict(step=torch.tensor(2.0), exp_avg=st["exp_avg"].clone(), exp_avg_sq=st["exp_avg_sq"].clone())
+    before = {k: leaf.detach().clone() for k, leaf in tr.leaves.items()}
+    bce_ref, reg_ref = tr.step(torch.from_numpy(X[2 * B:]), torch.from_numpy(y[2 * B:]))
+    eng.reset_epoch_sums()
+    eng.train_step(Xd[2 * B:], yd[2 * B:])
+    bce, reg = eng.epoch_sums()
+    assert bce == pytest.approx(bce_ref, rel=2e-6)
+    assert reg == pytest.approx(reg_ref, rel=2e-5)
+    got, gopt = sd_to_cpu(model), model.optimizer_state_dict()
+    assert gopt["step"] == 3
+    Xl = torch.from_numpy(X[2 * B:]).long()
+    checked_tables = 0
+    for k, leaf in tr.leaves.items():
+        if leaf not in tr.optim.state or k not in gopt["state"]:
+            continue
+        ref_m, ref_v = tr.optim.state[leaf]["exp_avg"], tr.optim.state[leaf]["exp_avg_sq"]
+        if float(ref_m.abs().max()) < 1e-8:
+            continue
+        m, v = gopt["state"][k]["exp_avg"], gopt["state"][k]["exp_avg_sq"]
+        groups = [("all", slice(None))]
+        if k.startswith("embedding_dict."):
+            col = bench.ALICCP_FIELDS.index(k.split(".")[1])
+            hit = torch.zeros(leaf.shape[0], dtype=torch.bool)
+            hit[Xl[:, col]] = True
+            groups = [("gathered", hit), ("not gathered", ~hit)]
+            checked_tables += 1
+        for what, sel in groups:
+            rm, rv, gm, gv = ref_m[sel], ref_v[sel], m[sel], v[sel]
+            if rm.numel() == 0:
+                continue
+            np.testing.assert_allclose(gm.numpy(), rm.numpy(), rtol=1e-5, atol=1e-4 * float(rm.abs().max()) + 1e-30,
+                                       err_msg=f"exp_avg/{k} ({what} rows)")
+            np.testing.assert_allclose(gv.numpy(), rv.numpy(), rtol=1e-5, atol=2e-4 * float(rv.abs().max()) + 1e-30,
+                                       err_msg=f"exp_avg_sq/{k} ({what} rows)")
+            delta = (got[k][sel] - leaf.detach()[sel]).abs()
+            vhat = rv / (1 - 0.999 ** 3)
+            ok = vhat.sqrt() > 1e-4 * max(float(vhat.sqrt().max()), 1e-30)
+            if bool(ok.any()):
+                assert float(delta[ok].max()) <= 2e-2 * lr, (k, what, float(delta[ok].max()))
+            assert float(delta.max()) <= 2.0 * lr + 1e-6, (k, what)
+            if what == "not gathered":
+                # regulariser-only step: the row moved, and it moved like the oracle's dense step moved it
+                moved_ref = (leaf.detach()[sel] - before[k][sel]).abs()
+                assert float(moved_ref.median()) > 0
+                assert float(delta.median()) <= 1e-3 * float(moved_ref.median()), (k, float(delta.median()))
+    assert checked_tables == len(bench.ALICCP_FIELDS)
+
+
 def test_lazy_adam_is_bitwise_the_streaming_adam():
     """The lazy-exact optimizer path (postponed regulariser-only steps, replayed before a row is gathered and by the
     flush) must leave EXACTLY the tables, moments and epoch sums of the every-step streaming kernel."""
@@ -1052,12 +1139,14 @@ def test_regulariser_sum_of_tiny_batches(monkeypatch, B):
     assert sums["1"][1] == pytest.approx(sums["0"][1], rel=1e-9)
 
 
-def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path):
+@pytest.mark.parametrize("small_rows", ["20", "0"])
+def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path, small_rows):
     """RCCL for real on a one-GPU box: a ONE-rank nccl process group, created before anything touches the GPU, with the
     training step forced through its multi-rank branch (SATRANS_FORCE_EXCHANGE=1): device-pointer int32 all-gather of the
     row ids, SUM all-reduce of the flat gradient, asynchronous fp32 all-gather of the gradient rows + wait(), global sort.
     With one rank every collective is an identity, so the result must equal the local step with the same table classes
-    bit for bit - parameters, tables and both Adam moments."""
+    bit for bit - parameters, tables and both Adam moments.  small_rows = 0 makes every table a large one: the exchanged list
+    is then as long as the rank's own [B, F] row matrix and must still go through the device-wide sort."""
     import socket
     import subprocess
     import sys
@@ -1070,7 +1159,7 @@ def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path):
         out = str(tmp_path / f"{mode}.pt")
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("SATRANS_FORCE_EXCHANGE", None)
-        r = subprocess.run([sys.executable, script, mode, "aliccp_sota", "3", out, str(port)], env=env,
+        r = subprocess.run([sys.executable, script, mode, "aliccp_sota", "3", out, str(port), small_rows], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-4000:]
         outs[mode] = torch.load(out)
@@ -1215,7 +1304,7 @@ def test_ragged_batches_gradients_match_the_oracle(name, B):
         np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9, err_msg=k)
 
 
-def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21):
+def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=False):
     from satrans_amd import SATrans, SparseFeat
     rng = np.random.RandomState(D + F)
     fields = [f"f{i}" for i in range(F)]
@@ -1223,7 +1312,7 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21):
     vocab[fields[0]] = 4                                   # the scenario column: ids 1..3
     cols = [SparseFeat(f, vocabulary_size=vocab[f] + 1, embedding_dim=D) for f in fields]
     torch.manual_seed(3)
-    model = SATrans(cols, cols, [fields[0]], [3], att_layer_num=0, domain_att_layer_num=2, att_head_num=H, use_linear=False,
+    model = SATrans(cols, cols, [fields[0]], [3], att_layer_num=0, domain_att_layer_num=L, att_head_num=H, use_linear=False,
                     use_dnn=False, meta_mode='QK', meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag='sota')
     with torch.no_grad():                                  # weights far enough from zero for every gradient to matter
         for k, p in model.named_parameters():
@@ -1236,19 +1325,20 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21):
     X = np.stack([rng.randint(1 if f == fields[0] else 0, vocab[f], size=B) for f in fields], axis=1).astype(np.float32)
     y = (rng.rand(B) < 0.4).astype(np.float32)
     spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(fields)], dense=[], domain_cols=[0], embedding_dim=D, head_num=H,
-                      layer_num=2, flag='sota', meta_mode='QK', meta_units=[D, U, D])
+                      layer_num=L, flag='sota', meta_mode='QK', meta_units=[D, U, D])
     Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    Xg = Xt.long() if int_ids else Xt                     # the id matrix as the kernels get it (int64: SATRANS_ID_I64)
     model.to(DEV); model.device = DEV
     model.compile("adam", "binary_crossentropy")
     for train in (False, True):
         model.train(train)
         eng = model._require_engine()
-        bce, reg, grads = eng.loss_and_grads(Xt.to(DEV), yt.to(DEV))
+        bce, reg, grads = eng.loss_and_grads(Xg.to(DEV), yt.to(DEV))
         assert bool(eng._ws[B]["generic"]) == generic, "unexpected layer path"
-        drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, F, D, H, 2, 0.1)) if train else None
+        drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, F, D, H, L, 0.1)) if train else None
         bce_ref, reg_ref, g_ref = O.loss_and_grads(state, Xt, yt, spec, drop)
         if not train:
-            model(Xt.to(DEV))
+            model(Xg.to(DEV))
             _, logit_ref = O.forward(state, Xt, spec)
             np.testing.assert_allclose(eng.last_logit().cpu().numpy().reshape(-1), logit_ref.numpy().reshape(-1), rtol=0,
                                        atol=2e-5 * max(1.0, float(logit_ref.abs().max())))
@@ -1268,6 +1358,61 @@ def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U
     logits and every gradient, evaluation mode and training mode with replayed dropout masks, on a ragged batch."""
     monkeypatch.setenv("SATRANS_GENERIC", "1")             # (small batches of these shapes would otherwise go to the LDS kernels)
     _synthetic_shape_against_oracle(D, H, U, F, generic=True)
+
+
+def test_configs4_shape_against_the_oracle():
+    """BASELINE configs[4] at ITS shape - 64 fields, embedding_dim 64, MetaNet hidden 128, 4 heads, 6 layers, int64 ids - on a
+    batch the CPU oracle finishes in seconds (B = 256): logits and every gradient, evaluation mode and training mode with the
+    kernels' dropout masks replayed through the oracle (the general path picks itself at this shape)."""
+    _synthetic_shape_against_oracle(64, 4, 128, 64, generic=True, B=256, L=6, int_ids=True)
+
+
+def test_size_independent_properties_at_the_configs4_batch():
+    """configs[4] shape at the full batch (8192 samples x 64 int64 fields, D = 64, 6 layers; tables scaled to 2 M rows - their
+    size plays no part in these properties), where the oracle is too slow to be the checker - the twin of
+    test_size_independent_properties_at_the_baseline_batch on the general path: the gather is a copy, a sample's output does
+    not depend on its batch-mates, and two training runs from one seed leave identical bits everywhere."""
+    import bench
+    cfg = bench.make_config("c5", 2_000_000)
+    B = 8192
+    X, y = bench.synth_batches(2 * B, 13, cfg=cfg)
+    assert X.dtype == np.int64
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+
+    def fresh():
+        m = bench.build_model("cpu", cfg["lr"], cfg=cfg)
+        m.to(DEV)
+        m.device = DEV
+        return m
+
+    m1 = fresh()
+    m1.eval()
+    eng = m1._require_engine()
+    p = m1(Xd[:B])
+    assert eng._ws[B]["generic"], "configs[4] runs on the general path"
+    rows = Xd[:B] + eng.row_span[:, 0][None, :]
+    assert torch.equal(eng.layer_outputs(B)[0], m1.embedding_arena[rows])
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    assert torch.equal(m1(Xd[:B][perm]), p[perm]), "a sample's output depends on the order of the batch"
+    assert torch.equal(m1(Xd[:1000]), p[:1000]), "a sample's output depends on the batch size"
+    assert bool(torch.isfinite(p).all()) and float(p.min()) > 0 and float(p.max()) < 1
+
+    def train(m):
+        m.train()
+        e = m._require_engine()
+        for i in range(2):
+            e.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        return sd, float(e.epoch_sums()[0])
+
+    sd1, loss1 = train(m1)
+    del m1, eng
+    torch.cuda.empty_cache()
+    m2 = fresh()
+    sd2, loss2 = train(m2)
+    assert loss1 == loss2
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), f"run-to-run difference in {k}"
 
 
 @pytest.mark.parametrize("F,B", [(3, 50), (7, 21), (13, 64), (20, 21), (25, 33), (32, 21)])

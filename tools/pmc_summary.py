@@ -21,10 +21,12 @@ out = {}
 for k, cs in acc.items():
     out[k] = {c: a[0] / a[1] for c, a in cs.items()}
     out[k]["launches"] = max(a[1] for a in cs.values())
-import hashlib
-lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "satrans_amd", "libsatrans_hip.so")
-sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
-keep = [k for k in out if "layer_" in k or "gather_rows" in k or "lazy_" in k or "touched" in k or "head_kernel" in k]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from satrans_amd import native  # noqa: E402
+keep = [k for k in out if "layer_" in k or "gather_rows" in k or "lazy_" in k or "touched" in k or "head_kernel" in k
+        or k.startswith("gen_")]
 res = {k: out[k] for k in sorted(keep)}
-res["_lib_sha256"] = sha
+# provenance: the hash of the kernel SOURCES (two builds of the same sources give different .so bytes) and the bench config
+res["_source_sha256"] = native.source_hash()
+res["_config"] = sys.argv[2] if len(sys.argv) > 2 else "aliccp"
 print(json.dumps(res, indent=1))
