@@ -391,15 +391,23 @@ def main():
         eng.flush_lazy()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        sus_timers = {}
         for i in range(n_sus):
             j = i % n_distinct
+            eng.timers = sus_timers if (i % 50 == 49 and not args.no_phase_timing) else None   # a phase sample every 50th step
             eng.train_step(Xsd[j * B:(j + 1) * B], ysd[j * B:(j + 1) * B])
+        eng.timers = sus_timers if not args.no_phase_timing else None
         eng.flush_lazy()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        sus_ph = eng.phase_ms() if eng.timers is not None else {}
+        eng.timers = None
         sustained = {"steps": n_sus, "distinct_batches": n_distinct, "ms_per_step": round(dt / n_sus * 1e3, 4),
                      "samples_per_s": round(n_sus * B / dt, 1), "wall_s": round(dt, 2),
-                     "note": "same step as `value`, lazy flush inside the timed region, one rank"}
+                     "phase_ms_per_launch": {k: round(v, 4) for k, v in sus_ph.items()},
+                     "note": "same step as `value`, lazy flush inside the timed region, one rank; phases sampled every 50th step "
+                             "(a row's postponed optimizer steps are replayed when it is next gathered: the replay chains are "
+                             "longer here than in the 20-step headline)"}
         del Xsd, ysd
 
     # ---- fit()-level leg: the public API as reference main.py drives it (dict of columns, verbose=1 with its per-step

@@ -154,11 +154,6 @@ typedef struct satrans_layer_desc {
  * 2 = LDS-resident kernels with MFMA products. */
 int satrans_set_layer_impl(int impl);
 
-/* Which fused backward kernel satrans_layer_bwd uses where both are built ((D,U,H) = (32,64,4) or (16,32,2), F <= 32):
- * 0 = the 4-wave kernel (one wave per SIMD, a full copy of the weight-gradient accumulators per wave; the default),
- * 1 = the 8-wave kernel of csrc/layer_bwd8.hip (two waves per SIMD, split accumulators, recomputed softmax backward),
- * -1 = back to the initial value (SATRANS_BWD8 in the environment, else 0).  Same results to rounding, same slab layout. */
-int satrans_set_layer_bwd8(int on);
 
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);

@@ -415,10 +415,15 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
     if (!idle) {
-        stage_image(a.w_query, wq, D, D, LD, false);
-        stage_image(a.w_key, wk, D, D, LD, false);
-        stage_image(a.w_value, wv, D, D, LD, false);
-        stage_image(a.w_out, woT, D, D, LD, true);
+        // (without transposed copies the images are swizzled: by-columns AND by-rows reads conflict-free, layer_fused_common.h)
+        auto stage_w = [&](const float* g_, float* s_, int R_, int C_, int ld_, bool tr_) {
+            if constexpr (TR) stage_image(g_, s_, R_, C_, ld_, tr_);
+            else stage_image_sw(g_, s_, R_, C_, ld_, tr_);
+        };
+        stage_w(a.w_query, wq, D, D, LD, false);
+        stage_w(a.w_key, wk, D, D, LD, false);
+        stage_w(a.w_value, wv, D, D, LD, false);
+        stage_w(a.w_out, woT, D, D, LD, true);
         if constexpr (TR) {
             stage_image(a.w_query, wqT, D, D, LD, true);
             stage_image(a.w_key, wkT, D, D, LD, true);
@@ -436,8 +441,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     }
     __syncthreads();
 
-    const int lo_d = g4 * LD + n, lo_u = g4 * LU + n;          // per-lane offset into an image: row 4g, column n
-    const int lt_d = n * LD + g4, lt_u = n * LU + g4;          // ... for a read by rows (chain_t): row n, column 4g
+    // per-lane offsets into an image: by columns (chain: row 4g + r, column n) and by rows (chain_t: row n, column 4g); the
+    // swizzle of the non-TR images flips one address bit per lane group / per row
+    const int fl_g = (!TR && (g == 1 || g == 2)) ? 4 : 0, fl_n = (!TR && n >= 4 && n < 12) ? 1 : 0;
+    const int lo_d = g4 * LD + (n ^ fl_g), lo_u = g4 * LU + (n ^ fl_g);
+    const int lt_d = n * LD + 4 * (g ^ fl_n), lt_u = n * LU + 4 * (g ^ fl_n);
     // (sample, head, row) of this thread's attention task - the same in every tile and every attention phase
     const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
@@ -466,10 +474,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     float* my_v = sv + (size_t)(row0 + n) * LD + g4;
     float* my_o = so + (size_t)(row0 + n) * LD + g4;
     float* my_g = sg + (size_t)(row0 + n) * LD + g4;
-    const float* wg_q = sq + (size_t)(row0 + g) * LD + n;   // token-contraction access (one float per step)
-    const float* wg_v = sv + (size_t)(row0 + g) * LD + n;
-    const float* wg_o = so + (size_t)(row0 + g) * LD + n;
-    const float* wg_g = sg + (size_t)(row0 + g) * LD + n;
+    const float* wg_q = sq + (size_t)(row0 + g4) * LD + n;   // token-contraction access: lane group g reads rows 4g + ks
+    const float* wg_v = sv + (size_t)(row0 + g4) * LD + n;
+    const float* wg_o = so + (size_t)(row0 + g4) * LD + n;
+    const float* wg_g = sg + (size_t)(row0 + g4) * LD + n;
 
     // output: [G][CSZ] scenario-independent part, then [G + S][TSZ] generated-weight records (record index =
     // workgroup + scenario: strictly increasing along the global tile list, hence unique)
@@ -511,8 +519,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       // ---- this scenario's generated MetaNet weights, both orientations (previous tile loop ended on a barrier) -----
       if (meta_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-          stage_image(row, w1q, D, U, LU, false);
-          stage_image(row + D * U, w2q, U, D, LD, false);
+          if constexpr (TR) { stage_image(row, w1q, D, U, LU, false); stage_image(row + D * U, w2q, U, D, LD, false); }
+          else { stage_image_sw(row, w1q, D, U, LU, false); stage_image_sw(row + D * U, w2q, U, D, LD, false); }
           if constexpr (TR) {
               stage_image(row, w1qT, D, U, LD, true);
               stage_image(row + D * U, w2qT, U, D, LU, true);
@@ -520,8 +528,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       }
       if (meta_k && (!same_tab || !meta_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-          stage_image(row, w1k, D, U, LU, false);
-          stage_image(row + D * U, w2k, U, D, LD, false);
+          if constexpr (TR) { stage_image(row, w1k, D, U, LU, false); stage_image(row + D * U, w2k, U, D, LD, false); }
+          else { stage_image_sw(row, w1k, D, U, LU, false); stage_image_sw(row + D * U, w2k, U, D, LD, false); }
           if constexpr (TR) {
               stage_image(row, w1kT, D, U, LD, true);
               stage_image(row + D * U, w2kT, U, D, LU, true);
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             store_frag<KT>(my_k, k);
             store_frag<KT>(my_v, v);
         }
-        __syncthreads();
+        lds_barrier();
 
         STAMP(1);
         // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             st_keep[task] = keep;
             store_row<d>(so + (size_t)(tls * F + i) * LD + h * d, oacc, inv);
         }
-        __syncthreads();
+        lds_barrier();
 
         STAMP(2);
         // ================= phase C: output block forward + backward ======================================================
@@ -753,13 +761,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     gy[t][r] *= keep[t][r];                                     // du
                 }
             store_frag<KT>(my_g, gy);                                           // du rows (zero for padding tokens)
-            wgrad<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
+            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
             float go[KT][4];
             if constexpr (TR) chain<KT, KT, LD>(wo + lo_d, gy, go);             // go = du Wo
             else chain_t<KT, KT, LD>(wo + lt_d, gy, go);
             store_frag<KT>(my_o, go);
         }
-        __syncthreads();
+        lds_barrier();
 
         STAMP(3);
         // ================= phase D: softmax backward by rows: dS_ij (cached for phase E) and dq_i =========================
@@ -834,7 +842,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             ATTN_CHUNKS(j0, chunk4, SATRANS_UD2);
             store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
         }
-        __syncthreads();
+        lds_barrier();
 
         STAMP(4);
         // ================= phase E: by columns: dk_j = sum_i dS_ij q_i, dv_j = sum_i P_ij mask_ij go_i (in place of k_j, v_j)
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             store_row<d>(sk + (size_t)(tls * F + j) * LD + h * d, dk, 1.0f);
             store_row<d>(sv + (size_t)(tls * F + j) * LD + h * d, dv, 1.0f);
         }
-        __syncthreads();
+        lds_barrier();
 
         STAMP(5);
         // ================= phase F: MetaNet and projection backward, weight gradients, dx ==================================
@@ -916,8 +924,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, dm);
-                    wgrad<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
-                    if constexpr (HB == 2) wgrad<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
+                    wgrad_r4<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
+                    if constexpr (HB == 2) wgrad_r4<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
@@ -943,8 +951,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, in0, valid);
-                    wgrad<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
-                    if constexpr (HB == 2) wgrad<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
+                    wgrad_r4<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
+                    if constexpr (HB == 2) wgrad_r4<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
@@ -968,10 +976,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
-            wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
+            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
             store_frag<KT>(my_o, gk);
-            wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
-            wgrad<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
+            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
+            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
             float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
             if constexpr (TR) chain<KT, KT, LD>(wqT + lo_d, gq, back);
@@ -995,7 +1003,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
         if (tile + 1 < t1) fetch_tile(tile + 1);
-        __syncthreads();
+        lds_barrier();
         STAMP(6);
       }
       // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
@@ -1285,21 +1293,16 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     return launch_fwd<64, 16, 4>(d, y, att, stream);
 }
 
-// the 8-wave backward (layer_bwd8.hip): preferred where it is built and fits; same slab layout, same reduction
-extern "C" int satrans_layer_bwd8_supported(const satrans_layer_desc* d);
-extern "C" int64_t satrans_layer_bwd8_slab_floats(const satrans_layer_desc* d);
-extern "C" int satrans_layer_bwd8_launch(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, int* T_out,
-                                         int* G_out, void* stream);
 
 extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
     FusedBwdPlan p;
-    return d && (satrans_layer_bwd8_supported(d) || fused_bwd_plan(d, p)) ? 1 : 0;
+    return d && fused_bwd_plan(d, p) ? 1 : 0;
 }
 
 extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d) {
     FusedBwdPlan p;
     if (!d) return -1;
-    int64_t n = satrans_layer_bwd8_supported(d) ? satrans_layer_bwd8_slab_floats(d) : -1;
+    int64_t n = -1;
     if (fused_bwd_plan(d, p)) {
         const int64_t CSZ = 4 * (int64_t)d->D * d->D + 6 * d->D, TSZ = 4 * (int64_t)d->D * d->U;
         n = std::max<int64_t>(n, (int64_t)p.G * CSZ + (int64_t)(p.G + d->S) * TSZ);
@@ -1315,10 +1318,7 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
     const bool same = d->tab_q == d->tab_k;
     int rc;
-    const bool use8 = satrans_layer_bwd8_supported(d);
-    if (use8) {
-        rc = satrans_layer_bwd8_launch(d, dy, dx, slabs, &p.T, &p.G, stream_);
-    } else {
+    {
     SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");
     static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
     // the AliCCP field count as a compile-time constant: -11 % (0.868 -> 0.777 ms over three layers).  The same for the 16

@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256) void gen_attn_fwd_mfma_kernel(const float* __r
 }
 
 // ---- attention backward, one lane per (head, row) of one sample per workgroup: dq_i (row pass) and dk_i, dv_i (column pass)
-// with P recomputed from q, k and the saved row statistics; dot_i = go_i . o_i          (same scheme as layer_bwd8.hip)
+// with P recomputed from q, k and the saved row statistics; dot_i = go_i . o_i          (the recomputing scheme of round 2's 8-wave fused backward)
 template <int d>
 __global__ __launch_bounds__(256) void gen_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, const float* __restrict__ o,

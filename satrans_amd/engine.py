@@ -389,7 +389,7 @@ class PathEngine:
 
     def bwd_kernel_name(self) -> str:
         """Name of the fused backward kernel this process launches (profiles and bench.py's roofline line match on it)."""
-        return "layer_bwd8_kernel" if os.environ.get("SATRANS_BWD8", "0") == "1" else "layer_bwd_fused_kernel"
+        return "layer_bwd_fused_kernel"
 
     def _layer_tables(self, tabs, l):
         if self.pos:

@@ -10,7 +10,7 @@ occupy HBM:
     every batch is gathered into one of two PINNED staging buffers and copied to one of two device buffers on a side stream
     while the previous step computes; integer ids travel as integers (no 2**24 limit), dense features as a float block.
   * `load_npy_columns` / `load_h5_columns`: dict-of-columns loaders with the reference's column naming
-    (`<split>/<column>`); HDF5 needs h5py, which this image does not ship - the loader raises a clear error without it.
+    (`<split>/<column>`); the HDF5 side is read by satrans_amd/h5lite.py (no h5py in this image), memory-mapped.
 """
 from __future__ import annotations
 
@@ -30,16 +30,23 @@ def load_npy_columns(directory: str, columns: Iterable[str], split: Optional[str
     return {c: np.load(os.path.join(base, f"{c}.npy"), mmap_mode="r" if mmap else None) for c in columns}
 
 
-def load_h5_columns(path: str, group: str, columns: Iterable[str]) -> Dict[str, np.ndarray]:
+def load_h5_columns(path: str, group: Optional[str], columns: Optional[Iterable[str]] = None, mmap: bool = True) -> Dict[str, np.ndarray]:
     """{column: array} from the datasets `<group>/<column>` of an HDF5 file - the layout of the reference's `alicpp.h5`
-    (`ctr_train/<col>`, `ctr_test/<col>`; utils.py:266-278 reads them with h5py)."""
+    (`ctr_train/<col>`, `ctr_test/<col>`; utils.py:266-278) or, with group None, of `alimama.h5` (root-level datasets;
+    utils.py:22-30).  Read by satrans_amd/h5lite.py, a parser of what `h5py.File(path, 'w')` + `f[name] = array` write
+    (no h5py needed; memory-mapped by default); files outside that subset (chunked / compressed datasets, libver='latest')
+    fall back to h5py when it is installed."""
+    from . import h5lite
     try:
-        import h5py
-    except ImportError as e:      # not installed in this image (SURVEY.md §8c); the .npy loader above has no such dependency
-        raise ImportError("load_h5_columns needs h5py; convert the file once with "
-                          "`{c: f[group][c][:] for c in columns}` -> np.save, or install h5py") from e
-    with h5py.File(path, "r") as f:
-        return {c: f[group][c][:] for c in columns}
+        return h5lite.read_h5_columns(path, group, columns, mmap=mmap)
+    except NotImplementedError as sub:
+        try:
+            import h5py
+        except ImportError:
+            raise sub
+        with h5py.File(path, "r") as f:
+            g = f[group] if group else f
+            return {c: g[c][:] for c in (columns if columns is not None else g.keys())}
 
 
 class HostBatchFeeder:

@@ -458,46 +458,6 @@ def test_other_layer_implementations_match_golden_too(name, impl):
         N.check(N.lib().satrans_set_layer_impl(0), "set_layer_impl")
 
 
-@pytest.mark.parametrize("name", ["aliccp_sota", "small_qkv", "small_q", "small_k", "small_none", "small_pos_dense",
-                                  "small_relu", "small_onlyemb", "small_multidomain"])
-def test_eight_wave_backward_kernel_matches_golden_and_the_oracle(name):
-    """The 8-wave backward kernel (csrc/layer_bwd8.hip: two waves per SIMD, split weight-gradient accumulators, recomputed
-    softmax backward), selected explicitly: every gradient against the reference's golden vectors, a ragged batch, and a
-    training-mode step whose counter-based dropout masks are replayed through the oracle."""
-    from satrans_amd import native as N
-    c = Case(name)
-    N.check(N.lib().satrans_set_layer_bwd8(1), "set_layer_bwd8")
-    try:
-        model = build_model(c, DEV)
-        model.compile("adam", "binary_crossentropy")
-        model.eval()
-        eng = model._require_engine()
-        if name != "small_relu":
-            bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
-            assert bce == pytest.approx(float(c.z["train/bce"]), rel=2e-6)
-            for k, g in c.arrays("grad").items():
-                scale = max(1e-6, float(np.abs(g).max()))
-                np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
-        for B, train in ((5, False), (c.X.shape[0], True)):
-            model.train(train)
-            X, y = c.X[:B], c.y[:B]
-            bce, reg, grads = eng.loss_and_grads(X.to(DEV), y.to(DEV))
-            m = c.meta
-            drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, len(m["fields"]), m["D"],
-                                                            m["H"], m["L"], 0.1)) if train else None
-            bce_ref, reg_ref, g_ref = O.loss_and_grads(c.tensors("param"), X, y, c.spec(), drop)
-            assert bce == pytest.approx(bce_ref, rel=5e-6)
-            for k, g in g_ref.items():
-                if k in grads:
-                    # (same bounds as test_ragged_batches_gradients_match_the_oracle: with a handful of samples some
-                    # gradients are ~1e-5 and carry ~1e-9 of fp32 cancellation noise in any fp32 evaluation)
-                    scale = max(1e-6, float(g.abs().max()))
-                    np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9,
-                                               err_msg=f"{k} B={B} train={train}")
-    finally:
-        N.check(N.lib().satrans_set_layer_bwd8(-1), "set_layer_bwd8")
-
-
 @pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
 def test_bf16_forward_stays_within_bf16_rounding_of_the_reference(name):
     """BASELINE.json configs[1] "bf16 forward, fp32 ref-parity check": evaluation forward with the dense products on the bf16
@@ -1304,7 +1264,7 @@ def test_ragged_batches_gradients_match_the_oracle(name, B):
         np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9, err_msg=k)
 
 
-def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=False):
+def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=False, ref64=False, grad_tol=2e-4, kink_frac=0.0):
     from satrans_amd import SATrans, SparseFeat
     rng = np.random.RandomState(D + F)
     fields = [f"f{i}" for i in range(F)]
@@ -1328,6 +1288,9 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
                       layer_num=L, flag='sota', meta_mode='QK', meta_units=[D, U, D])
     Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
     Xg = Xt.long() if int_ids else Xt                     # the id matrix as the kernels get it (int64: SATRANS_ID_I64)
+    if ref64:                                             # the oracle in fp64: the difference is then the kernels' rounding alone
+        conv = {}
+        state = {k: conv.setdefault(id(v), v.double()) for k, v in state.items()}
     model.to(DEV); model.device = DEV
     model.compile("adam", "binary_crossentropy")
     for train in (False, True):
@@ -1340,14 +1303,23 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
         if not train:
             model(Xg.to(DEV))
             _, logit_ref = O.forward(state, Xt, spec)
-            np.testing.assert_allclose(eng.last_logit().cpu().numpy().reshape(-1), logit_ref.numpy().reshape(-1), rtol=0,
+            np.testing.assert_allclose(eng.last_logit().cpu().numpy().reshape(-1), logit_ref.float().numpy().reshape(-1), rtol=0,
                                        atol=2e-5 * max(1.0, float(logit_ref.abs().max())))
         assert bce == pytest.approx(bce_ref, rel=1e-5)
         for k, g in g_ref.items():
             if k in grads:
                 scale = max(1e-6, float(g.abs().max()))
-                np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=2e-4 * scale + 1e-8,
-                                           err_msg=f"{k} train={train}")
+                got_g, want_g = grads[k].cpu().numpy().astype(np.float64), g.double().numpy()
+                if kink_frac > 0:
+                    # ReLU kinks: a MetaNet hidden unit whose pre-activation is within rounding of zero takes one branch here and
+                    # the other in the oracle (any two evaluation orders do that to each other); its dh then reaches - or does not
+                    # reach - the rows of ONE token.  With tens of millions of hidden units per step a few such tokens are certain,
+                    # so a small fraction of a tensor's elements is held to 10x the bound only.
+                    err = np.abs(got_g - want_g)
+                    assert float((err > grad_tol * scale + 1e-8).mean()) <= kink_frac, (k, train, float((err > grad_tol * scale + 1e-8).mean()))
+                    assert float(err.max()) <= 10 * grad_tol * scale + 1e-8, (k, train, float(err.max()), scale)
+                    continue
+                np.testing.assert_allclose(got_g, want_g, rtol=0, atol=grad_tol * scale + 1e-8, err_msg=f"{k} train={train}")
 
 
 @pytest.mark.parametrize("D,H,U,F", [(128, 8, 64, 9), (64, 8, 32, 33), (32, 2, 64, 70), (64, 4, 48, 24), (16, 1, 16, 5)])
@@ -1363,8 +1335,12 @@ def test_general_layer_path_on_shapes_without_a_golden_case(monkeypatch, D, H, U
 def test_configs4_shape_against_the_oracle():
     """BASELINE configs[4] at ITS shape - 64 fields, embedding_dim 64, MetaNet hidden 128, 4 heads, 6 layers, int64 ids - on a
     batch the CPU oracle finishes in seconds (B = 256): logits and every gradient, evaluation mode and training mode with the
-    kernels' dropout masks replayed through the oracle (the general path picks itself at this shape)."""
-    _synthetic_shape_against_oracle(64, 4, 128, 64, generic=True, B=256, L=6, int_ids=True)
+    kernels' dropout masks replayed through the oracle (the general path picks itself at this shape).
+    The oracle runs in fp64 here, so the comparison sees the kernels' fp32 rounding alone: every tensor but a handful agrees to
+    1e-6 of its largest element (measured 2e-7 .. 2e-6 on the 64 embedding tables); the bound is 2e-4, with at most 1 % of a
+    tensor's elements - the rows of tokens that sit on a ReLU kink of one of the 25 M MetaNet hidden units - held to 2e-3."""
+    _synthetic_shape_against_oracle(64, 4, 128, 64, generic=True, B=256, L=6, int_ids=True, ref64=True, grad_tol=2e-4,
+                                    kink_frac=0.01)
 
 
 def test_size_independent_properties_at_the_configs4_batch():

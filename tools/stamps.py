@@ -32,37 +32,27 @@ X, y = bench.synth_batches(4 * B, 5)
 Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
 model.train()
 lib = C.CDLL(os.path.join(ROOT, "satrans_amd/libsatrans_hip.so"))
-buf = (C.c_ulonglong * 16)()
+RS = False
+buf = (C.c_ulonglong * 32)()
+read = lib.satrans_debug_read_stamps
 for i in range(2):
     eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
 torch.cuda.synchronize()
-lib.satrans_debug_read_stamps(buf, 1)
-if os.environ.get("SATRANS_BWD8", "1") != "0":
-    lib.satrans_debug_read_stamps8(buf, 1)
+read(buf, 1)
 for i in range(2, 4):
     eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
 torch.cuda.synchronize()
-lib.satrans_debug_read_stamps(buf, 0)
-if os.environ.get("SATRANS_BWD8", "1") != "0":
-    lib.satrans_debug_read_stamps8(buf, 0)
-    names8 = ["tile top", "A fwd chain", "B attn fwd", "C out block", "D dWo + softmax bwd", "D write-back", "F round 1 compute",
-              "F round 1 products", "F round 2 compute", "F round 2 products", "F round 3 stores", "F round 3 products + dx",
-              "flush records", "prologue"]
-    vals = [buf[i] for i in range(14)]
-    tot = sum(vals)
-    for n, v in zip(names8, vals):
-        print(f"{n:26s} {v / tot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
-    sys.exit(0)
-names = ["stage weights(scenario)", "A fwd chain", "B attn fwd", "C out block", "D rows", "E cols", "F metanet/proj bwd",
+read(buf, 0)
+names = ["tile top / dx tail", "A fwd chain", "B attn fwd", "C out block", "D rows", "E cols", "F metanet/proj bwd",
          "rec flush", "prologue"]
-vals = [buf[i] for i in range(9)]
-tot = sum(vals)
-# slot k holds the time BEFORE stamp k: 0 = scenario staging/loop top, 1 = phase A, ... 6 = phase F, 7 = record flush, 8 = prologue
-for n, v in zip(names, vals):
-    print(f"{n:26s} {v / tot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
-# the forward kernel's slots (three launches per step, two steps)
-fnames = ["fwd staging / loop top", "fwd 1 projections + MetaNet", "fwd 2 attention", "fwd 3 out block"]
-fvals = [buf[i] for i in range(9, 13)]
-ftot = sum(fvals) or 1
-for n, v in zip(fnames, fvals):
-    print(f"{n:26s} {v / ftot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
+# slot k holds the time BEFORE stamp k (stamps sit behind the phase's closing barrier, so a slot includes the wait for the
+# slowest wave): 0 = loop top, 1 = phase A, ... 6 = phase F, 7 = record flush, 8 = prologue; 6 backward launches (2 steps x 3 layers)
+for role, off in ((("Q-role wave 0", 0), ("K-role wave 4", 16)) if RS else (("wave 0", 0),)):
+    vals = [buf[off + i] for i in range(9)]
+    tot = sum(vals)
+    if tot == 0:
+        print(f"{role}: no stamps recorded (is the library built with SATRANS_EXTRA_FLAGS=-DSATRANS_STAMPS?)")
+        continue
+    print(f"--- {role}: {tot / (6 * 256) / 1e3:.1f} kcycles per workgroup-launch")
+    for nme, v in zip(names, vals):
+        print(f"{nme:26s} {v / tot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
