@@ -20,6 +20,10 @@
 
 namespace satrans {
 
+#ifndef SATRANS_FWD_PREFETCH_X
+#define SATRANS_FWD_PREFETCH_X 0
+#endif
+
 template <int D, int U, int H, int WAVES = kFusedWaves>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                       float* __restrict__ y, float* __restrict__ att) {
@@ -44,6 +48,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     float* sq = take(rows * LD);
     float* sk = take(rows * LD);
     float* sv = take(rows * LD);
+    float* sx = take(rows * LD);      // the tile's input rows: read from global memory ONCE (phase 1), re-read here for the residual
 
     stage_image(a.w_query, W.wq, D, D, LD, false);
     stage_image(a.w_key, W.wk, D, D, LD, false);
@@ -89,6 +94,21 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
           stage_image(row + D * U, W.w2k, U, D, LD, false);
       }
       __syncthreads();
+      // The input row of a wave's (first) token tile is fetched one tile ahead, behind the output block of the previous tile:
+      // sample index -> row address -> row are two dependent global loads (HBM misses for the first layer, whose rows come
+      // straight from the embedding arena), which three waves per SIMD do not hide at the top of phase 1.
+#if SATRANS_FWD_PREFETCH_X
+      float xn[KT][4];
+#endif
+      auto fetch_x = [&](int first_, int tt_, float (&dst)[KT][4]) {
+          const int tok_ = 16 * tt_ + n, ntok_ = min(Tsamp, hi - first_) * F;
+          const bool valid_ = tok_ < ntok_;
+          const int ls_ = valid_ ? tok_ / F : 0, f_ = valid_ ? tok_ - ls_ * F : 0;
+          load_frag<KT>(layer_x_row(a, a.order[first_ + ls_], f_, F, D) + g4, dst);
+      };
+#if SATRANS_FWD_PREFETCH_X
+      if (16 * wave < min(Tsamp, hi - lo) * F) fetch_x(lo, wave, xn);
+#endif
       for (int first = lo; first < hi; first += Tsamp) {
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
@@ -100,13 +120,20 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             const bool valid = tok < ntok;
             const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
             const int b = samp[ls];
-            const float* xrow = layer_x_row(a, b, f, F, D) + g4;
             float x[KT][4], q[KT][4], k[KT][4], v[KT][4];
+#if SATRANS_FWD_PREFETCH_X
+            if (tt == wave) {
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                const float4 xv = *reinterpret_cast<const float4*>(xrow + 16 * t);
-                x[t][0] = xv.x; x[t][1] = xv.y; x[t][2] = xv.z; x[t][3] = xv.w;
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[t][r] = xn[t][r];
+            } else {
+                fetch_x(first, tt, x);
             }
+#else
+            fetch_x(first, tt, x);
+#endif
+            store_frag<KT>(sx + (size_t)tok * LD + g4, x);
             chain<KT, KT, LD>(wq_l, x, q);                                               // satrans.py:55-57
             chain<KT, KT, LD>(wk_l, x, k);
             chain<KT, KT, LD>(wv_l, x, v);
@@ -300,7 +327,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 o[t][0] = ov.x; o[t][1] = ov.y; o[t][2] = ov.z; o[t][3] = ov.w;
             }
             chain<KT, KT, LD>(wo_l, o, u);
-            const float* xrow = layer_x_row(a, b, f, F, D) + g4;
+            const float* xrow = sx + (size_t)tok * LD + g4;
             const uint32_t skey = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
             const uint32_t kb = dc.on ? token_keep_bits<KT>(skey, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
 #pragma unroll
@@ -325,6 +352,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                     *reinterpret_cast<float4*>(yrow + 16 * t) = make_float4(u[t][0], u[t][1], u[t][2], u[t][3]);
             }
         }
+#if SATRANS_FWD_PREFETCH_X
+        if (first + Tsamp < hi && 16 * wave < min(Tsamp, hi - first - Tsamp) * F) fetch_x(first + Tsamp, wave, xn);
+#endif
         __syncthreads();
         STAMP(12);
       }
@@ -1168,7 +1198,7 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
 static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
     const int64_t rows = (((int64_t)T * F + 15) / 16) * 16;
-    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 3 * rows * LD + 64;
+    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 4 * rows * LD + 64;
 }
 
 template <int D, int U, int H, int WAVES>

@@ -162,6 +162,12 @@ class PathEngine:
         # replayed - same arithmetic, same result bit for bit - when a row is next gathered, or for all rows by
         # flush_lazy() (epoch end, before predict / state_dict).  SATRANS_LAZY_ADAM=0: streaming kernel every step.
         self.lazy = os.environ.get("SATRANS_LAZY_ADAM", "1") != "0"
+        # Lazy form: bring ALL rows up to date every `flush_every` steps (0 = only when something needs current tables: epoch
+        # end, predict, state_dict).  The total arithmetic is the same either way (every row-step is executed exactly once,
+        # at replay or at flush time), but a row that waits 1,000 steps for its next gather is replayed as ONE lane's chain of
+        # 1,000 dependent steps inside the step that gathers it, while the flush runs the same steps with every lane busy.
+        self.flush_every = int(os.environ.get("SATRANS_LAZY_FLUSH_EVERY", "64"))
+        self._since_flush = 0
         # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
         # standalone gather kernel + activation buffer, as in round 1
         self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
@@ -826,10 +832,13 @@ class PathEngine:
                         "satrans_embed_adam_touched")
         if self.lazy:
             self._lazy_pending = True
+            self._since_flush += 1
         self._stepped_since_forward = True
         h_flat = self._hparams(0.0)
         with self.phase("adam_flat"):
             self._flat_step(h_flat, ws, st)
+        if self.lazy and self.flush_every and self._since_flush >= self.flush_every:
+            self.flush_lazy()
 
     def _train_step_dense(self, X, y, cfg):
         """One step of SGD / Adagrad / RMSprop with the reference's dense semantics (models/meta_basemodel.py:612-640): the
@@ -895,6 +904,8 @@ class PathEngine:
         with self.phase("lazy_flush"):
             self._flush_launches(m, h, st, table)
         self._lazy_pending = False
+        self._since_flush = 0
+        self.flush_count = getattr(self, "flush_count", 0) + 1
 
     def _flush_launches(self, m, h, st, table):
         N.check(self.lib.satrans_embed_lazy_flush(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
