@@ -168,6 +168,14 @@ class PathEngine:
         # 1,000 dependent steps inside the step that gathers it, while the flush runs the same steps with every lane busy.
         self.flush_every = int(os.environ.get("SATRANS_LAZY_FLUSH_EVERY", "64"))
         self._since_flush = 0
+        # Several ranks: "owner" (default) = every rank owns a contiguous 1/N slice of the large tables' rows and is the only one
+        # to step them (per-rank optimizer work and traffic independent of N); "replicated" = round 2's exchange, every rank
+        # applies every rank's updates (satrans_amd/parallel.py).
+        self.dp_mode = os.environ.get("SATRANS_DP_MODE", "owner")
+        self._x_src = None               # (row buffer, row index per (b, f)): layer 0 reads its tokens from here instead of the arena
+        self._owner_world = 0            # > 0: large-table rows outside this rank's slice may be stale until _sync_replicas()
+        self._replicas_stale = False
+        self.reg_small = torch.zeros(1, dtype=torch.float64, device=self.dev)
         # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
         # standalone gather kernel + activation buffer, as in round 1
         self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
@@ -376,6 +384,8 @@ class PathEngine:
             # flagged in `status`; the fused layer reads that row where the standalone gather writes zeros.  Either way the
             # batch is invalid and raise_if_bad_ids() raises before any result is handed to the caller.)
             d.x, d.x_rows = self.m.embedding_arena.data_ptr(), ws["rows"].data_ptr()
+            if self._x_src is not None:      # owner-mode step: the rows came from their owners (this step's current values)
+                d.x, d.x_rows = self._x_src[0].data_ptr(), self._x_src[1].data_ptr()
         d.sid, d.order, d.seg = ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr()
         d.w_query, d.w_key, d.w_value = lay.W_Query.data_ptr(), lay.W_Key.data_ptr(), lay.W_Value.data_ptr()
         d.w_out = lay.Out_linear.weight.data_ptr()
@@ -437,7 +447,7 @@ class PathEngine:
                                              ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr(),
                                              self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
                 "satrans_bucket_scenarios")
-        fuse = self.fuse_gather
+        fuse = self.fuse_gather or self._x_src is not None
         ws["acts0_of"] = None if fuse else X
         if not (fuse and rows_ready):
             with self.phase("gather_fwd"):
@@ -609,10 +619,17 @@ class PathEngine:
     def reset_epoch_sums(self):
         self.loss_sum.zero_()
         self.reg_sum.zero_()
+        self.reg_small.zero_()
 
     def epoch_sums(self):
+        """(sum of this rank's sample losses, sum over the epoch's steps of the regulariser l2 * |tables|^2).  Collective in
+        the owner form of several ranks: a rank accumulates the regulariser of the rows it owns, the total is their sum."""
         self.flush_lazy()          # the regulariser sums of postponed steps belong to this epoch
-        return float(self.loss_sum.item()), float(self.reg_sum.item())
+        reg = self.reg_sum
+        if self._owner_world:
+            from . import parallel
+            reg = parallel.all_reduce_scalars(self.reg_sum.clone()) + self.reg_small
+        return float(self.loss_sum.item()), float(reg.item())
 
     def _hparams(self, l2: float) -> N.AdamHParams:
         cfg = self.m._adam_cfg
@@ -641,7 +658,7 @@ class PathEngine:
             self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
-            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather)
+            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather or self._x_src is not None)
             lay = f"domain_int_layers.{l}."
             gq = gk = glnq = glnk = None
             if modulated:
@@ -694,6 +711,11 @@ class PathEngine:
             return self._train_step_dense(X, y, cfg)
         world = parallel.world_size()
         exch = parallel.exchange_enabled()            # several ranks (or one rank made to run its collectives: tests)
+        if exch and self.dp_mode == "owner" and self.lazy and self.F_small < self.F:
+            return self._train_step_owner(X, y, B, world, self.train_workspace(B, 1, False))
+        if self._owner_world:                          # (a run that switches forms mid-way: bring the replicas together first)
+            self.flush_lazy()
+            self._owner_world = 0
         ws = self.train_workspace(B, world, exch)
         lib, m, D = self.lib, self.m, self.D
         main = torch.cuda.current_stream(self.dev)
@@ -840,6 +862,178 @@ class PathEngine:
         if self.lazy and self.flush_every and self._since_flush >= self.flush_every:
             self.flush_lazy()
 
+    # ------------------------------------------------------------------------------------------------
+    # several ranks, row-ownership form
+    # ------------------------------------------------------------------------------------------------
+    def _owner_ranges(self, world: int) -> List[int]:
+        """Arena row boundaries of the owners' slices of the LARGE tables: rank o steps rows [b[o], b[o+1]).  (Small tables sit
+        first in the arena, are stepped densely by every rank from the all-reduced gradient and have no owner.)"""
+        lo0 = self.small_rows
+        chunk = -(-(self.total_rows - lo0) // world)
+        return [min(self.total_rows, lo0 + o * chunk) for o in range(world + 1)]
+
+    def _owner_ws(self, ws: dict, n_b: int, need: int) -> dict:
+        """Buffers for the lists an owner receives.  Their length depends on the ids of the step (about n_b with uniform ids, up
+        to world * n_b when every rank gathers from one slice): capacity doubles when a step outgrows it."""
+        ow = ws.get("_owner")
+        if ow is not None and ow["cap"] >= need:
+            return ow
+        lib, D, dev = self.lib, self.D, self.dev
+        cap = max(2 * n_b, 1024, 1 << max(need - 1, 1).bit_length())
+        i32 = dict(dtype=torch.int32, device=dev)
+        n_reg = int(lib.satrans_embed_reg_partials(self.total_rows, cap, D))
+        ow = dict(cap=cap, n_reg=n_reg,
+                  sorted=torch.empty(cap, **i32), src=torch.empty(cap, **i32), iota=torch.arange(cap, **i32),
+                  sort_ws=torch.empty(int(lib.satrans_embed_sort_workspace_bytes(cap, self.total_rows)), dtype=torch.uint8, device=dev),
+                  partial_ws=torch.empty(int(lib.satrans_embed_partial_ws_floats(cap, D)), dtype=torch.float32, device=dev),
+                  reg=torch.zeros(n_reg + (cap * D + 255) // 256, dtype=torch.float64, device=dev))
+        ws["_owner"] = ow
+        return ow
+
+    def _train_step_owner(self, X, y, B, world, ws):
+        """One optimizer step of every data-parallel rank with row OWNERSHIP (reference semantics unchanged: per-GPU batches,
+        loss summed over all samples, one dense Adam + L2 step, meta_basemodel.py:272-275,317; main.py:343).
+
+        Rank o owns a contiguous 1/N slice of the large tables' rows - values, both Adam moments and the lazy form's `last` -
+        and is the only rank that reads or writes them during training:
+          ids      every rank sorts its batch's rows; the large-table part splits into N runs by owner   all-to-all (int32)
+          values   the owner replays the postponed steps of the requested rows, reads them               all-to-all back (fp32)
+                   -> layer 0 reads its tokens from the received rows (plus the replicated small tables)
+          grads    gradient rows of the large tables, packed in sorted order                             all-to-all (fp32)
+                   -> the owner sorts what it received (rank-major, then position: the order of the replicated form, hence the
+                      same bits), ordered segmented sums, Adam on its slice
+          small tables and dense parameters: one SUM all-reduce of the flat gradient buffer, dense step on every rank
+        Per rank and step: ~n_b rows received and stepped, 2 x n_b x D x 4 bytes moved each way (8.4 MB at B = 8192) instead
+        of N x n_b rows sorted, replayed and stepped and N x 8.4 MB received; the flush of the postponed steps covers 1/N of
+        the rows.  The replicas of rows a rank does not own go stale; flush_lazy() brings them together again (slice broadcasts)
+        before anything reads the tables as a whole."""
+        from . import parallel
+        lib, m, D, st = self.lib, self.m, self.D, self._stream()
+        rank = parallel.rank()
+        n_loc, n_s = B * self.F, B * self.F_small
+        n_b = n_loc - n_s
+        l2 = m.l2_reg_embedding
+        arena_t, am_t, av_t = m.embedding_arena, self.adam_m, self.adam_v
+        arena, am, av = arena_t.data_ptr(), am_t.data_ptr(), av_t.data_ptr()
+        if self._owner_world != world:
+            self.flush_lazy()                         # (first owner-form step: everything current and identical everywhere)
+            self._owner_world = world
+        bounds = self._owner_ranges(world)
+        if "xg" not in ws:
+            ws["xg"] = torch.empty(n_loc, D, dtype=torch.float32, device=self.dev)
+            ws["inv"] = torch.empty(n_loc, dtype=torch.int32, device=self.dev)
+            ws["iota_loc"] = torch.arange(n_loc, dtype=torch.int32, device=self.dev)
+            ws["packed_o"] = torch.empty(max(n_b, 1), D, dtype=torch.float32, device=self.dev)
+            ws["bounds_t"] = {}
+        if world not in ws["bounds_t"]:
+            ws["bounds_t"][world] = torch.tensor(bounds[1:-1], dtype=torch.int32, device=self.dev)
+
+        # ---- 1. this batch's arena rows, sorted; the large-table part is N runs, one per owner -----------------------------
+        N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
+                                       N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
+                                       self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
+        with self.phase("embed_sort"):
+            if self._sort_fields is not None and B <= 8192:
+                f_, lo_, n_ = self._sort_fields
+                N.check(lib.satrans_embed_sort_fields(ws["rows"].data_ptr(), B, self.F, f_, lo_, n_, ws["sorted_rows"].data_ptr(),
+                                                      ws["src"].data_ptr(), st), "satrans_embed_sort_fields")
+            else:
+                N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_loc, self.total_rows, ws["sorted_rows"].data_ptr(),
+                                               ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
+                                               ws["iota"].data_ptr(), st), "satrans_embed_sort")
+        self.adam_t += 1
+        h_emb = self._hparams(l2)
+        big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
+        with self.phase("owner_ids"):
+            cut = torch.searchsorted(big_sorted, ws["bounds_t"][world]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
+            edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n_b)])
+            counts = parallel.gather_counts(edges[1:] - edges[:-1])            # [N, N] on the host: the step's one read-back
+            send, recv = counts[rank].tolist(), counts[:, rank].tolist()
+            n_recv = int(sum(recv))
+            o_rows = parallel.all_to_all_rows(big_sorted, send, recv, "all_to_all_row_ids_i32")
+        ow = self._owner_ws(ws, n_b, max(n_recv, 1))
+        ow["reg"].zero_()                                                        # (slot counts follow n_recv: no stale partials)
+        # ---- 2. the owner's side: sort what was asked for, replay the postponed steps of exactly those rows, answer ---------
+        if n_recv:
+            with self.phase("embed_sort_global"):
+                N.check(lib.satrans_embed_sort(o_rows.data_ptr(), n_recv, self.total_rows, ow["sorted"].data_ptr(),
+                                               ow["src"].data_ptr(), None, ow["sort_ws"].data_ptr(), ow["sort_ws"].numel(),
+                                               ow["iota"].data_ptr(), st), "satrans_embed_sort(owner)")
+            if self.adam_t > 1:
+                with self.phase("lazy_replay"):
+                    table, h = self._table(self.adam_t), self._hparams(l2)
+                    N.check(lib.satrans_embed_lazy_replay(arena, am, av, self.last_step.data_ptr(), D, ow["sorted"].data_ptr(),
+                                                          n_recv, self.adam_t - 1, table.data_ptr(), C.byref(h),
+                                                          ow["reg"][ow["n_reg"]:].data_ptr(), st), "satrans_embed_lazy_replay")
+        with self.phase("owner_rows"):
+            vals = torch.empty(n_recv, D, dtype=torch.float32, device=self.dev)
+            if n_recv:
+                N.check(lib.satrans_embed_pack_rows(o_rows.data_ptr(), n_recv, arena, D, vals.data_ptr(), st),
+                        "satrans_embed_pack_rows(values)")
+            got = parallel.all_to_all_rows(vals, recv, send, "all_to_all_rows_f32")      # [n_b, D], in big_sorted order
+            # the batch's rows in sorted order: replicated small tables from the arena, large tables from their owners; token
+            # (b, f) is row inv[b, f] of that buffer
+            xg, inv = ws["xg"], ws["inv"]
+            if n_s:
+                N.check(lib.satrans_embed_pack_rows(ws["sorted_rows"].data_ptr(), n_s, arena, D, xg.data_ptr(), st),
+                        "satrans_embed_pack_rows(small)")
+            if n_b:
+                xg[n_s:].copy_(got)
+            inv[ws["src"].long()] = ws["iota_loc"]
+        # ---- 3. forward, loss, backward on the received rows ------------------------------------------------------------------
+        self._x_src = (xg, inv)
+        try:
+            gemb = self.backward(X, y, ws, rows_ready=True)
+        finally:
+            self._x_src = None
+        # ---- 4. small tables + dense parameters: one all-reduce; large tables: gradient rows to their owners -------------------
+        if n_s > 0:
+            with self.phase("adam_small"):
+                N.check(lib.satrans_embed_segment_sums(ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(), n_s, gemb.data_ptr(), D,
+                                                       ws["partial_ws"].data_ptr(), ws["reg_unused"].data_ptr(),
+                                                       self.g_small.data_ptr(), st), "satrans_embed_segment_sums")
+        parallel.all_reduce_flat(self.g_exchange)
+        with self.phase("owner_grads"):
+            if n_b:
+                N.check(lib.satrans_embed_pack_rows(big_src.data_ptr(), n_b, gemb.data_ptr(), D, ws["packed_o"].data_ptr(), st),
+                        "satrans_embed_pack_rows(grads)")
+            recv_g = parallel.all_to_all_rows(ws["packed_o"][:n_b], send, recv, "all_to_all_grad_rows_f32")
+        if self.small_rows > 0:
+            with self.phase("adam_small"):
+                N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, self.small_rows, D,
+                                                    self.g_small.data_ptr(), C.byref(h_emb), self.adam_t,
+                                                    ws["reg_rows"].data_ptr(), st), "satrans_embed_adam_rows")
+                N.check(lib.satrans_sum_f64(ws["reg_rows"].data_ptr(), ws["reg_rows"].numel(), self.reg_small.data_ptr(), 1, st),
+                        "satrans_sum_f64")
+        if n_recv:
+            with self.phase("adam_touched"):
+                N.check(lib.satrans_embed_adam_touched(arena, am, av, D, ow["sorted"].data_ptr(), ow["src"].data_ptr(), n_recv,
+                                                       recv_g.data_ptr(), ow["partial_ws"].data_ptr(), C.byref(h_emb),
+                                                       ow["reg"].data_ptr(), self.last_step.data_ptr(), self.adam_t, st),
+                        "satrans_embed_adam_touched")
+        self._lazy_pending = True
+        self._replicas_stale = True
+        self._since_flush += 1
+        self._stepped_since_forward = True
+        with self.phase("adam_flat"):
+            self._flat_step(self._hparams(0.0), {"reg_partials": ow["reg"]}, st)
+        if self.flush_every and self._since_flush >= self.flush_every:
+            self.flush_lazy(sync=False)               # own slice only: nobody reads the other replicas during training
+
+    def _sync_replicas(self):
+        """Owner form: every rank receives the other owners' slices (values, both moments) - after this the replicas are
+        identical everywhere and every row is at the current step."""
+        from . import parallel
+        if self._owner_world:
+            b = self._owner_ranges(self._owner_world)
+            with self.phase("sync_replicas"):
+                for o in range(self._owner_world):
+                    if b[o + 1] > b[o]:
+                        for t in (self.m.embedding_arena, self.adam_m, self.adam_v):
+                            parallel.broadcast_slice(t[b[o]:b[o + 1]], o)
+                self.last_step.fill_(self.adam_t)
+        self._replicas_stale = False
+
     def _train_step_dense(self, X, y, cfg):
         """One step of SGD / Adagrad / RMSprop with the reference's dense semantics (models/meta_basemodel.py:612-640): the
         gradient of EVERY table row (gathered rows + 2 l2 p) is materialised once and one elementwise kernel steps the tables,
@@ -893,23 +1087,33 @@ class PathEngine:
             self._hp_cfg = key
         return self._hp_table
 
-    def flush_lazy(self):
-        """Bring every table row to the current step (no-op when nothing is pending)."""
-        if not (self.lazy and self._lazy_pending):
-            return
-        m = self.m
-        h = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
-        st = self._stream()
-        table = self._table(self.adam_t)
-        with self.phase("lazy_flush"):
-            self._flush_launches(m, h, st, table)
-        self._lazy_pending = False
-        self._since_flush = 0
-        self.flush_count = getattr(self, "flush_count", 0) + 1
+    def flush_lazy(self, sync: bool = True):
+        """Bring every table row (owner form: every row this rank owns) to the current step - a no-op when nothing is pending -
+        and, with `sync`, make the replicas of all ranks identical again (owner form: collective; every rank reaches the flush
+        points - epoch end, evaluation forward, state_dict, optimizer_state - together, as it reaches the steps together)."""
+        if self.lazy and self._lazy_pending:
+            m = self.m
+            h = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
+            st = self._stream()
+            table = self._table(self.adam_t)
+            with self.phase("lazy_flush"):
+                self._flush_launches(m, h, st, table)
+            self._lazy_pending = False
+            self._since_flush = 0
+            self.flush_count = getattr(self, "flush_count", 0) + 1
+        if sync and self._replicas_stale:
+            self._sync_replicas()
 
     def _flush_launches(self, m, h, st, table):
-        N.check(self.lib.satrans_embed_lazy_flush(m.embedding_arena.data_ptr(), self.adam_m.data_ptr(),
-                                                  self.adam_v.data_ptr(), self.last_step.data_ptr(), self.total_rows,
+        lo, hi = 0, self.total_rows
+        if self._owner_world:          # only the rows this rank steps: its slice of the large tables (small tables are never lazy)
+            from . import parallel
+            b = self._owner_ranges(self._owner_world)
+            lo, hi = b[parallel.rank()], b[parallel.rank() + 1]
+            if hi <= lo:
+                return
+        N.check(self.lib.satrans_embed_lazy_flush(m.embedding_arena[lo:].data_ptr(), self.adam_m[lo:].data_ptr(),
+                                                  self.adam_v[lo:].data_ptr(), self.last_step[lo:].data_ptr(), hi - lo,
                                                   self.D, self.adam_t, table.data_ptr(), C.byref(h), 0,
                                                   self._flush_reg.data_ptr(), st), "satrans_embed_lazy_flush")
         N.check(self.lib.satrans_sum_f64(self._flush_reg.data_ptr(), self._flush_reg.numel(), self.reg_sum.data_ptr(),

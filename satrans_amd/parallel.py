@@ -115,6 +115,57 @@ def gather_grad_rows_async(gemb: torch.Tensor):
     return out, dist.all_gather_into_tensor(out, gemb, async_op=True)
 
 
+# ---- row-ownership exchange (engine: SATRANS_DP_MODE=owner) -----------------------------------------------------------------
+def gather_counts(counts: torch.Tensor) -> torch.Tensor:
+    """[W] int64 per-destination counts of this rank -> [W, W] on the HOST (row r = what rank r sends to each owner).  The one
+    device-to-host read of the owner-mode step: all_to_all_single needs its split sizes as Python ints."""
+    w = world_size()
+    counts = counts.to(torch.int64).reshape(-1)
+    if not exchange_enabled():
+        return counts.reshape(1, -1).cpu()
+    out = torch.empty(w * counts.numel(), dtype=torch.int64, device=counts.device)
+    _all_gather(out, counts)
+    _count("all_gather_counts_i64", counts.numel() * 8, out.numel() * 8)
+    return out.reshape(w, -1).cpu()
+
+
+def all_to_all_rows(inp: torch.Tensor, send_splits, recv_splits, name: str) -> torch.Tensor:
+    """Uneven all-to-all along dim 0: rows [sum(send_splits), ...] -> [sum(recv_splits), ...]; chunk o of `inp` goes to rank o,
+    chunk r of the result came from rank r.  RCCL: grouped point-to-point over xGMI (every pair has its own link)."""
+    send_splits, recv_splits = [int(v) for v in send_splits], [int(v) for v in recv_splits]
+    inp = inp.contiguous()
+    out = torch.empty((sum(recv_splits),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    row_bytes = inp.element_size()
+    for dim in inp.shape[1:]:
+        row_bytes *= int(dim)
+    _count(name, sum(send_splits) * row_bytes, sum(recv_splits) * row_bytes)
+    if not exchange_enabled() or (world_size() == 1 and dist.get_backend() == "gloo"):
+        out.copy_(inp)
+        return out
+    if _host_staged(inp):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), recv_splits, send_splits)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, inp, recv_splits, send_splits)
+    return out
+
+
+def broadcast_slice(t: torch.Tensor, src: int) -> None:
+    """In-place broadcast of one owner's slice of a replicated table (replica synchronisation at flush points)."""
+    if not exchange_enabled() or world_size() == 1:
+        return
+    _count("broadcast_table_slices_f32", t.numel() * t.element_size() if rank() == src else 0,
+           t.numel() * t.element_size() if rank() != src else 0)
+    if _host_staged(t):
+        host = t.cpu()
+        dist.broadcast(host, src)
+        if rank() != src:
+            t.copy_(host)
+    else:
+        dist.broadcast(t, src)
+
+
 def all_reduce_scalars(t: torch.Tensor) -> torch.Tensor:
     """Sum of per-rank scalars (losses, counts) for logging."""
     if exchange_enabled():

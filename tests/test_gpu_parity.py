@@ -1017,15 +1017,17 @@ def test_lazy_flush_equals_streaming_steps_on_edge_values(D):
     assert torch.equal(Pr.cpu()[untouched_rows], P[untouched_rows])
 
 
-def _dp_worker(rank, world, port, name, steps, out_dir, small_rows):
+def _dp_worker(rank, world, port, name, steps, out_dir, small_rows, mode="owner"):
     """One data-parallel rank of the engine; both ranks share cuda:0 and talk over gloo (host-staged), which runs
     exactly the code path of an RCCL job: ids all-gathered before the forward, gradient rows after the backward."""
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["SATRANS_SMALL_TABLE_ROWS"] = str(small_rows)
+    os.environ["SATRANS_DP_MODE"] = mode
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from satrans_amd import parallel
         c = Case(name)
         model = build_model(c, DEV)
         model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
@@ -1033,21 +1035,36 @@ def _dp_worker(rank, world, port, name, steps, out_dir, small_rows):
         eng = model._require_engine()
         n = c.X.shape[0] // world
         X, y = c.X[rank * n:(rank + 1) * n].to(DEV), c.y[rank * n:(rank + 1) * n].to(DEV)
+        eng.reset_epoch_sums()
         for _ in range(steps):
             eng.train_step(X, y)
-        torch.save(sd_to_cpu(model), os.path.join(out_dir, f"rank{rank}.pt"))
+        sums = eng.epoch_sums()                                   # (collective in the owner form)
+        res = sd_to_cpu(model)
+        opt = model.optimizer_state_dict()
+        for k, st_ in opt["state"].items():
+            res["exp_avg/" + k], res["exp_avg_sq/" + k] = st_["exp_avg"], st_["exp_avg_sq"]
+        res["__reg__"] = torch.tensor(sums[1], dtype=torch.float64)
+        res["__owner__"] = torch.tensor(eng._owner_world)
+        res["__calls__"] = torch.tensor(sorted(parallel.STATS).index("all_to_all_rows_f32") if "all_to_all_rows_f32" in parallel.STATS else -1)
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("small_rows", [16384, 100, 0])
+@pytest.mark.parametrize("mode", ["owner", "replicated"])
+@pytest.mark.parametrize("small_rows", [16384, 20, 0])
 @pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
-def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows, tmp_path):
+def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows, mode, tmp_path):
     """Reference semantics of several GPUs (meta_basemodel.py:272-275, 317): per-GPU batches, loss SUMMED over all
     samples, one optimizer step on the summed gradient.  Two ranks with half of the golden batch each must therefore
     land where the reference's single full-batch steps land, and the two replicas must be bit-identical.
     `small_rows` moves the boundary between the table classes of the exchange: 16384 = every golden table takes the dense
-    all-reduced path, 0 = every table goes through the all-gathered sorted (row, gradient) lists, 100 = a mix."""
+    all-reduced path, 0 = every table goes through the exchanged sorted (row, gradient) lists, 20 = a mix (the golden tables
+    have 3 .. 42 rows).
+    `mode`: "owner" = every rank steps only the slice of the large tables it owns (ids to the owners, current rows back,
+    gradient rows to the owners; replicas brought together at the flush points), "replicated" = every rank applies every
+    rank's updates.  Both must leave bit-identical replicas - parameters AND Adam moments - and the two forms must agree with
+    each other to the rounding of a sum (same summation order: rank-major, then position)."""
     import socket
     import torch.multiprocessing as mp
     c = Case(name)
@@ -1057,10 +1074,40 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows,
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     steps = c.meta["adam_steps"]
-    mp.spawn(_dp_worker, args=(2, port, name, steps, str(tmp_path), small_rows), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, name, steps, str(tmp_path), small_rows, mode), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    owner_ran = int(r0.pop("__owner__")) == 2
+    r1.pop("__owner__"); r0.pop("__calls__"); r1.pop("__calls__")
+    assert owner_ran == (mode == "owner" and small_rows < 42), "unexpected data-parallel form"
     for k in r0:
         assert torch.equal(r0[k], r1[k]), f"replicas diverged at {k}"
+    reg = float(r0.pop("__reg__")); r1.pop("__reg__")
+    moments = {k: r0.pop(k) for k in list(r0) if k.startswith("exp_avg")}
+    # the logged regulariser sum covers ALL rows whichever rank stepped them (reference: l2 * sum(w^2) over every table,
+    # meta_basemodel.py:577-593): against the oracle's dense steps on the full batch
+    tr = O.OracleTrainer(c.tensors("param"), c.spec(), lr=c.meta["lr"])
+    reg_ref = sum(tr.step(c.X, c.y)[1] for _ in range(steps))
+    assert reg == pytest.approx(reg_ref, rel=5e-5), (reg, reg_ref)
+    if mode == "owner":
+        # The other form on the same inputs.  Both add a row's gradient rows in the same ORDER (rank-major, then position), but
+        # the ordered segmented sums bracket by 32-position chunks of the list they run over - all ranks' rows there, one
+        # owner's slice here - so the two forms may differ in the last bit of a sum: moments to 1e-5 of their largest element,
+        # parameters wherever Adam's quotient does not amplify that (same criterion as the trajectory test).
+        other = tmp_path / "replicated"
+        other.mkdir()
+        mp.spawn(_dp_worker, args=(2, port + 1 if port < 65000 else port - 1, name, steps, str(other), small_rows, "replicated"),
+                 nprocs=2, join=True)
+        q0 = torch.load(other / "rank0.pt")
+        for k, v in moments.items():
+            if float(q0[k].abs().max()) < 1e-8:
+                continue                          # mathematically-zero gradient: its moments are rounding noise
+            np.testing.assert_allclose(v.numpy(), q0[k].numpy(), rtol=1e-5, atol=1e-5 * float(q0[k].abs().max()) + 1e-30, err_msg=k)
+        gold = c.arrays("grad")
+        for k, v in r0.items():
+            diff = (v - q0[k]).abs().flatten().double()
+            assert float(diff.max()) <= 2.0 * c.meta["lr"] * steps + 1e-6, k
+            if k in gold and float(np.abs(gold[k]).max()) >= 1e-7:     # (zero-gradient tensors: Adam on rounding noise)
+                assert float(diff.median()) <= 2e-4 * c.meta["lr"] * steps, (k, float(diff.median()))
     want, grads, init, lr = c.tensors("adam"), c.arrays("grad"), c.tensors("param"), c.meta["lr"]
     for k, w in want.items():     # same bounds as test_adam_steps_match_reference_golden
         err = (r0[k] - w).abs().flatten().double()
@@ -1099,13 +1146,15 @@ def test_regulariser_sum_of_tiny_batches(monkeypatch, B):
     assert sums["1"][1] == pytest.approx(sums["0"][1], rel=1e-9)
 
 
+@pytest.mark.parametrize("mode", ["owner", "replicated"])
 @pytest.mark.parametrize("small_rows", ["20", "0"])
-def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path, small_rows):
+def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path, small_rows, mode):
     """RCCL for real on a one-GPU box: a ONE-rank nccl process group, created before anything touches the GPU, with the
     training step forced through its multi-rank branch (SATRANS_FORCE_EXCHANGE=1): device-pointer int32 all-gather of the
     row ids, SUM all-reduce of the flat gradient, asynchronous fp32 all-gather of the gradient rows + wait(), global sort.
-    With one rank every collective is an identity, so the result must equal the local step with the same table classes
-    bit for bit - parameters, tables and both Adam moments.  small_rows = 0 makes every table a large one: the exchanged list
+    (`mode` "replicated"; "owner": int64 all-gather of the per-owner counts, int32 all-to-all of the row ids, fp32 all-to-alls
+    of the rows and of the gradient rows.)  With one rank every collective is an identity, so the result must equal the local
+    step with the same table classes bit for bit - parameters, tables and both Adam moments.  small_rows = 0 makes every table a large one: the exchanged list
     is then as long as the rank's own [B, F] row matrix and must still go through the device-wide sort."""
     import socket
     import subprocess
@@ -1115,18 +1164,20 @@ def test_rccl_single_rank_exchange_is_bitwise_the_local_step(tmp_path, small_row
         port = s.getsockname()[1]
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank.py")
     outs = {}
-    for mode in ("nccl", "plain"):
-        out = str(tmp_path / f"{mode}.pt")
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for how in ("nccl", "plain"):
+        out = str(tmp_path / f"{how}.pt")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SATRANS_DP_MODE=mode)
         env.pop("SATRANS_FORCE_EXCHANGE", None)
-        r = subprocess.run([sys.executable, script, mode, "aliccp_sota", "3", out, str(port), small_rows], env=env,
+        r = subprocess.run([sys.executable, script, how, "aliccp_sota", "3", out, str(port), small_rows], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-4000:]
-        outs[mode] = torch.load(out)
+        outs[how] = torch.load(out)
     a, b = outs["nccl"], outs["plain"]
     assert a["__backend__"] == "nccl" and a["__exchange__"] and not b["__exchange__"]
     stats = a["__stats__"]
-    for name in ("all_gather_rows_i32", "all_reduce_flat_f32", "all_gather_grad_rows_f32"):
+    names = ("all_gather_rows_i32", "all_reduce_flat_f32", "all_gather_grad_rows_f32") if mode == "replicated" else \
+        ("all_gather_counts_i64", "all_to_all_row_ids_i32", "all_to_all_rows_f32", "all_reduce_flat_f32", "all_to_all_grad_rows_f32")
+    for name in names:
         assert stats[name]["calls"] == 3 and stats[name]["bytes_in"] > 0, (name, stats)
     assert not b["__stats__"]
     for k in a:

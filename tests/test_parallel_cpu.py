@@ -105,3 +105,59 @@ def test_single_process_is_a_no_op():
     parallel.all_reduce_flat(flat)
     out, pending = parallel.gather_grad_rows_async(g)
     assert torch.equal(out, g) and pending is None and torch.equal(flat, before)
+
+
+def _owner_worker(rank, world, port, out):
+    """The collectives of the owner-form step (engine._train_step_owner) with synthetic rows: ids to their owners, the owners'
+    values back, gradient rows to the owners, then the slice broadcasts that bring the replicas together."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from satrans_amd import parallel
+        torch.set_num_threads(1)
+        R, D, n = 1000, 4, 257                                        # table rows, row width, positions per rank
+        g = torch.Generator().manual_seed(100 + rank)
+        # skewed on purpose: rank r asks mostly for rows of owner (r + 1) % world, and nobody asks owner 3 for anything but rank 2
+        hot = (rank + 1) % world
+        rows = torch.cat([torch.randint(hot * 250, hot * 250 + 250, (n - 40,), generator=g),
+                          torch.randint(0, 750, (40,), generator=g)]).to(torch.int32)
+        rows, _ = torch.sort(rows)
+        table = torch.arange(R * D, dtype=torch.float32).reshape(R, D)          # the same replica everywhere
+        bounds = torch.tensor([250, 500, 750], dtype=torch.int32)
+        cut = torch.searchsorted(rows, bounds)
+        edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n)])
+        counts = parallel.gather_counts(edges[1:] - edges[:-1])
+        send, recv = counts[rank].tolist(), counts[:, rank].tolist()
+        assert sum(send) == n and counts.shape == (world, world)
+        got_ids = parallel.all_to_all_rows(rows, send, recv, "ids")
+        assert got_ids.numel() == sum(recv)
+        assert bool(((got_ids >= rank * 250) & (got_ids < rank * 250 + 250)).all()), "an owner received a row outside its slice"
+        vals = table[got_ids.long()] + 0.5 * rank                     # the owner's (current) values: tagged with the owner
+        back = parallel.all_to_all_rows(vals, recv, send, "values")
+        want = table[rows.long()] + 0.5 * (rows // 250).float()[:, None]
+        assert torch.equal(back, want), "values did not come back in the order the ids were sent"
+        grads = torch.randn(n, D, generator=g)
+        recv_g = parallel.all_to_all_rows(grads, send, recv, "grads")
+        # owner-side dense sum of what it received, then replica sync by slice broadcasts
+        dense = torch.zeros(R, D).index_add_(0, got_ids.long(), recv_g)
+        for o in range(world):
+            parallel.broadcast_slice(dense[o * 250:(o + 1) * 250], o)
+        torch.save(dict(rows=rows, grads=grads, dense=dense, stats={k: dict(v) for k, v in parallel.STATS.items()}),
+                   os.path.join(out, f"owner{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_owner_exchange_world_size_4(tmp_path):
+    """World size 4 on gloo: uneven all-to-alls sized from the exchanged counts (one owner receives nothing from three of the
+    ranks), values returned in request order, and slice broadcasts after which every replica holds the sum over ALL ranks."""
+    world = 4
+    mp.spawn(_owner_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"owner{k}.pt")) for k in range(world)]
+    full = torch.zeros(1000, 4)
+    for k in range(world):                                             # rank-major accumulation = the owners' receive order
+        full.index_add_(0, r[k]["rows"].long(), r[k]["grads"])
+    for k in range(world):
+        assert torch.equal(r[k]["dense"], r[0]["dense"]), "replicas differ after the slice broadcasts"
+    np.testing.assert_allclose(r[0]["dense"].numpy(), full.numpy(), rtol=0, atol=1e-5)
+    assert r[0]["stats"]["ids"]["calls"] == 1 and r[0]["stats"]["broadcast_table_slices_f32"]["calls"] == world
