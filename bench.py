@@ -444,7 +444,10 @@ def main():
     F, D, L, U = len(CFG["fields"]), CFG["D"], CFG["L"], CFG["units"][0]
     total_rows = model.embedding_arena.shape[0]
     uniq = int(torch.unique(eng._ws[B]["rows"]).numel()) if B in eng._ws else 0
-    fwd_flops = 2.0 * (4 * F * D * D + 4 * F * D * U + 2 * F * F * D) * B          # per layer launch (U = 2 D: 12 F D^2)
+    # per layer launch: projections + output 4 F D^2, MetaNet of Q and K 4 F D U (U = 2 D: 12 F D^2 in all),
+    # attention 2 F^2 D MACs per sample; flag `gate` has no MetaNet (an elementwise product), `bilinear` a d x d map per head of q
+    meta_macs = 0 if "gate" in args.flag else (F * D * (D // CFG["H"]) if "bilinear" in args.flag else 4 * F * D * U)
+    fwd_flops = 2.0 * (4 * F * D * D + meta_macs + 2 * F * F * D) * B
     # which kernels a "layer_fwd" / "layer_bwd" phase of THIS configuration consists of: one fused kernel (+ its reduction
     # launch) on the fused path; on the general path (configs[4], gate / bilinear) a phase is a chain of ~25 / ~45 launches
     # of the gen_* families, so the phase's rate is a whole-layer rate and no single kernel's counters describe it

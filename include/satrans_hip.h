@@ -155,6 +155,12 @@ typedef struct satrans_layer_desc {
 int satrans_set_layer_impl(int impl);
 
 
+/* 1 when the register-chained fused kernels (csrc/layer_fused.hip) are built for this layer: (D, H) = (32, 4) or (16, 2) with the
+ * MetaNet width U = 2 D, or with SATRANS_GATE / SATRANS_BILINEAR (which replace the MetaNet: satrans.py:61-64,68-71,79-81);
+ * forward only also (64, 4) with U = 16.  satrans_layer_fwd / _bwd pick them on their own; callers ask in order to choose
+ * between this path and the general one (satrans_layer_generic_supported). */
+int satrans_layer_fused_supported(const satrans_layer_desc* d);
+
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);
 

@@ -32,7 +32,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     const int F = a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
-    const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
+    // flags 'gate' / 'bilinear' (satrans.py:61-64,68-71,79-81) replace the MetaNet: q, k *= 2 * vec[scenario] (vec = the generated
+    // row, width D), or q_h = q_h M[scenario, h] (generated row = H matrices d x d).  They reuse the MetaNet's LDS: the doubled
+    // gate vectors sit in the MetaNet LayerNorm slots, the bilinear maps as ONE block-diagonal D x D image in the W1 slot.
+    const bool gate = a.flags & SATRANS_GATE, bilin = a.flags & SATRANS_BILINEAR;
+    const bool meta_q = (a.flags & SATRANS_META_Q) && !bilin, meta_k = (a.flags & SATRANS_META_K) && !bilin;
+    const bool mlp_q = meta_q && !gate, mlp_k = meta_k && !gate;          // the MetaNet proper
     const bool same_tab = a.tab_q == a.tab_k;
 
     // ---- carve LDS, stage the scenario-independent weights once --------------------------------------------
@@ -56,8 +61,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     stage_image(a.w_out, W.woT, D, D, LD, true);      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         W.ln_g[i] = a.ln_g[i]; W.ln_b[i] = a.ln_b[i];
-        if (meta_q) { W.lnq_g[i] = a.lnq_g[i]; W.lnq_b[i] = a.lnq_b[i]; }
-        if (meta_k) { W.lnk_g[i] = a.lnk_g[i]; W.lnk_b[i] = a.lnk_b[i]; }
+        if (mlp_q) { W.lnq_g[i] = a.lnq_g[i]; W.lnq_b[i] = a.lnq_b[i]; }
+        if (mlp_k) { W.lnk_g[i] = a.lnk_g[i]; W.lnk_b[i] = a.lnk_b[i]; }
     }
 
     const int wl = n;  // per-lane offset inside an image: row 4g, column n
@@ -83,15 +88,28 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
       const int lo = max(a.seg[scen], p0), hi = min(a.seg[scen + 1], p1);
       if (lo >= hi) continue;
       // ---- this scenario's generated MetaNet weights (the previous tile loop ended on a barrier) ------------------
-      if (meta_q) {
+      if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
           stage_image(row, W.w1q, D, U, LU, false);
           stage_image(row + D * U, W.w2q, U, D, LD, false);
       }
-      if (meta_k && (!same_tab || !meta_q)) {
+      if (mlp_k && (!same_tab || !mlp_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
           stage_image(row, W.w1k, D, U, LU, false);
           stage_image(row + D * U, W.w2k, U, D, LD, false);
+      }
+      if (gate) {
+          for (int i = threadIdx.x; i < D; i += blockDim.x) {
+              if (meta_q) W.lnq_g[i] = 2.0f * a.tab_q[(size_t)scen * a.tab_stride + i];
+              if (meta_k) W.lnk_g[i] = 2.0f * a.tab_k[(size_t)scen * a.tab_stride + i];
+          }
+      }
+      if (bilin) {                                   // block-diagonal image: wb[h d + i][h d + j] = M[scenario, h][i][j]
+          const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+          for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
+              const int r = e / D, c = e - r * D;
+              W.w1q[r * LD + c] = (r / d == c / d) ? row[(r / d) * d * d + (r % d) * d + (c % d)] : 0.f;
+          }
       }
       __syncthreads();
       // The input row of a wave's (first) token tile is fetched one tile ahead, behind the output block of the previous tile:
@@ -138,7 +156,23 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             chain<KT, KT, LD>(wk_l, x, k);
             chain<KT, KT, LD>(wv_l, x, v);
             float mean, rstd;
-            if (meta_q) {                                                                  // satrans.py:60-66
+            if (gate) {                                                                    // satrans.py:61-62,68-69
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 vq = *reinterpret_cast<const float4*>(W.lnq_g + 16 * t + g4);
+                    const float4 vk = *reinterpret_cast<const float4*>(W.lnk_g + 16 * t + g4);
+                    if (meta_q) { q[t][0] *= vq.x; q[t][1] *= vq.y; q[t][2] *= vq.z; q[t][3] *= vq.w; }
+                    if (meta_k) { k[t][0] *= vk.x; k[t][1] *= vk.y; k[t][2] *= vk.z; k[t][3] *= vk.w; }
+                }
+            } else if (bilin) {                                                            // satrans.py:79-81
+                float qb[KT][4];
+                chain<KT, KT, LD>(W.w1q + g4 * LD + wl, q, qb);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[t][r] = qb[t][r];
+            }
+            if (mlp_q) {                                                                  // satrans.py:60-66
                 float h[UT][4], o[KT][4];
                 metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
                                    drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd);
@@ -147,7 +181,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 #pragma unroll
                     for (int r = 0; r < 4; ++r) q[t][r] = o[t][r];
             }
-            if (meta_k) {                                                                  // satrans.py:67-73
+            if (mlp_k) {                                                                  // satrans.py:67-73
                 float h[UT][4], o[KT][4];
                 metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
                                    drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd);
@@ -411,7 +445,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
-    const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
+    // flags 'gate' / 'bilinear' replace the MetaNet (see the forward kernel): doubled gate vectors in the MetaNet LayerNorm slots,
+    // the bilinear maps as one block-diagonal D x D image in the W1 slot; their gradients accumulate in the (then unused) MetaNet
+    // LayerNorm / W1 accumulators and leave through the scenario records
+    const bool gate = a.flags & SATRANS_GATE, bilin = a.flags & SATRANS_BILINEAR;
+    const bool meta_q = (a.flags & SATRANS_META_Q) && !bilin, meta_k = (a.flags & SATRANS_META_K) && !bilin;
+    const bool mlp_q = meta_q && !gate, mlp_k = meta_k && !gate;          // the MetaNet proper
     constexpr bool same_tab = SAME;
     const bool relu_out = a.flags & SATRANS_RELU_OUT, use_res = !(a.flags & SATRANS_NO_RES);
 
@@ -462,8 +501,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         }
         for (int i = threadIdx.x; i < D; i += blockDim.x) {
             ln_g[i] = a.ln_g[i]; ln_b[i] = a.ln_b[i];
-            if (meta_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
-            if (meta_k) { lnk_g[i] = a.lnk_g[i]; lnk_b[i] = a.lnk_b[i]; }
+            if (mlp_q) { lnq_g[i] = a.lnq_g[i]; lnq_b[i] = a.lnq_b[i]; }
+            if (mlp_k) { lnk_g[i] = a.lnk_g[i]; lnk_b[i] = a.lnk_b[i]; }
         }
         // rows of padding tokens are multiplied by exact zeros in the token-contraction products: they must hold
         // finite numbers from the start (0 * NaN would poison an accumulator)
@@ -547,7 +586,20 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       pre += nt_s;
       if (t0 >= t1) continue;
       // ---- this scenario's generated MetaNet weights, both orientations (previous tile loop ended on a barrier) -----
-      if (meta_q) {
+      if (gate) {
+          for (int i = threadIdx.x; i < D; i += blockDim.x) {
+              if (meta_q) lnq_g[i] = 2.0f * a.tab_q[(size_t)scen * a.tab_stride + i];
+              if (meta_k) lnk_g[i] = 2.0f * a.tab_k[(size_t)scen * a.tab_stride + i];
+          }
+      }
+      if (bilin) {                                   // block-diagonal image: wb[h d + i][h d + j] = M[scenario, h][i][j]
+          const float* row = a.tab_q + (size_t)scen * a.tab_stride;
+          for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
+              const int r = e / D, c = e - r * D;
+              w1q[r * LD + (TR ? c : c ^ img_flip(r))] = (r / d == c / d) ? row[(r / d) * d * d + (r % d) * d + (c % d)] : 0.f;
+          }
+      }
+      if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
           if constexpr (TR) { stage_image(row, w1q, D, U, LU, false); stage_image(row + D * U, w2q, U, D, LD, false); }
           else { stage_image_sw(row, w1q, D, U, LU, false); stage_image_sw(row + D * U, w2q, U, D, LD, false); }
@@ -556,7 +608,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
               stage_image(row + D * U, w2qT, U, D, LU, true);
           }
       }
-      if (meta_k && (!same_tab || !meta_q)) {
+      if (mlp_k && (!same_tab || !mlp_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
           if constexpr (TR) { stage_image(row, w1k, D, U, LU, false); stage_image(row + D * U, w2k, U, D, LD, false); }
           else { stage_image_sw(row, w1k, D, U, LU, false); stage_image_sw(row + D * U, w2k, U, D, LD, false); }
@@ -615,7 +667,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             chain<KT, KT, LD>(wq + lo_d, x, q0);
             chain<KT, KT, LD>(wk + lo_d, x, k0);
             chain<KT, KT, LD>(wv + lo_d, x, v);
-            if (meta_q) {
+            if (mlp_q) {
                 float m[KT][4];
                 chain<KT, UT, LU>(w1q + lo_u, q0, hq);
 #pragma unroll
@@ -639,13 +691,18 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     q[t][0] = zhq[t][0] * gg.x + bb.x; q[t][1] = zhq[t][1] * gg.y + bb.y;
                     q[t][2] = zhq[t][2] * gg.z + bb.z; q[t][3] = zhq[t][3] * gg.w + bb.w;
                 }
+            } else if (bilin) {
+                chain<KT, KT, LD>(w1q + lo_d, q0, q);                          // q_h = q0_h M[s, h]
             } else {
 #pragma unroll
-                for (int t = 0; t < KT; ++t)
+                for (int t = 0; t < KT; ++t) {
+                    const float4 vq = *reinterpret_cast<const float4*>(lnq_g + 16 * t + g4);
+                    const float gv_[4] = {vq.x, vq.y, vq.z, vq.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) q[t][r] = q0[t][r];
+                    for (int r = 0; r < 4; ++r) q[t][r] = (gate && meta_q) ? q0[t][r] * gv_[r] : q0[t][r];
+                }
             }
-            if (meta_k) {
+            if (mlp_k) {
                 float m[KT][4];
                 chain<KT, UT, LU>(w1k + lo_u, k0, hk);
 #pragma unroll
@@ -671,9 +728,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < KT; ++t)
+                for (int t = 0; t < KT; ++t) {
+                    const float4 vk = *reinterpret_cast<const float4*>(lnk_g + 16 * t + g4);
+                    const float gv_[4] = {vk.x, vk.y, vk.z, vk.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) k[t][r] = k0[t][r];
+                    for (int r = 0; r < 4; ++r) k[t][r] = (gate && meta_k) ? k0[t][r] * gv_[r] : k0[t][r];
+                }
             }
             store_frag<KT>(my_q, q);
             store_frag<KT>(my_k, k);
@@ -994,9 +1054,33 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     for (int r = 0; r < 4; ++r) gout[t][r] += back[t][r];
             };
 
-            if (meta_q)
+            if (gate) {                         // q = q0 * 2 vec: d vec += 2 gq q0 (the 2 is applied at the flush), gq0 = gq * 2 vec
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 vq = *reinterpret_cast<const float4*>(lnq_g + 16 * t + g4);
+                    const float4 vk = *reinterpret_cast<const float4*>(lnk_g + 16 * t + g4);
+                    const float gq_[4] = {vq.x, vq.y, vq.z, vq.w}, gk_[4] = {vk.x, vk.y, vk.z, vk.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (meta_q) { agq[t][r] = fmaf(gq[t][r], q0[t][r], agq[t][r]); gq[t][r] *= gq_[r]; }
+                        if (meta_k) { agk[t][r] = fmaf(gk[t][r], k0[t][r], agk[t][r]); gk[t][r] *= gk_[r]; }
+                    }
+                }
+            }
+            if (bilin) {                        // q_h = q0_h M: dM += q0^T gq (block-diagonal part kept by the reducer), gq0 = gq M^T
+                store_frag<KT>(my_q, q0, valid);
+                store_frag<KT>(my_o, gq);
+                wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_w1q);
+                float back[KT][4];
+                chain_t<KT, KT, LD>(w1q + lt_d, gq, back);                    // (by rows of the one image, with or without TR)
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gq[t][r] = back[t][r];
+            }
+            if (mlp_q)
                 metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, 0, hq, q0, w2qT, w1qT, acc_w1q, acc_w2q);
-            if (meta_k) {
+            if (mlp_k) {
                 if constexpr (SAME)   // one table: both roles add into the same accumulators
                     metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
                 else
@@ -1039,7 +1123,36 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       // ---- this scenario's generated-weight gradients: record (workgroup + scenario) ---------------------------------
       // with one shared table both roles accumulated into acc_w1q / acc_w2q; the reducer reads the part of a role only
       // when that role is active, so the sums go to the Q part when Q is modulated, else to the K part
-      {
+      if (gate) {
+          // gate vectors: [dvec_q D | dvec_k D] at the head of the record; per-lane sums -> token lanes -> waves, fixed order
+          float* rec = records + (size_t)(blockIdx.x + scen) * TSZ;
+          auto flush_vec = [&](float (&ag)[KT][4], float* dst) {
+#pragma unroll
+              for (int t = 0; t < KT; ++t)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                      float sv_ = ag[t][r];
+#pragma unroll
+                      for (int m = 1; m < 16; m <<= 1) sv_ += __shfl_xor(sv_, m, 64);
+                      if (n == 0) stage[wave * D + 16 * t + g4 + r] = sv_;
+                      ag[t][r] = 0.f;
+                  }
+              __syncthreads();
+              for (int e = threadIdx.x; e < D; e += kFusedBlock)
+                  dst[e] = 2.0f * (((stage[e] + stage[D + e]) + stage[2 * D + e]) + stage[3 * D + e]);
+              __syncthreads();
+          };
+          flush_vec(agq, rec);
+          flush_vec(agk, rec + D);
+      } else if (bilin) {
+          float* rec = records + (size_t)(blockIdx.x + scen) * TSZ;      // the full D x D product; the reducer keeps the H blocks
+          f32x4 tmp[KT][KT];
+#pragma unroll
+          for (int i = 0; i < KT; ++i)
+#pragma unroll
+              for (int j = 0; j < KT; ++j) { tmp[i][j] = acc_w1q[i][j]; acc_w1q[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          flush(tmp, KTc{}, KTc{}, rec, true);
+      } else {
           float* rec = records + (size_t)(blockIdx.x + scen) * TSZ;
           const bool to_k = SAME && !meta_q;
           flush(acc_w1q, KTc{}, UTc{}, rec + (to_k ? 2 * D * U : 0), true);
@@ -1099,7 +1212,8 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
     const int CSZ = 4 * D * D + 6 * D, DD = D * D;
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = block * 32 + lane;
-    const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    const bool plain = !(flags & (SATRANS_GATE | SATRANS_BILINEAR));        // gate / bilinear: no MetaNet, no MetaNet LayerNorm
+    const bool mq = plain && (flags & SATRANS_META_Q) && g_lnq, mk = plain && (flags & SATRANS_META_K) && g_lnk;
     // without 'pos' the Q and K MetaNets share ONE LayerNorm (satrans.py:46): one thread adds both roles, Q first
     const bool shared = mq && mk && g_lnq == g_lnk;
     const int r = e - 4 * DD;
@@ -1134,10 +1248,16 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
 }
 
 __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ records, const int32_t* __restrict__ seg,
-                                                     int S, int T, int G, int D, int U, int flags, int64_t tab_stride,
+                                                     int S, int T, int G, int D, int U, int H, int flags, int64_t tab_stride,
                                                      float* g_tab_q, float* g_tab_k, int block, int s) {
     __shared__ float s_q[kRG][32], s_k[kRG][32];
-    const int half = 2 * D * U;                                  // one role: [W1 D*U | W2 U*D] = the generated row layout
+    // One record per (workgroup, scenario), TSZ = 4 D U floats apart.  What it holds and which elements of the generated row
+    // they are:   MetaNet   [W1q | W2q | W1k | W2k]: role r = elements [r * 2DU, (r + 1) * 2DU) = the row itself
+    //             gate      [dvec_q D | dvec_k D]
+    //             bilinear  the full D x D product q0^T gq; row element (h, i, j) = entry (h d + i, h d + j)   (queries only)
+    const int TSZ = 4 * D * U, d = D / H;
+    const bool gate = flags & SATRANS_GATE, bil = flags & SATRANS_BILINEAR;
+    const int half = gate ? D : (bil ? D * d : 2 * D * U);      // elements of one role's generated row
     const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = block * 32 + lane;
     // the workgroups whose tile range intersects scenario s (same arithmetic as work_range in the kernel)
@@ -1152,14 +1272,19 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
     const int w_lo = pre / per, w_hi = (pre + nt - 1) / per;
     const int share = (w_hi - w_lo + kRG) / kRG;
     const int a = w_lo + grp * share, b = min(w_hi + 1, a + share);
-    const bool mq = flags & SATRANS_META_Q, mk = flags & SATRANS_META_K;
+    const bool mq = bil || (flags & SATRANS_META_Q), mk = !bil && (flags & SATRANS_META_K);
+    int src_q = e, src_k = half + e;
+    if (bil && e < half) {
+        const int h = e / (d * d), i = (e / d) % d, j = e % d;
+        src_q = (h * d + i) * D + h * d + j;
+    }
     float aq = 0.f, ak = 0.f;
     if (e < half) {
 #pragma unroll 4
         for (int w = a; w < b; ++w) {
-            const float* rec = records + (size_t)(w + s) * 2 * half;
-            if (mq) aq += rec[e];
-            if (mk) ak += rec[half + e];
+            const float* rec = records + (size_t)(w + s) * TSZ;
+            if (mq) aq += rec[src_q];
+            if (mk) ak += rec[src_k];
         }
     }
     s_q[grp][lane] = aq;
@@ -1178,7 +1303,7 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
 
 __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __restrict__ common, const float* __restrict__ records,
                                                          const int32_t* __restrict__ seg, int S, int T, int G, int D, int U,
-                                                         int flags, int64_t tab_stride, int common_blocks, int record_blocks,
+                                                         int H, int flags, int64_t tab_stride, int common_blocks, int record_blocks,
                                                          float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
                                                          float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k) {
     const int bx = blockIdx.x;
@@ -1186,7 +1311,7 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
         fused_common_reduce(common, G, D, flags, bx, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk);
     } else {
         const int rb = bx - common_blocks;
-        fused_records_reduce(records, seg, S, T, G, D, U, flags, tab_stride, g_tab_q, g_tab_k, rb % record_blocks,
+        fused_records_reduce(records, seg, S, T, G, D, U, H, flags, tab_stride, g_tab_q, g_tab_k, rb % record_blocks,
                              rb / record_blocks);
     }
 }
@@ -1269,7 +1394,7 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     // makes the kernel 4 % faster (0.934 -> 0.895 ms per step) and leaves 37 KB of LDS free.  SATRANS_BWD_TR=1 keeps the
     // transposed copies where they fit (D = 32 with one shared generated-weight table) for comparison.
     static const int force_tr = getenv("SATRANS_BWD_TR") ? atoi(getenv("SATRANS_BWD_TR")) : 0;
-    p.tr = force_tr == 1 && same_tab && d->D == 32;
+    p.tr = force_tr == 1 && same_tab && d->D == 32 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR));
     p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, p.tr) * 4;
     if (p.lds > 160 * 1024) return false;
     const int64_t tiles = ceil_div(d->B, p.T) + d->S;
@@ -1299,13 +1424,14 @@ using namespace satrans;
 // 1 when the fused kernels are built for this shape
 extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d) {
     if (!d) return 0;
-    if (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) return 0;
+    if ((d->flags & SATRANS_GATE) && (d->flags & SATRANS_BILINEAR)) return 0;
     if (d->F > 64) return 0;
     const int D = d->D, U = d->U, H = d->H;
-    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
+    const bool alt = d->flags & (SATRANS_GATE | SATRANS_BILINEAR);      // gate / bilinear: no MetaNet, its width plays no part
+    const bool meta = (d->flags & (SATRANS_META_Q | SATRANS_META_K)) && !alt;
     if (D == 32 && H == 4 && (!meta || U == 64)) return 1;
     if (D == 16 && H == 2 && (!meta || U == 32)) return 1;
-    if (D == 64 && H == 4 && (!meta || U == 16)) return 1;
+    if (D == 64 && H == 4 && (!meta || U == 16) && !alt) return 1;
     return 0;
 }
 
@@ -1364,10 +1490,12 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     if (rc) return rc;
     const int D = d->D, U = d->U, CSZ = 4 * D * D + 6 * D;
     float* records = slabs + (size_t)p.G * CSZ;
-    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K);
-    const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(2 * D * U, 32);
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K | SATRANS_BILINEAR);
+    const int row_elems = (d->flags & SATRANS_GATE) ? D : ((d->flags & SATRANS_BILINEAR) ? D * (D / d->H) : 2 * D * U);
+    SATRANS_REQUIRE(!meta || g_tab_q, SATRANS_E_BADARG, "layer_bwd: null generated-row gradient");
+    const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(row_elems, 32);
     fused_reduce_kernel<<<(unsigned)(common_blocks + (meta ? record_blocks * d->S : 0)), 32 * kRG, 0, stream>>>(
-        slabs, records, d->seg, d->S, p.T, p.G, D, U, d->flags, d->tab_stride, common_blocks, record_blocks, g_wq, g_wk, g_wv,
+        slabs, records, d->seg, d->S, p.T, p.G, D, U, d->H, d->flags, d->tab_stride, common_blocks, record_blocks, g_wq, g_wk, g_wv,
         g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
     SATRANS_CHECK_LAUNCH("fused_reduce_kernel");
     return SATRANS_OK;

@@ -239,10 +239,11 @@ class PathEngine:
         probe = self._layer_desc(ws, 0, B, None, None, False)
         fits = int(self.lib.satrans_layer_bwd_slab_floats(C.byref(probe))) >= 0
         can = bool(self.lib.satrans_layer_generic_supported(C.byref(probe)))
-        # `gate` / `bilinear` have no fused kernels: the general path (HBM-rate products) instead of the LDS kernels, whose
-        # backward is an order of magnitude slower (SATRANS_GENERIC=0 keeps the LDS kernels, for the comparison)
+        # (`gate` / `bilinear`: fused kernels at the shapes they are built for - D = 32 / 4 heads, D = 16 / 2 heads - since round 3;
+        # elsewhere the general path rather than the LDS kernels, whose backward is an order of magnitude slower)
         choice = os.environ.get("SATRANS_GENERIC")
-        ws["generic"] = can and (choice == "1" or not fits or (choice is None and (self.gate or self.bilinear)))
+        fused = fits and bool(self.lib.satrans_layer_fused_supported(C.byref(probe)))
+        ws["generic"] = can and (choice == "1" or not fits or (choice is None and (self.gate or self.bilinear) and not fused))
         if ws["generic"]:
             n = int(self.lib.satrans_layer_generic_saved_floats(C.byref(probe)))
             ws["gen_saved"] = [torch.empty(n, **f32)]

@@ -683,28 +683,52 @@ def test_general_layer_path_matches_golden_and_the_oracle(monkeypatch, name):
                                            err_msg=f"{k} B={B} train={train}")
 
 
+@pytest.mark.parametrize("family", ["fused", "lds"])
 @pytest.mark.parametrize("name", ["small_gate", "small_bilinear"])
-def test_gate_and_bilinear_on_the_lds_kernels(monkeypatch, name):
-    """`gate` / `bilinear` run on the general path by default; the LDS-resident kernels (csrc/layer_lds.hip) still serve them
-    with SATRANS_GENERIC=0 and must keep matching the reference's golden outputs and gradients."""
+def test_gate_and_bilinear_kernel_families(monkeypatch, name, family):
+    """`gate` / `bilinear` (satrans.py:61-64,68-71,79-81) on the fused kernels - their default since round 3: the doubled gate
+    vector / the block-diagonal per-head maps take the MetaNet's place in LDS - and on the LDS-resident kernels
+    (csrc/layer_lds.hip, satrans_set_layer_impl(2)); the general path runs the same cases in
+    test_general_layer_path_matches_golden_and_the_oracle.  Golden outputs and every gradient, then a ragged batch and a
+    training-mode step with the kernels' dropout masks replayed through the oracle."""
+    from satrans_amd import native as N
     monkeypatch.setenv("SATRANS_GENERIC", "0")
     c = Case(name)
-    model = build_model(c, DEV)
-    model.compile("adam", "binary_crossentropy")
-    model.eval()
-    model(c.X.to(DEV))
-    eng = model._engine
-    assert not eng._ws[c.X.shape[0]]["generic"]
-    want = c.arrays("out")
-    acts = eng.layer_outputs(c.X.shape[0])
-    for l in range(c.meta["L"]):
-        np.testing.assert_allclose(acts[l + 1].cpu().numpy(), want[f"layer{l}"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(eng.last_logit().cpu().numpy(), want["logit"], rtol=0, atol=LOGIT_ATOL)
-    bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
-    assert bce == pytest.approx(float(c.z["train/bce"]), rel=2e-6)
-    for k, g in c.arrays("grad").items():
-        scale = max(1e-6, float(np.abs(g).max()))
-        np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
+    if family == "lds":
+        N.check(N.lib().satrans_set_layer_impl(2), "set_layer_impl")
+    try:
+        model = build_model(c, DEV)
+        model.compile("adam", "binary_crossentropy")
+        model.eval()
+        model(c.X.to(DEV))
+        eng = model._engine
+        assert not eng._ws[c.X.shape[0]]["generic"]
+        want = c.arrays("out")
+        acts = eng.layer_outputs(c.X.shape[0])
+        for l in range(c.meta["L"]):
+            np.testing.assert_allclose(acts[l + 1].cpu().numpy(), want[f"layer{l}"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(eng.last_logit().cpu().numpy(), want["logit"], rtol=0, atol=LOGIT_ATOL)
+        bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+        assert bce == pytest.approx(float(c.z["train/bce"]), rel=2e-6)
+        for k, g in c.arrays("grad").items():
+            scale = max(1e-6, float(np.abs(g).max()))
+            np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
+        m = c.meta
+        for B, train in ((5, False), (c.X.shape[0], True)):
+            model.train(train)
+            X, y = c.X[:B], c.y[:B]
+            bce, reg, grads = eng.loss_and_grads(X.to(DEV), y.to(DEV))
+            drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, len(m["fields"]), m["D"],
+                                                            m["H"], m["L"], 0.1)) if train else None
+            bce_ref, reg_ref, g_ref = O.loss_and_grads(c.tensors("param"), X, y, c.spec(), drop)
+            assert bce == pytest.approx(bce_ref, rel=5e-6)
+            for k, g in g_ref.items():
+                if k in grads:
+                    scale = max(1e-6, float(g.abs().max()))
+                    np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9,
+                                               err_msg=f"{k} B={B} train={train}")
+    finally:
+        N.check(N.lib().satrans_set_layer_impl(0), "set_layer_impl")
 
 
 def test_general_path_attention_arms_agree():

@@ -1,5 +1,12 @@
 """Diagnostic: compute-side cost of one rank's step in an N-rank job, measured on ONE GPU.
 
+    python tools/fake_world.py [--mode owner|replicated] [N ...]
+
+`--mode owner` (default, the engine's default for several ranks): rank 0 of N.  The stand-ins deliver what the owner of slice 0
+would receive - the rows of N-1 other synthetic batches that fall into its slice, and as many gradient rows - and hand back rows
+for the ids this rank asked the other owners for (read from the local arena: the cost of writing the received buffer).
+`--mode replicated`: round 2's exchange (below).
+
 `parallel.world_size / gather_rows / gather_grad_rows_async / all_reduce_flat` are replaced by stand-ins that append the arena rows of N-1
 other synthetic batches (what the all-gather of ids would deliver) and tile the local gradient rows N times (what
 the all-gather of gradient rows would deliver; the tiling copy costs about what writing the received buffer does).
@@ -20,7 +27,81 @@ import bench  # noqa: E402
 from satrans_amd import parallel  # noqa: E402
 
 
+def run_owner(N, steps=12, warmup=4, B=8192):
+    os.environ["SATRANS_DP_MODE"] = "owner"
+    model = bench.build_model("cpu", 0.005)
+    model.to("cuda:0"); model.device = "cuda:0"
+    eng = model._require_engine()
+    model.train()
+    X, y = bench.synth_batches((steps + warmup) * B, 100)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    bounds = eng._owner_ranges(N)
+    lo, hi = bounds[0], bounds[1]
+    others = []
+    if N > 1:                                   # rows of the other ranks' batches that fall into slice 0, per step, rank-major
+        Xo, _ = bench.synth_batches((steps + warmup) * B * (N - 1), 777)
+        Xo = torch.from_numpy(Xo).cuda().long()
+        big = eng.row_span[:, 0] >= eng.small_rows
+        off = eng.row_span[big, 0][None, :]
+        rows_o = (Xo[:, eng.cols.long()[big]] + off).to(torch.int32).reshape(steps + warmup, N - 1, -1)
+        for i in range(steps + warmup):
+            per = []
+            for r in range(N - 1):
+                v = rows_o[i, r]
+                v = torch.sort(v[(v >= lo) & (v < hi)])[0]
+                per.append(v)
+            others.append(per)
+    state = {"i": 0, "send": None}
+    arena = model.embedding_arena
+    parallel.world_size = lambda: N
+    parallel.rank = lambda: 0
+    parallel.exchange_enabled = lambda: N > 1
+
+    def gather_counts(c):
+        c = c.to(torch.int64).cpu()
+        out = torch.zeros(N, N, dtype=torch.int64)
+        out[0] = c
+        for r in range(1, N):
+            out[r, 0] = others[state["i"]][r - 1].numel()
+        return out
+
+    def all_to_all_rows(inp, send, recv, name):
+        if name == "all_to_all_row_ids_i32":            # my slice-0 segment + what the other ranks ask owner 0 for
+            state["ids"] = inp
+            return torch.cat([inp[:send[0]]] + others[state["i"]])
+        if name == "all_to_all_rows_f32":               # values for every id I asked for (the other owners' answers: an arena read)
+            return arena[state["ids"].long()]
+        n_recv = sum(recv)                              # gradient rows: mine for slice 0 + as many rows as the others send
+        reps = -(-n_recv // max(inp.shape[0], 1))
+        return inp.repeat(reps, 1)[:n_recv].contiguous()
+
+    parallel.gather_counts, parallel.all_to_all_rows = gather_counts, all_to_all_rows
+    parallel.all_reduce_flat = lambda flat: None
+    parallel.broadcast_slice = lambda t, src: None
+    parallel.all_reduce_scalars = lambda t: t
+    eng.timers = None
+    for i in range(warmup):
+        state["i"] = i
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    eng.flush_lazy(sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        state["i"] = i
+        eng.timers = {} if i == warmup + steps - 1 else None
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    ph = eng.phase_ms()
+    eng.timers = None
+    eng.flush_lazy(sync=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(f"owner form, N={N}: {ms:.3f} ms/step per rank (no communication; the slice flush of the {steps} steps included) -> "
+          f"{N * B / ms / 1e3:.2f} M samples/s if comm were free; phases of the last step: " +
+          ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
+
+
 def run(N, steps=12, warmup=4, B=8192):
+    os.environ["SATRANS_DP_MODE"] = "replicated"
     model = bench.build_model("cpu", 0.005)
     model.to("cuda:0"); model.device = "cuda:0"
     eng = model._require_engine()
@@ -61,5 +142,9 @@ def run(N, steps=12, warmup=4, B=8192):
 
 
 if __name__ == "__main__":
-    for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
-        run(n)
+    args = sys.argv[1:]
+    mode = "owner"
+    if args and args[0] == "--mode":
+        mode, args = args[1], args[2:]
+    for n in ([int(a) for a in args] or [1, 2, 4, 8]):
+        (run_owner if mode == "owner" and n > 1 else run)(n)
