@@ -361,6 +361,37 @@ class BaseModel(nn.Module):
             cols = [c.astype(np.float64) for c in cols]                  # ids beyond 2**24 next to float columns: exact in fp64
         return np.concatenate(cols, axis=-1)
 
+    def _columns(self, x) -> List[np.ndarray]:
+        """dict / list of per-feature arrays -> the [N, w] column blocks in `feature_index` order, nothing concatenated."""
+        if isinstance(x, dict):
+            x = [x[name] for name in self.feature_index]
+        cols = [np.asarray(a) for a in x]
+        return [c.reshape(-1, 1) if c.ndim == 1 else c for c in cols]
+
+    def _device_matrix_from_columns(self, cols: List[np.ndarray], lo: int = 0, hi: Optional[int] = None):
+        """The resident [N, C] id matrix assembled ON the device: every column block is uploaded as it is (integers stay
+        integers on the wire) and cast into its columns of the fp32 matrix there - the values `_pack` + `astype(float32)`
+        produce (ids below 2**24 are exact in fp32, float columns are rounded to nearest either way) without the host-side
+        concatenate / cast passes over the whole dataset (the reference builds that matrix on the host:
+        meta_basemodel.py:257-264).  Vocabularies of 2**24 and above keep the host path (`_host_matrices`: int64 ids + dense
+        block)."""
+        sparse, _, _ = split_columns(self.dnn_feature_columns)
+        if max(c.vocabulary_size for c in sparse) >= (1 << 24):
+            return self._to_device_matrix(np.concatenate([c[lo:hi] for c in cols], axis=-1))
+        n = (cols[0].shape[0] if hi is None else hi) - lo
+        data = torch.empty(n, sum(c.shape[1] for c in cols), dtype=torch.float32, device=self.device)
+        j = 0
+        for c in cols:
+            w = c.shape[1]
+            block = np.ascontiguousarray(c[lo:hi])
+            if block.dtype == np.float64 or not (np.issubdtype(block.dtype, np.integer) or np.issubdtype(block.dtype, np.floating)):
+                block = block.astype(np.float32)                  # (numpy's rounding, as the host path)
+            elif block.dtype.kind == "u" and block.dtype.itemsize > 1:
+                block = block.astype(np.int64)                    # (torch has no wide unsigned tensors to upload)
+            data[:, j:j + w] = torch.from_numpy(block).to(self.device)
+            j += w
+        return data
+
     def _to_device_matrix(self, packed: np.ndarray) -> torch.Tensor:
         """The reference ships ids as fp32 (exact below 2**24, models/meta_basemodel.py:311).  That layout is kept
         while every vocabulary is below 2**24.  Above it an id would not survive the round trip through fp32 (the
@@ -402,7 +433,8 @@ class BaseModel(nn.Module):
         engine = self._require_engine()
         if isinstance(x, dict) and getattr(self, "domain_column_list", None):
             self.domain_id_offset = np.asarray(x[self.domain_column_list[0]]).min()
-        packed = self._pack(x)
+        cols = self._columns(x)                               # [N, w] blocks; concatenated on the host only when streamed
+        n_cols = sum(c.shape[1] for c in cols)
         y = np.asarray(y, dtype=np.float32).reshape(-1)
 
         do_validation, val_x, val_y = False, None, []
@@ -414,13 +446,14 @@ class BaseModel(nn.Module):
             val_x, val_y = self._pack(validation_data[0]), np.asarray(validation_data[1])
         elif validation_split and 0. < validation_split < 1.:
             do_validation = True
-            split_at = int(packed.shape[0] * (1. - validation_split))
-            packed, val_x = packed[:split_at], packed[split_at:]
+            split_at = int(cols[0].shape[0] * (1. - validation_split))
+            val_x = np.concatenate([c[split_at:] for c in cols], axis=-1)
+            cols = [c[:split_at] for c in cols]
             y, val_y = y[:split_at], y[split_at:]
 
         if batch_size is None:
             batch_size = 256
-        sample_num = packed.shape[0]
+        sample_num = cols[0].shape[0]
         self._check_ranks_agree(sample_num, batch_size)
         steps_per_epoch = (sample_num - 1) // batch_size + 1
         steps_to_valid = steps_per_epoch // valid_cnt_per_epoch + 1
@@ -430,12 +463,16 @@ class BaseModel(nn.Module):
         import os as _os
         stream = getattr(self, "stream_input", None)
         if stream is None:
-            stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or packed.nbytes > (8 << 30)
+            stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or sample_num * n_cols * 4 > (8 << 30)
         data = labels = None
         if stream:
+            packed = np.concatenate(cols, axis=-1)
+            if any(np.issubdtype(c.dtype, np.integer) and c.size and int(c.max()) >= (1 << 24) for c in cols) and \
+                    any(not np.issubdtype(c.dtype, np.integer) for c in cols):
+                packed = np.concatenate([c.astype(np.float64) for c in cols], axis=-1)   # (as _pack)
             host_ids, host_dense = self._host_matrices(packed)
         else:
-            data = self._to_device_matrix(packed)             # whole training set resident in HBM
+            data = self._device_matrix_from_columns(cols)     # whole training set resident in HBM, assembled there
             labels = torch.from_numpy(y).to(self.device)
         self.train()
 
@@ -457,6 +494,8 @@ class BaseModel(nn.Module):
             train_result: Dict[str, list] = {}
             engine.reset_epoch_sums()
             order = self._epoch_order(sample_num, shuffle)
+            if not stream and torch.is_tensor(data):
+                engine.plan_owner_counts(data, order, batch_size)      # several ranks, owner form: the epoch's exchange sizes at once
             feeder = None
             if stream:
                 from .pipeline import HostBatchFeeder
@@ -588,21 +627,24 @@ class BaseModel(nn.Module):
         engine = self._require_engine()
         was_training = self.training
         self.eval()
-        packed = x if isinstance(x, np.ndarray) and x.ndim == 2 and not isinstance(x, (dict, list)) else self._pack(x)
+        is_matrix = isinstance(x, np.ndarray) and x.ndim == 2 and not isinstance(x, (dict, list))
+        cols = [x] if is_matrix else self._columns(x)
+        n_rows, n_cols = cols[0].shape[0], sum(c.shape[1] for c in cols)
         import os as _os
         stream = getattr(self, "stream_input", None)
         if stream is None:
-            stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or packed.nbytes > (8 << 30)
-        out = torch.empty((packed.shape[0], 1), dtype=torch.float32, device=self.device)
+            stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or n_rows * n_cols * 4 > (8 << 30)
+        out = torch.empty((n_rows, 1), dtype=torch.float32, device=self.device)
         if stream:                                      # host-resident, double-buffered (satrans_amd/pipeline.py)
             from .pipeline import HostBatchFeeder
+            packed = x if is_matrix else self._pack(x)
             host_ids, host_dense = self._host_matrices(packed)
             lo = 0
             for xb, _ in HostBatchFeeder(host_ids, None, batch_size, self.device, None, host_dense):
                 out[lo:lo + len(xb)] = engine.forward(xb, training=False)
                 lo += len(xb)
         else:
-            data = self._to_device_matrix(packed)
+            data = self._to_device_matrix(x) if is_matrix else self._device_matrix_from_columns(cols)
             for lo in range(0, data.shape[0], batch_size):
                 hi = min(data.shape[0], lo + batch_size)
                 out[lo:hi] = engine.forward(data[lo:hi], training=False)

@@ -873,6 +873,37 @@ class PathEngine:
         chunk = -(-(self.total_rows - lo0) // world)
         return [min(self.total_rows, lo0 + o * chunk) for o in range(world + 1)]
 
+    def plan_owner_counts(self, ids: torch.Tensor, order: Optional[torch.Tensor], batch_size: int) -> None:
+        """Owner form, optional: the per-step all-to-all split sizes of a whole epoch in ONE pass and ONE read-back, for callers
+        that know the epoch's batches ahead (`fit`: the resident id matrix [N, C] and the epoch's sample order).  Without a plan
+        every step gathers its counts and reads them back before it can size its exchange, which drains the launch queue once
+        per step.  Consumed step by step by train_step; a batch whose size does not match the plan falls back to the read-back."""
+        from . import parallel
+        self._owner_plan = None
+        world = parallel.world_size()
+        if not (parallel.exchange_enabled() and self.dp_mode == "owner" and self.lazy and self.F_small < self.F) or world == 1:
+            return
+        if ids.dtype not in (torch.float32, torch.int32, torch.int64) or ids.dim() != 2:
+            return
+        big = (self.row_span[:, 0] >= self.small_rows).nonzero().reshape(-1)
+        cols = self.cols.long()[big]
+        chunk = -(-(self.total_rows - self.small_rows) // world)
+        n = ids.shape[0]
+        steps = (n - 1) // batch_size + 1
+        per = torch.zeros(steps, world, dtype=torch.int64, device=self.dev)
+        step_of = torch.arange(n, device=self.dev) // batch_size                       # position in the epoch -> step
+        for lo in range(0, n, 1 << 22):                                                # (bounded temporaries on 42 M-row datasets)
+            hi = min(n, lo + (1 << 22))
+            sel = order[lo:hi] if order is not None else slice(lo, hi)
+            rows = ids[sel][:, cols].long() + self.row_span[big, 0][None, :]
+            owner = ((rows - self.small_rows) // chunk).clamp_(0, world - 1)
+            key = step_of[lo:hi, None] * world + owner
+            per.view(-1).scatter_add_(0, key.reshape(-1), torch.ones_like(key.reshape(-1)))
+        allc = torch.empty(world * per.numel(), dtype=torch.int64, device=self.dev)
+        parallel._all_gather(allc, per.reshape(-1))
+        self._owner_plan = dict(counts=allc.reshape(world, steps, world).permute(1, 0, 2).contiguous().cpu(), step=0,
+                                batch=batch_size, last=n - (steps - 1) * batch_size)
+
     def _owner_ws(self, ws: dict, n_b: int, need: int) -> dict:
         """Buffers for the lists an owner receives.  Their length depends on the ids of the step (about n_b with uniform ids, up
         to world * n_b when every rank gathers from one slice): capacity doubles when a step outgrows it."""
@@ -946,9 +977,20 @@ class PathEngine:
         h_emb = self._hparams(l2)
         big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
         with self.phase("owner_ids"):
-            cut = torch.searchsorted(big_sorted, ws["bounds_t"][world]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
-            edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n_b)])
-            counts = parallel.gather_counts(edges[1:] - edges[:-1])            # [N, N] on the host: the step's one read-back
+            counts = None
+            plan = getattr(self, "_owner_plan", None)
+            if plan is not None:                      # an epoch plan (plan_owner_counts): no read-back, the queue stays full
+                i = plan["step"]
+                steps = plan["counts"].shape[0]
+                if i < steps and B == (plan["last"] if i == steps - 1 else plan["batch"]):
+                    counts = plan["counts"][i]
+                    plan["step"] = i + 1
+                else:
+                    self._owner_plan = None
+            if counts is None:
+                cut = torch.searchsorted(big_sorted, ws["bounds_t"][world]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
+                edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n_b)])
+                counts = parallel.gather_counts(edges[1:] - edges[:-1])        # [N, N] on the host: the step's one read-back
             send, recv = counts[rank].tolist(), counts[:, rank].tolist()
             n_recv = int(sum(recv))
             o_rows = parallel.all_to_all_rows(big_sorted, send, recv, "all_to_all_row_ids_i32")

@@ -1141,6 +1141,79 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows,
         assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
 
 
+def _dp_fit_worker(rank, world, port, name, out_dir, mode):
+    """Two ranks through the public `fit` (shuffled epochs, a ragged last batch): the owner form sizes its exchanges from the
+    epoch plan `fit` hands the engine (engine.plan_owner_counts), not from a per-step read-back."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["SATRANS_SMALL_TABLE_ROWS"] = "20"
+    os.environ["SATRANS_DP_MODE"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = Case(name)
+        torch.manual_seed(77)                                       # the same shuffles in both forms
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        model._require_engine().drop_p = 0.0
+        n = c.X.shape[0] // world
+        Xr, yr = c.X[rank * n:(rank + 1) * n].numpy(), c.y[rank * n:(rank + 1) * n].numpy()
+        x = {f: Xr[:, i] for i, f in enumerate(c.meta["feature_names"])}
+        eng = model._require_engine()
+        seen = []
+        orig = eng.plan_owner_counts
+
+        def spy(*a, **k):
+            orig(*a, **k)
+            seen.append(None if eng._owner_plan is None else eng._owner_plan["counts"].shape)
+        eng.plan_owner_counts = spy
+        hist = model.fit(x=x, y=yr, batch_size=10, epochs=2, verbose=0, shuffle=True)
+        plan = eng._owner_plan
+        res = sd_to_cpu(model)
+        res["__loss__"] = torch.tensor(hist.history["loss"], dtype=torch.float64)
+        res["__plan__"] = torch.tensor([-1, -1] if plan is None else [plan["step"], plan["counts"].shape[0]])
+        res["__plans__"] = torch.tensor(len([s_ for s_ in seen if s_ is not None]))
+        torch.save(res, os.path.join(out_dir, f"fit{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_fit_plans_the_owner_exchange_per_epoch(tmp_path):
+    """`fit` on two ranks (golden rows split in halves, batch 10: 4 steps per epoch, the last one ragged, shuffle on): in the
+    owner form every epoch's exchange sizes come from ONE plan (no per-step read-back) and every step of the epoch consumes its
+    entry; replicas identical; loss history and parameters equal to the replicated form's to the rounding of a sum."""
+    import socket
+    import torch.multiprocessing as mp
+    name = "aliccp_sota"
+    c = Case(name)
+    res = {}
+    for mode in ("owner", "replicated"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = tmp_path / mode
+        out.mkdir()
+        mp.spawn(_dp_fit_worker, args=(2, port, name, str(out), mode), nprocs=2, join=True)
+        r0, r1 = torch.load(out / "fit0.pt"), torch.load(out / "fit1.pt")
+        for k in r0:
+            if not k.startswith("__"):
+                assert torch.equal(r0[k], r1[k]), f"{mode}: replicas diverged at {k}"
+        res[mode] = r0
+    steps = (c.X.shape[0] // 2 - 1) // 10 + 1
+    assert res["owner"]["__plan__"].tolist() == [steps, steps], "the epoch plan was not consumed step by step"
+    assert int(res["owner"]["__plans__"]) == 2 and res["replicated"]["__plan__"].tolist() == [-1, -1]
+    np.testing.assert_allclose(res["owner"]["__loss__"].numpy(), res["replicated"]["__loss__"].numpy(), rtol=1e-6)
+    gold = c.arrays("grad")
+    lr = c.meta["lr"]
+    for k, v in res["owner"].items():
+        if k.startswith("__"):
+            continue
+        diff = (v - res["replicated"][k]).abs().flatten().double()
+        assert float(diff.max()) <= 2.0 * lr * 2 * steps + 1e-6, k
+        if k in gold and float(np.abs(gold[k]).max()) >= 1e-7:
+            assert float(diff.median()) <= 2e-4 * lr * 2 * steps, (k, float(diff.median()))
+
+
 @pytest.mark.parametrize("B", [1, 2])
 def test_regulariser_sum_of_tiny_batches(monkeypatch, B):
     """A batch of one or two samples makes every partial-sum group of the touched-row kernels a single block (their slots

@@ -8,15 +8,29 @@ import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+LAYERS = 3          # bench --config aliccp: the layer kernels run in the order l0 l1 l2 (forward), l2 l1 l0 (backward) every step
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
-        for row in csv.DictReader(f):
-            k = row.get("Kernel_Name") or row.get("Kernel Name")
-            c, v = row["Counter_Name"], float(row["Counter_Value"])
-            short = k.split("(")[0].replace("void ", "").replace("satrans::", "")[:48]
-            a = acc[short][c]
-            a[0] += v
-            a[1] += 1
+        rows = sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"]))
+    seen = collections.defaultdict(lambda: collections.defaultdict(int))      # per kernel and counter: dispatches so far
+    for row in rows:
+        k = row.get("Kernel_Name") or row.get("Kernel Name")
+        c, v = row["Counter_Name"], float(row["Counter_Value"])
+        short = k.split("(")[0].replace("void ", "").replace("satrans::", "")[:48]
+        a = acc[short][c]
+        a[0] += v
+        a[1] += 1
+        # the fused layer kernels also per layer: layer 0 gathers its rows from the embedding arena (fused gather)
+        if short.startswith(("layer_fwd_fused_kernel", "layer_bwd_fused_kernel")):
+            i = seen[short][c] % LAYERS
+            seen[short][c] += 1
+            layer = i if short.startswith("layer_fwd") else LAYERS - 1 - i
+            b = acc[f"{short} @layer{layer}"][c]
+            b[0] += v
+            b[1] += 1
+            b_t = acc[f"{short} @layer{layer}"]["duration_ns"]
+            b_t[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            b_t[1] += 1
 out = {}
 for k, cs in acc.items():
     out[k] = {c: a[0] / a[1] for c, a in cs.items()}
