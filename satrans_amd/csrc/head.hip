@@ -115,6 +115,7 @@ __global__ __launch_bounds__(32 * kReduceGroups) void head_reduce_kernel(const f
             for (int k = lo; k < hi; ++k) acc += (double)partial[(size_t)k * (ncol + 2) + c];
         } else {
             float a32 = 0.f;
+#pragma unroll 8                   // (the loads of eight rows in flight; the adds stay in index order)
             for (int k = lo; k < hi; ++k) a32 += partial[(size_t)k * (ncol + 2) + c];
             acc = (double)a32;
         }

@@ -24,7 +24,9 @@ namespace satrans {
 #define SATRANS_FWD_PREFETCH_X 0
 #endif
 
-template <int D, int U, int H, int WAVES = kFusedWaves>
+// MOD: what modulates q / k - 0 the MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear' (compile time: the main instantiation
+// pays nothing for the other two)
+template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                       float* __restrict__ y, float* __restrict__ att) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     // flags 'gate' / 'bilinear' (satrans.py:61-64,68-71,79-81) replace the MetaNet: q, k *= 2 * vec[scenario] (vec = the generated
     // row, width D), or q_h = q_h M[scenario, h] (generated row = H matrices d x d).  They reuse the MetaNet's LDS: the doubled
     // gate vectors sit in the MetaNet LayerNorm slots, the bilinear maps as ONE block-diagonal D x D image in the W1 slot.
-    const bool gate = a.flags & SATRANS_GATE, bilin = a.flags & SATRANS_BILINEAR;
+    constexpr bool gate = MOD == 1, bilin = MOD == 2;
     const bool meta_q = (a.flags & SATRANS_META_Q) && !bilin, meta_k = (a.flags & SATRANS_META_K) && !bilin;
     const bool mlp_q = meta_q && !gate, mlp_k = meta_k && !gate;          // the MetaNet proper
     const bool same_tab = a.tab_q == a.tab_k;
@@ -431,7 +433,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
         _Pragma("unroll 1") for (int VAR = 0; VAR < F; VAR += 4) BODY(VAR);                                      \
     }
 
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0>      // FT: the field count as a constant (0 = a.F)
+// FT: the field count as a constant (0 = a.F).  MOD: 0 MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear'
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // flags 'gate' / 'bilinear' replace the MetaNet (see the forward kernel): doubled gate vectors in the MetaNet LayerNorm slots,
     // the bilinear maps as one block-diagonal D x D image in the W1 slot; their gradients accumulate in the (then unused) MetaNet
     // LayerNorm / W1 accumulators and leave through the scenario records
-    const bool gate = a.flags & SATRANS_GATE, bilin = a.flags & SATRANS_BILINEAR;
+    constexpr bool gate = MOD == 1, bilin = MOD == 2;
     const bool meta_q = (a.flags & SATRANS_META_Q) && !bilin, meta_k = (a.flags & SATRANS_META_K) && !bilin;
     const bool mlp_q = meta_q && !gate, mlp_k = meta_k && !gate;          // the MetaNet proper
     constexpr bool same_tab = SAME;
@@ -1326,7 +1329,7 @@ static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 4 * rows * LD + 64;
 }
 
-template <int D, int U, int H, int WAVES>
+template <int D, int U, int H, int WAVES, int MOD = 0>
 static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipStream_t stream) {
     const bool same_tab = d->tab_q == d->tab_k;
     // samples per tile: as many as keep `per_cu` workgroups per CU, preferring tiles that fill their 16-token MFMA rows
@@ -1346,7 +1349,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab) * 4;
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
@@ -1354,7 +1357,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int64_t tiles = ceil_div(d->B, best);                        // (the kernel splits the batch by samples)
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
-    layer_fwd_fused_kernel<D, U, H, WAVES><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
+    layer_fwd_fused_kernel<D, U, H, WAVES, MOD><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1402,17 +1405,17 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     return true;
 }
 
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
                       hipStream_t stream) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1442,6 +1445,9 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     // ten samples per tile) beats two 4-wave workgroups (two waves per SIMD) by 11 % (0.275 vs 0.309 ms per step);
     // SATRANS_FWD_WAVES = 4 | 8 selects the other builds
     static const int fwd_waves = getenv("SATRANS_FWD_WAVES") ? atoi(getenv("SATRANS_FWD_WAVES")) : 12;
+    const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
+    if (mod && d->D == 32) return mod == 1 ? launch_fwd_w<32, 64, 4, 12, 1>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 2>(d, y, att, stream);
+    if (mod) return mod == 1 ? launch_fwd_w<16, 32, 2, kFusedWaves, 1>(d, y, att, stream) : launch_fwd_w<16, 32, 2, kFusedWaves, 2>(d, y, att, stream);
     if (d->D == 32 && fwd_waves == 8) return launch_fwd_w<32, 64, 4, 8>(d, y, att, stream);
     if (d->D == 32 && fwd_waves == 4) return launch_fwd<32, 64, 4>(d, y, att, stream);
     if (d->D == 32) return launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
@@ -1479,7 +1485,18 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
     // the AliCCP field count as a compile-time constant: -11 % (0.868 -> 0.777 ms over three layers).  The same for the 16
     // fields of the Alimama `sota-pos` shape (separate Q / K tables) spills 34 VGPRs and gains nothing: not instantiated.
-    if (d->D == 32 && same && !p.tr && d->F == 19 && f_const)
+    const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
+    if (mod == 1)
+        rc = d->D == 32 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 1>(d, p, dy, dx, slabs, stream)
+                                : launch_bwd<32, 64, 4, false, false, 0, 1>(d, p, dy, dx, slabs, stream))
+                        : (same ? launch_bwd<16, 32, 2, true, false, 0, 1>(d, p, dy, dx, slabs, stream)
+                                : launch_bwd<16, 32, 2, false, false, 0, 1>(d, p, dy, dx, slabs, stream));
+    else if (mod == 2)
+        rc = d->D == 32 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
+                                : launch_bwd<32, 64, 4, false, false, 0, 2>(d, p, dy, dx, slabs, stream))
+                        : (same ? launch_bwd<16, 32, 2, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
+                                : launch_bwd<16, 32, 2, false, false, 0, 2>(d, p, dy, dx, slabs, stream));
+    else if (d->D == 32 && same && !p.tr && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32) rc = same ? (p.tr ? launch_bwd<32, 64, 4, true, true>(d, p, dy, dx, slabs, stream)
                                       : launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream))

@@ -866,12 +866,41 @@ class PathEngine:
     # ------------------------------------------------------------------------------------------------
     # several ranks, row-ownership form
     # ------------------------------------------------------------------------------------------------
-    def _owner_ranges(self, world: int) -> List[int]:
+    def _owner_ranges(self, world: int, B: Optional[int] = None) -> List[int]:
         """Arena row boundaries of the owners' slices of the LARGE tables: rank o steps rows [b[o], b[o+1]).  (Small tables sit
-        first in the arena, are stepped densely by every rank from the all-reduced gradient and have no owner.)"""
+        first in the arena, are stepped densely by every rank from the all-reduced gradient and have no owner.)
+
+        The slices carry equal WORK, not equal row counts.  Every field sends B positions per rank and step into its table
+        whatever the table's size (AliCCP: one table holds 66 % of the large rows and receives 1/8 of the positions), and an
+        owner pays per received position (sort, replay, ordered sums, Adam: ~2.3 ns) and per owned row (the postponed
+        regulariser steps at flush time: ~0.026 ns per row and step).  With uniform ids a row of a table with R rows used by k
+        fields costs  90 * k * N B / R + 1  row-flush units per step (N ranks); the boundaries cut the cumulative cost into equal parts.
+        Fixed at the first owner-form step (ownership of optimizer state must not move with the batch size) until the replicas
+        are brought together again.  A pure function of the model, `world` and that first B: identical on every rank."""
+        cached = getattr(self, "_owner_bounds", None)
+        if cached is not None and cached[0] == world:
+            return cached[1]
         lo0 = self.small_rows
-        chunk = -(-(self.total_rows - lo0) // world)
-        return [min(self.total_rows, lo0 + o * chunk) for o in range(world + 1)]
+        spans = sorted({(int(lo), int(hi)) for lo, hi in self.row_span.tolist() if lo >= lo0})
+        uses = {sp: sum(1 for lo, hi in self.row_span.tolist() if (int(lo), int(hi)) == sp) for sp in spans}
+        Bn = float(B or 8192) * world                                                      # positions per field and step, all ranks
+        dens = [90.0 * uses[sp] * Bn / max(1, sp[1] - sp[0]) + 1.0 for sp in spans]       # cost units per row
+        total = sum(d * (sp[1] - sp[0]) for d, sp in zip(dens, spans))
+        bounds, acc, k = [lo0], 0.0, 1
+        for d, (lo, hi) in zip(dens, spans):
+            cost = d * (hi - lo)
+            while k < world and acc + cost >= total * k / world:
+                bounds.append(min(hi, lo + int(math.ceil((total * k / world - acc) / d))))
+                k += 1
+            acc += cost
+        while len(bounds) < world:
+            bounds.append(self.total_rows)
+        bounds.append(self.total_rows)
+        for i in range(1, len(bounds)):
+            bounds[i] = max(bounds[i], bounds[i - 1])
+        if B is not None:
+            self._owner_bounds = (world, bounds)
+        return bounds
 
     def plan_owner_counts(self, ids: torch.Tensor, order: Optional[torch.Tensor], batch_size: int) -> None:
         """Owner form, optional: the per-step all-to-all split sizes of a whole epoch in ONE pass and ONE read-back, for callers
@@ -887,7 +916,11 @@ class PathEngine:
             return
         big = (self.row_span[:, 0] >= self.small_rows).nonzero().reshape(-1)
         cols = self.cols.long()[big]
-        chunk = -(-(self.total_rows - self.small_rows) // world)
+        if self._owner_world != world:                 # (the plan and the steps must cut the rows at the same places)
+            self.flush_lazy()
+            self._owner_bounds = None
+            self._owner_world = world
+        inner = torch.tensor(self._owner_ranges(world, batch_size)[1:-1], dtype=torch.int64, device=self.dev)
         n = ids.shape[0]
         steps = (n - 1) // batch_size + 1
         per = torch.zeros(steps, world, dtype=torch.int64, device=self.dev)
@@ -896,7 +929,7 @@ class PathEngine:
             hi = min(n, lo + (1 << 22))
             sel = order[lo:hi] if order is not None else slice(lo, hi)
             rows = ids[sel][:, cols].long() + self.row_span[big, 0][None, :]
-            owner = ((rows - self.small_rows) // chunk).clamp_(0, world - 1)
+            owner = torch.bucketize(rows, inner, right=True)                              # rows >= a boundary belong to the next owner
             key = step_of[lo:hi, None] * world + owner
             per.view(-1).scatter_add_(0, key.reshape(-1), torch.ones_like(key.reshape(-1)))
         allc = torch.empty(world * per.numel(), dtype=torch.int64, device=self.dev)
@@ -949,16 +982,17 @@ class PathEngine:
         arena, am, av = arena_t.data_ptr(), am_t.data_ptr(), av_t.data_ptr()
         if self._owner_world != world:
             self.flush_lazy()                         # (first owner-form step: everything current and identical everywhere)
+            self._owner_bounds = None
             self._owner_world = world
-        bounds = self._owner_ranges(world)
+        bounds = self._owner_ranges(world, B)
         if "xg" not in ws:
             ws["xg"] = torch.empty(n_loc, D, dtype=torch.float32, device=self.dev)
             ws["inv"] = torch.empty(n_loc, dtype=torch.int32, device=self.dev)
             ws["iota_loc"] = torch.arange(n_loc, dtype=torch.int32, device=self.dev)
             ws["packed_o"] = torch.empty(max(n_b, 1), D, dtype=torch.float32, device=self.dev)
-            ws["bounds_t"] = {}
-        if world not in ws["bounds_t"]:
-            ws["bounds_t"][world] = torch.tensor(bounds[1:-1], dtype=torch.int32, device=self.dev)
+        bt = getattr(self, "_owner_bounds_t", None)
+        if bt is None or bt[0] is not bounds:
+            bt = self._owner_bounds_t = (bounds, torch.tensor(bounds[1:-1], dtype=torch.int32, device=self.dev))
 
         # ---- 1. this batch's arena rows, sorted; the large-table part is N runs, one per owner -----------------------------
         N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
@@ -988,7 +1022,7 @@ class PathEngine:
                 else:
                     self._owner_plan = None
             if counts is None:
-                cut = torch.searchsorted(big_sorted, ws["bounds_t"][world]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
+                cut = torch.searchsorted(big_sorted, bt[1]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
                 edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n_b)])
                 counts = parallel.gather_counts(edges[1:] - edges[:-1])        # [N, N] on the host: the step's one read-back
             send, recv = counts[rank].tolist(), counts[:, rank].tolist()

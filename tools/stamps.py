@@ -56,3 +56,10 @@ for role, off in ((("Q-role wave 0", 0), ("K-role wave 4", 16)) if RS else (("wa
     print(f"--- {role}: {tot / (6 * 256) / 1e3:.1f} kcycles per workgroup-launch")
     for nme, v in zip(names, vals):
         print(f"{nme:26s} {v / tot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
+# the forward kernel's slots (three launches per step, two steps; wave 0 of every workgroup)
+fnames = ["fwd staging / loop top", "fwd 1 projections + MetaNet", "fwd 2 attention", "fwd 3 out block"]
+fvals = [buf[i] for i in range(9, 13)]
+ftot = sum(fvals) or 1
+print(f"--- forward, wave 0: {ftot / (6 * 256) / 1e3:.1f} kcycles per workgroup-launch")
+for nme, v in zip(fnames, fvals):
+    print(f"{nme:28s} {v / ftot * 100:6.2f} %   {v / (6 * 256) / 1e3:9.1f} kcycles per workgroup-launch")
