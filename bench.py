@@ -326,6 +326,10 @@ def main():
     def step(i):
         eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
 
+    if world > 1:
+        # several ranks, owner form: the exchange sizes of the W + K resident batches in one pass (what `fit` does per epoch),
+        # instead of one count read-back per step
+        eng.plan_owner_counts(Xd, None, B)
     for i in range(W):
         step(i)
     # the postponed row updates of the WARM-UP steps belong to the warm-up: bring every row up to date before the clock starts, so
