@@ -263,12 +263,19 @@ class BaseModel(nn.Module):
     def _refresh_adam_cfg(self):
         """Re-read lr / betas / eps from the torch optimizer given to compile() (LR schedulers and manual edits of
         `param_groups` take effect at the next step, as they do for torch.optim.Adam).  Steps that are still postponed
-        (lazy-exact form) belong to the old values and are applied first."""
+        (lazy-exact form) belong to the old values."""
         opt = getattr(self, "optim", None)
         if isinstance(opt, torch.optim.Optimizer):
             new = self._read_optimizer(opt)
             if new != self._adam_cfg:
-                self._flush_engine()
+                old = self._adam_cfg
+                # A learning-rate change alone (what an LR scheduler does every step) needs no flush: the replay of postponed
+                # steps reads the rate each step was taken with from the engine's per-step table (engine._table).  Anything
+                # else (betas, eps, another optimizer) applies the postponed steps under the old values first.
+                only_lr = new.get("kind") == "adam" and old.get("kind") == "adam" and \
+                    {k: v for k, v in new.items() if k != "lr"} == {k: v for k, v in old.items() if k != "lr"}
+                if not only_lr:
+                    self._flush_engine()
                 self._adam_cfg = new
         return self._adam_cfg
 

@@ -612,6 +612,8 @@ class PathEngine:
             self.flat_m.copy_(st["flat_m"].to(self.dev))
             self.flat_v.copy_(st["flat_v"].to(self.dev))
             self.last_step.fill_(self.adam_t)            # the state was taken after a flush: every row is current
+            self._table_lr = self._table_dirty = self._lr_hist = None    # (rows of earlier steps are never replayed again)
+            self._hp_table = None
         else:
             self._opt_state_arena.copy_(st["acc_arena"].to(self.dev))
             self._opt_state_flat.copy_(st["acc_flat"].to(self.dev))
@@ -761,6 +763,7 @@ class PathEngine:
         with self.phase("embed_sort"):
             sort(ws["rows"], n_loc, ws["sorted_rows"], ws["src"], None, per_field=True)
         self.adam_t += 1
+        self._note_lr(cfg["lr"])
         h_emb = self._hparams(l2)
         # ---- 2. lazy form: replay the postponed steps of exactly these rows up to t-1, so that the gather reads current
         #         values (small-table rows are always current: they take a dense step every step) --------------------------
@@ -1008,6 +1011,7 @@ class PathEngine:
                                                ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
                                                ws["iota"].data_ptr(), st), "satrans_embed_sort")
         self.adam_t += 1
+        self._note_lr(m._adam_cfg["lr"])
         h_emb = self._hparams(l2)
         big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
         with self.phase("owner_ids"):
@@ -1150,18 +1154,60 @@ class PathEngine:
                                           ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(),
                                           self.reg_sum.data_ptr(), st), "satrans_adam_flat_sum")
 
+    def _note_lr(self, lr: float) -> None:
+        """Called by every Adam step right after it has advanced `adam_t`: step adam_t (and, until further notice, every later
+        one) is taken with learning rate `lr`.  When the rate differs from the one the per-step table holds for this step (an LR
+        scheduler, an edited param_group) the rows from this step on are rewritten - the rows of earlier, possibly still
+        postponed, steps keep the rate they were taken with, so a rate change needs no flush."""
+        hist = getattr(self, "_lr_hist", None)
+        if hist is None:
+            hist = self._lr_hist = {}                   # step -> rate, only where it changed: {first step of a segment: rate}
+        prev = getattr(self, "_table_lr", None)
+        if prev is None or lr != prev:
+            hist[self.adam_t] = lr
+            self._table_lr = lr
+            if self._hp_table is not None:
+                d = getattr(self, "_table_dirty", None)
+                self._table_dirty = self.adam_t if d is None else min(d, self.adam_t)
+
+    def _rates(self, lo: int, hi: int):
+        """Learning rate of the steps [lo, hi) as an fp64 array: the rate of the last change at or before each step (steps before
+        the first recorded change - a resumed run - take the first recorded rate; they are never replayed)."""
+        import numpy as np
+        hist = getattr(self, "_lr_hist", None) or {0: self.m._adam_cfg["lr"]}
+        starts = sorted(hist)
+        out = np.empty(max(0, hi - lo), dtype=np.float64)
+        for i, st in enumerate(starts):
+            a_, b_ = max(lo, st if i else 0), (starts[i + 1] if i + 1 < len(starts) else hi)
+            if b_ > a_:
+                out[a_ - lo:min(b_, hi) - lo] = hist[st]
+        return out
+
     def _table(self, upto: int) -> torch.Tensor:
-        """Per-step Adam constants for the replay kernels, computed on the host exactly like `_hparams`."""
-        cfg = self.m._adam_cfg
-        key = (cfg["lr"], cfg["betas"])
-        if self._hp_table is None or self._hp_cfg != key or self._hp_table.shape[0] <= upto:
+        """Per-step Adam constants for the replay kernels: row s = (fp32(lr_s / (1 - beta1^s)), 1 / fp32(sqrt(1 - beta2^s))),
+        exactly what `_hparams` hands the step kernels at step s (same Python arithmetic for the powers; the division and the
+        fp32 rounding are IEEE operations in numpy as in Python), lr_s = the rate step s was / will be taken with (`_note_lr`)."""
+        import numpy as np
+        betas = tuple(self.m._adam_cfg["betas"])
+        dirty = getattr(self, "_table_dirty", None)
+        if self._hp_table is None or self._hp_cfg != betas or self._hp_table.shape[0] <= upto:
             cap = max(4096, 2 * (upto + 1))
-            b1, b2 = cfg["betas"]
-            import numpy as np
+            b1, b2 = betas
             f32 = lambda x: float(np.float32(x))          # the value the fp32 kernels (and torch's fp32 step) see
-            rows = [(0.0, 1.0)] + [(f32(cfg["lr"] / (1.0 - b1 ** s)), 1.0 / f32(math.sqrt(1.0 - b2 ** s))) for s in range(1, cap)]
-            self._hp_table = torch.tensor(rows, dtype=torch.float64, device=self.dev).contiguous()
-            self._hp_cfg = key
+            self._hp_bc1 = np.array([1.0] + [1.0 - b1 ** s_ for s_ in range(1, cap)], dtype=np.float64)
+            col1 = np.array([1.0] + [1.0 / f32(math.sqrt(1.0 - b2 ** s_)) for s_ in range(1, cap)], dtype=np.float64)
+            col0 = np.float32(self._rates(0, cap) / self._hp_bc1).astype(np.float64)
+            col0[0] = 0.0
+            self._hp_table = torch.from_numpy(np.stack([col0, col1], axis=1)).to(self.dev).contiguous()
+            self._hp_cfg = betas
+            self._table_dirty = None
+        elif dirty is not None:
+            cap = self._hp_table.shape[0]
+            col0 = np.float32(self._rates(dirty, cap) / self._hp_bc1[dirty:]).astype(np.float64)
+            if dirty == 0:
+                col0[0] = 0.0
+            self._hp_table[dirty:, 0].copy_(torch.from_numpy(col0))
+            self._table_dirty = None
         return self._hp_table
 
     def flush_lazy(self, sync: bool = True):
