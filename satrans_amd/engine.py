@@ -1121,9 +1121,11 @@ class PathEngine:
         another the remaining parameters.  One sweep over the tables per step - these optimizers are accepted for API parity,
         the Adam path (reference main.py:343) is the tuned one."""
         from . import parallel
-        if parallel.exchange_enabled():
-            raise NotImplementedError("data-parallel training with optimizers other than Adam")
         B = X.shape[0]
+        world, exch = parallel.world_size(), parallel.exchange_enabled()
+        if self._owner_world:                          # (Adam steps in the owner form came before: replicas together first)
+            self.flush_lazy()
+            self._owner_world = 0
         ws = self.train_workspace(B, 1, False)
         lib, m, D, st = self.lib, self.m, self.D, self._stream()
         l2 = float(m.l2_reg_embedding)
@@ -1131,12 +1133,31 @@ class PathEngine:
             self.reg_sum += l2 * torch.sum(torch.square(m.embedding_arena.double()))
         gemb = self.backward(X, y, ws)
         n_rows = B * self.F
-        N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_rows, self.total_rows, ws["sorted_rows"].data_ptr(),
-                                       ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
-                                       ws["iota"].data_ptr(), st), "satrans_embed_sort")
+        rows_t, grads_t = ws["rows"], gemb
+        if exch:
+            # several ranks (reference semantics as for Adam: per-GPU batches, summed loss): the dense parameters' gradient is
+            # all-reduced, the (row, gradient row) lists of all ranks are concatenated rank-major; the dense table gradient is
+            # then built from the merged list exactly as on one rank, identically on every rank (the regulariser term once)
+            parallel.all_reduce_flat(self.flat_g[:m.flat_params.numel()])
+            rows_t = parallel.gather_rows(ws["rows"])
+            grads_t, pending = parallel.gather_grad_rows_async(gemb)
+            if pending is not None:
+                pending.wait()
+            n_rows *= world
+            if ws.get("_dense_n", 0) < n_rows:
+                i32 = dict(dtype=torch.int32, device=self.dev)
+                ws["dn_sorted"], ws["dn_src"] = torch.empty(n_rows, **i32), torch.empty(n_rows, **i32)
+                ws["dn_iota"] = torch.arange(n_rows, **i32)
+                ws["dn_sort_ws"] = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n_rows, self.total_rows)),
+                                               dtype=torch.uint8, device=self.dev)
+                ws["_dense_n"] = n_rows
+        srt, src = (ws["dn_sorted"], ws["dn_src"]) if exch else (ws["sorted_rows"], ws["src"])
+        sort_ws, iota = (ws["dn_sort_ws"], ws["dn_iota"]) if exch else (ws["sort_ws"], ws["iota"])
+        N.check(lib.satrans_embed_sort(rows_t.data_ptr(), n_rows, self.total_rows, srt.data_ptr(), src.data_ptr(), None,
+                                       sort_ws.data_ptr(), sort_ws.numel(), iota.data_ptr(), st), "satrans_embed_sort")
         self._g_arena.zero_()
-        N.check(lib.satrans_embed_grad_dense(m.embedding_arena.data_ptr(), ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(),
-                                             n_rows, gemb.data_ptr(), self.total_rows, D, l2, self._g_arena.data_ptr(), st),
+        N.check(lib.satrans_embed_grad_dense(m.embedding_arena.data_ptr(), srt.data_ptr(), src.data_ptr(),
+                                             n_rows, grads_t.data_ptr(), self.total_rows, D, l2, self._g_arena.data_ptr(), st),
                 "satrans_embed_grad_dense")
         kind = {"sgd": 1, "adagrad": 2, "rmsprop": 3}[cfg["kind"]]
         lr, alpha, eps = float(cfg["lr"]), float(cfg.get("alpha", 0.0)), float(cfg.get("eps", 0.0))

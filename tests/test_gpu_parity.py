@@ -1179,6 +1179,63 @@ def test_two_data_parallel_ranks_reproduce_the_full_batch_step(name, small_rows,
         assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
 
 
+def _dp_dense_worker(rank, world, port, name, opt, steps, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = Case(name)
+        model = build_model(c, DEV)
+        model.compile(opt, "binary_crossentropy")
+        model.eval()
+        eng = model._require_engine()
+        n = c.X.shape[0] // world
+        X, y = c.X[rank * n:(rank + 1) * n].to(DEV), c.y[rank * n:(rank + 1) * n].to(DEV)
+        for _ in range(steps):
+            eng.train_step(X, y)
+        torch.save(sd_to_cpu(model), os.path.join(out_dir, f"dense{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_two_ranks_with_the_other_optimizers(opt, tmp_path):
+    """Several ranks with SGD / Adagrad / RMSprop (`engine.py` used to raise): all-reduced dense gradient, the
+    ranks' (row, gradient row) lists merged rank-major into the dense table gradient.  Two ranks with half the golden batch
+    each: replicas identical and on torch's own optimizer applied to the oracle's full-batch gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    c = Case("small_qkv")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    steps = 3
+    mp.spawn(_dp_dense_worker, args=(2, port, "small_qkv", opt, steps, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "dense0.pt"), torch.load(tmp_path / "dense1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"replicas diverged at {k}"
+    lr = {"sgd": 0.01, "adagrad": 0.01}[opt]
+    tr = O.OracleTrainer(c.tensors("param"), c.spec(), lr=lr, optimizer=opt)
+    n = (c.X.shape[0] // 2) * 2
+    for _ in range(steps):
+        tr.step(c.X[:n], c.y[:n])
+    init = c.tensors("param")
+    for k, w in tr.state().items():
+        moved = float((w - init[k]).abs().max())
+        if moved == 0.0:
+            assert torch.equal(r0[k], w), k
+            continue
+        err = (r0[k] - w).abs().flatten().double()
+        if opt == "sgd":
+            assert float(err.max()) <= 2e-4 * moved + 1e-9, (k, float(err.max()), moved)
+        else:
+            gmax = float(tr.leaves[k].grad.abs().max()) if tr.leaves[k].grad is not None else 0.0
+            if gmax >= 1e-5:
+                assert float(err.median()) <= 2e-3 * lr * steps, (k, float(err.median()))
+            assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
+
+
 def _dp_fit_worker(rank, world, port, name, out_dir, mode):
     """Two ranks through the public `fit` (shuffled epochs, a ragged last batch): the owner form sizes its exchanges from the
     epoch plan `fit` hands the engine (engine.plan_owner_counts), not from a per-step read-back."""
