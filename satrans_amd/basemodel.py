@@ -18,6 +18,7 @@ state_dict key names.  What differs is underneath:
 from __future__ import annotations
 
 import time
+import warnings
 from collections import OrderedDict
 from typing import Dict, List, Optional
 
@@ -395,7 +396,9 @@ class BaseModel(nn.Module):
                 block = block.astype(np.float32)                  # (numpy's rounding, as the host path)
             elif block.dtype.kind == "u" and block.dtype.itemsize > 1:
                 block = block.astype(np.int64)                    # (torch has no wide unsigned tensors to upload)
-            data[:, j:j + w] = torch.from_numpy(block).to(self.device)
+            with warnings.catch_warnings():                       # (a read-only memory map of an HDF5 column is only read)
+                warnings.simplefilter("ignore", UserWarning)
+                data[:, j:j + w] = torch.from_numpy(block).to(self.device)
             j += w
         return data
 

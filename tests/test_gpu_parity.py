@@ -1309,6 +1309,43 @@ def test_two_rank_fit_plans_the_owner_exchange_per_epoch(tmp_path):
             assert float(diff.median()) <= 2e-4 * lr * 2 * steps, (k, float(diff.median()))
 
 
+def test_reference_main_flow_from_an_hdf5_file(tmp_path):
+    """examples/aliccp_main.py - the SATrans branch of the reference's main.py on this package - end to end on a small
+    `alicpp.h5`-shaped file (written byte by byte by tests/h5_fixture.py; read through satrans_amd/h5lite.py): train one epoch,
+    per-scenario report, result line, state_dict dump with the reference's keys; the reported AUCs equal sklearn's on the
+    predictions of the dumped weights."""
+    import importlib.util
+    import json
+    from sklearn.metrics import roc_auc_score
+    from tests.h5_fixture import write_h5
+    spec = importlib.util.spec_from_file_location("aliccp_main", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "aliccp_main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.RandomState(1)
+    small = {f: min(v, 500) for f, v in mod.DATA_MAX.items()}
+
+    def split(n):
+        d = {f: rng.randint(1 if f == '301' else 0, small[f] + 1, size=n).astype(np.int64) for f in mod.SPARSE}
+        d['click'] = ((d['121'] % 2 == 0) & (rng.rand(n) < 0.6) | (rng.rand(n) < 0.05)).astype(np.int64)
+        return d
+    path = str(tmp_path / "alicpp.h5")
+    write_h5(path, {"ctr_train": split(6000), "ctr_test": split(2500)})
+    dump, results = str(tmp_path / "model.pt"), str(tmp_path / "res.csv")
+    rep = mod.main(["--h5", path, "--batch_size", "1024", "--epochs", "2", "--data_max", json.dumps(small), "--dump", dump,
+                    "--results", results])
+    assert 0.5 < rep["auc"] <= 1.0 and set(rep["domain_auc"]) == {1, 2, 3}
+    line = open(results).read().strip().split(",")
+    assert len(line) == 1 + 1 + 3 + 1 and "SATrans_32_0.005_3_4_QK_1021_301_sota" in line[0]
+    sd = torch.load(dump)
+    assert "embedding_dict.101.weight" in sd and "domain_int_layers.2.W_Query" in sd and sd["embedding_dict.205.weight"].shape == (502, 32)
+    from satrans_amd.pipeline import load_h5_columns
+    test = load_h5_columns(path, "ctr_test", ["click", "301"])
+    assert rep["auc"] == pytest.approx(roc_auc_score(np.asarray(test["click"]), rep["pred"].reshape(-1)), abs=1e-9)
+    sel = np.asarray(test["301"]) == 2
+    assert rep["domain_auc"][2] == pytest.approx(roc_auc_score(np.asarray(test["click"])[sel], rep["pred"].reshape(-1)[sel]), abs=1e-9)
+
+
 @pytest.mark.parametrize("B", [1, 2])
 def test_regulariser_sum_of_tiny_batches(monkeypatch, B):
     """A batch of one or two samples makes every partial-sum group of the touched-row kernels a single block (their slots
