@@ -161,6 +161,16 @@ int satrans_set_layer_impl(int impl);
  * between this path and the general one (satrans_layer_generic_supported). */
 int satrans_layer_fused_supported(const satrans_layer_desc* d);
 
+/* How the fused kernels evaluate the weight products (projections, MetaNet, Out_linear; satrans.py:55-57,60-73,91) of the
+ * (D,U,H) = (32,64,4) MetaNet shape:
+ * 0 = fp32: v_mfma_f32_16x16x4_f32, bit for bit a chain of fmaf - what torch's CPU matmul computes up to summation order;
+ * 1 = split: every fp32 operand as a bf16 pair hi + lo, a product as a_lo w_hi + a_hi w_lo + a_hi w_hi on
+ *     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what is dropped is <= 2^-16 of a term; measured ~2.6x the error of plain
+ *     fp32 products against an fp64 evaluation of the same graph).  Weights are split once per workgroup, activations on the fly.
+ * The start value comes from SATRANS_PRODUCTS=f32|split.  Returns SATRANS_E_BADARG for any other mode. */
+int satrans_set_product_mode(int mode);
+int satrans_get_product_mode(void);
+
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);
 

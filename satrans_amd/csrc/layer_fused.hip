@@ -25,11 +25,16 @@ namespace satrans {
 #endif
 
 // MOD: what modulates q / k - 0 the MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear' (compile time: the main instantiation
-// pays nothing for the other two)
-template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0>
+// pays nothing for the other two).  PROD: 0 = fp32 products on v_mfma_f32_16x16x4_f32, 1 = split products (fp32 operands as bf16
+// pairs, three v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block: layer_fused_common.h) - MOD 0 only
+template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, int PROD = 0>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                       float* __restrict__ y, float* __restrict__ att) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
+    constexpr int KD = D + 8, KU = U + 8;                 // row lengths (bf16) of the split-product images
+    static_assert(!PROD || (MOD == 0 && KT % 2 == 0 && UT % 2 == 0), "split products: MetaNet shapes with D, U multiples of 32");
+    // floats of LDS per image: [K][LD]-style fp32 images, or a hi + lo pair of [OUT][K + 8] bf16 images
+    constexpr int SZ_DD = PROD ? D * KD : D * LD, SZ_W1 = PROD ? U * KD : D * LU, SZ_W2 = PROD ? D * KU : U * LD;
     extern __shared__ __align__(16) float lds[];
     const int F = a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,10 +51,10 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     float* p = lds;
     auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
     FwdImages<D, U> W;
-    W.wq = take(D * LD); W.wk = take(D * LD); W.wv = take(D * LD); W.woT = take(D * LD);
-    W.w1q = take(D * LU); W.w2q = take(U * LD);
-    W.w1k = same_tab ? W.w1q : take(D * LU);
-    W.w2k = same_tab ? W.w2q : take(U * LD);
+    W.wq = take(SZ_DD); W.wk = take(SZ_DD); W.wv = take(SZ_DD); W.woT = take(SZ_DD);
+    W.w1q = take(SZ_W1); W.w2q = take(SZ_W2);
+    W.w1k = same_tab ? W.w1q : take(SZ_W1);
+    W.w2k = same_tab ? W.w2q : take(SZ_W2);
     W.lnq_g = take(D); W.lnq_b = take(D); W.lnk_g = take(D); W.lnk_b = take(D); W.ln_g = take(D); W.ln_b = take(D);
     const int rows = ((Tsamp * F + 15) >> 4) << 4;
     float* sq = take(rows * LD);
@@ -57,10 +62,18 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     float* sv = take(rows * LD);
     float* sx = take(rows * LD);      // the tile's input rows: read from global memory ONCE (phase 1), re-read here for the residual
 
-    stage_image(a.w_query, W.wq, D, D, LD, false);
-    stage_image(a.w_key, W.wk, D, D, LD, false);
-    stage_image(a.w_value, W.wv, D, D, LD, false);
-    stage_image(a.w_out, W.woT, D, D, LD, true);      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
+    auto bimg = [](float* f_) { return reinterpret_cast<__bf16*>(f_); };
+    if constexpr (PROD) {
+        stage_split(a.w_query, bimg(W.wq), D, D, KD, true);
+        stage_split(a.w_key, bimg(W.wk), D, D, KD, true);
+        stage_split(a.w_value, bimg(W.wv), D, D, KD, true);
+        stage_split(a.w_out, bimg(W.woT), D, D, KD, false);      // nn.Linear [out][in]: y = x @ Wo^T
+    } else {
+        stage_image(a.w_query, W.wq, D, D, LD, false);
+        stage_image(a.w_key, W.wk, D, D, LD, false);
+        stage_image(a.w_value, W.wv, D, D, LD, false);
+        stage_image(a.w_out, W.woT, D, D, LD, true);      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
+    }
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         W.ln_g[i] = a.ln_g[i]; W.ln_b[i] = a.ln_b[i];
         if (mlp_q) { W.lnq_g[i] = a.lnq_g[i]; W.lnq_b[i] = a.lnq_b[i]; }
@@ -76,6 +89,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     const float* w2q_l = W.w2q + g4 * LD + wl;
     const float* w1k_l = W.w1k + g4 * LU + wl;
     const float* w2k_l = W.w2k + g4 * LD + wl;
+    // split products: this lane's 16-byte fragment of a row (chunk g, flipped for rows 4..11 of a tile) in images of D / U inputs
+    const int sl_d = n * KD + ((8 * g) ^ split_flip(n)), sl_u = n * KU + ((8 * g) ^ split_flip(n));
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);   // scores * (1/sqrt d): within 1 ulp of the reference's true division
     // Work split by SAMPLES, not by tiles: workgroup w owns the sorted sample positions [B w / G, B (w+1) / G) and walks its share
@@ -92,13 +107,23 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
       // ---- this scenario's generated MetaNet weights (the previous tile loop ended on a barrier) ------------------
       if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-          stage_image(row, W.w1q, D, U, LU, false);
-          stage_image(row + D * U, W.w2q, U, D, LD, false);
+          if constexpr (PROD) {
+              stage_split(row, bimg(W.w1q), U, D, KD, true);               // W1 [D][U]: in-major, K = D
+              stage_split(row + D * U, bimg(W.w2q), D, U, KU, true);       // W2 [U][D]: in-major, K = U
+          } else {
+              stage_image(row, W.w1q, D, U, LU, false);
+              stage_image(row + D * U, W.w2q, U, D, LD, false);
+          }
       }
       if (mlp_k && (!same_tab || !mlp_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-          stage_image(row, W.w1k, D, U, LU, false);
-          stage_image(row + D * U, W.w2k, U, D, LD, false);
+          if constexpr (PROD) {
+              stage_split(row, bimg(W.w1k), U, D, KD, true);
+              stage_split(row + D * U, bimg(W.w2k), D, U, KU, true);
+          } else {
+              stage_image(row, W.w1k, D, U, LU, false);
+              stage_image(row + D * U, W.w2k, U, D, LD, false);
+          }
       }
       if (gate) {
           for (int i = threadIdx.x; i < D; i += blockDim.x) {
@@ -154,9 +179,17 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             fetch_x(first, tt, x);
 #endif
             store_frag<KT>(sx + (size_t)tok * LD + g4, x);
-            chain<KT, KT, LD>(wq_l, x, q);                                               // satrans.py:55-57
-            chain<KT, KT, LD>(wk_l, x, k);
-            chain<KT, KT, LD>(wv_l, x, v);
+            if constexpr (PROD) {
+                bf16x8 xh[KT / 2], xl[KT / 2];
+                split_frag<KT>(x, xh, xl);
+                chain_split<KT / 2, KT, KD>(bimg(W.wq) + sl_d, D * KD, xh, xl, q);             // satrans.py:55-57
+                chain_split<KT / 2, KT, KD>(bimg(W.wk) + sl_d, D * KD, xh, xl, k);
+                chain_split<KT / 2, KT, KD>(bimg(W.wv) + sl_d, D * KD, xh, xl, v);
+            } else {
+                chain<KT, KT, LD>(wq_l, x, q);                                               // satrans.py:55-57
+                chain<KT, KT, LD>(wk_l, x, k);
+                chain<KT, KT, LD>(wv_l, x, v);
+            }
             float mean, rstd;
             if (gate) {                                                                    // satrans.py:61-62,68-69
 #pragma unroll
@@ -176,6 +209,10 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             }
             if (mlp_q) {                                                                  // satrans.py:60-66
                 float h[UT][4], o[KT][4];
+                if constexpr (PROD)
+                    metanet_frag_split<D, U>(bimg(W.w1q) + sl_d, bimg(W.w2q) + sl_u, W.lnq_g, W.lnq_b, g4, dc,
+                                             drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, o, mean, rstd);
+                else
                 metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
                                    drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd);
 #pragma unroll
@@ -185,6 +222,10 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             }
             if (mlp_k) {                                                                  // satrans.py:67-73
                 float h[UT][4], o[KT][4];
+                if constexpr (PROD)
+                    metanet_frag_split<D, U>(bimg(W.w1k) + sl_d, bimg(W.w2k) + sl_u, W.lnk_g, W.lnk_b, g4, dc,
+                                             drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, o, mean, rstd);
+                else
                 metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
                                    drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd);
 #pragma unroll
@@ -362,7 +403,13 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * t);
                 o[t][0] = ov.x; o[t][1] = ov.y; o[t][2] = ov.z; o[t][3] = ov.w;
             }
-            chain<KT, KT, LD>(wo_l, o, u);
+            if constexpr (PROD) {
+                bf16x8 oh[KT / 2], ol[KT / 2];
+                split_frag<KT>(o, oh, ol);
+                chain_split<KT / 2, KT, KD>(bimg(W.woT) + sl_d, D * KD, oh, ol, u);
+            } else {
+                chain<KT, KT, LD>(wo_l, o, u);
+            }
             const float* xrow = sx + (size_t)tok * LD + g4;
             const uint32_t skey = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
             const uint32_t kb = dc.on ? token_keep_bits<KT>(skey, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
@@ -433,8 +480,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
         _Pragma("unroll 1") for (int VAR = 0; VAR < F; VAR += 4) BODY(VAR);                                      \
     }
 
-// FT: the field count as a constant (0 = a.F).  MOD: 0 MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear'
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0>
+// FT: the field count as a constant (0 = a.F).  MOD: 0 MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear'.
+// PROD: 0 = fp32 products, 1 = split products for the token-wise chains (forward recomputation and the gradients of the
+// activations; the token-contraction products of the weight gradients stay on the fp32 instruction).  Split products read one
+// image per DIRECTION of a weight (a fragment is 8 consecutive contraction indices of one output row), so both orientations of
+// every weight live in LDS as hi / lo bf16 pairs: SAME tables, MOD 0, no TR only.
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
@@ -444,6 +495,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     constexpr int NB = (UT < KT) ? UT : KT;          // 16-feature tiles of such an operand held by one row buffer
     static_assert(HB <= 2 && UT == HB * NB, "MetaNet hidden width must be D/.. or 2*D for the fused backward");
     static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
+    static_assert(64 * H <= kFusedBlock, "one attention task per thread: a tile holds at most 64 tokens x H heads");
+    static_assert(!PROD || (SAME && !TR && MOD == 0 && KT % 2 == 0 && UT % 2 == 0), "split products: one shared MetaNet table, D and U multiples of 32");
+    constexpr int KD = D + 8, KU = U + 8;                 // row lengths (bf16) of the split-product images
+    constexpr int SZ_DD = PROD ? D * KD : D * LD, SZ_W1 = PROD ? U * KD : D * LU, SZ_W2 = PROD ? D * KU : U * LD;
     extern __shared__ __align__(16) float lds[];
     const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -460,16 +515,21 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // ---- LDS: forward images, transposed images, LN vectors, 5 row buffers, softmax cache ------------------------
     float* p = lds;
     auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
-    float* wq = take(D * LD); float* wk = take(D * LD); float* wv = take(D * LD); float* woT = take(D * LD);
-    float* w1q = take(D * LU); float* w2q = take(U * LD);
-    float* w1k = same_tab ? w1q : take(D * LU);
-    float* w2k = same_tab ? w2q : take(U * LD);
-    // transposed copies (TR) or, without them, the forward images again (read by rows: chain_t)
-    float* wqT = TR ? take(D * LD) : wq; float* wkT = TR ? take(D * LD) : wk; float* wvT = TR ? take(D * LD) : wv;
-    float* wo = TR ? take(D * LD) : woT;
-    float* w1qT = TR ? take(U * LD) : w1q; float* w2qT = TR ? take(D * LU) : w2q;   // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]
-    float* w1kT = TR ? (same_tab ? w1qT : take(U * LD)) : w1k;
-    float* w2kT = TR ? (same_tab ? w2qT : take(D * LU)) : w2k;
+    auto bimg = [](float* f_) { return reinterpret_cast<__bf16*>(f_); };
+    float* wq = take(SZ_DD); float* wk = take(SZ_DD); float* wv = take(SZ_DD); float* woT = take(SZ_DD);
+    float* w1q = take(SZ_W1); float* w2q = take(SZ_W2);
+    float* w1k = same_tab ? w1q : take(SZ_W1);
+    float* w2k = same_tab ? w2q : take(SZ_W2);
+    // transposed copies (TR), the images of the backward direction (PROD) or, without either, the forward images again (read by
+    // rows: chain_t)
+    constexpr bool TWO = TR || PROD;
+    float* wqT = TWO ? take(SZ_DD) : wq; float* wkT = TWO ? take(SZ_DD) : wk; float* wvT = TWO ? take(SZ_DD) : wv;
+    float* wo = TWO ? take(SZ_DD) : woT;
+    // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]   (PROD: rows = the weight's input index, [D][KU] for W1 and [U][KD] for W2)
+    float* w1qT = PROD ? take(D * KU) : (TR ? take(U * LD) : w1q);
+    float* w2qT = PROD ? take(U * KD) : (TR ? take(D * LU) : w2q);
+    float* w1kT = TWO ? (same_tab ? w1qT : take(U * LD)) : w1k;
+    float* w2kT = TWO ? (same_tab ? w2qT : take(D * LU)) : w2k;
     float* lnq_g = take(D); float* lnk_g = take(D); float* ln_g = take(D);
     float* lnq_b = take(D); float* lnk_b = take(D); float* ln_b = take(D);
     constexpr int ROWS = 64;
@@ -492,10 +552,18 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if constexpr (TR) stage_image(g_, s_, R_, C_, ld_, tr_);
             else stage_image_sw(g_, s_, R_, C_, ld_, tr_);
         };
+        if constexpr (PROD) {
+            // forward direction: rows = the weight's output index; backward direction: rows = its input index
+            stage_split(a.w_query, bimg(wq), D, D, KD, true);   stage_split(a.w_query, bimg(wqT), D, D, KD, false);
+            stage_split(a.w_key, bimg(wk), D, D, KD, true);     stage_split(a.w_key, bimg(wkT), D, D, KD, false);
+            stage_split(a.w_value, bimg(wv), D, D, KD, true);   stage_split(a.w_value, bimg(wvT), D, D, KD, false);
+            stage_split(a.w_out, bimg(woT), D, D, KD, false);   stage_split(a.w_out, bimg(wo), D, D, KD, true);   // nn.Linear [out][in]
+        } else {
         stage_w(a.w_query, wq, D, D, LD, false);
         stage_w(a.w_key, wk, D, D, LD, false);
         stage_w(a.w_value, wv, D, D, LD, false);
         stage_w(a.w_out, woT, D, D, LD, true);
+        }
         if constexpr (TR) {
             stage_image(a.w_query, wqT, D, D, LD, true);
             stage_image(a.w_key, wkT, D, D, LD, true);
@@ -518,6 +586,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const int fl_g = (!TR && (g == 1 || g == 2)) ? 4 : 0, fl_n = (!TR && n >= 4 && n < 12) ? 1 : 0;
     const int lo_d = g4 * LD + (n ^ fl_g), lo_u = g4 * LU + (n ^ fl_g);
     const int lt_d = n * LD + 4 * (g ^ fl_n), lt_u = n * LU + 4 * (g ^ fl_n);
+    // split products: this lane's 16-byte fragment of an image row of D / U contraction indices
+    const int sl_d = n * KD + ((8 * g) ^ split_flip(n)), sl_u = n * KU + ((8 * g) ^ split_flip(n));
     // (sample, head, row) of this thread's attention task - the same in every tile and every attention phase
     const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
@@ -602,6 +672,15 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
               w1q[r * LD + (TR ? c : c ^ img_flip(r))] = (r / d == c / d) ? row[(r / d) * d * d + (r % d) * d + (c % d)] : 0.f;
           }
       }
+      if constexpr (PROD) {
+          if (mlp_q || mlp_k) {                      // (SAME: one table for both roles)
+              const float* row = (mlp_q ? a.tab_q : a.tab_k) + (size_t)scen * a.tab_stride;
+              stage_split(row, bimg(w1q), U, D, KD, true);              // W1 [D][U]: rows = hidden unit, K = D
+              stage_split(row + D * U, bimg(w2q), D, U, KU, true);      // W2 [U][D]: rows = output feature, K = U
+              stage_split(row, bimg(w1qT), D, U, KU, false);            // backward through W1: rows = its input, K = U
+              stage_split(row + D * U, bimg(w2qT), U, D, KD, false);    // backward through W2: rows = hidden unit, K = D
+          }
+      } else {
       if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
           if constexpr (TR) { stage_image(row, w1q, D, U, LU, false); stage_image(row + D * U, w2q, U, D, LD, false); }
@@ -620,32 +699,50 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
               stage_image(row + D * U, w2kT, U, D, LU, true);
           }
       }
+      }
       __syncthreads();
       const int lo = a.seg[scen], hi = a.seg[scen + 1];
-      // The sample index and the input row of a tile are fetched one tile ahead (at the end of phase F, when the registers
-      // of the current x are free): with one wave per SIMD nothing else would hide those two dependent global loads.
+      // With one wave per SIMD nothing hides a global load that is waited for where it is issued, and the counter the waits use
+      // (vmcnt) retires loads IN ORDER - a wait for a young load also waits for every older one.  The loads of a tile are therefore
+      // spread over the PREVIOUS tile, each issued where the ones before it have long landed, all of them unconditionally (a
+      // load inside a divergent branch makes the compiler flush the counter where the branch rejoins):
+      //   top of tile t      sample indices of tile t + 1 (token lane: b_next; attention task lane: tb_next)
+      //   after phase A      the upstream gradient rows dy of tile t (consumed in phase C)
+      //   after phase C      row id of the input row of tile t + 1 (first layer with the gather fused in: x_rows[b f])
+      //   end of phase F     the input row of tile t + 1 (consumed behind the dropout hashing at the top of that tile)
+      // Tile t1 - 1 "prefetches" itself again (clamped index): a few wasted loads instead of a branch.
       const int tok = row0 + n;
       const int ls_tok = tok / F, f_tok = tok - ls_tok * F;      // this lane's (sample, field) inside any tile that holds it
-      int b_next = 0;
       float x_next[KT][4];
-      auto fetch_tile = [&](int tile_) {
+      auto sample_of = [&](int tile_) {
           const int first_ = lo + tile_ * Tsamp;
-          const int ntok_ = min(Tsamp, hi - first_) * F;
-          const bool has_ = wave < ((ntok_ + 15) >> 4);
-          const bool valid_ = has_ && tok < ntok_;
-          const int ls_ = valid_ ? ls_tok : 0, f_ = valid_ ? f_tok : 0;
-          b_next = a.order[first_ + ls_];
-          if (has_) load_frag<KT>(layer_x_row(a, b_next, f_, F, D) + g4, x_next);
+          return a.order[first_ + (tok < min(Tsamp, hi - first_) * F ? ls_tok : 0)];
       };
-      fetch_tile(t0);
+      auto task_sample_of = [&](int tile_) {
+          const int first_ = lo + tile_ * Tsamp;
+          return a.order[first_ + min(t0_ls, min(Tsamp, hi - first_) - 1)];
+      };
+      // row of a.x that holds this lane's input row: the position b F + f itself, or - gather fused in - the id stored there
+      // (the raw loaded id travels to the point of use: any arithmetic on it right here - a sign extension - would be a wait
+      // right here.  B F < 2^31: checked by the launcher)
+      auto row_of = [&](int tile_, int b_) -> int {
+          const int first_ = lo + tile_ * Tsamp;
+          const int at = b_ * F + (tok < min(Tsamp, hi - first_) * F ? f_tok : 0);
+          return a.x_rows ? a.x_rows[at] : at;
+      };
+      int b_next = sample_of(t0), tb_next = task_sample_of(t0);
+      int xrow_next = row_of(t0, b_next);
+      load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
       for (int tile = t0; tile < t1; ++tile) {
         const int first = lo + tile * Tsamp;
-        const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
         const bool has_tile = wave < ntt;
         const bool valid = has_tile && tok < ntok;
         const int f = valid ? f_tok : 0;
-        const int b = b_next;
+        const int b = b_next, tb0 = tb_next;
+        const int tile_n = min(tile + 1, t1 - 1);
+        b_next = sample_of(tile_n);
+        tb_next = task_sample_of(tile_n);
         const uint32_t key_q = drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b);
         const uint32_t key_k = drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b);
         const uint32_t key_o = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
@@ -667,17 +764,44 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[t][r] = x_next[t][r];
             float v[KT][4], q[KT][4], k[KT][4];
+            // out = in x weight along the forward direction of an image (PROD: split operands)
+            auto fwd_w1 = [&](float* img, const float (&in_)[KT][4], float (&out_)[UT][4]) {
+                if constexpr (PROD) {
+                    bf16x8 ih_[KT / 2], il_[KT / 2];
+                    split_frag<KT>(in_, ih_, il_);
+                    chain_split<KT / 2, UT, KD>(bimg(img) + sl_d, U * KD, ih_, il_, out_);
+                } else {
+                    chain<KT, UT, LU>(img + lo_u, in_, out_);
+                }
+            };
+            auto fwd_w2 = [&](float* img, const float (&in_)[UT][4], float (&out_)[KT][4]) {
+                if constexpr (PROD) {
+                    bf16x8 ih_[UT / 2], il_[UT / 2];
+                    split_frag<UT>(in_, ih_, il_);
+                    chain_split<UT / 2, KT, KU>(bimg(img) + sl_u, D * KU, ih_, il_, out_);
+                } else {
+                    chain<UT, KT, LD>(img + lo_d, in_, out_);
+                }
+            };
+            if constexpr (PROD) {
+                bf16x8 xh[KT / 2], xl[KT / 2];
+                split_frag<KT>(x, xh, xl);
+                chain_split<KT / 2, KT, KD>(bimg(wq) + sl_d, D * KD, xh, xl, q0);
+                chain_split<KT / 2, KT, KD>(bimg(wk) + sl_d, D * KD, xh, xl, k0);
+                chain_split<KT / 2, KT, KD>(bimg(wv) + sl_d, D * KD, xh, xl, v);
+            } else {
             chain<KT, KT, LD>(wq + lo_d, x, q0);
             chain<KT, KT, LD>(wk + lo_d, x, k0);
             chain<KT, KT, LD>(wv + lo_d, x, v);
+            }
             if (mlp_q) {
                 float m[KT][4];
-                chain<KT, UT, LU>(w1q + lo_u, q0, hq);
+                fwd_w1(w1q, q0, hq);
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hq[t][r] = fmaxf(hq[t][r], 0.f);
-                chain<UT, KT, LD>(w2q + lo_d, hq, m);
+                fwd_w2(w2q, hq, m);
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -695,7 +819,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     q[t][2] = zhq[t][2] * gg.z + bb.z; q[t][3] = zhq[t][3] * gg.w + bb.w;
                 }
             } else if (bilin) {
-                chain<KT, KT, LD>(w1q + lo_d, q0, q);                          // q_h = q0_h M[s, h]
+                if constexpr (!PROD) chain<KT, KT, LD>(w1q + lo_d, q0, q);     // q_h = q0_h M[s, h]
             } else {
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
@@ -707,12 +831,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             }
             if (mlp_k) {
                 float m[KT][4];
-                chain<KT, UT, LU>(w1k + lo_u, k0, hk);
+                fwd_w1(w1k, k0, hk);
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hk[t][r] = fmaxf(hk[t][r], 0.f);
-                chain<UT, KT, LD>(w2k + lo_d, hk, m);
+                fwd_w2(w2k, hk, m);
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -745,19 +869,17 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         lds_barrier();
 
         STAMP(1);
+        // the upstream gradient rows of phase C: issued here, a phase ahead (HBM latency under the attention forward); padding
+        // lanes read a real row (sample 0 of the tile, field 0) and are masked where the rows are consumed
+        float gy_pre[KT][4];
+        load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy_pre);
         // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
         // Scores are staged in the task's row of the numerator cache (pre-scaled by log2(e)/sqrt(d)), keys in chunks of
         // four with all loads of a chunk issued before its results are stored; padding keys of the last chunk read the
         // last real row and are masked arithmetically.
-        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
-            int tls = t0_ls, h = t0_h, i = t0_i;
-            if (task != (int)threadIdx.x) {          // only when a tile holds more tasks than the workgroup has threads
-                tls = task / (H * F);
-                const int rem = task - tls * H * F;
-                h = rem / F;
-                i = rem - h * F;
-            }
-            const int tb = samp[tls];
+        if (const int task = threadIdx.x; task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
+            const int tls = t0_ls, h = t0_h, i = t0_i;
+            const int tb = tb0;
             f32x2 qi[d / 2];
             load_row<d>(sq + (size_t)(tls * F + i) * LD + h * d, qi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
@@ -827,7 +949,20 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         if (has_tile) {
             float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4];
             load_frag<KT>(my_o, o);
-            chain<KT, KT, LD>(woT + lo_d, o, u);
+            // out = in x (D x D weight), along the forward direction of the image `f_` or the backward direction (image `b_`)
+            auto prod_dd = [&](float* img, bool back_, const float (&in_)[KT][4], float (&out_)[KT][4]) {
+                if constexpr (PROD) {
+                    bf16x8 ih_[KT / 2], il_[KT / 2];
+                    split_frag<KT>(in_, ih_, il_);
+                    chain_split<KT / 2, KT, KD>(bimg(img) + sl_d, D * KD, ih_, il_, out_);
+                } else if (!back_) {
+                    chain<KT, KT, LD>(img + lo_d, in_, out_);
+                } else {
+                    if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
+                    else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
+                }
+            };
+            prod_dd(woT, false, o, u);
             float keep[KT][4];      // multiplicative factor of du: dropout mask times ReLU mask
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -844,7 +979,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
             float rstd_o;
             layer_norm_keep<KT>(u, zh, rstd_o);
-            load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy, valid);
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gy[t][r] = valid ? gy_pre[t][r] : 0.f;
             layer_norm_bwd<KT>(gy, zh, rstd_o, ln_g, g4, agl, abl);          // gy is now dr
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -856,25 +994,19 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             store_frag<KT>(my_g, gy);                                           // du rows (zero for padding tokens)
             wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
             float go[KT][4];
-            if constexpr (TR) chain<KT, KT, LD>(wo + lo_d, gy, go);             // go = du Wo
-            else chain_t<KT, KT, LD>(wo + lt_d, gy, go);
+            prod_dd(wo, true, gy, go);                                          // go = du Wo
             store_frag<KT>(my_o, go);
         }
         lds_barrier();
 
         STAMP(3);
+        xrow_next = row_of(tile_n, b_next);
         // ================= phase D: softmax backward by rows: dS_ij (cached for phase E) and dq_i =========================
         // pass 1: dP_ij = (go_i . v_j) * mask_ij staged in the task's row of the dS cache, dot_i = sum_j P_ij dP_ij;
         // pass 2: dS_ij = P_ij (dP_ij - dot_i) / sqrt(d) replaces it, the numerator cache row becomes P_ij * mask_ij
         //         (the coefficient of dv_j), dq_i = sum_j dS_ij k_j.
-        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
-            int tls = t0_ls, h = t0_h, i = t0_i;
-            if (task != (int)threadIdx.x) {          // only when a tile holds more tasks than the workgroup has threads
-                tls = task / (H * F);
-                const int rem = task - tls * H * F;
-                h = rem / F;
-                i = rem - h * F;
-            }
+        if (const int task = threadIdx.x; task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
+            const int tls = t0_ls, h = t0_h, i = t0_i;
             f32x2 gi[d / 2];
             load_row<d>(so + (size_t)(tls * F + i) * LD + h * d, gi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
@@ -939,14 +1071,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
         STAMP(4);
         // ================= phase E: by columns: dk_j = sum_i dS_ij q_i, dv_j = sum_i P_ij mask_ij go_i (in place of k_j, v_j)
-        for (int task = threadIdx.x; task < nS * H * F; task += kFusedBlock) {
-            int tls = t0_ls, h = t0_h, j = t0_i;
-            if (task != (int)threadIdx.x) {          // only when a tile holds more tasks than the workgroup has threads
-                tls = task / (H * F);
-                const int rem = task - tls * H * F;
-                h = rem / F;
-                j = rem - h * F;
-            }
+        if (const int task = threadIdx.x; task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
+            const int tls = t0_ls, h = t0_h, j = t0_i;
             f32x2 dk[d / 2], dv[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) { dk[e] = f32x2{0.f, 0.f}; dv[e] = f32x2{0.f, 0.f}; }
@@ -1022,7 +1148,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
-                if constexpr (TR) chain<KT, UT, LU>(w2T + lo_u, dm, dh);
+                if constexpr (PROD) {
+                    bf16x8 ih_[KT / 2], il_[KT / 2];
+                    split_frag<KT>(dm, ih_, il_);
+                    chain_split<KT / 2, UT, KD>(bimg(const_cast<float*>(w2T)) + sl_d, U * KD, ih_, il_, dh);
+                } else if constexpr (TR) chain<KT, UT, LU>(w2T + lo_u, dm, dh);
                 else chain_t<KT, UT, LD>(w2T + lt_d, dm, dh);              // w2T is then the forward image W2 [U][LD]
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
@@ -1049,7 +1179,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
-                if constexpr (TR) chain<UT, KT, LD>(w1T + lo_d, dh, back);
+                if constexpr (PROD) {
+                    bf16x8 ih_[UT / 2], il_[UT / 2];
+                    split_frag<UT>(dh, ih_, il_);
+                    chain_split<UT / 2, KT, KU>(bimg(const_cast<float*>(w1T)) + sl_u, D * KU, ih_, il_, back);
+                } else if constexpr (TR) chain<UT, KT, LD>(w1T + lo_d, dh, back);
                 else chain_t<UT, KT, LU>(w1T + lt_u, dh, back);            // ... the forward image W1 [D][LU]
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
@@ -1075,7 +1209,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 store_frag<KT>(my_o, gq);
                 wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_w1q);
                 float back[KT][4];
-                chain_t<KT, KT, LD>(w1q + lt_d, gq, back);                    // (by rows of the one image, with or without TR)
+                if constexpr (!PROD) chain_t<KT, KT, LD>(w1q + lt_d, gq, back);   // (by rows of the one image, with or without TR)
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1099,27 +1233,32 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
             float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
-            if constexpr (TR) chain<KT, KT, LD>(wqT + lo_d, gq, back);
-            else chain_t<KT, KT, LD>(wqT + lt_d, gq, back);
+            auto back_dd = [&](float* img, const float (&in_)[KT][4], float (&out_)[KT][4]) {
+                if constexpr (PROD) {
+                    bf16x8 ih_[KT / 2], il_[KT / 2];
+                    split_frag<KT>(in_, ih_, il_);
+                    chain_split<KT / 2, KT, KD>(bimg(img) + sl_d, D * KD, ih_, il_, out_);
+                } else if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
+                else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
+            };
+            back_dd(wqT, gq, back);
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
-            if constexpr (TR) chain<KT, KT, LD>(wkT + lo_d, gk, back);
-            else chain_t<KT, KT, LD>(wkT + lt_d, gk, back);
+            back_dd(wkT, gk, back);
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
-            if constexpr (TR) chain<KT, KT, LD>(wvT + lo_d, gv, back);
-            else chain_t<KT, KT, LD>(wvT + lt_d, gv, back);
+            back_dd(wvT, gv, back);
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
-        if (tile + 1 < t1) fetch_tile(tile + 1);
+        load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
         lds_barrier();
         STAMP(6);
       }
@@ -1323,13 +1462,26 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
 // host side
 // -------------------------------------------------------------------------------------------------------------------
 
-static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
+// How the fused kernels evaluate the weight products of the D = 32 MetaNet shapes: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit for bit an
+// fmaf chain), 1 = split (fp32 operands as bf16 pairs, three v_mfma_f32_16x16x32_bf16 per block; layer_fused_common.h).
+// SATRANS_PRODUCTS=f32|split sets the start value, satrans_set_product_mode changes it (tests run both).
+static int g_product_mode = -1;
+static int product_mode() {
+    if (g_product_mode < 0) {
+        const char* e = getenv("SATRANS_PRODUCTS");
+        g_product_mode = (e && (!strcmp(e, "split") || !strcmp(e, "bf16x3"))) ? 1 : 0;
+    }
+    return g_product_mode;
+}
+static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab, bool split = false) {
     const int LD = D + 4, LU = U + 4;
     const int64_t rows = (((int64_t)T * F + 15) / 16) * 16;
-    return 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D + 4 * rows * LD + 64;
+    const int64_t dd = split ? (int64_t)D * (D + 8) : (int64_t)D * LD;
+    const int64_t mlp = split ? (int64_t)U * (D + 8) + (int64_t)D * (U + 8) : (int64_t)D * LU + (int64_t)U * LD;
+    return 4 * dd + (same_tab ? 1 : 2) * mlp + 6 * D + 4 * rows * LD + 64;
 }
 
-template <int D, int U, int H, int WAVES, int MOD = 0>
+template <int D, int U, int H, int WAVES, int MOD = 0, int PROD = 0>
 static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipStream_t stream) {
     const bool same_tab = d->tab_q == d->tab_k;
     // samples per tile: as many as keep `per_cu` workgroups per CU, preferring tiles that fill their 16-token MFMA rows
@@ -1338,7 +1490,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int budgets[2] = {WAVES > 4 ? 156 * 1024 : 78 * 1024, 156 * 1024};   // two 4-wave workgroups per CU if any tile fits
     for (int budget : budgets) {
         for (int t = 1; t <= 4 * WAVES; ++t) {
-            if (fused_fwd_lds_floats(t, d->F, D, U, same_tab) * 4 > budget) break;
+            if (fused_fwd_lds_floats(t, d->F, D, U, same_tab, PROD) * 4 > budget) break;
             const int tok = t * d->F, ntt = (tok + 15) / 16;
             const double eff = (double)tok / (16.0 * ntt) * (double)ntt / (double)(ceil_div(ntt, WAVES) * WAVES);
             if (eff >= best_eff) { best_eff = eff; best = t; }
@@ -1346,10 +1498,10 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
         if (best) break;
     }
     SATRANS_REQUIRE(best > 0, SATRANS_E_UNSUPPORTED, "layer_fwd(fused): F=%d does not fit LDS", d->F);
-    const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab) * 4;
+    const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab, PROD) * 4;
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
@@ -1357,7 +1509,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int64_t tiles = ceil_div(d->B, best);                        // (the kernel splits the batch by samples)
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
-    layer_fwd_fused_kernel<D, U, H, WAVES, MOD><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
+    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1373,19 +1525,21 @@ extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d);
 
 namespace satrans {
 
-static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr) {
+static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr, bool split = false) {
     const int LD = D + 4, LU = U + 4;
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
     const int64_t tasks = (int64_t)T * H * F;
-    const int copies = tr ? 2 : 1;         // forward images, and their transposes when they fit
-    return copies * 4 * (int64_t)D * LD + (same_tab ? 1 : 2) * copies * ((int64_t)D * LU + (int64_t)U * LD) + 6 * D +
-           5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + 64;
+    const int copies = (tr || split) ? 2 : 1;         // forward images, and their transposes when they fit
+    const int64_t dd = split ? (int64_t)D * (D + 8) : (int64_t)D * LD;
+    const int64_t mlp = split ? (int64_t)U * (D + 8) + (int64_t)D * (U + 8) : (int64_t)D * LU + (int64_t)U * LD;
+    return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + 64;
 }
 
 struct FusedBwdPlan {
     int T, G;
     size_t lds;
     bool tr;      // transposed weight images in LDS
+    bool split;   // split products (both directions of every weight as bf16 hi / lo images)
 };
 
 static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
@@ -1398,24 +1552,27 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     // transposed copies where they fit (D = 32 with one shared generated-weight table) for comparison.
     static const int force_tr = getenv("SATRANS_BWD_TR") ? atoi(getenv("SATRANS_BWD_TR")) : 0;
     p.tr = force_tr == 1 && same_tab && d->D == 32 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR));
-    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, p.tr) * 4;
+    p.split = product_mode() == 1 && !p.tr && same_tab && d->D == 32 && d->U == 64 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) &&
+              (d->flags & (SATRANS_META_Q | SATRANS_META_K)) &&
+              (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, false, true) * 4 <= 160 * 1024;
+    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, p.tr, p.split) * 4;
     if (p.lds > 160 * 1024) return false;
     const int64_t tiles = ceil_div(d->B, p.T) + d->S;
     p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
     return true;
 }
 
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
                       hipStream_t stream) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1423,6 +1580,13 @@ static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const 
 }  // namespace satrans
 
 using namespace satrans;
+
+extern "C" int satrans_set_product_mode(int mode) {
+    if (mode != 0 && mode != 1) return SATRANS_E_BADARG;
+    satrans::g_product_mode = mode;
+    return SATRANS_OK;
+}
+extern "C" int satrans_get_product_mode(void) { return product_mode(); }
 
 // 1 when the fused kernels are built for this shape
 extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d) {
@@ -1450,6 +1614,7 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     if (mod) return mod == 1 ? launch_fwd_w<16, 32, 2, kFusedWaves, 1>(d, y, att, stream) : launch_fwd_w<16, 32, 2, kFusedWaves, 2>(d, y, att, stream);
     if (d->D == 32 && fwd_waves == 8) return launch_fwd_w<32, 64, 4, 8>(d, y, att, stream);
     if (d->D == 32 && fwd_waves == 4) return launch_fwd<32, 64, 4>(d, y, att, stream);
+    if (d->D == 32 && product_mode() == 1) return launch_fwd_w<32, 64, 4, 12, 0, 1>(d, y, att, stream);
     if (d->D == 32) return launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
     if (d->D == 16) return launch_fwd<16, 32, 2>(d, y, att, stream);
     return launch_fwd<64, 16, 4>(d, y, att, stream);
@@ -1482,6 +1647,7 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     int rc;
     {
     SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");
+    SATRANS_REQUIRE((int64_t)d->B * d->F < ((int64_t)1 << 31), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): B * F must stay below 2^31");
     static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
     // the AliCCP field count as a compile-time constant: -11 % (0.868 -> 0.777 ms over three layers).  The same for the 16
     // fields of the Alimama `sota-pos` shape (separate Q / K tables) spills 34 VGPRs and gains nothing: not instantiated.
@@ -1496,6 +1662,10 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
                                 : launch_bwd<32, 64, 4, false, false, 0, 2>(d, p, dy, dx, slabs, stream))
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
                                 : launch_bwd<16, 32, 2, false, false, 0, 2>(d, p, dy, dx, slabs, stream));
+    else if (p.split && d->F == 19 && f_const)
+        rc = launch_bwd<32, 64, 4, true, false, 19, 0, 1>(d, p, dy, dx, slabs, stream);
+    else if (p.split)
+        rc = launch_bwd<32, 64, 4, true, false, 0, 0, 1>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32 && same && !p.tr && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32) rc = same ? (p.tr ? launch_bwd<32, 64, 4, true, true>(d, p, dy, dx, slabs, stream)

@@ -133,6 +133,95 @@ __device__ __forceinline__ void chain_t(const float* __restrict__ wl, const floa
     }
 }
 
+// ---- split products: fp32 operands as bf16 pairs on the bf16 matrix instruction -------------------------------------------------
+// v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi) (both round-to-nearest-even); a product of two such operands is
+// evaluated as  a_lo w_hi + a_hi w_lo + a_hi w_hi  (each bf16 x bf16 product is exact in fp32, the sums accumulate in fp32 inside
+// v_mfma_f32_16x16x32_bf16): three instructions of 16 cycles for a 16 x 16 x 32 block against eight v_mfma_f32_16x16x4_f32 of 32
+// cycles.  What is dropped is a_lo w_lo (<= 2^-16 of a term) and the rounding of the lo parts (<= 2^-17): measured against the
+// same graph in fp64, the AliCCP-shaped golden case loses 2.6x the accuracy plain fp32 products have (logits 4.8e-8 against
+// 1.8e-8, worst gradient 3.6e-5 against 1.3e-5 of the largest entry: tools/experiments/r03_split_products_sim.py).
+// Weights are split ONCE per workgroup while they are staged into LDS; activations on the fly (~3 VALU instructions per value).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Image of a weight for split products: rows = output features, RS = K + 8 bf16 per row (16 bytes of padding: the row stride is an
+// odd number of 16-byte slots), the hi image followed by the lo image.  Inside a row the contraction index k sits where the B
+// operand of a CHAINED product presents it: K-step s = k / 32, then lane group g, element j with k % 32 = 16 (j / 4) + 4 g + j % 4
+// (the accumulator layout of the previous product), so an A fragment is ONE 16-byte read; the 16-byte chunk index carries the XOR
+// flip of img_flip (rows 4..11 of every 16 swap chunks g and g ^ 1), which makes the reads of a service group of 16 lanes hit 16
+// different slots.
+__device__ __forceinline__ int split_pos(int k) {
+    const int s = k >> 5, kk = k & 31;
+    const int t = kk >> 4, g = (kk & 15) >> 2, r = kk & 3;
+    return 32 * s + 8 * g + 4 * t + r;
+}
+__device__ __forceinline__ int split_flip(int row) { return ((row & 15) >= 4 && (row & 15) < 12) ? 8 : 0; }   // in bf16 elements
+
+// global fp32 weight -> hi / lo images [OUT][RS].  in_major: g[k * OUT + o] (W[in][out]); else g[o * K + k] (nn.Linear [out][in]).
+// transpose = the image of W^T (the backward products): roles of the two indices swapped.
+__device__ __forceinline__ void stage_split(const float* __restrict__ g, __bf16* __restrict__ hi, int OUT, int K, int RS, bool in_major) {
+    __bf16* lo = hi + OUT * RS;
+    for (int i = threadIdx.x; i < OUT * K; i += blockDim.x) {
+        int o, k;
+        if (in_major) { k = i / OUT; o = i - k * OUT; } else { o = i / K; k = i - o * K; }
+        const float v = g[i];
+        const __bf16 h = (__bf16)v;
+        const int at = o * RS + (split_pos(k) ^ split_flip(o));
+        hi[at] = h;
+        lo[at] = (__bf16)(v - (float)h);
+    }
+}
+
+// a D-layout fragment (16 KT_ features of 16 tokens) as the hi / lo B operands of KT_ / 2 K-steps
+template <int KT_>
+__device__ __forceinline__ void split_frag(const float (&in)[KT_][4], bf16x8 (&bh)[KT_ / 2], bf16x8 (&bl)[KT_ / 2]) {
+    static_assert(KT_ % 2 == 0, "a K-step of the bf16 MFMA spans two 16-feature tiles");
+#pragma unroll
+    for (int s = 0; s < KT_ / 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = in[2 * s + (j >> 2)][j & 3];
+            const __bf16 h = (__bf16)v;
+            bh[s][j] = h;
+            bl[s][j] = (__bf16)(v - (float)h);
+        }
+}
+
+// out[mt] (16 output features x 16 tokens, D-layout) = sum over the 32 * KS input features of the split operand.
+// hl: hi image + n * RS + (8 g ^ split_flip(n)); lo_off: distance of the lo image (OUT * RS elements)
+template <int KS, int MT_, int RS>
+__device__ __forceinline__ void chain_split(const __bf16* __restrict__ hl, int lo_off, const bf16x8 (&bh)[KS], const bf16x8 (&bl)[KS],
+                                            float (&out)[MT_][4]) {
+    f32x4 acc[MT_];
+    bf16x8 ah[KS][MT_], al[KS][MT_];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) {
+            ah[s][mt] = *reinterpret_cast<const bf16x8*>(hl + 16 * mt * RS + 32 * s);
+            al[s][mt] = *reinterpret_cast<const bf16x8*>(hl + lo_off + 16 * mt * RS + 32 * s);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the small terms first
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][mt], bh[s], acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][mt], bl[s], acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][mt], bh[s], acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) {
+        out[mt][0] = acc[mt][0]; out[mt][1] = acc[mt][1]; out[mt][2] = acc[mt][2]; out[mt][3] = acc[mt][3];
+    }
+}
+
 // ---- conflict-free operand paths of the backward kernel (PMC of round 2: SQ_LDS_BANK_CONFLICT 62 % of its LDS-active cycles) ----
 // Weight images carry an XOR swizzle: the 16-byte chunk c of row k is stored at chunk c ^ [4 <= k mod 16 < 12].  A by-rows
 // 16-byte read of a transposed product (chain_t: lane (n, g) reads row n, chunk g) is serviced in the lane groups
@@ -312,6 +401,34 @@ __device__ __forceinline__ void metanet_frag(const float* w1l, const float* w2l,
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
     chain<UT, KT, D + 4>(w2l, h, out);
+    const uint32_t kb = dc.on ? token_keep_bits<KT>(sample_key, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = out[t][r];
+            if (dc.on) m = (kb >> (4 * t + r)) & 1u ? m * dc.scale : 0.f;
+            out[t][r] = m + in[t][r];
+        }
+    layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
+}
+
+// metanet_frag on split products (images of W1 [U][D + 8] and W2 [D][U + 8], see stage_split)
+template <int D, int U>
+__device__ __forceinline__ void metanet_frag_split(const __bf16* w1l, const __bf16* w2l, const float* gam, const float* bet,
+                                                   int g4, const FusedDrop& dc, uint32_t sample_key, int f,
+                                                   const float (&in)[D / 16][4], float (&out)[D / 16][4], float& mean, float& rstd) {
+    constexpr int KT = D / 16, UT = U / 16;
+    float h[UT][4];
+    bf16x8 ih[KT / 2], il[KT / 2], hh[UT / 2], hl_[UT / 2];
+    split_frag<KT>(in, ih, il);
+    chain_split<KT / 2, UT, D + 8>(w1l, U * (D + 8), ih, il, h);
+#pragma unroll
+    for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
+    split_frag<UT>(h, hh, hl_);
+    chain_split<UT / 2, KT, U + 8>(w2l, D * (U + 8), hh, hl_, out);
     const uint32_t kb = dc.on ? token_keep_bits<KT>(sample_key, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
 #pragma unroll
     for (int t = 0; t < KT; ++t)

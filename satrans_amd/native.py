@@ -74,6 +74,8 @@ SIGNATURES = {
     "satrans_gather_read_probe": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
     "satrans_set_layer_impl": (C.c_int, [C.c_int]),
     "satrans_layer_fused_supported": (C.c_int, [C.POINTER(LayerDesc)]),
+    "satrans_set_product_mode": (C.c_int, [C.c_int]),
+    "satrans_get_product_mode": (C.c_int, []),
     "satrans_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp]),
 "satrans_layer_fwd_bf16_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "satrans_layer_fwd_bf16": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
