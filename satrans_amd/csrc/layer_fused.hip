@@ -473,9 +473,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 #define SATRANS_UD2 1
 #define SATRANS_UE 1
 #endif
+#ifndef SATRANS_ATTN_SB
+#define SATRANS_ATTN_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 #define ATTN_CHUNKS(VAR, BODY, UNROLL)                                                                          \
     if constexpr (FT != 0 && (UNROLL)) {                                                                                  \
-        _Pragma("unroll") for (int VAR = 0; VAR < FT; VAR += 4) { BODY(VAR); __builtin_amdgcn_sched_barrier(0); } \
+        _Pragma("unroll") for (int VAR = 0; VAR < FT; VAR += 4) { BODY(VAR); SATRANS_ATTN_SB; } \
     } else {                                                                                                    \
         _Pragma("unroll 1") for (int VAR = 0; VAR < F; VAR += 4) BODY(VAR);                                      \
     }
@@ -510,6 +513,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const bool meta_q = (a.flags & SATRANS_META_Q) && !bilin, meta_k = (a.flags & SATRANS_META_K) && !bilin;
     const bool mlp_q = meta_q && !gate, mlp_k = meta_k && !gate;          // the MetaNet proper
     constexpr bool same_tab = SAME;
+    // SAME = one generated-weight table AND one MetaNet LayerNorm for the Q and K roles (no 'pos' flag: satrans.py:46 - the
+    // launcher checks both): the LayerNorm gradients of both roles then share one set of accumulators, as the W1 / W2 ones do
+    constexpr bool SHLN = SAME && MOD == 0;
     const bool relu_out = a.flags & SATRANS_RELU_OUT, use_res = !(a.flags & SATRANS_NO_RES);
 
     // ---- LDS: forward images, transposed images, LN vectors, 5 row buffers, softmax cache ------------------------
@@ -1218,7 +1224,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (mlp_q)
                 metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, 0, hq, q0, w2qT, w1qT, acc_w1q, acc_w2q);
             if (mlp_k) {
-                if constexpr (SAME)   // one table: both roles add into the same accumulators
+                if constexpr (SHLN)   // one table and one LayerNorm: both roles add into the same accumulators
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agq, abq, 8, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
+                else if constexpr (SAME)
                     metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
                 else
                     metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1k, acc_w2k);
@@ -1332,8 +1340,16 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         __syncthreads();
     };
     flush_ln(agl, abl, 4 * D * D);
-    flush_ln(agq, abq, 4 * D * D + 2 * D);
-    flush_ln(agk, abk, 4 * D * D + 4 * D);
+    if constexpr (SHLN) {
+        // one MetaNet LayerNorm for both roles: the sums of both sit in agq / abq.  The reducer adds the Q and the K slot when
+        // both roles are modulated and reads the K slot alone when only K is (fused_common_reduce)
+        const int off_sum = 4 * D * D + (mlp_q ? 2 * D : 4 * D), off_zero = 4 * D * D + (mlp_q ? 4 * D : 2 * D);
+        flush_ln(agq, abq, off_sum);
+        for (int e = threadIdx.x; e < 2 * D; e += kFusedBlock) common[off_zero + e] = 0.f;
+    } else {
+        flush_ln(agq, abq, 4 * D * D + 2 * D);
+        flush_ln(agk, abk, 4 * D * D + 4 * D);
+    }
 }
 
 
@@ -1464,12 +1480,12 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
 
 // How the fused kernels evaluate the weight products of the D = 32 MetaNet shapes: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit for bit an
 // fmaf chain), 1 = split (fp32 operands as bf16 pairs, three v_mfma_f32_16x16x32_bf16 per block; layer_fused_common.h).
-// SATRANS_PRODUCTS=f32|split sets the start value, satrans_set_product_mode changes it (tests run both).
+// SATRANS_PRODUCTS=f32|split sets the start value (split when unset), satrans_set_product_mode changes it (tests run both).
 static int g_product_mode = -1;
 static int product_mode() {
     if (g_product_mode < 0) {
         const char* e = getenv("SATRANS_PRODUCTS");
-        g_product_mode = (e && (!strcmp(e, "split") || !strcmp(e, "bf16x3"))) ? 1 : 0;
+        g_product_mode = (e && (!strcmp(e, "f32") || !strcmp(e, "fp32"))) ? 0 : 1;      // split unless asked otherwise
     }
     return g_product_mode;
 }
@@ -1544,7 +1560,7 @@ struct FusedBwdPlan {
 
 static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     if (!satrans_layer_fused_supported(d) || d->D > 32 || d->F > 32) return false;   // keep bits: one 32-bit word per row
-    const bool same_tab = d->tab_q == d->tab_k;
+    const bool same_tab = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;   // (as satrans_layer_bwd_fused picks SAME)
     p.T = 64 / d->F;
     // No transposed copies of the weight images: the backward products read the forward images by rows (chain_t).  The
     // four-way bank conflicts of those reads cost nothing measurable, while staging half as many images per workgroup
@@ -1643,7 +1659,8 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
     hipStream_t stream = (hipStream_t)stream_;
     FusedBwdPlan p;
     SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
-    const bool same = d->tab_q == d->tab_k;
+    // (a caller with one table but two LayerNorm vectors gets the two-table instantiation: it stages the table twice, nothing else)
+    const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
     int rc;
     {
     SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsatrans_hip.so")
+LIB_PATH = os.environ.get("SATRANS_LIB_PATH") or os.path.join(_HERE, "libsatrans_hip.so")   # (override: kernel experiments)
 ABI_VERSION = 3
 
 ID_F32, ID_I32, ID_I64 = 0, 1, 2

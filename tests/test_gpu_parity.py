@@ -16,6 +16,34 @@ DEV = "cuda:0"
 LOGIT_ATOL = 1e-5
 
 
+def split_products() -> bool:
+    """True when the fused kernels evaluate the weight products of the (D, U, H) = (32, 64, 4) MetaNet shape as split products
+    (fp32 operands as bf16 pairs, three bf16 MFMAs per block - include/satrans_hip.h: satrans_set_product_mode; the library's
+    default) rather than on the fp32 instruction (SATRANS_PRODUCTS=f32).  Split products carry ~2.6x the error of plain fp32
+    products against an fp64 evaluation of the same graph (test_product_modes_against_the_fp64_oracle): the golden gates (1e-5
+    on logits, 5e-5 of the largest entry on gradients) hold in both modes; the few bounds below that were set at the fp32
+    kernels' own noise floor are stated per mode."""
+    from satrans_amd import native
+    return native.lib().satrans_get_product_mode() == 1
+
+
+def assert_close_but_for_kinks(got, want, rtol, atol, err_msg, frac=5e-4, slack=20.0):
+    """assert_allclose, except that under split products a fraction `frac` of the elements may sit up to `slack` x outside it.
+    A ReLU whose pre-activation is within the products' error of zero takes the other branch than the oracle's: the gradient
+    of the one sample involved then changes by O(1) of that sample's share, which an element-wise bound at 1e-4 of the
+    largest entry sees in the table rows that sample touched.  With fp32 products (error ~1e-7) 8,192 samples x 2 x 64 hidden
+    units x 19 fields almost never hold such a unit, with split products (~1e-5 near a kink) a handful do: measured 29 of
+    259,744 elements of one table's exp_avg, the largest 9e-4 of the tensor's largest entry."""
+    if not split_products():
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=err_msg)
+        return
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    bad = err > tol
+    assert float(bad.mean()) <= frac, (err_msg, float(bad.mean()))
+    assert bool((err <= slack * tol).all()), (err_msg, float((err / tol).max()))
+
+
 def sd_to_cpu(model):
     return {k: v.detach().cpu() for k, v in model.state_dict().items()}
 
@@ -58,6 +86,74 @@ def test_gradients_match_reference_golden(name):
     for k, g in want.items():
         scale = max(1e-6, float(np.abs(g).max()))
         np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=rel * scale + floor, err_msg=k)
+
+
+def _with_product_mode(mode, fn):
+    from satrans_amd import native
+    lib = native.lib()
+    before = lib.satrans_get_product_mode()
+    assert lib.satrans_set_product_mode(mode) == 0
+    try:
+        return fn()
+    finally:
+        lib.satrans_set_product_mode(before)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32-products", "split-products"])
+def test_parity_gates_hold_in_both_product_modes(mode):
+    """The golden forward, the golden gradients, the replayed-mask training gradients, the step-by-step Adam trajectory and the
+    run-to-run bit identity of the AliCCP-shaped case under fp32 products AND under split products, whichever of the two the
+    library starts in (satrans_set_product_mode; SATRANS_PRODUCTS)."""
+    from satrans_amd import native
+    assert native.lib().satrans_set_product_mode(2) != 0, "an unknown mode must be refused"
+
+    def body():
+        test_forward_matches_reference_golden("aliccp_sota")
+        test_gradients_match_reference_golden("aliccp_sota")
+        test_training_mode_gradients_match_oracle_with_same_masks()
+        test_adam_trajectory_step_by_step_against_the_oracle("aliccp_sota")
+        c = Case("aliccp_sota")
+        outs = []
+        for _ in range(2):                                  # same inputs, same weights: the same bits
+            model = build_model(c, DEV)
+            model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+            model.eval()
+            _, _, grads = model._require_engine().loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+            outs.append({k: g.cpu() for k, g in grads.items()})
+        assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
+    _with_product_mode(mode, body)
+
+
+def test_product_modes_against_the_fp64_oracle():
+    """How much accuracy split products cost, measured: logits and every gradient of the AliCCP-shaped golden case in both modes
+    against the SAME graph evaluated in fp64 by the oracle.  Recorded on an MI355X: logits 1.4e-8 (fp32 products) and 4.8e-8
+    (split) on values of ~0.1; worst gradient 1.8e-5 / 5.0e-5 of the tensor's largest entry (the cancellation-dominated
+    W_Query / W_Key gradients) - the CPU simulation of tools/experiments/r03_split_products_sim.py says 1.3e-5 / 3.6e-5 with
+    fp64 accumulation."""
+    c = Case("aliccp_sota")
+    spec = c.spec()
+    P64 = c.tensors("param", torch.float64)
+    _, logit64 = O.forward(P64, c.X, spec)
+    _, _, ref = O.loss_and_grads(P64, c.X, c.y, spec)             # BCE(sum) + regulariser, as loss_and_grads of the engine
+
+    def run():
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        model.eval()
+        eng = model._require_engine()
+        model(c.X.to(DEV))
+        logit_err = float((eng.last_logit().cpu().double().reshape(-1) - logit64.detach().reshape(-1)).abs().max())
+        _, _, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+        worst = 0.0
+        for k, g in grads.items():
+            if k in ref and float(ref[k].abs().max()) > 1e-7:
+                worst = max(worst, float((g.cpu().double() - ref[k]).abs().max() / ref[k].abs().max()))
+        return logit_err, worst
+    (l32, g32), (lsp, gsp) = _with_product_mode(0, run), _with_product_mode(1, run)
+    print(f"fp32 products: logit {l32:.2e} gradient {g32:.2e} | split products: logit {lsp:.2e} gradient {gsp:.2e}")
+    assert l32 <= 2e-7 and lsp <= 5e-7, (l32, lsp)
+    assert g32 <= 3e-5 and gsp <= 1e-4, (g32, gsp)
+    assert gsp <= 5.0 * g32 + 1e-6, "split products are expected within a small factor of plain fp32 products"
 
 
 @pytest.mark.parametrize("name", NATIVE_ADAM_CASES)
@@ -151,8 +247,10 @@ def test_adam_trajectory_step_by_step_against_the_oracle(name):
             delta = (got[k] - leaf.detach()).abs()
             vhat = ref_v / (1 - 0.999 ** (step + 1))
             ok = vhat.sqrt() > 1e-4 * max(float(vhat.sqrt().max()), 1e-30)
+            # (split products: an element at 1e-4 of the largest gradient sees 2.6x the relative error: 4e-2 of a step)
             if bool(ok.any()):
-                assert float(delta[ok].max()) <= 2e-2 * lr, (step, k, float(delta[ok].max()))
+                bound = (4e-2 if split_products() else 2e-2) * lr
+                assert float(delta[ok].max()) <= bound, (step, k, float(delta[ok].max()))
             assert float(delta.max()) <= 2.0 * lr + 1e-6, (step, k)
 
 
@@ -832,7 +930,8 @@ def test_fit_predict_at_baseline_config_scale():
                       embedding_dim=32, head_num=4, layer_num=3, flag='sota', meta_mode='QK', meta_units=[32, 64, 32])
     X = np.stack([x[f] for f in bench.ALICCP_FIELDS], axis=1).astype(np.float32)[:4096]
     p_ref, _ = O.forward(sd_to_cpu(model), torch.from_numpy(X), spec)
-    np.testing.assert_allclose(pred[:4096], p_ref.numpy().astype(np.float64), rtol=0, atol=5e-6)
+    # (trained weights: |logit| up to ~5, where 5e-6 on a probability is the fp32 kernels' own floor; split products: 2e-5)
+    np.testing.assert_allclose(pred[:4096], p_ref.numpy().astype(np.float64), rtol=0, atol=2e-5 if split_products() else 5e-6)
     ev = model.evaluate(dict(x), y, 8192 * 4)
     assert set(ev) == {"binary_crossentropy", "auc"}
 
@@ -939,9 +1038,9 @@ def test_teacher_forced_step_at_the_baseline_batch_on_full_size_tables():
             rm, rv, gm, gv = ref_m[sel], ref_v[sel], m[sel], v[sel]
             if rm.numel() == 0:
                 continue
-            np.testing.assert_allclose(gm.numpy(), rm.numpy(), rtol=1e-5, atol=1e-4 * float(rm.abs().max()) + 1e-30,
+            assert_close_but_for_kinks(gm.numpy(), rm.numpy(), rtol=1e-5, atol=1e-4 * float(rm.abs().max()) + 1e-30,
                                        err_msg=f"exp_avg/{k} ({what} rows)")
-            np.testing.assert_allclose(gv.numpy(), rv.numpy(), rtol=1e-5, atol=2e-4 * float(rv.abs().max()) + 1e-30,
+            assert_close_but_for_kinks(gv.numpy(), rv.numpy(), rtol=1e-5, atol=2e-4 * float(rv.abs().max()) + 1e-30,
                                        err_msg=f"exp_avg_sq/{k} ({what} rows)")
             delta = (got[k][sel] - leaf.detach()[sel]).abs()
             vhat = rv / (1 - 0.999 ** 3)
