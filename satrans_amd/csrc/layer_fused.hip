@@ -488,6 +488,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 // activations; the token-contraction products of the weight gradients stay on the fp32 instruction).  Split products read one
 // image per DIRECTION of a weight (a fragment is 8 consecutive contraction indices of one output row), so both orientations of
 // every weight live in LDS as hi / lo bf16 pairs: SAME tables, MOD 0, no TR only.
+// token-contraction products: on the fp32 instruction, or (PROD) on split operands
+#define WGRAD wgrad_sel<PROD>::template run
 template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     gy[t][r] *= keep[t][r];                                     // du
                 }
             store_frag<KT>(my_g, gy);                                           // du rows (zero for padding tokens)
-            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_g, wg_o, acc_wo);                    // dWo[o][i] += du^T o
             float go[KT][4];
             prod_dd(wo, true, gy, go);                                          // go = du Wo
             store_frag<KT>(my_o, go);
@@ -1149,8 +1151,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, dm);
-                    wgrad_r4<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
-                    if constexpr (HB == 2) wgrad_r4<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
+                    WGRAD<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
+                    if constexpr (HB == 2) WGRAD<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
@@ -1180,8 +1182,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, in0, valid);
-                    wgrad_r4<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
-                    if constexpr (HB == 2) wgrad_r4<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
+                    WGRAD<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
+                    if constexpr (HB == 2) WGRAD<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (bilin) {                        // q_h = q0_h M: dM += q0^T gq (block-diagonal part kept by the reducer), gq0 = gq M^T
                 store_frag<KT>(my_q, q0, valid);
                 store_frag<KT>(my_o, gq);
-                wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_w1q);
+                WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_w1q);
                 float back[KT][4];
                 if constexpr (!PROD) chain_t<KT, KT, LD>(w1q + lt_d, gq, back);   // (by rows of the one image, with or without TR)
 #pragma unroll
@@ -1235,10 +1237,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
-            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
             store_frag<KT>(my_o, gk);
-            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
-            wgrad_r4<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
             float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
             auto back_dd = [&](float* img, const float (&in_)[KT][4], float (&out_)[KT][4]) {
@@ -1354,6 +1356,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
 
 // -------------------------------------------------------------------------------------------------------------------
+#undef WGRAD
 // Reduction of the backward kernel's output, fixed order (bitwise reproducible):
 //   common  [G][CSZ]   CSZ = 4*D*D + 6*D : [wq|wk|wv|wo|ln g,b|lnq g,b|lnk g,b] per workgroup
 //   records [G+S][TSZ] TSZ = 4*D*U       : [w1q|w2q|w1k|w2k] of (workgroup w, scenario s) at index w + s

@@ -272,6 +272,62 @@ __device__ __forceinline__ void wgrad_r4(const float* al, const float* gl, f32x4
                 acc[MOFF + mt][NOFF + nt] = mfma4(av[ks][mt], gv[ks][nt], acc[MOFF + mt][NOFF + nt]);
 }
 
+// wgrad_r4 on split operands: the SAME four fp32 reads per operand tile (lane group g: token rows 4 g .. 4 g + 3), split in
+// registers, and the 32 contraction slots of v_mfma_f32_16x16x32_bf16 hold the wave's 16 tokens twice: slots 0-3 of a lane
+// group carry the hi parts of its four tokens, slots 4-7 the lo parts on the A side; the B side carries g_hi in both halves for
+// one instruction and g_lo in both halves for the other, so the two instructions add up to (a_hi + a_lo)(g_hi + g_lo): all four
+// cross terms, 32 cycles instead of the 128 of four fp32 instructions.
+__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, __bf16 (&h)[4], __bf16 (&l)[4]) {
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)v[j];
+        l[j] = (__bf16)(v[j] - (float)h[j]);
+    }
+}
+template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
+__device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
+    float ar[4][MT_], gr[4][NT_];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < MT_; ++mt) ar[ks][mt] = al[ks * LDA + 16 * mt];
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt) gr[ks][nt] = gl[ks * LDG + 16 * nt];
+    }
+    bf16x8 av[MT_], gh[NT_], gl_[NT_];
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt) {
+        __bf16 h[4], l[4];
+        split4(ar[0][mt], ar[1][mt], ar[2][mt], ar[3][mt], h, l);
+        av[mt] = bf16x8{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) {
+        __bf16 h[4], l[4];
+        split4(gr[0][nt], gr[1][nt], gr[2][nt], gr[3][nt], h, l);
+        gh[nt] = bf16x8{h[0], h[1], h[2], h[3], h[0], h[1], h[2], h[3]};
+        gl_[nt] = bf16x8{l[0], l[1], l[2], l[3], l[0], l[1], l[2], l[3]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT_; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt) {
+            f32x4 c = acc[MOFF + mt][NOFF + nt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], gl_[nt], c, 0, 0, 0);
+            acc[MOFF + mt][NOFF + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], gh[nt], c, 0, 0, 0);
+        }
+}
+
+template <int PROD>
+struct wgrad_sel {
+    template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
+    static __device__ __forceinline__ void run(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
+        if constexpr (PROD) wgrad_split<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
+        else wgrad_r4<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
+    }
+};
+
 // Workgroup barrier for LDS hand-offs inside a tile loop.  __syncthreads() makes hipcc wait for EVERY outstanding memory
 // operation (s_waitcnt vmcnt(0)) in front of s_barrier, which stalls the waves on global loads that are meant to fly across
 // the phases (next tile's sample index and input row, dy); only the LDS traffic has to be complete here.  Not for hand-offs
