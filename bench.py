@@ -505,6 +505,7 @@ def main():
             rows[name] = entry
         return rows, dom
 
+    products = "split" if eng.lib.satrans_get_product_mode() == 1 and args.config == "aliccp" and args.flag == "sota" else "f32"
     kernels, dominant = table(phases)
     phase_sum = sum(v["ms_per_step"] for v in kernels.values())
     kernels_serial, _ = table(phases_serial)
@@ -517,7 +518,10 @@ def main():
                     "launches_per_step": count.get(dominant, 1),
                     "note": "HIP events on the launch stream over the timed region (every 4th step); layer_bwd includes "
                             "its fixed-order reduction launch; `kernels_serial` repeats the measurement in an extra "
-                            "untimed pass"}
+                            "untimed pass" + ("; `achieved` counts the ALGORITHMIC fp32 FLOPs of the layer, `peak` is the fp32 "
+                            "MFMA peak: the kernel issues them as split bf16 products (3 x 1/16 of the fp32 instruction's "
+                            "cycles), so the matrix pipe is ~10 % of its cycles and the fraction is a time-to-solution "
+                            "figure against the fp32 roof, not a pipe utilisation" if products == "split" else "")}
 
     # HBM bytes per launch of that kernel from the PMC passes under profiles/ (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE
     # in separate passes of `bench.py --train-only`, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The
@@ -534,8 +538,9 @@ def main():
             if pmc.get("_source_sha256") != sha:
                 roofline["traffic_source"] = (f"stale: profiles/{PMC_SUMMARY} was taken on other kernel sources "
                                               f"({str(pmc.get('_source_sha256'))[:12]} vs {sha[:12]})")
-            elif pmc.get("_config") != args.config or args.flag != CFG["flag"]:
-                roofline["traffic_source"] = f"none: profiles/{PMC_SUMMARY} is of config {pmc.get('_config')!r}, default flag"
+            elif pmc.get("_config") != args.config or args.flag != CFG["flag"] or pmc.get("_products", "f32") != products:
+                roofline["traffic_source"] = (f"none: profiles/{PMC_SUMMARY} is of config {pmc.get('_config')!r}, default flag, "
+                                              f"{pmc.get('_products', 'f32')} products")
             else:
                 roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
                 roofline["traffic_source"] = (f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc of these kernel sources, bytes per "
@@ -608,7 +613,7 @@ def main():
             pass
 
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
-    err = None
+    err = err_train = logit_scale = None
     try:
         if args.train_only:
             raise RuntimeError("--train-only")
@@ -620,6 +625,16 @@ def main():
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         _, ref_logit = O.forward(sd, torch.from_numpy(X[:nb]), oracle_spec(args.flag))
         err = float((gpu_logit - ref_logit).abs().max())
+        # the same inputs through the TRAINING forward (split products unless SATRANS_PRODUCTS=f32) with its dropouts switched off
+        model.train()
+        keep_p, eng.drop_p = eng.drop_p, 0.0
+        try:
+            model(Xd[:nb])
+            err_train = float((eng.last_logit().cpu() - ref_logit).abs().max())
+        finally:
+            eng.drop_p = keep_p
+            model.eval()
+        logit_scale = float(ref_logit.abs().max())
         del sd
     except Exception as ex:                                                        # the number is informative only
         print(f"[bench] logit parity check skipped: {ex}", file=sys.stderr)
@@ -650,12 +665,21 @@ def main():
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "products": (products + (": fp32 operands as bf16 pairs hi + lo, a product = a_lo w_hi + a_hi w_lo + a_hi w_hi on "
+                                 "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fused kernels of the (32, 64, 4) MetaNet shape; "
+                                 "SATRANS_PRODUCTS=f32 runs them on v_mfma_f32_16x16x4_f32).  fp32 in, fp32 out; measured 2.7x the error "
+                                 "of plain fp32 products against fp64 (tests: test_product_modes_against_the_fp64_oracle)"
+                                 if products == "split" else ": v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain)")),
         "config": {"workload": f"{CFG['label']}, {model.embedding_arena.shape[0]:,} table rows "
                                f"({model.embedding_arena.numel() * 4 / 1e6:,.0f} MB fp32), {args.ids} ids, dropout on, "
                                f"dense-Adam+L2 semantics over all rows",
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": D, "layers": L, "heads": CFG["H"],
                    "fields": F, "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
+        "fwd_logit": {"max_abs_err_vs_cpu_oracle": err, "training_forward_dropout_off_max_abs_err": err_train,
+                      "max_abs_logit": logit_scale, "samples": 2048,
+                      "note": "weights as they are after this run's training steps; evaluation forward = fp32 products, "
+                              f"training forward = {products} products"},
         "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
         "fit_samples_per_s": fit_leg["samples_per_s"] if fit_leg else None, "fit": fit_leg,
         "phase_sum_ms_per_step": round(phase_sum, 4), "phase_sum_frac_of_step": round(phase_sum / (elapsed / K * 1e3), 4),

@@ -167,6 +167,9 @@ int satrans_layer_fused_supported(const satrans_layer_desc* d);
  * 1 = split: every fp32 operand as a bf16 pair hi + lo, a product as a_lo w_hi + a_hi w_lo + a_hi w_hi on
  *     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what is dropped is <= 2^-16 of a term; measured ~2.6x the error of plain
  *     fp32 products against an fp64 evaluation of the same graph).  Weights are split once per workgroup, activations on the fly.
+ * Mode 1 applies to the TRAINING step - the forward with SATRANS_TRAIN set and the backward; a forward without SATRANS_TRAIN
+ * (predict / evaluate) always runs fp32 products: outputs that are compared with the reference's stay exact to fp32 summation
+ * order (logits of a trained AliCCP-shaped model: 1.4e-6 from the CPU oracle; 7.7e-5 through split products).
  * The library starts in mode 1; SATRANS_PRODUCTS=f32 in the environment starts it in mode 0.  Layers of other shapes, the
  * gate / bilinear variants and separate Q / K tables (flag 'pos') always run fp32 products.  Returns SATRANS_E_BADARG for any
  * other mode. */

@@ -17,9 +17,10 @@ LOGIT_ATOL = 1e-5
 
 
 def split_products() -> bool:
-    """True when the fused kernels evaluate the weight products of the (D, U, H) = (32, 64, 4) MetaNet shape as split products
-    (fp32 operands as bf16 pairs, three bf16 MFMAs per block - include/satrans_hip.h: satrans_set_product_mode; the library's
-    default) rather than on the fp32 instruction (SATRANS_PRODUCTS=f32).  Split products carry ~2.6x the error of plain fp32
+    """True when the TRAINING step of the fused kernels (forward with dropout, backward) evaluates the weight products of the
+    (D, U, H) = (32, 64, 4) MetaNet shape as split products (fp32 operands as bf16 pairs, three bf16 MFMAs per block -
+    include/satrans_hip.h: satrans_set_product_mode; the library's default) rather than on the fp32 instruction
+    (SATRANS_PRODUCTS=f32; evaluation forwards always use it).  Split products carry ~2.6x the error of plain fp32
     products against an fp64 evaluation of the same graph (test_product_modes_against_the_fp64_oracle): the golden gates (1e-5
     on logits, 5e-5 of the largest entry on gradients) hold in both modes; the few bounds below that were set at the fp32
     kernels' own noise floor are stated per mode."""
@@ -238,9 +239,12 @@ def test_adam_trajectory_step_by_step_against_the_oracle(name):
             if float(ref_m.abs().max()) < 1e-8:
                 continue                                  # mathematically-zero gradient: rounding noise
             m, v = gopt["state"][k]["exp_avg"], gopt["state"][k]["exp_avg_sq"]
-            np.testing.assert_allclose(m.numpy(), ref_m.numpy(), rtol=1e-5, atol=1e-4 * float(ref_m.abs().max()),
+            # (1e-4 / 2e-4 of the largest element is where the fp32 kernels' own rounding sits for the cancellation-heavy
+            # tensors - the scenario embeddings: 128 numbers that sum every token of the batch; split products carry 2.7x that)
+            wide = 3.0 if split_products() else 1.0
+            np.testing.assert_allclose(m.numpy(), ref_m.numpy(), rtol=1e-5, atol=wide * 1e-4 * float(ref_m.abs().max()),
                                        err_msg=f"step {step} exp_avg/{k}")
-            np.testing.assert_allclose(v.numpy(), ref_v.numpy(), rtol=1e-5, atol=2e-4 * float(ref_v.abs().max()),
+            np.testing.assert_allclose(v.numpy(), ref_v.numpy(), rtol=1e-5, atol=wide * 2e-4 * float(ref_v.abs().max()),
                                        err_msg=f"step {step} exp_avg_sq/{k}")
             # the parameter itself: tight where |m_hat| / (sqrt(v_hat) + eps) is insensitive to 1e-4 relative changes of m
             # and v, i.e. where sqrt(v_hat) >> eps; elsewhere one step can differ by up to lr
@@ -930,8 +934,8 @@ def test_fit_predict_at_baseline_config_scale():
                       embedding_dim=32, head_num=4, layer_num=3, flag='sota', meta_mode='QK', meta_units=[32, 64, 32])
     X = np.stack([x[f] for f in bench.ALICCP_FIELDS], axis=1).astype(np.float32)[:4096]
     p_ref, _ = O.forward(sd_to_cpu(model), torch.from_numpy(X), spec)
-    # (trained weights: |logit| up to ~5, where 5e-6 on a probability is the fp32 kernels' own floor; split products: 2e-5)
-    np.testing.assert_allclose(pred[:4096], p_ref.numpy().astype(np.float64), rtol=0, atol=2e-5 if split_products() else 5e-6)
+    # (predict is an evaluation forward: fp32 products in either product mode)
+    np.testing.assert_allclose(pred[:4096], p_ref.numpy().astype(np.float64), rtol=0, atol=5e-6)
     ev = model.evaluate(dict(x), y, 8192 * 4)
     assert set(ev) == {"binary_crossentropy", "auc"}
 
