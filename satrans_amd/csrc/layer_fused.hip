@@ -1151,8 +1151,19 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, dm);
+                    if constexpr (PROD && !SATRANS_WGRAD_F32) {           // (dm is read and split once for both halves of h)
+                        bf16x8 av_[NB], gh_[KT], gl_[KT];
+                        load_split_g<KT, LD>(wg_g, gh_, gl_);
+                        load_split_a<NB, LD>(wg_q, av_);
+                        mma_split<NB, KT, 0, 0>(av_, gh_, gl_, acc_w2);
+                        if constexpr (HB == 2) {
+                            load_split_a<NB, LD>(wg_o, av_);
+                            mma_split<NB, KT, NB, 0>(av_, gh_, gl_, acc_w2);
+                        }
+                    } else {
                     WGRAD<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
                     if constexpr (HB == 2) WGRAD<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
+                    }
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
@@ -1182,8 +1193,19 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, in0, valid);
+                    if constexpr (PROD && !SATRANS_WGRAD_F32) {           // (in0 once for both halves of dh)
+                        bf16x8 av_[KT], gh_[NB], gl_[NB];
+                        load_split_a<KT, LD>(wg_g, av_);
+                        load_split_g<NB, LD>(wg_q, gh_, gl_);
+                        mma_split<KT, NB, 0, 0>(av_, gh_, gl_, acc_w1);
+                        if constexpr (HB == 2) {
+                            load_split_g<NB, LD>(wg_o, gh_, gl_);
+                            mma_split<KT, NB, 0, NB>(av_, gh_, gl_, acc_w1);
+                        }
+                    } else {
                     WGRAD<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
                     if constexpr (HB == 2) WGRAD<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
+                    }
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
@@ -1237,10 +1259,22 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
+            if constexpr (PROD && !SATRANS_WGRAD_F32) {                   // (x once for the three products)
+                bf16x8 av_[KT], gh_[KT], gl_[KT];
+                load_split_a<KT, LD>(wg_q, av_);
+                load_split_g<KT, LD>(wg_o, gh_, gl_);
+                mma_split<KT, KT, 0, 0>(av_, gh_, gl_, acc_wq);
+                store_frag<KT>(my_o, gk);
+                load_split_g<KT, LD>(wg_o, gh_, gl_);
+                mma_split<KT, KT, 0, 0>(av_, gh_, gl_, acc_wk);
+                load_split_g<KT, LD>(wg_v, gh_, gl_);
+                mma_split<KT, KT, 0, 0>(av_, gh_, gl_, acc_wv);
+            } else {
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
             store_frag<KT>(my_o, gk);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
+            }
             float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
             auto back_dd = [&](float* img, const float (&in_)[KT][4], float (&out_)[KT][4]) {

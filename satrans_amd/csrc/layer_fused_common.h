@@ -294,23 +294,29 @@ __device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, _
         l[j] = (__bf16)(v[j] - (float)h[j]);
     }
 }
-template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
-__device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
-    float ar[4][MT_], gr[4][NT_];
+// the A side of a token-contraction product: MT_ tiles of 16 features, [hi | lo] of the lane group's four tokens
+template <int MT_, int LDA>
+__device__ __forceinline__ void load_split_a(const float* al, bf16x8 (&av)[MT_]) {
+    float ar[4][MT_];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int mt = 0; mt < MT_; ++mt) ar[ks][mt] = al[ks * LDA + 16 * mt];
-#pragma unroll
-        for (int nt = 0; nt < NT_; ++nt) gr[ks][nt] = gl[ks * LDG + 16 * nt];
-    }
-    bf16x8 av[MT_], gh[NT_], gl_[NT_];
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt) {
         __bf16 h[4], l[4];
         split4(ar[0][mt], ar[1][mt], ar[2][mt], ar[3][mt], h, l);
         av[mt] = bf16x8{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
     }
+}
+// the B side: [hi | hi] and [lo | lo]
+template <int NT_, int LDG>
+__device__ __forceinline__ void load_split_g(const float* gl, bf16x8 (&gh)[NT_], bf16x8 (&gl_)[NT_]) {
+    float gr[4][NT_];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT_; ++nt) gr[ks][nt] = gl[ks * LDG + 16 * nt];
 #pragma unroll
     for (int nt = 0; nt < NT_; ++nt) {
         __bf16 h[4], l[4];
@@ -318,6 +324,10 @@ __device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f3
         gh[nt] = bf16x8{h[0], h[1], h[2], h[3], h[0], h[1], h[2], h[3]};
         gl_[nt] = bf16x8{l[0], l[1], l[2], l[3], l[0], l[1], l[2], l[3]};
     }
+}
+template <int MT_, int NT_, int MOFF, int NOFF, int MFULL, int NFULL>
+__device__ __forceinline__ void mma_split(const bf16x8 (&av)[MT_], const bf16x8 (&gh)[NT_], const bf16x8 (&gl_)[NT_],
+                                          f32x4 (&acc)[MFULL][NFULL]) {
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt)
 #pragma unroll
@@ -326,6 +336,13 @@ __device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f3
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], gl_[nt], c, 0, 0, 0);
             acc[MOFF + mt][NOFF + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], gh[nt], c, 0, 0, 0);
         }
+}
+template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
+__device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
+    bf16x8 av[MT_], gh[NT_], gl_[NT_];
+    load_split_a<MT_, LDA>(al, av);
+    load_split_g<NT_, LDG>(gl, gh, gl_);
+    mma_split<MT_, NT_, MOFF, NOFF>(av, gh, gl_, acc);
 }
 
 #ifndef SATRANS_WGRAD_F32
