@@ -473,6 +473,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 #define SATRANS_UD2 1
 #define SATRANS_UE 1
 #endif
+#ifndef SATRANS_DP_REGS
+#define SATRANS_DP_REGS 0      // 1: dP of phase D in registers between its two passes - 60 spilled VGPRs, +10 % (measured)
+#endif
 #ifndef SATRANS_ATTN_SB
 #define SATRANS_ATTN_SB __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -1025,6 +1028,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
             float dot = 0.f;
+            // with the field count a constant both passes are unrolled and dP stays in registers between them
+            constexpr bool kDpRegs = FT != 0 && SATRANS_UD1 && SATRANS_UD2 && SATRANS_DP_REGS;
+            float dpr[kDpRegs ? ((FT + 3) & ~3) : 1];
             auto chunk3 = [&](const int j0) {
                 f32x2 vr[4][d / 2];
                 float pj[4], dp[4];
@@ -1043,8 +1049,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     dot = fmaf(pj[u], dp[u], dot);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) drow[j0 + u] = dp[u];
+                for (int u = 0; u < 4; ++u) {
+                    if constexpr (kDpRegs) dpr[j0 + u] = dp[u];
+                    else if (j0 + u < F) drow[j0 + u] = dp[u];
+                }
             };
             ATTN_CHUNKS(j0, chunk3, SATRANS_UD1);
             f32x2 dq[d / 2];
@@ -1057,7 +1065,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
                     pj[u] = prow[j];
-                    ds[u] = drow[j];
+                    if constexpr (kDpRegs) ds[u] = dpr[j0 + u];
+                    else ds[u] = drow[j];
                     load_row<d>(kbase + (size_t)j * LD, kr[u]);
                 }
 #pragma unroll

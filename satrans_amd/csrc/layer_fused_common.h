@@ -142,6 +142,9 @@ __device__ __forceinline__ void chain_t(const float* __restrict__ wl, const floa
 // 1.8e-8, worst gradient 3.6e-5 against 1.3e-5 of the largest entry: tools/experiments/r03_split_products_sim.py).
 // Weights are split ONCE per workgroup while they are staged into LDS; activations on the fly (~3 VALU instructions per value).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef SATRANS_SPLIT_SB
+#define SATRANS_SPLIT_SB __builtin_amdgcn_sched_barrier(0)      // keeps the fragment reads of a chain above its MFMAs
+#endif
 #ifndef SATRANS_SPLIT_TERMS
 #define SATRANS_SPLIT_TERMS 3      // 4 = the a_lo w_lo term as well (one more instruction per block)
 #endif
@@ -203,7 +206,7 @@ __device__ __forceinline__ void chain_split(const __bf16* __restrict__ hl, int l
             ah[s][mt] = *reinterpret_cast<const bf16x8*>(hl + 16 * mt * RS + 32 * s);
             al[s][mt] = *reinterpret_cast<const bf16x8*>(hl + lo_off + 16 * mt * RS + 32 * s);
         }
-    __builtin_amdgcn_sched_barrier(0);
+    SATRANS_SPLIT_SB;
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the small terms first
