@@ -1647,7 +1647,8 @@ def test_ragged_batches_gradients_match_the_oracle(name, B):
         np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9, err_msg=k)
 
 
-def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=False, ref64=False, grad_tol=2e-4, kink_frac=0.0):
+def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=False, ref64=False, grad_tol=2e-4, kink_frac=0.0,
+                                    meta_mode='QK'):
     from satrans_amd import SATrans, SparseFeat
     rng = np.random.RandomState(D + F)
     fields = [f"f{i}" for i in range(F)]
@@ -1656,7 +1657,7 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
     cols = [SparseFeat(f, vocabulary_size=vocab[f] + 1, embedding_dim=D) for f in fields]
     torch.manual_seed(3)
     model = SATrans(cols, cols, [fields[0]], [3], att_layer_num=0, domain_att_layer_num=L, att_head_num=H, use_linear=False,
-                    use_dnn=False, meta_mode='QK', meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag='sota')
+                    use_dnn=False, meta_mode=meta_mode, meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag='sota')
     with torch.no_grad():                                  # weights far enough from zero for every gradient to matter
         for k, p in model.named_parameters():
             if "embedding" in k:
@@ -1668,7 +1669,7 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
     X = np.stack([rng.randint(1 if f == fields[0] else 0, vocab[f], size=B) for f in fields], axis=1).astype(np.float32)
     y = (rng.rand(B) < 0.4).astype(np.float32)
     spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(fields)], dense=[], domain_cols=[0], embedding_dim=D, head_num=H,
-                      layer_num=L, flag='sota', meta_mode='QK', meta_units=[D, U, D])
+                      layer_num=L, flag='sota', meta_mode=meta_mode, meta_units=[D, U, D])
     Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
     Xg = Xt.long() if int_ids else Xt                     # the id matrix as the kernels get it (int64: SATRANS_ID_I64)
     if ref64:                                             # the oracle in fp64: the difference is then the kernels' rounding alone
@@ -1782,6 +1783,14 @@ def test_fused_kernels_on_field_counts_without_a_golden_case(F, B):
     geometry (samples per tile 64 / F: 21 ... 2), the task-to-lane maps of the attention phases and the generic (runtime field
     count) backward instantiation, against the oracle in evaluation and training mode."""
     _synthetic_shape_against_oracle(32, 4, 64, F, generic=False, B=B)
+
+
+@pytest.mark.parametrize("meta_mode", ["Q", "K", "V"])
+def test_fused_kernels_with_one_or_no_modulated_role(meta_mode):
+    """The AliCCP layer shape with only the queries, only the keys or neither of them modulated (meta_mode 'Q' / 'K' / 'V': the
+    golden cases of these modes are D = 16): one role's MetaNet chain, its weight-gradient products and the shared LayerNorm
+    accumulators on the split-product kernels (no MetaNet at all: fp32 products), eval and replayed-mask training."""
+    _synthetic_shape_against_oracle(32, 4, 64, 19, generic=False, B=23, meta_mode=meta_mode)
 
 
 @pytest.mark.parametrize("B", [1, 37, 1024, 3000, 8192])
