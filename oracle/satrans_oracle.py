@@ -358,20 +358,19 @@ def dropout_keep(seed: int, step: int, layer: int, site: int, sample, elem, p: f
         key = _mix32(np.uint32(seed) ^ (np.uint32(step) * np.uint32(0x9E3779B9)))
         key = _mix32(key ^ np.uint32((layer * 4 + site + 1) * 0x85EBCA6B & 0xFFFFFFFF))
         h = _mix32(np.asarray(sample, dtype=np.uint32) * np.uint32(0xC2B2AE35) ^ key)
-        # blocks of four consecutive elements: the block's hash is the word of its first element, one xorshift32 step
-        # each of the next three (rng.h: drop_keep4)
+        # blocks of four consecutive elements (rng.h: drop_block_hash, drop_keep4): one multiply round on key + block * C, the
+        # top 24 bits are the word of the block's first element, one step of a full-period 24-bit LCG each of the next three
         elem = np.asarray(elem, dtype=np.uint32)
-        h = _mix32(h ^ ((elem >> np.uint32(2)) * np.uint32(0x27D4EB2F)))
-        h, r = np.broadcast_arrays(h, elem & np.uint32(3))
-        h = h.copy()
+        t = (h + ((elem >> np.uint32(2)) & np.uint32(0xFFFFFF)) * np.uint32(0x9E3779)).astype(np.uint32)
+        t ^= t >> np.uint32(15)
+        t = (t * np.uint32(0x2C1B3C6D)).astype(np.uint32)
+        t ^= t >> np.uint32(12)
+        u, r = np.broadcast_arrays(t >> np.uint32(8), elem & np.uint32(3))
+        u = u.astype(np.uint64)
         for k in (1, 2, 3):
-            x = h.copy()
-            x ^= (x << np.uint32(13)).astype(np.uint32)
-            x ^= x >> np.uint32(17)
-            x ^= (x << np.uint32(5)).astype(np.uint32)
-            h = np.where(r >= k, x, h)
-    thresh = np.uint32(int(p * 16777216.0))
-    return (h >> np.uint32(8)) >= thresh
+            nxt = (u * np.uint64(0xF1EA5D) + np.uint64(0x3C6EF3)) & np.uint64(0xFFFFFF)
+            u = np.where(r >= k, nxt, u)
+    return u >= np.uint64(int(p * 16777216.0))
 
 
 def dropout_masks(seed: int, step: int, B: int, Fn: int, D: int, H: int, L: int, p: float) -> Dict:

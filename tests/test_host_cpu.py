@@ -98,6 +98,20 @@ def test_dropout_mask_statistics():
     assert abs(k0.mean() - 0.9) < 0.005
     for other in (k1, k2):
         assert abs((k0 & other).mean() - 0.81) < 0.01
+    # element by element: every one of the 608 positions keeps 90 % of 16,384 samples (sigma 0.0023), neighbours inside a
+    # block of four (one LCG step apart), across blocks and 38 apart (the same field position of the next head) are independent
+    b = np.arange(16384, dtype=np.uint32)[:, None]
+    k = dropout_keep(7, 3, 2, 2, b, e, 0.1)
+    rate = k.mean(0)
+    assert np.abs(rate - 0.9).max() < 5 * 0.0023, float(np.abs(rate - 0.9).max())
+    for lag in (1, 2, 3, 4, 8, 38):
+        both = (k[:, :-lag] & k[:, lag:]).mean(0)
+        assert np.abs(both - 0.81).max() < 5 * 0.0031, (lag, float(np.abs(both - 0.81).max()))
+        drop2 = (~k[:, :-lag] & ~k[:, lag:]).mean(0)
+        assert np.abs(drop2 - 0.01).max() < 5.5 * 0.00078, (lag, float(np.abs(drop2 - 0.01).max()))
+    # ... and so are consecutive samples at the same element (the per-sample key is a finalised hash of the sample index)
+    both = (k[:-1] & k[1:]).mean(0)
+    assert np.abs(both - 0.81).max() < 5 * 0.0031
 
 
 def test_division_by_a_constant_through_its_double_reciprocal_is_the_fp32_quotient():
