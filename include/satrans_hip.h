@@ -144,7 +144,15 @@ typedef struct satrans_layer_desc {
                             * reads token (b,f) from x + x_rows[b*F+f]*D, i.e. `x` is the embedding arena and the    *
                             * gather is fused into the first layer (meta_basemodel.py:533-535 + satrans.py:211 never *
                             * materialise [B,F,D]); forward and backward alike                                       */
+    float* attn_save;      /* NULL, or satrans_layer_attn_save_floats(d) floats: the forward leaves what the backward  *
+                            * would otherwise recompute of the attention (softmax numerators, 1 / sum, dropout keep   *
+                            * word and the attention output, per SORTED sample position) and a satrans_layer_bwd on    *
+                            * the same batch, bucket order and dropout counters reads it instead of running its       *
+                            * attention-forward phase.  Fused kernels only (others ignore it)                          */
 } satrans_layer_desc;
+
+/* Floats of `attn_save` for this layer (B samples), 0 when the kernels that would run it do not use one. */
+int64_t satrans_layer_attn_save_floats(const satrans_layer_desc* d);
 
 /* Which implementation evaluates satrans_layer_fwd/_bwd (process-wide; initial value from SATRANS_LAYER_IMPL):
  * 0 = automatic: register-chained f32-MFMA kernels for the shapes they are built for ((D,U,H) = (32,64,4), (16,32,2),

@@ -24,6 +24,7 @@ int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, float* att, v
 int satrans_layer_fwd_lds(const satrans_layer_desc* d, float* y, float* att, void* stream);
 int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d);
 int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d);
+int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc* d);
 int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq, float* g_wk,
                             float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
                             float* g_tab_k, void* stream);
@@ -70,6 +71,13 @@ int64_t satrans_layer_bwd_slab_floats(const satrans_layer_desc* d) {
         if (f > n) n = f;
     }
     return n;
+}
+
+// what satrans_layer_fwd leaves for satrans_layer_bwd in d->attn_save: only the fused kernels use it
+int64_t satrans_layer_attn_save_floats(const satrans_layer_desc* d) {
+    if (satrans_layer_validate(d, "layer_attn_save")) return -1;
+    if (satrans_layer_impl() != 0 || !satrans_layer_fused_supported(d) || !satrans_layer_bwd_fused_supported(d)) return 0;
+    return satrans_layer_attn_save_floats_fused(d);
 }
 
 int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq, float* g_wk,

@@ -27,7 +27,8 @@ namespace satrans {
 // MOD: what modulates q / k - 0 the MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear' (compile time: the main instantiation
 // pays nothing for the other two).  PROD: 0 = fp32 products on v_mfma_f32_16x16x4_f32, 1 = split products (fp32 operands as bf16
 // pairs, three v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block: layer_fused_common.h) - MOD 0 only
-template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, int PROD = 0>
+// SAVE: leave the attention's numerators / statistics / output in a.attn_save for the backward of this step
+template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, int PROD = 0, bool SAVE = false>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                       float* __restrict__ y, float* __restrict__ att) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
@@ -283,6 +284,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             float sum = 0.f;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)b);
             const uint32_t block0 = drop_attn_elem(h, F, i, 0) >> 2;
+            // a.attn_save: what the backward of this step would recompute, per SORTED sample position p = first + ls (the layout
+            // the backward tiles walk): numerators [p][j][H F], then 1 / sum [p][H F], keep word [p][H F], attention output
+            // [p][F][D]; lanes of one sample are consecutive tasks, so every store instruction writes runs of up to H F floats
+            const int HF = H * F;
+            float* save_p = SAVE ? a.attn_save + (size_t)(first + ls) * F * HF + rem : nullptr;
+            uint32_t keepw = 0xFFFFFFFFu;
 #pragma unroll
             for (int c = 0; c < kRowChunks; ++c) {
                 if (4 * c < F) {
@@ -290,16 +297,27 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 #pragma unroll
                     for (int u = 0; u < 4; ++u) load_row<d>(vbase + (size_t)min(4 * c + u, F - 1) * LD, vr[u]);
                     const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)c, dc.thresh) : 0xFu;
+                    keepw &= ~((~kb & 0xFu) << (4 * c));
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float ex = __builtin_amdgcn_exp2f(sc[4 * c + u] - mx);
                         sum += ex;
+                        if (SAVE && 4 * c + u < F) save_p[(size_t)(4 * c + u) * HF] = ex;
                         float pe = ex;
                         if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
                         sc[4 * c + u] = pe;
                         axpy_row<d>(pe, vr[u], oacc);
                     }
                 }
+            }
+            if constexpr (SAVE) {
+                float* inv_all = a.attn_save + (size_t)a.B * F * HF;
+                float* keep_all = inv_all + (size_t)a.B * HF;
+                float* o_all = keep_all + (size_t)a.B * HF;
+                const size_t t_ = (size_t)(first + ls) * HF + rem;
+                inv_all[t_] = 1.0f / sum;
+                keep_all[t_] = __uint_as_float(keepw);
+                store_row<d>(o_all + ((size_t)(first + ls) * F + i) * D + h * d, oacc, 1.0f / sum);
             }
             if (att) {   // normalized_att_scores [H,B,F,F], after dropout (satrans.py:87); rarely requested
                 float* arow = att + (((size_t)h * a.B + b) * F + i) * F;
@@ -493,7 +511,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 // every weight live in LDS as hi / lo bf16 pairs: SAME tables, MOD 0, no TR only.
 // token-contraction products: on the fp32 instruction, or (PROD) on split operands
 #define WGRAD wgrad_sel<PROD>::template run
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0>
+// SAVE: a.attn_save holds what the forward of this step left of the attention (split-product instantiations only)
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
@@ -604,6 +623,15 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);
+    // a.attn_save: the forward of this step left the attention's softmax numerators [p][j][H F], 1 / sum [p][H F], keep words
+    // [p][H F] and outputs [p][F][D] per SORTED sample position p (layer_fwd_fused_kernel): phase B is then a copy - straight
+    // into LDS, issued at the top of the tile and complete by the end of phase A - instead of a recomputation
+    const int HF = H * F;
+    constexpr bool has_save = SAVE;
+    const float* save_inv = a.attn_save + (size_t)a.B * F * HF;
+    const float* save_keep = save_inv + (size_t)a.B * HF;
+    const float* save_o = save_keep + (size_t)a.B * HF;
+    using lds_ptr = __attribute__((address_space(3))) void*;
 
     // ---- register accumulators of the weight gradients (whole kernel) ----------------------------------------------
     f32x4 acc_wq[KT][KT], acc_wk[KT][KT], acc_wv[KT][KT], acc_wo[KT][KT];
@@ -741,7 +769,18 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
           const int at = b_ * F + (tok < min(Tsamp, hi - first_) * F ? f_tok : 0);
           return a.x_rows ? a.x_rows[at] : at;
       };
+      // (saved attention: the tile's dy rows are copied straight into LDS, 16 bytes per lane and KT rounds; lane c of round k
+      // copies from sample (c + 256 k) / (F D / 4) of the tile - its index, too, is fetched a tile ahead)
+      const int per4 = F * D / 4;
+      int cb_next[KT];
+      auto copy_samples_of = [&](int tile_) {
+          const int first_ = lo + tile_ * Tsamp;
+          const int last_ = min(Tsamp, hi - first_) - 1;
+#pragma unroll
+          for (int k_ = 0; k_ < KT; ++k_) cb_next[k_] = a.order[first_ + min(((int)threadIdx.x + kFusedBlock * k_) / per4, last_)];
+      };
       int b_next = sample_of(t0), tb_next = task_sample_of(t0);
+      if (has_save) copy_samples_of(t0);
       int xrow_next = row_of(t0, b_next);
       load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
       for (int tile = t0; tile < t1; ++tile) {
@@ -754,6 +793,32 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         const int tile_n = min(tile + 1, t1 - 1);
         b_next = sample_of(tile_n);
         tb_next = task_sample_of(tile_n);
+        if (has_save) {      // (the caches are dead since the previous tile's phase E; nothing touches them before this tile's phase C)
+            // dy rows [sample of the tile][F][D] and the saved attention outputs, unpadded, into the dS cache (dead until phase D;
+            // phase C reads each row once: bank conflicts do not matter)
+#pragma unroll
+            for (int k_ = 0; k_ < KT; ++k_) {
+                const int c = (int)threadIdx.x + kFusedBlock * k_;
+                const int ls_ = c / per4;
+                if (c < nS * per4) {
+                    __builtin_amdgcn_global_load_lds(dy + (size_t)cb_next[k_] * F * D + 4 * (c - ls_ * per4),
+                                                     (lds_ptr)(sDS + 4 * (kFusedBlock * k_ + 64 * wave)), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(save_o + (size_t)first * F * D + 4 * c,
+                                                     (lds_ptr)(sDS + Tsamp * F * D + 4 * (kFusedBlock * k_ + 64 * wave)), 16, 0, 0);
+                }
+            }
+            copy_samples_of(tile_n);
+            const int n4 = nS * F * HF / 4;
+            const float* gp = a.attn_save + (size_t)first * F * HF;
+            for (int c0 = 0; c0 < n4; c0 += kFusedBlock) {
+                const int c = c0 + (int)threadIdx.x;
+                if (c < n4) __builtin_amdgcn_global_load_lds(gp + 4 * c, (lds_ptr)(sP + 4 * (c0 + 64 * wave)), 16, 0, 0);
+            }
+            if ((int)threadIdx.x < nS * HF) {
+                __builtin_amdgcn_global_load_lds(save_inv + (size_t)first * HF + threadIdx.x, (lds_ptr)(st_inv + 64 * wave), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(save_keep + (size_t)first * HF + threadIdx.x, (lds_ptr)(st_keep + 64 * wave), 4, 0, 0);
+            }
+        }
         const uint32_t key_q = drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b);
         const uint32_t key_k = drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b);
         const uint32_t key_o = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
@@ -877,25 +942,26 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             store_frag<KT>(my_k, k);
             store_frag<KT>(my_v, v);
         }
+        if (has_save) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the caches have landed in LDS
         lds_barrier();
 
         STAMP(1);
         // the upstream gradient rows of phase C: issued here, a phase ahead (HBM latency under the attention forward); padding
         // lanes read a real row (sample 0 of the tile, field 0) and are masked where the rows are consumed
         float gy_pre[KT][4];
-        load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy_pre);
+        if (!has_save) load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy_pre);
         // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
         // Scores are staged in the task's row of the numerator cache (pre-scaled by log2(e)/sqrt(d)), keys in chunks of
         // four with all loads of a chunk issued before its results are stored; padding keys of the last chunk read the
         // last real row and are masked arithmetically.
-        if (const int task = threadIdx.x; task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
+        if (const int task = threadIdx.x; !has_save && task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
             const int tls = t0_ls, h = t0_h, i = t0_i;
             const int tb = tb0;
             f32x2 qi[d / 2];
             load_row<d>(sq + (size_t)(tls * F + i) * LD + h * d, qi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
-            float* prow = sP + (size_t)task * F;
+            float* prow = sP + (size_t)tls * F * HF + (h * F + i);       // numerator of key j at prow[j HF]: [sample][key][task]
             const float sc_scale = inv_sqrt_d * kLog2e;
             float mx = -INFINITY;
             auto chunk1 = [&](const int j0) {
@@ -910,7 +976,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) prow[j0 + u] = sc[u];
+                    if (j0 + u < F) prow[(j0 + u) * HF] = sc[u];
             };
             ATTN_CHUNKS(j0, chunk1, SATRANS_UB1);
             f32x2 oacc[d / 2];
@@ -927,7 +993,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
-                    ex[u] = prow[j];
+                    ex[u] = prow[j * HF];
                     load_row<d>(vbase + (size_t)j * LD, vr[u]);
                 }
 #pragma unroll
@@ -945,7 +1011,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) prow[j0 + u] = ex[u];
+                    if (j0 + u < F) prow[(j0 + u) * HF] = ex[u];
             };
             ATTN_CHUNKS(j0, chunk2, SATRANS_UB2);
             const float inv = 1.0f / sum;
@@ -959,7 +1025,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // ================= phase C: output block forward + backward ======================================================
         if (has_tile) {
             float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4];
-            load_frag<KT>(my_o, o);
+            const float* staged = sDS + ((size_t)(valid ? ls_tok : 0) * F + f) * D + g4;      // (saved attention: this token's dy row)
+            if (has_save) {
+                load_frag<KT>(staged + Tsamp * F * D, o, valid);
+                store_frag<KT>(my_o, o);          // (dWo below reads the wave's o rows from LDS)
+            } else {
+                load_frag<KT>(my_o, o);
+            }
             // out = in x (D x D weight), along the forward direction of the image `f_` or the backward direction (image `b_`)
             auto prod_dd = [&](float* img, bool back_, const float (&in_)[KT][4], float (&out_)[KT][4]) {
                 if constexpr (PROD) {
@@ -994,6 +1066,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gy[t][r] = valid ? gy_pre[t][r] : 0.f;
+            if (has_save) load_frag<KT>(staged, gy, valid);
             layer_norm_bwd<KT>(gy, zh, rstd_o, ln_g, g4, agl, abl);          // gy is now dr
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -1022,7 +1095,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             load_row<d>(so + (size_t)(tls * F + i) * LD + h * d, gi);
             const float* kbase = sk + (size_t)(tls * F) * LD + h * d;
             const float* vbase = sv + (size_t)(tls * F) * LD + h * d;
-            float* prow = sP + (size_t)task * F;
+            float* prow = sP + (size_t)tls * F * HF + (h * F + i);
             float* drow = sDS + (size_t)task * F;
             const float inv = st_inv[task];
             const uint32_t keep = st_keep[task];
@@ -1037,7 +1110,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
-                    pj[u] = prow[j];
+                    pj[u] = prow[j * HF];
                     load_row<d>(vbase + (size_t)j * LD, vr[u]);
                 }
 #pragma unroll
@@ -1064,7 +1137,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
-                    pj[u] = prow[j];
+                    pj[u] = prow[j * HF];
                     if constexpr (kDpRegs) ds[u] = dpr[j0 + u];
                     else ds[u] = drow[j];
                     load_row<d>(kbase + (size_t)j * LD, kr[u]);
@@ -1079,7 +1152,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) { drow[j0 + u] = ds[u]; prow[j0 + u] = pj[u]; }
+                    if (j0 + u < F) { drow[j0 + u] = ds[u]; prow[(j0 + u) * HF] = pj[u]; }
             };
             ATTN_CHUNKS(j0, chunk4, SATRANS_UD2);
             store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
@@ -1096,7 +1169,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* qbase = sq + (size_t)(tls * F) * LD + h * d;
             const float* gbase = so + (size_t)(tls * F) * LD + h * d;
             const float* dcol = sDS + (size_t)((tls * H + h) * F) * F + j;
-            const float* pcol = sP + (size_t)((tls * H + h) * F) * F + j;
+            const float* pcol = sP + (size_t)tls * F * HF + (size_t)j * HF + h * F;      // the P of (query i, key j) at pcol[i]
             auto chunk5 = [&](const int i0) {
                 f32x2 qr[4][d / 2], gr[4][d / 2];
                 float ds[4], pm[4];
@@ -1104,7 +1177,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int u = 0; u < 4; ++u) {
                     const int i = min(i0 + u, F - 1);
                     ds[u] = dcol[(size_t)i * F];
-                    pm[u] = pcol[(size_t)i * F];
+                    pm[u] = pcol[i];
                     load_row<d>(qbase + (size_t)i * LD, qr[u]);
                     load_row<d>(gbase + (size_t)i * LD, gr[u]);
                 }
@@ -1543,7 +1616,7 @@ static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab, b
     return 4 * dd + (same_tab ? 1 : 2) * mlp + 6 * D + 4 * rows * LD + 64;
 }
 
-template <int D, int U, int H, int WAVES, int MOD = 0, int PROD = 0>
+template <int D, int U, int H, int WAVES, int MOD = 0, int PROD = 0, bool SAVE = false>
 static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipStream_t stream) {
     const bool same_tab = d->tab_q == d->tab_k;
     // samples per tile: as many as keep `per_cu` workgroups per CU, preferring tiles that fill their 16-token MFMA rows
@@ -1563,7 +1636,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab, PROD) * 4;
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
@@ -1571,7 +1644,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int64_t tiles = ceil_div(d->B, best);                        // (the kernel splits the batch by samples)
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
-    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
+    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1584,6 +1657,7 @@ static int launch_fwd(const satrans_layer_desc* d, float* y, float* att, hipStre
 }  // namespace satrans
 
 extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d);
+extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc* d);
 
 namespace satrans {
 
@@ -1624,17 +1698,17 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     return true;
 }
 
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
                       hipStream_t stream) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1679,8 +1753,10 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     // split products in the TRAINING forward only: predict / evaluate keep the fp32 instruction - what a user compares with the
     // reference's outputs is exact to fp32 summation order (logits of a trained model: 1.4e-6 from the CPU oracle against
     // 7.7e-5 with split products), what sits under dropout and minibatch noise is fast
-    if (d->D == 32 && product_mode() == 1 && (d->flags & SATRANS_TRAIN)) return launch_fwd_w<32, 64, 4, 12, 0, 1>(d, y, att, stream);
-    if (d->D == 32) return launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
+    const bool save = d->attn_save && d->D == 32 && d->F <= 32 && satrans_layer_attn_save_floats_fused(d) > 0;   // (as the backward decides)
+    if (d->D == 32 && product_mode() == 1 && (d->flags & SATRANS_TRAIN))
+        return save ? launch_fwd_w<32, 64, 4, 12, 0, 1, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 0, 1>(d, y, att, stream);
+    if (d->D == 32) return save ? launch_fwd_w<32, 64, 4, 12, 0, 0, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
     if (d->D == 16) return launch_fwd<16, 32, 2>(d, y, att, stream);
     return launch_fwd<64, 16, 4>(d, y, att, stream);
 }
@@ -1689,6 +1765,16 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
 extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
     FusedBwdPlan p;
     return d && fused_bwd_plan(d, p) ? 1 : 0;
+}
+
+extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc* d) {
+    FusedBwdPlan p;
+    if (!d || !fused_bwd_plan(d, p) || !p.split) return 0;      // (built for the split-product backward only)
+    const int64_t HF = (int64_t)d->H * d->F;
+    // the forward saves from its register-resident score row (F <= 32), the backward copies the numerators 16 bytes at a time
+    // ... and stages the tile's dy and saved output rows in the dS cache (T H F F floats): H F >= 2 D
+    if (d->F > 32 || (d->F * HF) % 4 != 0 || HF < 2 * d->D) return 0;
+    return (int64_t)d->B * (d->F * HF + 2 * HF + (int64_t)d->F * d->D);
 }
 
 extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d) {
@@ -1728,6 +1814,9 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
                                 : launch_bwd<32, 64, 4, false, false, 0, 2>(d, p, dy, dx, slabs, stream))
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
                                 : launch_bwd<16, 32, 2, false, false, 0, 2>(d, p, dy, dx, slabs, stream));
+    else if (p.split && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0)
+        rc = d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, 1, true>(d, p, dy, dx, slabs, stream)
+                                   : launch_bwd<32, 64, 4, true, false, 0, 0, 1, true>(d, p, dy, dx, slabs, stream);
     else if (p.split && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19, 0, 1>(d, p, dy, dx, slabs, stream);
     else if (p.split)

@@ -179,6 +179,10 @@ class PathEngine:
         # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
         # standalone gather kernel + activation buffer, as in round 1
         self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
+        # SATRANS_SAVE_ATTENTION=1: the forward of a training step leaves the attention's softmax numerators / statistics /
+        # output for its backward, which then copies them into LDS instead of recomputing them.  Measured:
+        # backward 216 -> 200 us, forward 63 -> 73 us per layer, the step does not move, +72 MB per layer at B = 8192: off by default.
+        self.save_attention = os.environ.get("SATRANS_SAVE_ATTENTION", "0") == "1"
         # evaluation forwards (predict / evaluate / model.eval()(X)) with the dense products in bf16 on the matrix pipe
         # (csrc/layer_fwd_bf16.hip; BASELINE.json configs[1]).  Off by default: fp32 is the parity path.  Also
         # model.set_forward_precision("bf16" | "fp32").
@@ -274,6 +278,10 @@ class PathEngine:
                 ws["slabs"] = torch.empty(1, **f32)
             else:
                 ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
+                # what the forward leaves for the backward of the same step (softmax numerators, 1 / sum, keep words, attention
+                # output): the backward then skips its attention-forward phase.  One buffer per layer (72 MB at B = 8192).
+                n_save = int(lib.satrans_layer_attn_save_floats(C.byref(desc))) if self.save_attention else 0
+                ws["attn_save"] = [torch.empty(n_save, **f32) for _ in range(self.L)] if n_save > 0 else None
             ws["sorted_rows"] = torch.empty(n_loc, **i32)       # this rank's rows, sorted, and their source positions
             ws["src"] = torch.empty(n_loc, **i32)
             ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
@@ -367,7 +375,7 @@ class PathEngine:
             self._grad_view("qkvid_embeddings.weight").data_ptr() if self.pos else None, self.L, st),
                 "satrans_scenario_inputs_bwd")
 
-    def _layer_desc(self, ws, l, B, x, tabs, training, fuse=False) -> N.LayerDesc:
+    def _layer_desc(self, ws, l, B, x, tabs, training, fuse=False, attn_save=False) -> N.LayerDesc:
         m = self.m
         lay = m.domain_int_layers[l]
         d = N.LayerDesc()
@@ -378,6 +386,7 @@ class PathEngine:
         d.seed, d.step = self.drop_seed, self.drop_step & 0xFFFFFFFF
         d.x = N.ptr(x) if x is not None else ws["acts"][l].data_ptr()
         d.x_rows = None
+        d.attn_save = ws["attn_save"][l].data_ptr() if attn_save and ws.get("attn_save") else None
         if fuse and l == 0:
             # gather fused into the first layer: token (b, f) is read straight from the embedding arena through the row
             # numbers the rows-only gather launch left in ws["rows"]; [B,F,D] is never written nor read back.
@@ -437,7 +446,7 @@ class PathEngine:
             raise NotImplementedError("integer id matrix together with dense features: pass inputs.PackedInput(ids, dense)")
         return X
 
-    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False):
+    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         sx, sidt, sstride, scol = X, idt, X.stride(0), self.dom_col
@@ -459,7 +468,7 @@ class PathEngine:
         self._last_X = X
         self._stepped_since_forward = False
         for l in range(self.L):
-            desc = self._layer_desc(ws, l, B, None, tabs, training, fuse)
+            desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn)
             att = att_list[l].data_ptr() if att_list is not None else None
             with self.phase("layer_fwd"):
                 if ws["generic"] and not (self.fwd_bf16 and not training and att is None
@@ -656,12 +665,13 @@ class PathEngine:
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
         tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
-        self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready)
+        self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready, save_attn=True)
         with self.phase("head"):
             self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
-            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather or self._x_src is not None)
+            desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather or self._x_src is not None,
+                                    attn_save=True)
             lay = f"domain_int_layers.{l}."
             gq = gk = glnq = glnk = None
             if modulated:

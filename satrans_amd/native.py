@@ -38,6 +38,7 @@ class LayerDesc(C.Structure):
         ("lnq_g", _vp), ("lnq_b", _vp), ("lnk_g", _vp), ("lnk_b", _vp),
         ("tab_q", _vp), ("tab_k", _vp),
         ("x_rows", _vp),
+        ("attn_save", _vp),
     ]
 
 
@@ -95,6 +96,7 @@ SIGNATURES = {
     "satrans_metanet_fwd": (C.c_int, [C.POINTER(MetaNetDesc), _vp, _vp, _vp]),
     "satrans_metanet_bwd": (C.c_int, [C.POINTER(MetaNetDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "satrans_layer_bwd_slab_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
+    "satrans_layer_attn_save_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
     "satrans_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp]),
     "satrans_head_scratch_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

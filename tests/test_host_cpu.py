@@ -84,7 +84,7 @@ def test_library_exports_every_declared_symbol():
     # argument validation works without touching a device
     assert lib.satrans_gather_fwd(None, None, None, None, 0, 0, 1, 1, 32, None, None, None, None) == -1
     assert b"null pointer" in lib.satrans_last_error()
-    assert ctypes.sizeof(native.LayerDesc) == 8 * 4 + 4 + 4 + 4 + 4 + 8 + 17 * 8   # mirrors satrans_layer_desc
+    assert ctypes.sizeof(native.LayerDesc) == 8 * 4 + 4 + 4 + 4 + 4 + 8 + 18 * 8   # mirrors satrans_layer_desc
 
 
 def test_dropout_mask_statistics():
