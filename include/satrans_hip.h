@@ -417,6 +417,12 @@ int satrans_embed_grad_dense(const float* arena, const int32_t* sorted_rows, con
 /* Sum of `count` doubles in index order -> out[0] (+= when accumulate != 0). */
 int satrans_sum_f64(const double* v, int64_t count, double* out, int accumulate, void* stream);
 
+/* The per-step training metrics of fit(verbose > 0) (meta_basemodel.py:330-337: sklearn log_loss and roc_auc_score on host
+ * copies of every batch) for one batch in one launch: out[0] = log_loss(y, p.astype(float64)) (probabilities clipped to
+ * [eps, 1 - eps] with the fp64 eps, mean), out[1] = roc_auc_score(y, p) (tied scores count one half; NaN when only one class
+ * is present).  y, p: [n] fp32, n <= 8192; out: two doubles in device memory.  Fixed summation order. */
+int satrans_batch_metrics(const float* y, const float* p, int n, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -502,6 +502,7 @@ class BaseModel(nn.Module):
             cbs.on_epoch_begin(epoch)
             start_time = time.time()
             train_result: Dict[str, list] = {}
+            fused_buf = None             # [steps, 2] float64 on the device: (log loss, AUC) of every step, one launch each
             engine.reset_epoch_sums()
             order = self._epoch_order(sample_num, shuffle)
             if not stream and torch.is_tensor(data):
@@ -531,8 +532,15 @@ class BaseModel(nn.Module):
                 if verbose > 0 and self.metrics and device_metrics:
                     # the reference's per-step train metrics (:330-337) evaluated on the device: no sync, read once per epoch
                     prob = engine.last_prob()
-                    for name in self.metrics:
-                        train_result.setdefault(name, []).append(DM.BY_NAME[name](yb, prob))
+                    if DM.fused_supported(self.metrics, hi - lo, yb, prob):
+                        if fused_buf is None:
+                            fused_buf = torch.full((steps_per_epoch, 2), float("nan"), dtype=torch.float64, device=prob.device)
+                        DM.fused_logloss_auc(yb, prob, fused_buf[step])
+                        for name in self.metrics:
+                            train_result.setdefault(name, []).append(fused_buf[step, 1 if name == "auc" else 0])
+                    else:
+                        for name in self.metrics:
+                            train_result.setdefault(name, []).append(DM.BY_NAME[name](yb, prob))
                 elif verbose > 0 and self.metrics:
                     # ... or exactly as the reference computes them, on host copies (forces a device sync every step)
                     y_np = yb.cpu().numpy()

@@ -65,5 +65,24 @@ def per_domain_auc(y: torch.Tensor, p: torch.Tensor, domain_ids: torch.Tensor):
     return vals[0], {i: vals[2 + k] for k, i in enumerate(range(lo, hi + 1))}, vals[1]
 
 
+FUSED = ("binary_crossentropy", "logloss", "auc")       # what satrans_batch_metrics computes
+
+
+def fused_supported(names, n: int, y: torch.Tensor, p: torch.Tensor) -> bool:
+    """One launch of csrc/metrics.hip serves this batch: log loss and / or ROC AUC of at most 8,192 fp32 rows on the GPU."""
+    return (bool(names) and all(k in FUSED for k in names) and 0 < n <= 8192 and y.is_cuda and p.is_cuda
+            and y.dtype == torch.float32 and p.dtype == torch.float32)
+
+
+def fused_logloss_auc(y: torch.Tensor, p: torch.Tensor, out: torch.Tensor) -> None:
+    """out[0] = log_loss(y, p), out[1] = roc_auc(y, p) (same values as the functions above, sklearn's) by ONE kernel launch
+    (csrc/metrics.hip: the dozen torch launches of the two functions cost the host more than a training step takes).
+    `out`: two float64 on the device; nothing is read back."""
+    from . import native as N
+    y, p = y.reshape(-1).contiguous(), p.reshape(-1).contiguous()
+    N.check(N.lib().satrans_batch_metrics(y.data_ptr(), p.data_ptr(), y.numel(), out.data_ptr(), N.stream_handle(y.device)),
+            "satrans_batch_metrics")
+
+
 BY_NAME = {"binary_crossentropy": log_loss, "logloss": log_loss, "auc": roc_auc, "mse": mse, "accuracy": accuracy,
            "acc": accuracy}

@@ -97,6 +97,7 @@ SIGNATURES = {
     "satrans_metanet_bwd": (C.c_int, [C.POINTER(MetaNetDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "satrans_layer_bwd_slab_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
     "satrans_layer_attn_save_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
+    "satrans_batch_metrics": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "satrans_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp]),
     "satrans_head_scratch_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -767,6 +767,55 @@ def test_other_optimizers_and_losses_of_compile(opt, loss):
             assert float(err.max()) <= 2.0 * lr * 3 + 1e-6, (k, float(err.max()))
 
 
+def test_one_launch_batch_metrics_equal_sklearn():
+    """csrc/metrics.hip (satrans_batch_metrics; what fit(verbose > 0) launches once per step): log loss and ROC AUC of a batch
+    against sklearn on host copies - all scores distinct, 13 / 2 distinct levels (large tie groups), saturated and denormal
+    probabilities, every batch-size class of the kernel, one class only (NaN, as sklearn raises), run-to-run bit identity -
+    and fit()'s History through it against the reference's own per-step sklearn path."""
+    from sklearn.metrics import log_loss, roc_auc_score
+    from satrans_amd import device_metrics as DM
+    rng = np.random.RandomState(9)
+    for n, levels in ((8192, None), (8192, 13), (5000, 2), (4096, None), (2048, 5), (1500, None), (1024, 3), (257, 2), (2, None)):
+        p = rng.rand(n).astype(np.float32)
+        if levels:
+            p = (np.floor(p * levels) / levels).astype(np.float32)
+        if n >= 4:
+            p[:4] = [0.0, 1.0, 1e-30, 1 - 1e-7]
+        y = (rng.rand(n) < 0.2).astype(np.float32)
+        y[0], y[1] = 1.0, 0.0                                        # both classes present
+        yt, pt = torch.from_numpy(y).to(DEV), torch.from_numpy(p).to(DEV)
+        assert DM.fused_supported(["binary_crossentropy", "auc"], n, yt, pt)
+        out = torch.zeros(2, 2, dtype=torch.float64, device=DEV)
+        DM.fused_logloss_auc(yt, pt, out[0])
+        DM.fused_logloss_auc(yt.reshape(-1, 1), pt.reshape(-1, 1), out[1])
+        got = out.cpu().numpy()
+        assert np.array_equal(got[0], got[1]), "two launches on the same batch differ"
+        p64 = p.astype("float64")
+        assert got[0, 0] == pytest.approx(log_loss(y, p64), rel=1e-12), (n, levels)
+        assert got[0, 1] == pytest.approx(roc_auc_score(y, p64), rel=1e-12, abs=1e-15), (n, levels)
+    ones = torch.ones(100, device=DEV)
+    DM.fused_logloss_auc(ones, torch.rand(100, device=DEV), out[0])
+    assert bool(torch.isnan(out[0, 1])) and bool(torch.isfinite(out[0, 0]))
+    assert not DM.fused_supported(["auc", "mse"], 100, ones, ones) and not DM.fused_supported(["auc"], 8193, ones, ones)
+    # fit(): per-step metrics through the kernel == the reference's sklearn-on-host path (SATRANS_HOST_METRICS=1)
+    c = Case("aliccp_sota")
+    names = c.meta["feature_names"]
+    x = {nm: c.z[f"fit/x/{nm}"] for nm in names}
+    hist = []
+    for host in ("0", "1"):
+        os.environ["SATRANS_HOST_METRICS"] = host
+        try:
+            model = build_model(c, DEV)
+            model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+            model.eval()                                                # (no dropout: both runs see the same steps)
+            model.train = lambda mode=True: model                       # fit() switches to training mode: keep evaluation mode
+            hist.append(model.fit(x=dict(x), y=c.z["fit/y"], batch_size=64, epochs=1, verbose=2, shuffle=False).history)
+        finally:
+            os.environ.pop("SATRANS_HOST_METRICS", None)
+    for k in ("binary_crossentropy", "auc"):
+        assert hist[0][k][0] == pytest.approx(hist[1][k][0], rel=1e-9), k
+
+
 def test_device_metrics_and_the_per_scenario_report_equal_sklearn_on_the_gpu():
     """satrans_amd/device_metrics.py on device tensors (sort + searchsorted on the GPU) against sklearn on host copies - ties
     and saturated probabilities included - and `evaluate_domains`, the test report of reference main.py:353-374."""
