@@ -612,6 +612,31 @@ def main():
         except Exception:
             pass
 
+    # ---- the same K steps with the training step's weight products on the fp32 matrix instruction (SATRANS_PRODUCTS=f32): the
+    #      default evaluates them as split bf16 products; both numbers belong in one record ---------------------
+    fp32_leg = None
+    if (world == 1 and not args.train_only and args.config == "aliccp" and args.flag == "sota"
+            and eng.lib.satrans_get_product_mode() == 1):
+        eng.lib.satrans_set_product_mode(0)
+        try:
+            model.train()
+            eng.timers = None
+            for i in range(2):
+                step(i)
+            eng.flush_lazy()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(W, W + K):
+                step(i)
+            eng.flush_lazy(sync=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            fp32_leg = {"ms_per_step": round(dt / K * 1e3, 4), "samples_per_s": round(B * K / dt, 1), "steps": K,
+                        "note": "same protocol as `value` (K steps over the same resident batches, lazy flush inside) with "
+                                "satrans_set_product_mode(0): v_mfma_f32_16x16x4_f32 products in forward and backward"}
+        finally:
+            eng.lib.satrans_set_product_mode(1)
+
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = err_train = logit_scale = None
     try:
@@ -676,6 +701,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": D, "layers": L, "heads": CFG["H"],
                    "fields": F, "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
+        "fp32_products": fp32_leg,
         "fwd_logit": {"max_abs_err_vs_cpu_oracle": err, "training_forward_dropout_off_max_abs_err": err_train,
                       "max_abs_logit": logit_scale, "samples": 2048,
                       "note": "weights as they are after this run's training steps; evaluation forward = fp32 products, "
