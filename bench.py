@@ -505,7 +505,10 @@ def main():
             rows[name] = entry
         return rows, dom
 
-    products = "split" if eng.lib.satrans_get_product_mode() == 1 and args.config == "aliccp" and args.flag == "sota" else "f32"
+    # split products: the training forward of every D = 32 MetaNet layer on the fused kernels; the backward only with ONE generated
+    # table for both roles (no 'pos') and within the LDS budget (F <= 19)
+    split_on = eng.lib.satrans_get_product_mode() == 1 and D == 32 and args.config != "c5" and not ("gate" in args.flag or "bilinear" in args.flag)
+    products = "f32" if not split_on else ("split" if (args.config == "aliccp" and "pos" not in args.flag) else "split forward, f32 backward")
     kernels, dominant = table(phases)
     phase_sum = sum(v["ms_per_step"] for v in kernels.values())
     kernels_serial, _ = table(phases_serial)
@@ -694,7 +697,7 @@ def main():
                                  "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fused kernels of the (32, 64, 4) MetaNet shape; "
                                  "SATRANS_PRODUCTS=f32 runs them on v_mfma_f32_16x16x4_f32).  fp32 in, fp32 out; measured 2.7x the error "
                                  "of plain fp32 products against fp64 (tests: test_product_modes_against_the_fp64_oracle)"
-                                 if products == "split" else ": v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain)")),
+                                 if products.startswith("split") else ": v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain)")),
         "config": {"workload": f"{CFG['label']}, {model.embedding_arena.shape[0]:,} table rows "
                                f"({model.embedding_arena.numel() * 4 / 1e6:,.0f} MB fp32), {args.ids} ids, dropout on, "
                                f"dense-Adam+L2 semantics over all rows",
