@@ -166,14 +166,36 @@ __device__ __forceinline__ int split_flip(int row) { return ((row & 15) >= 4 && 
 // transpose = the image of W^T (the backward products): roles of the two indices swapped.
 __device__ __forceinline__ void stage_split(const float* __restrict__ g, __bf16* __restrict__ hi, int OUT, int K, int RS, bool in_major) {
     __bf16* lo = hi + OUT * RS;
-    for (int i = threadIdx.x; i < OUT * K; i += blockDim.x) {
+    // one unit = four consecutive contraction indices of one output row: they sit next to each other in the image (split_pos:
+    // ... + r), so a unit is two 8-byte LDS stores; in_major: threads run over the output index (coalesced 4-byte loads), else one
+    // 16-byte load per unit
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int K4 = K >> 2;
+    for (int u = threadIdx.x; u < OUT * K4; u += blockDim.x) {
         int o, k;
-        if (in_major) { k = i / OUT; o = i - k * OUT; } else { o = i / K; k = i - o * K; }
-        const float v = g[i];
-        const __bf16 h = (__bf16)v;
+        float v[4];
+        if (in_major) {
+            const int k4 = u / OUT;
+            o = u - k4 * OUT;
+            k = 4 * k4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = g[(size_t)(k + j) * OUT + o];
+        } else {
+            o = u / K4;
+            k = 4 * (u - o * K4);
+            const float4 t = *reinterpret_cast<const float4*>(g + (size_t)o * K + k);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 h = (__bf16)v[j];
+            h4[j] = h;
+            l4[j] = (__bf16)(v[j] - (float)h);
+        }
         const int at = o * RS + (split_pos(k) ^ split_flip(o));
-        hi[at] = h;
-        lo[at] = (__bf16)(v - (float)h);
+        *reinterpret_cast<bf16x4*>(hi + at) = h4;
+        *reinterpret_cast<bf16x4*>(lo + at) = l4;
     }
 }
 
