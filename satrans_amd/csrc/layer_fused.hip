@@ -65,10 +65,10 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 
     auto bimg = [](float* f_) { return reinterpret_cast<__bf16*>(f_); };
     if constexpr (PROD) {
-        stage_split(a.w_query, bimg(W.wq), D, D, KD, true);
-        stage_split(a.w_key, bimg(W.wk), D, D, KD, true);
-        stage_split(a.w_value, bimg(W.wv), D, D, KD, true);
-        stage_split(a.w_out, bimg(W.woT), D, D, KD, false);      // nn.Linear [out][in]: y = x @ Wo^T
+        const SplitJob jobs[4] = {{a.w_query, bimg(W.wq), D, D, KD, true}, {a.w_key, bimg(W.wk), D, D, KD, true},
+                                  {a.w_value, bimg(W.wv), D, D, KD, true},
+                                  {a.w_out, bimg(W.woT), D, D, KD, false}};      // nn.Linear [out][in]: y = x @ Wo^T
+        stage_split_batch<4, (D * D / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
     } else {
         stage_image(a.w_query, W.wq, D, D, LD, false);
         stage_image(a.w_key, W.wk, D, D, LD, false);
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
       if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
           if constexpr (PROD) {
-              stage_split(row, bimg(W.w1q), U, D, KD, true);               // W1 [D][U]: in-major, K = D
-              stage_split(row + D * U, bimg(W.w2q), D, U, KU, true);       // W2 [U][D]: in-major, K = U
+              const SplitJob jobs[2] = {{row, bimg(W.w1q), U, D, KD, true},               // W1 [D][U]: in-major, K = D
+                                        {row + D * U, bimg(W.w2q), D, U, KU, true}};      // W2 [U][D]: in-major, K = U
+              stage_split_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
           } else {
               stage_image(row, W.w1q, D, U, LU, false);
               stage_image(row + D * U, W.w2q, U, D, LD, false);
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
       if (mlp_k && (!same_tab || !mlp_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
           if constexpr (PROD) {
-              stage_split(row, bimg(W.w1k), U, D, KD, true);
-              stage_split(row + D * U, bimg(W.w2k), D, U, KU, true);
+              const SplitJob jobs[2] = {{row, bimg(W.w1k), U, D, KD, true}, {row + D * U, bimg(W.w2k), D, U, KU, true}};
+              stage_split_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
           } else {
               stage_image(row, W.w1k, D, U, LU, false);
               stage_image(row + D * U, W.w2k, U, D, LD, false);
@@ -584,10 +585,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         };
         if constexpr (PROD) {
             // forward direction: rows = the weight's output index; backward direction: rows = its input index
-            stage_split(a.w_query, bimg(wq), D, D, KD, true);   stage_split(a.w_query, bimg(wqT), D, D, KD, false);
-            stage_split(a.w_key, bimg(wk), D, D, KD, true);     stage_split(a.w_key, bimg(wkT), D, D, KD, false);
-            stage_split(a.w_value, bimg(wv), D, D, KD, true);   stage_split(a.w_value, bimg(wvT), D, D, KD, false);
-            stage_split(a.w_out, bimg(woT), D, D, KD, false);   stage_split(a.w_out, bimg(wo), D, D, KD, true);   // nn.Linear [out][in]
+            const SplitJob jobs[8] = {{a.w_query, bimg(wq), D, D, KD, true}, {a.w_query, bimg(wqT), D, D, KD, false},
+                                      {a.w_key, bimg(wk), D, D, KD, true},   {a.w_key, bimg(wkT), D, D, KD, false},
+                                      {a.w_value, bimg(wv), D, D, KD, true}, {a.w_value, bimg(wvT), D, D, KD, false},
+                                      {a.w_out, bimg(woT), D, D, KD, false}, {a.w_out, bimg(wo), D, D, KD, true}};   // nn.Linear [out][in]
+            stage_split_batch<8, (D * D / 4 + kFusedBlock - 1) / kFusedBlock>(jobs);
         } else {
         stage_w(a.w_query, wq, D, D, LD, false);
         stage_w(a.w_key, wk, D, D, LD, false);
@@ -714,10 +716,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       if constexpr (PROD) {
           if (mlp_q || mlp_k) {                      // (SAME: one table for both roles)
               const float* row = (mlp_q ? a.tab_q : a.tab_k) + (size_t)scen * a.tab_stride;
-              stage_split(row, bimg(w1q), U, D, KD, true);              // W1 [D][U]: rows = hidden unit, K = D
-              stage_split(row + D * U, bimg(w2q), D, U, KU, true);      // W2 [U][D]: rows = output feature, K = U
-              stage_split(row, bimg(w1qT), D, U, KU, false);            // backward through W1: rows = its input, K = U
-              stage_split(row + D * U, bimg(w2qT), U, D, KD, false);    // backward through W2: rows = hidden unit, K = D
+              const SplitJob jobs[4] = {{row, bimg(w1q), U, D, KD, true},              // W1 [D][U]: rows = hidden unit, K = D
+                                        {row + D * U, bimg(w2q), D, U, KU, true},      // W2 [U][D]: rows = output feature, K = U
+                                        {row, bimg(w1qT), D, U, KU, false},            // backward through W1: rows = its input, K = U
+                                        {row + D * U, bimg(w2qT), U, D, KD, false}};   // backward through W2: rows = hidden unit, K = D
+              stage_split_batch<4, (D * U / 4 + kFusedBlock - 1) / kFusedBlock>(jobs);
           }
       } else {
       if (mlp_q) {

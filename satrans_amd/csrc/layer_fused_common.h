@@ -199,6 +199,66 @@ __device__ __forceinline__ void stage_split(const float* __restrict__ g, __bf16*
     }
 }
 
+// Several images at once: ALL global loads first, then the conversions and the LDS stores.  One stage_split call is a loop of
+// load -> wait -> store; eight of them in a row are eight memory latencies with one wave per SIMD and nothing to hide them
+// (measured: the backward's prologue and per-scenario staging were ~5 % of the kernel).  UPT: units per thread and image,
+// >= ceil(OUT K / 4 / blockDim) of the largest image.
+struct SplitJob {
+    const float* g;
+    __bf16* hi;
+    int OUT, K, RS;
+    bool in_major;
+};
+template <int NJ, int UPT>
+__device__ __forceinline__ void stage_split_batch(const SplitJob (&jobs)[NJ]) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    float v[NJ][UPT][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const SplitJob& jb = jobs[j];
+        const int K4 = jb.K >> 2;
+#pragma unroll
+        for (int p = 0; p < UPT; ++p) {
+            const int u = (int)threadIdx.x + p * (int)blockDim.x;
+            if (u < jb.OUT * K4) {
+                if (jb.in_major) {
+                    const int k4 = u / jb.OUT, o = u - k4 * jb.OUT;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[j][p][q] = jb.g[(size_t)(4 * k4 + q) * jb.OUT + o];
+                } else {
+                    const float4 t = *reinterpret_cast<const float4*>(jb.g + 4 * (size_t)u);     // o K + k = 4 u
+                    v[j][p][0] = t.x; v[j][p][1] = t.y; v[j][p][2] = t.z; v[j][p][3] = t.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const SplitJob& jb = jobs[j];
+        const int K4 = jb.K >> 2;
+        __bf16* lo = jb.hi + jb.OUT * jb.RS;
+#pragma unroll
+        for (int p = 0; p < UPT; ++p) {
+            const int u = (int)threadIdx.x + p * (int)blockDim.x;
+            if (u < jb.OUT * K4) {
+                int o, k;
+                if (jb.in_major) { const int k4 = u / jb.OUT; o = u - k4 * jb.OUT; k = 4 * k4; }
+                else { o = u / K4; k = 4 * (u - o * K4); }
+                bf16x4 h4, l4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __bf16 h = (__bf16)v[j][p][q];
+                    h4[q] = h;
+                    l4[q] = (__bf16)(v[j][p][q] - (float)h);
+                }
+                const int at = o * jb.RS + (split_pos(k) ^ split_flip(o));
+                *reinterpret_cast<bf16x4*>(jb.hi + at) = h4;
+                *reinterpret_cast<bf16x4*>(lo + at) = l4;
+            }
+        }
+    }
+}
+
 // a D-layout fragment (16 KT_ features of 16 tokens) as the hi / lo B operands of KT_ / 2 K-steps
 template <int KT_>
 __device__ __forceinline__ void split_frag(const float (&in)[KT_][4], bf16x8 (&bh)[KT_ / 2], bf16x8 (&bl)[KT_ / 2]) {
