@@ -70,10 +70,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                                   {a.w_out, bimg(W.woT), D, D, KD, false}};      // nn.Linear [out][in]: y = x @ Wo^T
         stage_split_batch<4, (D * D / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
     } else {
-        stage_image(a.w_query, W.wq, D, D, LD, false);
-        stage_image(a.w_key, W.wk, D, D, LD, false);
-        stage_image(a.w_value, W.wv, D, D, LD, false);
-        stage_image(a.w_out, W.woT, D, D, LD, true);      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
+        const ImageJob jobs[4] = {{a.w_query, W.wq, D, D, LD, false}, {a.w_key, W.wk, D, D, LD, false}, {a.w_value, W.wv, D, D, LD, false},
+                                  {a.w_out, W.woT, D, D, LD, true}};      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
+        stage_image_batch<4, (D * D / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
     }
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         W.ln_g[i] = a.ln_g[i]; W.ln_b[i] = a.ln_b[i];
@@ -113,8 +112,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                                         {row + D * U, bimg(W.w2q), D, U, KU, true}};      // W2 [U][D]: in-major, K = U
               stage_split_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
           } else {
-              stage_image(row, W.w1q, D, U, LU, false);
-              stage_image(row + D * U, W.w2q, U, D, LD, false);
+              const ImageJob jobs[2] = {{row, W.w1q, D, U, LU, false}, {row + D * U, W.w2q, U, D, LD, false}};
+              stage_image_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
           }
       }
       if (mlp_k && (!same_tab || !mlp_q)) {
@@ -123,8 +122,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
               const SplitJob jobs[2] = {{row, bimg(W.w1k), U, D, KD, true}, {row + D * U, bimg(W.w2k), D, U, KU, true}};
               stage_split_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
           } else {
-              stage_image(row, W.w1k, D, U, LU, false);
-              stage_image(row + D * U, W.w2k, U, D, LD, false);
+              const ImageJob jobs[2] = {{row, W.w1k, D, U, LU, false}, {row + D * U, W.w2k, U, D, LD, false}};
+              stage_image_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
           }
       }
       if (gate) {
@@ -579,10 +578,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
     if (!idle) {
         // (without transposed copies the images are swizzled: by-columns AND by-rows reads conflict-free, layer_fused_common.h)
-        auto stage_w = [&](const float* g_, float* s_, int R_, int C_, int ld_, bool tr_) {
-            if constexpr (TR) stage_image(g_, s_, R_, C_, ld_, tr_);
-            else stage_image_sw(g_, s_, R_, C_, ld_, tr_);
-        };
         if constexpr (PROD) {
             // forward direction: rows = the weight's output index; backward direction: rows = its input index
             const SplitJob jobs[8] = {{a.w_query, bimg(wq), D, D, KD, true}, {a.w_query, bimg(wqT), D, D, KD, false},
@@ -591,10 +586,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                                       {a.w_out, bimg(woT), D, D, KD, false}, {a.w_out, bimg(wo), D, D, KD, true}};   // nn.Linear [out][in]
             stage_split_batch<8, (D * D / 4 + kFusedBlock - 1) / kFusedBlock>(jobs);
         } else {
-        stage_w(a.w_query, wq, D, D, LD, false);
-        stage_w(a.w_key, wk, D, D, LD, false);
-        stage_w(a.w_value, wv, D, D, LD, false);
-        stage_w(a.w_out, woT, D, D, LD, true);
+        const ImageJob jobs[4] = {{a.w_query, wq, D, D, LD, false}, {a.w_key, wk, D, D, LD, false}, {a.w_value, wv, D, D, LD, false},
+                                  {a.w_out, woT, D, D, LD, true}};
+        stage_image_batch<4, (D * D / 4 + kFusedBlock - 1) / kFusedBlock, !TR>(jobs);
         }
         if constexpr (TR) {
             stage_image(a.w_query, wqT, D, D, LD, true);
@@ -725,8 +719,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       } else {
       if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-          if constexpr (TR) { stage_image(row, w1q, D, U, LU, false); stage_image(row + D * U, w2q, U, D, LD, false); }
-          else { stage_image_sw(row, w1q, D, U, LU, false); stage_image_sw(row + D * U, w2q, U, D, LD, false); }
+          {
+              const ImageJob jobs[2] = {{row, w1q, D, U, LU, false}, {row + D * U, w2q, U, D, LD, false}};
+              stage_image_batch<2, (D * U / 4 + kFusedBlock - 1) / kFusedBlock, !TR>(jobs);
+          }
           if constexpr (TR) {
               stage_image(row, w1qT, D, U, LD, true);
               stage_image(row + D * U, w2qT, U, D, LU, true);
@@ -734,8 +730,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       }
       if (mlp_k && (!same_tab || !mlp_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-          if constexpr (TR) { stage_image(row, w1k, D, U, LU, false); stage_image(row + D * U, w2k, U, D, LD, false); }
-          else { stage_image_sw(row, w1k, D, U, LU, false); stage_image_sw(row + D * U, w2k, U, D, LD, false); }
+          {
+              const ImageJob jobs[2] = {{row, w1k, D, U, LU, false}, {row + D * U, w2k, U, D, LD, false}};
+              stage_image_batch<2, (D * U / 4 + kFusedBlock - 1) / kFusedBlock, !TR>(jobs);
+          }
           if constexpr (TR) {
               stage_image(row, w1kT, D, U, LD, true);
               stage_image(row + D * U, w2kT, U, D, LU, true);

@@ -557,6 +557,51 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ g, float* 
     }
 }
 
+// Several fp32 images at once (stage_image / stage_image_sw with all global loads first - see stage_split_batch).  SW: the
+// swizzled layout of the backward.  UPT >= ceil(R C / 4 / blockDim) of the largest image.
+struct ImageJob {
+    const float* g;
+    float* s;
+    int R, C, ld;
+    bool transpose;
+};
+template <int NJ, int UPT, bool SW>
+__device__ __forceinline__ void stage_image_batch(const ImageJob (&jobs)[NJ]) {
+    float4 v[NJ][UPT];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int p = 0; p < UPT; ++p) {
+            const int i = (int)threadIdx.x + p * (int)blockDim.x;
+            if (i < jobs[j].R * (jobs[j].C >> 2)) v[j][p] = *reinterpret_cast<const float4*>(jobs[j].g + 4 * (size_t)i);
+        }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const ImageJob& jb = jobs[j];
+        const int c4n = jb.C >> 2;
+#pragma unroll
+        for (int p = 0; p < UPT; ++p) {
+            const int i = (int)threadIdx.x + p * (int)blockDim.x;
+            if (i < jb.R * c4n) {
+                const int r = i / c4n, c = (i - r * c4n) << 2;
+                const float4 t = v[j][p];
+                float* s_ = jb.s;
+                const int ld = jb.ld;
+                if (jb.transpose) {   // image row = source column
+                    if constexpr (SW) {
+                        s_[c * ld + (r ^ img_flip(c))] = t.x; s_[(c + 1) * ld + (r ^ img_flip(c + 1))] = t.y;
+                        s_[(c + 2) * ld + (r ^ img_flip(c + 2))] = t.z; s_[(c + 3) * ld + (r ^ img_flip(c + 3))] = t.w;
+                    } else {
+                        s_[c * ld + r] = t.x; s_[(c + 1) * ld + r] = t.y; s_[(c + 2) * ld + r] = t.z; s_[(c + 3) * ld + r] = t.w;
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(s_ + r * ld + (SW ? (c ^ img_flip(r)) : c)) = t;
+                }
+            }
+        }
+    }
+}
+
 // MetaNet of one role on a D-layout fragment: out = LN(drop(relu(in W1) W2) + in)     submodules.py:77-103
 // Also hands back the hidden activations, the pre-norm rows and the statistics for the backward pass.
 template <int D, int U>
