@@ -1,5 +1,9 @@
 """Diagnostic: per-phase cycle shares of the fused backward kernel.  Needs a library built with
-SATRANS_EXTRA_FLAGS=-DSATRANS_STAMPS (bash satrans_amd/csrc/build.sh after touching layer_fused.hip)."""
+SATRANS_EXTRA_FLAGS=-DSATRANS_STAMPS (bash satrans_amd/csrc/build.sh after touching layer_fused.hip).
+
+Read the shares, not the totals: a stamp is an s_memtime plus a global atomic, and since the backward's loads are issued a
+phase ahead every `s_waitcnt vmcnt` behind a stamp also waits for that atomic - the instrumented kernel is
+~10 % slower than the shipped one and phases that start with a wait (C, D) look longer than they are."""
 import ctypes as C
 import os
 import subprocess
