@@ -71,6 +71,7 @@ CFG = make_config("aliccp")
 PMC_SUMMARY = "r03_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 
 
 def synth_batches(n_rows, seed, ids="uniform", cfg=None):
@@ -230,6 +231,28 @@ def gather_microbench(eng, Xd, B, F, D, launches=48):
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script on the GPUs of this node (one process per GPU, RCCL) and wait for them."""
+    import socket
+    import subprocess
+    share = os.environ.get("SATRANS_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()                       # (counts devices without initialising the GPU in this process)
+    if have < n and not share:
+        print(f"[bench] --gpus {n} but this node shows {have} GPU(s): refusing to report a {have}-GPU number as a {n}-GPU one "
+              f"(SATRANS_BENCH_SHARE_GPU=1 runs the {n}-rank step on one GPU over gloo as a functional check)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:                          # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +284,13 @@ def main():
     if args.config != "aliccp" and args.lr == 0.005:
         args.lr = CFG["lr"]
 
+    # ---- `python bench.py --gpus N` with N > 1 and no launcher around it: this process - which has made no GPU call - starts
+    #      the N ranks itself (torch.distributed.run as a CHILD process; nothing is exec'ed), relays rank 0's one JSON line and
+    #      exits with the children's status.  Under `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set
+    #      and this branch is not taken. ------------------------------------------------------------------------------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     # C libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line version banner there): keep the real
     # stdout for the ONE JSON line and send everything else to stderr
     sys.stdout.flush()
@@ -290,8 +320,12 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if args.gpus != world:
+        # the line's n_gpus must be what was asked for: a launcher that started another number of ranks is a usage error
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` "
+                         f"(it launches its own ranks) or with --nproc-per-node {args.gpus}")
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -487,7 +521,7 @@ def main():
     count = {"layer_fwd": L, "layer_bwd": L, "lazy_flush": n_flush / K}  # launches per step (the flush runs every
     #                                   SATRANS_LAZY_FLUSH_EVERY = 64 steps and once more at the end of the timed region)
 
-    def table(ph):
+    def table(ph, count=count):
         rows, dom, dom_time = {}, None, -1.0
         for name, ms in ph.items():
             per_step = ms * count.get(name, 1)
@@ -507,7 +541,8 @@ def main():
 
     # split products: the training forward of every D = 32 MetaNet layer on the fused kernels; the backward only with ONE generated
     # table for both roles (no 'pos') and within the LDS budget (F <= 19)
-    split_on = eng.lib.satrans_get_product_mode() == 1 and D == 32 and args.config != "c5" and not ("gate" in args.flag or "bilinear" in args.flag)
+    split_applies = D == 32 and args.config != "c5" and not ("gate" in args.flag or "bilinear" in args.flag)
+    split_on = eng.lib.satrans_get_product_mode() == 1 and split_applies
     products = "f32" if not split_on else ("split" if (args.config == "aliccp" and "pos" not in args.flag) else "split forward, f32 backward")
     kernels, dominant = table(phases)
     phase_sum = sum(v["ms_per_step"] for v in kernels.values())
@@ -615,30 +650,59 @@ def main():
         except Exception:
             pass
 
-    # ---- the same K steps with the training step's weight products on the fp32 matrix instruction (SATRANS_PRODUCTS=f32): the
-    #      default evaluates them as split bf16 products; both numbers belong in one record ---------------------
-    fp32_leg = None
-    if (world == 1 and not args.train_only and args.config == "aliccp" and args.flag == "sota"
-            and eng.lib.satrans_get_product_mode() == 1):
-        eng.lib.satrans_set_product_mode(0)
+    # ---- the OTHER product mode, as a named secondary object: the headline runs in the library's mode (default: fp32 products,
+    #      the reference's arithmetic); the opt-in split mode (fp32 operands as bf16 pairs) gets the same protocol -
+    #      W warm-up steps, flush, K timed steps over the same resident batches with the lazy flush inside, per-phase HIP events on
+    #      every 4th step - and its own kernel table and roofline, priced against BOTH roofs ----------------------------------------
+    other_leg, other_key = None, None
+    mode_now = eng.lib.satrans_get_product_mode()
+    if world == 1 and not args.train_only and split_applies:
+        other = 1 - mode_now
+        other_key = "split_products" if other == 1 else "fp32_products"
+        eng.lib.satrans_set_product_mode(other)
         try:
             model.train()
             eng.timers = None
-            for i in range(2):
+            for i in range(W):
                 step(i)
             eng.flush_lazy()
             torch.cuda.synchronize()
+            tm = {} if not args.no_phase_timing else None
+            fl0 = getattr(eng, "flush_count", 0)
             t1 = time.perf_counter()
             for i in range(W, W + K):
+                eng.timers = tm if (tm is not None and (i - W) % 4 == 0) else None
                 step(i)
+            eng.timers = tm
             eng.flush_lazy(sync=False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            fp32_leg = {"ms_per_step": round(dt / K * 1e3, 4), "samples_per_s": round(B * K / dt, 1), "steps": K,
-                        "note": "same protocol as `value` (K steps over the same resident batches, lazy flush inside) with "
-                                "satrans_set_product_mode(0): v_mfma_f32_16x16x4_f32 products in forward and backward"}
+            ph = eng.phase_ms() if tm is not None else {}
+            eng.timers = None
+            cnt = dict(count, lazy_flush=max(1, getattr(eng, "flush_count", 0) - fl0) / K)
+            kern_o, dom_o = table(ph, cnt)
+            roof_o = None
+            if dom_o:
+                e, spec = kern_o[dom_o], per_launch[dom_o]
+                roof_o = {"kernel": spec["kernel"], "bound": e["bound"], "achieved": e["achieved"], "unit": e["unit"],
+                          "launch_ms": e["ms_per_launch"], "algorithmic_per_launch": spec["work"],
+                          "peak_fp32_mfma": FP32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": round(e["achieved"] / FP32_PEAK_TFLOPS, 4)}
+                if other == 1:
+                    roof_o.update({"peak_bf16_mfma_dense": BF16_PEAK_TFLOPS,
+                                   "frac_of_bf16_mfma_peak_3_instructions": round(3.0 * e["achieved"] / BF16_PEAK_TFLOPS, 4),
+                                   "note": "`achieved` = ALGORITHMIC fp32 FLOPs of the layer / launch time.  The kernel issues each "
+                                           "product as three bf16 instructions, so the bf16 pipe carries 3 x that rate: that is "
+                                           "the second fraction (the kernel is bound by VALU issue and latency, not by the pipe)"})
+            other_leg = {"dtype": "bf16x3 (fp32 operands as bf16 pairs hi + lo; a_lo w_hi + a_hi w_lo + a_hi w_hi on "
+                                  "v_mfma_f32_16x16x32_bf16, fp32 accumulation)" if other == 1 else "f32",
+                         "ms_per_step": round(dt / K * 1e3, 4), "samples_per_s": round(B * K / dt, 1), "steps": K, "warmup": W,
+                         "kernels": kern_o, "roofline": roof_o,
+                         "note": ("opt-in fast mode (SATRANS_PRODUCTS=split / satrans_set_product_mode(1)): NOT the reference's "
+                                  "arithmetic - operands carry ~16 significant bits; on trained weights the training forward is "
+                                  "outside the 1e-5 logit bar (tests: test_trained_weights_regime_against_the_oracle)")
+                                 if other == 1 else "the reference's arithmetic (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain)"}
         finally:
-            eng.lib.satrans_set_product_mode(1)
+            eng.lib.satrans_set_product_mode(mode_now)
 
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = err_train = logit_scale = None
@@ -692,11 +756,12 @@ def main():
                   ("" if args.flag == "sota" else f" flag={args.flag}"),
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        # the arithmetic type the path computes its products in: the library's product mode decides, nothing is hard-coded
+        "dtype": "f32" if products == "f32" else "bf16x3 split products (fp32 storage and accumulation)", "data": "synthetic",
         "products": (products + (": fp32 operands as bf16 pairs hi + lo, a product = a_lo w_hi + a_hi w_lo + a_hi w_hi on "
-                                 "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fused kernels of the (32, 64, 4) MetaNet shape; "
-                                 "SATRANS_PRODUCTS=f32 runs them on v_mfma_f32_16x16x4_f32).  fp32 in, fp32 out; measured 2.7x the error "
-                                 "of plain fp32 products against fp64 (tests: test_product_modes_against_the_fp64_oracle)"
+                                 "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fused kernels of the (32, 64, 4) MetaNet shape): "
+                                 "the opt-in fast mode, NOT the reference's arithmetic (operands carry ~16 significant bits)"
                                  if products.startswith("split") else ": v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain)")),
         "config": {"workload": f"{CFG['label']}, {model.embedding_arena.shape[0]:,} table rows "
                                f"({model.embedding_arena.numel() * 4 / 1e6:,.0f} MB fp32), {args.ids} ids, dropout on, "
@@ -704,7 +769,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": D, "layers": L, "heads": CFG["H"],
                    "fields": F, "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
-        "fp32_products": fp32_leg,
+        **({other_key: other_leg} if other_key else {}),
         "fwd_logit": {"max_abs_err_vs_cpu_oracle": err, "training_forward_dropout_off_max_abs_err": err_train,
                       "max_abs_logit": logit_scale, "samples": 2048,
                       "note": "weights as they are after this run's training steps; evaluation forward = fp32 products, "

@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define SATRANS_ABI_VERSION 3
+/* 4: satrans_layer_desc gained the trailing `attn_save` field and satrans_set_layer_bwd8 left the library (round 3; the number
+ *    was bumped one round late); round 4 appended the `head` block of the fused last-layer step.  A caller built against an
+ *    older header passes a shorter struct: satrans_abi_version() must be compared with this constant before any other call. */
+#define SATRANS_ABI_VERSION 4
 
 /* error codes */
 #define SATRANS_OK 0
@@ -178,7 +181,8 @@ int satrans_layer_fused_supported(const satrans_layer_desc* d);
  * Mode 1 applies to the TRAINING step - the forward with SATRANS_TRAIN set and the backward; a forward without SATRANS_TRAIN
  * (predict / evaluate) always runs fp32 products: outputs that are compared with the reference's stay exact to fp32 summation
  * order (logits of a trained AliCCP-shaped model: 1.4e-6 from the CPU oracle; 7.7e-5 through split products).
- * The library starts in mode 1; SATRANS_PRODUCTS=f32 in the environment starts it in mode 0.  Layers of other shapes, the
+ * The library starts in mode 0 - the reference's arithmetic, and the mode every reported headline number is measured in;
+ * SATRANS_PRODUCTS=split in the environment (or this call) selects mode 1, an opt-in fast mode.  Layers of other shapes, the
  * gate / bilinear variants and separate Q / K tables (flag 'pos') always run fp32 products.  Returns SATRANS_E_BADARG for any
  * other mode. */
 int satrans_set_product_mode(int mode);

@@ -1600,12 +1600,13 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
 
 // How the fused kernels evaluate the weight products of the D = 32 MetaNet shapes: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit for bit an
 // fmaf chain), 1 = split (fp32 operands as bf16 pairs, three v_mfma_f32_16x16x32_bf16 per block; layer_fused_common.h).
-// SATRANS_PRODUCTS=f32|split sets the start value (split when unset), satrans_set_product_mode changes it (tests run both).
+// The library starts in mode 0 (the reference's arithmetic); SATRANS_PRODUCTS=split starts it in mode 1 (the opt-in fast mode),
+// satrans_set_product_mode changes it (tests run both).
 static int g_product_mode = -1;
 static int product_mode() {
     if (g_product_mode < 0) {
         const char* e = getenv("SATRANS_PRODUCTS");
-        g_product_mode = (e && (!strcmp(e, "f32") || !strcmp(e, "fp32"))) ? 0 : 1;      // split unless asked otherwise
+        g_product_mode = (e && !strcmp(e, "split")) ? 1 : 0;      // fp32 products unless the fast mode is asked for
     }
     return g_product_mode;
 }
@@ -1672,6 +1673,11 @@ static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same
     return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + 64;
 }
 
+// MetaNet width the fused kernels are INSTANTIATED with for an embedding dim (U = 2 D; forward-only D = 64: 16).  With a MetaNet
+// d->U equals it (satrans_layer_fused_supported); gate / bilinear layers ignore d->U, but the kernels' LDS layout and their
+// generated-row records are laid out with the template width whatever d->U says - every size below must use this one.
+static int fused_width(const satrans_layer_desc* d) { return d->D == 64 ? 16 : 2 * d->D; }
+
 struct FusedBwdPlan {
     int T, G;
     size_t lds;
@@ -1689,10 +1695,11 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     // transposed copies where they fit (D = 32 with one shared generated-weight table) for comparison.
     static const int force_tr = getenv("SATRANS_BWD_TR") ? atoi(getenv("SATRANS_BWD_TR")) : 0;
     p.tr = force_tr == 1 && same_tab && d->D == 32 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR));
+    const int Uw = fused_width(d);
     p.split = product_mode() == 1 && !p.tr && same_tab && d->D == 32 && d->U == 64 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) &&
               (d->flags & (SATRANS_META_Q | SATRANS_META_K)) &&
-              (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, false, true) * 4 <= 160 * 1024;
-    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, d->U, d->H, same_tab, p.tr, p.split) * 4;
+              (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, false, true) * 4 <= 160 * 1024;
+    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, p.tr, p.split) * 4;
     if (p.lds > 160 * 1024) return false;
     const int64_t tiles = ceil_div(d->B, p.T) + d->S;
     p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
@@ -1783,7 +1790,7 @@ extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc*
     if (!d) return -1;
     int64_t n = -1;
     if (fused_bwd_plan(d, p)) {
-        const int64_t CSZ = 4 * (int64_t)d->D * d->D + 6 * d->D, TSZ = 4 * (int64_t)d->D * d->U;
+        const int64_t CSZ = 4 * (int64_t)d->D * d->D + 6 * d->D, TSZ = 4 * (int64_t)d->D * fused_width(d);
         n = std::max<int64_t>(n, (int64_t)p.G * CSZ + (int64_t)(p.G + d->S) * TSZ);
     }
     return n;
@@ -1831,7 +1838,7 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
                    : launch_bwd<16, 32, 2, false, false>(d, p, dy, dx, slabs, stream);
     }
     if (rc) return rc;
-    const int D = d->D, U = d->U, CSZ = 4 * D * D + 6 * D;
+    const int D = d->D, U = fused_width(d), CSZ = 4 * D * D + 6 * D;      // (record stride: the kernel's template width)
     float* records = slabs + (size_t)p.G * CSZ;
     const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K | SATRANS_BILINEAR);
     const int row_elems = (d->flags & SATRANS_GATE) ? D : ((d->flags & SATRANS_BILINEAR) ? D * (D / d->H) : 2 * D * U);

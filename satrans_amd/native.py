@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SATRANS_LIB_PATH") or os.path.join(_HERE, "libsatrans_hip.so")   # (override: kernel experiments)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ID_F32, ID_I32, ID_I64 = 0, 1, 2
 META_Q, META_K, RELU_OUT, NO_RES, TRAIN, GATE, BILINEAR = 1, 2, 4, 8, 16, 32, 64

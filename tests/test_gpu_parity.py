@@ -19,8 +19,8 @@ LOGIT_ATOL = 1e-5
 def split_products() -> bool:
     """True when the TRAINING step of the fused kernels (forward with dropout, backward) evaluates the weight products of the
     (D, U, H) = (32, 64, 4) MetaNet shape as split products (fp32 operands as bf16 pairs, three bf16 MFMAs per block -
-    include/satrans_hip.h: satrans_set_product_mode; the library's default) rather than on the fp32 instruction
-    (SATRANS_PRODUCTS=f32; evaluation forwards always use it).  Split products carry ~2.6x the error of plain fp32
+    include/satrans_hip.h: satrans_set_product_mode; opt-in, SATRANS_PRODUCTS=split) rather than on the fp32 instruction
+    (the library's default and the reference's arithmetic; evaluation forwards always use it).  Split products carry ~2.6x the error of plain fp32
     products against an fp64 evaluation of the same graph (test_product_modes_against_the_fp64_oracle): the golden gates (1e-5
     on logits, 5e-5 of the largest entry on gradients) hold in both modes; the few bounds below that were set at the fp32
     kernels' own noise floor are stated per mode."""
@@ -67,18 +67,36 @@ def assert_grad_close_but_for_kinks(got, want, atol, err_msg, frac=0.02, outlier
     contributes - or does not - to the rows / columns of the generated-weight gradient it touches and to everything downstream
     of them (measured: 440 of 131,072 elements of the scenario encoder's weight gradient, the largest 1.5 % of the tensor's
     largest entry).  Any two evaluation orders do this to each other; with split products (~1e-5 near a kink instead of ~1e-7)
-    a step over 10^5 hidden units holds such a unit more often than not.  So: at most `frac` of a tensor's elements outside
-    `atol`, none of them by more than `outlier` of the tensor's largest entry."""
+    a step over 10^5 hidden units holds such a unit more often than not.  So, UNDER SPLIT PRODUCTS ONLY: at most `frac` of a
+    tensor's elements outside `atol`, none of them by more than `outlier` of the tensor's largest entry.  With fp32 products
+    (the default, the reference's arithmetic) the bound is element-wise, as it was before split products existed."""
     err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
     bad = err > atol
     if not bad.any():
         return
+    if not split_products():
+        np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), rtol=0, atol=atol,
+                                   err_msg=err_msg)
     assert float(bad.mean()) <= frac, (err_msg, "fraction outside the bound", float(bad.mean()))
     assert float(err.max()) <= outlier * float(np.abs(want).max()) + atol, (err_msg, float(err.max()), float(np.abs(want).max()))
 
 
 def sd_to_cpu(model):
     return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def sd_aliased(model, dtype=None):
+    """state_dict on the CPU with the reference's ALIASING kept: keys that share storage in the model (K_/V_meta_mlp and
+    domain_map_dnn_K/V are the Q objects without 'pos', satrans.py:46) share ONE tensor, so the oracle sees one leaf and its
+    gradient is the sum over the roles - as in the reference."""
+    out, by_ptr = {}, {}
+    for k, v in model.state_dict().items():
+        key = (v.data_ptr(), tuple(v.shape))
+        if key not in by_ptr:
+            t = v.detach().cpu()
+            by_ptr[key] = t.to(dtype) if dtype is not None else t
+        out[k] = by_ptr[key]
+    return out
 
 
 @pytest.mark.parametrize("name", NATIVE_CASES)
@@ -143,7 +161,10 @@ def test_parity_gates_hold_in_both_product_modes(mode):
     def body():
         test_forward_matches_reference_golden("aliccp_sota")
         test_gradients_match_reference_golden("aliccp_sota")
-        test_training_mode_gradients_match_oracle_with_same_masks()
+        test_training_mode_gradients_match_oracle_with_same_masks("small_qkv")
+        # D = 32, F = 19, meta_mode QK: the instantiation of the headline step (layer_bwd_fused_kernel<32,64,4,true,false,19,0,PROD>)
+        # in TRAINING mode, masks replayed through the oracle - the split-product backward is only reachable at this shape
+        test_training_mode_gradients_match_oracle_with_same_masks("aliccp_sota")
         test_adam_trajectory_step_by_step_against_the_oracle("aliccp_sota")
         c = Case("aliccp_sota")
         outs = []
@@ -187,6 +208,139 @@ def test_product_modes_against_the_fp64_oracle():
     assert l32 <= 2e-7 and lsp <= 5e-7, (l32, lsp)
     assert g32 <= 3e-5 and gsp <= 1e-4, (g32, gsp)
     assert gsp <= 5.0 * g32 + 1e-6, "split products are expected within a small factor of plain fp32 products"
+
+
+def _trained_aliccp_model(steps=120, B=8192, rows_cap=20000, seed=5):
+    """An AliCCP-shaped model (19 fields, D = 32, 3 layers, 4 heads, QK; tables capped at `rows_cap` rows per field so that the
+    oracle's dense step stays cheap) after `steps` training steps at the baseline batch on labels that can be learnt: logits of
+    order 1, MetaNet pre-activations and LayerNorm statistics of a trained network - the regime the near-init golden cases
+    (|logit| ~ 0.1) do not reach."""
+    from satrans_amd import SATrans, SparseFeat
+    import bench
+    rng = np.random.RandomState(seed)
+    vocab = {f: min(bench.ALICCP_MAX[f], rows_cap) + 2 for f in bench.ALICCP_FIELDS}
+    cols = [SparseFeat(f, vocabulary_size=vocab[f], embedding_dim=32) for f in bench.ALICCP_FIELDS]
+    N = (steps + 1) * B
+    X = np.stack([rng.randint(1 if f == '301' else 0, vocab[f] - 1, size=N) for f in bench.ALICCP_FIELDS], axis=1)
+    y = ((X[:, 1] % 2 == 0) & (rng.rand(N) < 0.6) | (rng.rand(N) < 0.05)).astype(np.float32)
+    X = X.astype(np.float32)
+    model = SATrans(cols, cols, ['301'], [3], att_layer_num=0, domain_att_layer_num=3, att_head_num=4,
+                    use_linear=False, use_dnn=False, meta_mode='QK', seed='1021', device=DEV, flag='sota')
+    model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy")
+    model.train()
+    eng = model._require_engine()
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    for i in range(steps):
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(bench.ALICCP_FIELDS)], dense=[], domain_cols=[18],
+                      embedding_dim=32, head_num=4, layer_num=3, flag='sota', meta_mode='QK', meta_units=[32, 64, 32])
+    return model, spec, X[steps * B:], y[steps * B:]
+
+
+# measured on an MI355X (printed by the test; bounds = ~2x the measurement): {mode: (logit bound, gradient bound as a fraction
+# of the tensor's largest entry)}
+TRAINED_BOUNDS = {0: (1e-5, 1e-4), 1: (2e-4, 1e-3)}
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32-products", "split-products"])
+def test_trained_weights_regime_against_the_oracle(mode):
+    """VERDICT r03 item 1b.  After 120 training steps at B = 8,192 (trained weights, |logit| of order 1):
+      (a) the TRAINING forward (the kernels of the training step, dropouts switched off) on 2,048 fresh samples against the CPU
+          oracle on the same weights: fp32 products within the 1e-5 bar of SURVEY 8c; split products within the bound stated in
+          TRAINED_BOUNDS (they are NOT within 1e-5 here - which is why they are an opt-in fast mode and not the headline);
+      (b) one training-mode step's gradients (dropout on, masks replayed through the oracle in fp64) at B = 1,024: every
+          tensor within the stated fraction of its largest entry - fp32 products element by element, split products but for
+          ReLU kinks."""
+    def body():
+        model, spec, X, y = _trained_aliccp_model()
+        eng = model._require_engine()
+        sd = sd_to_cpu(model)
+        nb = 2048
+        Xt = torch.from_numpy(X[:nb])
+        _, logit_ref = O.forward(sd, Xt, spec)
+        model.eval()
+        model(Xt.to(DEV))
+        err_eval = float((eng.last_logit().cpu() - logit_ref).abs().max())
+        model.train()
+        keep_p, eng.drop_p = eng.drop_p, 0.0
+        try:
+            model(Xt.to(DEV))
+            err_train = float((eng.last_logit().cpu() - logit_ref).abs().max())
+        finally:
+            eng.drop_p = keep_p
+        scale_logit = float(logit_ref.abs().max())
+        assert scale_logit > 1.0, f"the model did not train (max |logit| {scale_logit})"
+        assert err_eval <= 1e-5, ("evaluation forward (always fp32 products)", err_eval)
+        # (b) gradients of a training-mode step, masks replayed
+        B = 1024
+        Xb, yb = torch.from_numpy(X[:B]), torch.from_numpy(y[:B])
+        bce, reg, grads = eng.loss_and_grads(Xb.to(DEV), yb.to(DEV))
+        masks = O.dropout_masks(eng.drop_seed, eng.drop_step, B, 19, 32, 4, 3, 0.1)
+        sd64 = sd_aliased(model, torch.float64)
+        bce_ref, reg_ref, g_ref = O.loss_and_grads(sd64, Xb, yb, spec, O.Dropper("masks", 0.1, masks))
+        worst, worst_key = 0.0, None
+        for k, g in g_ref.items():
+            if k in grads and float(g.abs().max()) > 1e-7:
+                e = float((grads[k].cpu().double() - g).abs().max() / g.abs().max())
+                if e > worst:
+                    worst, worst_key = e, k
+        print(f"trained weights, products mode {mode}: max |logit| {scale_logit:.2f}; logit err eval {err_eval:.2e} train {err_train:.2e}; "
+              f"worst gradient {worst:.2e} of the tensor's largest entry ({worst_key})")
+        lb, gb = TRAINED_BOUNDS[mode]
+        assert err_train <= lb, (mode, err_train)
+        assert bce == pytest.approx(bce_ref, rel=1e-5 if mode == 0 else 1e-4)
+        for k, g in g_ref.items():
+            if k in grads:
+                sc = max(1e-6, float(g.abs().max()))
+                assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), gb * sc + softmax_side_floor(k, g_ref, 1e-8),
+                                                f"{k} (trained weights, mode {mode})")
+    _with_product_mode(mode, body)
+
+
+def test_gate_layer_with_a_metanet_width_that_is_not_2d():
+    """a `gate` layer ignores meta_dnn_hidden_units' hidden width, but the fused kernels lay LDS and their
+    generated-row records out with the width they are INSTANTIATED for (2 D); sizing either from the descriptor's U (here 48
+    at D = 32, and 16 at D = 16) left the softmax caches outside the allocation.  Logits and every gradient against the oracle."""
+    from satrans_amd import SATrans, SparseFeat
+    for D, H, U in ((32, 4, 48), (16, 2, 16), (32, 4, 32)):
+        for flag in ("sota-gate", "sota-bilinear"):
+            rng = np.random.RandomState(D + U)
+            F, B = 19, 45
+            fields = [f"f{i}" for i in range(F)]
+            vocab = {f: int(rng.randint(5, 60)) for f in fields}
+            vocab[fields[0]] = 4
+            cols = [SparseFeat(f, vocabulary_size=vocab[f] + 1, embedding_dim=D) for f in fields]
+            model = SATrans(cols, cols, [fields[0]], [3], att_layer_num=0, domain_att_layer_num=2, att_head_num=H, use_linear=False,
+                            use_dnn=False, meta_mode='QK', meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag=flag)
+            with torch.no_grad():
+                for k, p in model.named_parameters():
+                    if "embedding" in k:
+                        p.mul_(300.0)
+            state, by_ptr = {}, {}
+            for k, v in model.state_dict().items():
+                state[k] = by_ptr.setdefault(v.data_ptr(), v.detach().clone())
+            X = np.stack([rng.randint(1 if f == fields[0] else 0, vocab[f], size=B) for f in fields], axis=1).astype(np.float32)
+            y = (rng.rand(B) < 0.4).astype(np.float32)
+            spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(fields)], dense=[], domain_cols=[0], embedding_dim=D, head_num=H,
+                              layer_num=2, flag=flag, meta_mode='QK', meta_units=[D, U, D])
+            Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+            model.to(DEV); model.device = DEV
+            model.compile("adam", "binary_crossentropy")
+            model.eval()
+            eng = model._require_engine()
+            bce, reg, grads = eng.loss_and_grads(Xt.to(DEV), yt.to(DEV))
+            assert not eng._ws[B]["generic"], "the fused kernels were expected to take this shape"
+            bce_ref, reg_ref, g_ref = O.loss_and_grads(state, Xt, yt, spec)
+            model(Xt.to(DEV))
+            _, logit_ref = O.forward(state, Xt, spec)
+            np.testing.assert_allclose(eng.last_logit().cpu().numpy().reshape(-1), logit_ref.numpy().reshape(-1), rtol=0,
+                                       atol=2e-5 * max(1.0, float(logit_ref.abs().max())))
+            assert bce == pytest.approx(bce_ref, rel=1e-5)
+            for k, g in g_ref.items():
+                if k in grads:
+                    sc = max(1e-6, float(g.abs().max()))
+                    np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=2e-4 * sc + 1e-8,
+                                               err_msg=f"{k} D={D} U={U} {flag}")
 
 
 @pytest.mark.parametrize("name", NATIVE_ADAM_CASES)
@@ -557,8 +711,12 @@ def test_training_mode_dropout_matches_oracle_with_same_masks():
     assert float((eng.last_logit().cpu() - logit_ref).abs().max()) > 1e-4
 
 
-def test_training_mode_gradients_match_oracle_with_same_masks():
-    c = Case("small_qkv")
+@pytest.mark.parametrize("name", ["small_qkv", "aliccp_sota"])
+def test_training_mode_gradients_match_oracle_with_same_masks(name):
+    """Training-mode step (four dropout sites per layer on) against the oracle with the kernels' masks replayed.  `small_qkv` is
+    D = 16 (never on the split path); `aliccp_sota` is the headline shape (D = 32, U = 64, H = 4, F = 19, meta_mode QK): the fused
+    backward instantiation of the benchmark, in whichever product mode the library is in."""
+    c = Case(name)
     model = build_model(c, DEV)
     model.compile("adam", "binary_crossentropy")
     model.train()
@@ -573,7 +731,9 @@ def test_training_mode_gradients_match_oracle_with_same_masks():
         if k not in grads:                           # alias keys of the oracle (K_/V_meta_mlp, domain_map_dnn_K/V)
             continue
         scale = max(1e-6, float(g.abs().max()))
-        np.testing.assert_allclose(grads[k].cpu().numpy(), g.numpy(), rtol=0, atol=5e-5 * scale + 1e-9, err_msg=k)
+        # fp32 products: element by element.  Split products: the same bound but for ReLU kinks (assert_grad_close_but_for_kinks)
+        floor = softmax_side_floor(k, g_ref, 1e-9) if split_products() else 1e-9
+        assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), 5e-5 * scale + floor, k)
 
 
 def test_gather_bit_exact_and_out_of_range_ids():
