@@ -509,7 +509,12 @@ def main():
     one_kernel = not generic
     fwd_kernel = "layer_fwd_fused_kernel" if one_kernel else "general path, whole layer forward (~25 gen_* launches)"
     bwd_kernel = eng.bwd_kernel_name() if one_kernel else "general path, whole layer backward (~45 gen_* launches)"
+    # the last layer of a step as ONE launch with the head fused in (satrans_layer_bwd_head): its recomputed forward IS the
+    # layer's forward (no forward launch exists for it), so the launch carries forward + backward = 3 x the forward's FLOPs
+    fused_head = bool(eng._ws.get(B, {}).get("fuse_head"))
     per_launch = {
+        "layer_bwd_head": dict(kernel=bwd_kernel + " (HEADF instantiation: last layer forward + head + loss + backward)",
+                               bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=3.0 * fwd_flops / 1e12),
         "adam_untouched": dict(kernel="adam_untouched_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                                work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
         "layer_bwd": dict(kernel=bwd_kernel, bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=2.0 * fwd_flops / 1e12),
@@ -518,7 +523,8 @@ def main():
                            work=B * F * (D * 4 + 4) / 1e9),                        # read bytes (only timed with SATRANS_FUSE_GATHER=0)
     }
     n_flush = max(1, n_flush_timed)
-    count = {"layer_fwd": L, "layer_bwd": L, "lazy_flush": n_flush / K}  # launches per step (the flush runs every
+    n_sep = L - 1 if fused_head else L
+    count = {"layer_fwd": n_sep, "layer_bwd": n_sep, "layer_bwd_head": 1, "lazy_flush": n_flush / K}  # launches per step (the flush runs every
     #                                   SATRANS_LAZY_FLUSH_EVERY = 64 steps and once more at the end of the timed region)
 
     def table(ph, count=count):

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 4: satrans_layer_desc gained the trailing `attn_save` field and satrans_set_layer_bwd8 left the library (round 3; the number
- *    was bumped one round late); round 4 appended the `head` block of the fused last-layer step.  A caller built against an
+ *    was bumped one round late); round 4 added satrans_layer_bwd_head (a new entry point, no struct changed).  A caller built against an
  *    older header passes a shorter struct: satrans_abi_version() must be compared with this constant before any other call. */
 #define SATRANS_ABI_VERSION 4
 
@@ -298,6 +298,42 @@ int satrans_head(const float* a, const float* dense, int64_t dense_stride, const
 int satrans_head_loss(const float* a, const float* dense, int64_t dense_stride, const int32_t* dense_cols, int n_dense, int B,
                       int FD, const float* w, const float* bias, float* prob, float* logit, const float* y, double* loss_sum,
                       float* da, float* g_w, float* g_b, float* scratch, int loss_kind, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The LAST layer of a training step with the head fused in: one launch (plus two small fixed-order reductions) that replaces
+ *   satrans_layer_fwd(last layer) + satrans_head_loss + satrans_layer_bwd(last layer)
+ * i.e. reference satrans.py:50-100 (recomputed from the layer input, as satrans_layer_bwd does anyway), :244-255 (flatten +
+ * dense columns + Linear + sigmoid), meta_basemodel.py:317 (loss, reduction='sum') and their backward.  A workgroup tile holds
+ * whole samples, so the logit of a sample is a sum over rows the tile has in registers: neither the layer output [B,F,D] nor its
+ * gradient is written or read, and the step runs L - 1 forward launches instead of L.
+ *   d          the last layer (d->x = its input, flags / dropout counters as for its forward)
+ *   h          head operands: w [F*D + n_dense], bias [1], labels [B] (fp32); dense / dense_stride / h_dense_cols as in
+ *              satrans_head, except that h_dense_cols is a HOST array (the kernel takes the columns by value; n_dense <= 2);
+ *              outputs prob [B], logit [B] (optional), loss_sum[0] (double) += the batch's loss sum, g_w / g_b ACCUMULATED;
+ *              scratch: satrans_layer_bwd_head_scratch_floats(d, n_dense) floats
+ *   dx, slabs, g_* as satrans_layer_bwd.
+ * Built for the fused MetaNet shapes (D,U,H) = (32,64,4), (16,32,2) with fp32 products; satrans_layer_bwd_head_supported says
+ * whether a layer / head pair can take this path (callers fall back to the three separate calls otherwise). */
+typedef struct satrans_head_desc {
+    const float* w;
+    const float* bias;
+    const float* labels;
+    const float* dense;
+    int64_t dense_stride;
+    const int32_t* h_dense_cols; /* HOST array [n_dense] */
+    int32_t n_dense, loss_kind;  /* SATRANS_LOSS_* */
+    float* prob;
+    float* logit;
+    double* loss_sum;
+    float* g_w;
+    float* g_b;
+    float* scratch;
+} satrans_head_desc;
+int satrans_layer_bwd_head_supported(const satrans_layer_desc* d, const satrans_head_desc* h);
+int64_t satrans_layer_bwd_head_scratch_floats(const satrans_layer_desc* d, int n_dense);
+int satrans_layer_bwd_head(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, float* g_wq,
+                           float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
+                           float* g_tab_k, void* stream);
 
 /* Dense elementwise steps of the optimizers `compile` accepts besides Adam (models/meta_basemodel.py:612-640: torch.optim.SGD
  * lr 0.01, Adagrad lr 0.01 eps 1e-10, RMSprop lr 0.01 alpha 0.99 eps 1e-8), over n floats with the dense gradient g:

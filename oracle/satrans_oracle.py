@@ -153,6 +153,12 @@ def scenario_vectors(P: Dict[str, Tensor], X: Tensor, spec: PathSpec) -> List[Li
     return out
 
 
+# Test instrumentation: when a dict {"eps": e, "near_zero": 0} is installed here, metanet() counts the hidden units whose
+# pre-activation lies within e * max|pre-activation| of the ReLU's kink.  Such a unit may legitimately take the other branch
+# in another fp32 evaluation order; the parity tests allow their kink exception only when this count is non-zero.
+KINK_PROBE: Optional[Dict] = None
+
+
 def metanet(x: Tensor, vec: Tensor, gamma: Tensor, beta: Tensor, spec: PathSpec,
             drop: Dropper, layer: int, site: str) -> Tensor:
     """Per-sample generated MLP, no biases: LN(dropout(relu(x@W1)@W2...) + x).
@@ -169,6 +175,9 @@ def metanet(x: Tensor, vec: Tensor, gamma: Tensor, beta: Tensor, spec: PathSpec,
         off += n
         x = torch.matmul(x, W)
         if i < len(units) - 2:
+            if KINK_PROBE is not None:
+                xa = x.detach().abs()
+                KINK_PROBE["near_zero"] += int((xa <= KINK_PROBE["eps"] * float(xa.max())).sum())
             x = torch.relu(x)
     x = drop(x, layer, site) + res
     return F.layer_norm(x, (x.shape[-1],), gamma, beta, 1e-6)

@@ -33,6 +33,12 @@ int satrans_layer_bwd_lds(const satrans_layer_desc* d, const float* dy, float* d
                           float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
                           float* g_tab_k, void* stream);
 
+int satrans_layer_bwd_head_fused_supported(const satrans_layer_desc* d, const satrans_head_desc* h);
+int64_t satrans_layer_bwd_head_scratch_floats_fused(const satrans_layer_desc* d, int n_dense);
+int satrans_layer_bwd_head_fused(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, float* g_wq,
+                                 float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
+                                 float* g_tab_k, void* stream);
+
 const char* satrans_last_error(void) { return satrans::g_error; }
 int satrans_abi_version(void) { return SATRANS_ABI_VERSION; }
 
@@ -88,6 +94,28 @@ int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, f
     if (satrans_layer_impl() == 0 && satrans_layer_bwd_fused_supported(d))
         return satrans_layer_bwd_fused(d, dy, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
     return satrans_layer_bwd_lds(d, dy, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
+}
+
+// the last layer of a training step with the head fused in: fused kernels only (layer_fused.hip)
+int satrans_layer_bwd_head_supported(const satrans_layer_desc* d, const satrans_head_desc* h) {
+    if (!d || !h || satrans_layer_validate(d, "layer_bwd_head")) return 0;
+    return satrans_layer_impl() == 0 && satrans_layer_fused_supported(d) && satrans_layer_bwd_head_fused_supported(d, h);
+}
+
+int64_t satrans_layer_bwd_head_scratch_floats(const satrans_layer_desc* d, int n_dense) {
+    if (!d || satrans_layer_validate(d, "layer_bwd_head")) return -1;
+    return satrans_layer_bwd_head_scratch_floats_fused(d, n_dense);
+}
+
+int satrans_layer_bwd_head(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, float* g_wq,
+                           float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
+                           float* g_tab_k, void* stream) {
+    int rc = satrans_layer_validate(d, "layer_bwd_head");
+    if (rc) return rc;
+    SATRANS_REQUIRE(h, SATRANS_E_BADARG, "layer_bwd_head: null head descriptor");
+    SATRANS_REQUIRE(satrans_layer_bwd_head_supported(d, h), SATRANS_E_UNSUPPORTED,
+                    "layer_bwd_head: not built for this layer / head (use satrans_layer_fwd + satrans_head_loss + satrans_layer_bwd)");
+    return satrans_layer_bwd_head_fused(d, h, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
 }
 
 }  // extern "C"

@@ -139,6 +139,15 @@ __global__ __launch_bounds__(32 * kReduceGroups) void head_reduce_kernel(const f
 
 using namespace satrans;
 
+// internal: add `nblk` partial rows [g_w (ncol) | g_b | loss] in row order (the fused last-layer step writes one per workgroup)
+extern "C" int satrans_head_reduce_partials(const float* partial, int nblk, int ncol, float* g_w, float* g_b, double* loss_sum,
+                                            void* stream_) {
+    head_reduce_kernel<<<(unsigned)ceil_div(ncol + 2, 32), 32 * kReduceGroups, 0, (hipStream_t)stream_>>>(partial, nblk, ncol, g_w, g_b,
+                                                                                                    loss_sum);
+    SATRANS_CHECK_LAUNCH("head_reduce_kernel");
+    return SATRANS_OK;
+}
+
 extern "C" int64_t satrans_head_scratch_floats(int B, int FD, int n_dense) {
     if (B <= 0) return 0;
     return ceil_div(B, kSamplesPerBlock) * (int64_t)(FD + n_dense + 2);

@@ -512,11 +512,28 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 // token-contraction products: on the fp32 instruction, or (PROD) on split operands
 #define WGRAD wgrad_sel<PROD>::template run
 // SAVE: a.attn_save holds what the forward of this step left of the attention (split-product instantiations only)
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false>
+// HEADF: the LAST layer of a training step with the head fused in (satrans_layer_bwd_head): the output rows y this kernel
+// recomputes anyway ARE the layer's forward, a tile holds whole samples, and flatten + Linear + sigmoid + loss + their backward
+// (satrans.py:244-255, meta_basemodel.py:317) are sample-local - so the step needs neither a forward launch for this layer nor
+// the head launches nor the [B,F,D] round trips of y and dy: logit = sum of the sample's token dots (one barrier in the middle
+// of phase C), dy = dlogit * w_head in registers.  `dy` is not read; `hd` carries the head's operands.
+struct FusedHeadArgs {
+    const float* w;            // [F D + n_dense]
+    const float* bias;         // [1]
+    const float* labels;       // [B]
+    const float* dense;        // float matrix holding the dense columns; never null (n_dense == 0: any readable address)
+    int64_t dense_stride;      // (n_dense == 0: 0)
+    int32_t dense_col[2];      // its columns in feature order, by value (no dependent index load in the kernel)
+    int32_t n_dense, loss_kind;
+    float *prob, *logit;       // [B]
+    float* partial;            // [G][F D + n_dense + 2]: per-workgroup g_w | g_b | loss (rows of head_reduce_kernel)
+};
+constexpr int kHeadDenseMax = 2;      // dense columns the fused head carries (Alimama: 1); more -> the separate head launches
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false, bool HEADF = false>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
-                                                                         float* __restrict__ slabs) {
+                                                                         float* __restrict__ slabs, FusedHeadArgs hd) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
     constexpr int HB = (UT + KT - 1) / KT;          // row buffers needed to hold one U-wide operand (<= 2)
     constexpr int NB = (UT < KT) ? UT : KT;          // 16-feature tiles of such an operand held by one row buffer
@@ -573,6 +590,14 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     uint32_t* st_keep = (uint32_t*)take(ntask_max);   // bit j: attention-dropout keep flag of (i, j)   (F <= 32)
     float* sP = take(ntask_max * F);                  // exp(s_ij - max_i), the un-normalised softmax numerators
     float* sDS = take(ntask_max * F);                 // dP_ij, then dS_ij (phases D, E)
+    // HEADF: head weights [F][D], the tile's token dots, per-sample dense terms / loss / dlogit, per-lane head-gradient sums
+    float* s_wh = HEADF ? take(F * D + kHeadDenseMax) : nullptr;
+    float* s_dot = HEADF ? take(64) : nullptr;
+    float* s_dn = HEADF ? take(64) : nullptr;                            // dense-feature term of the logit per sample slot of the tile
+    float* s_fin = HEADF ? take(2 * 64) : nullptr;                       // kernel end: loss / dlogit sums per sample slot
+    float* s_hw = HEADF ? take(kFusedBlock * 4 * KT) : nullptr;          // 4 KT floats per lane: dW_head of the lane's (field, features)
+    float* s_hwd = HEADF ? take(64 * kHeadDenseMax) : nullptr;           // dW of the dense columns per sample slot
+    static_assert(!HEADF || (!SAVE && MOD == 0), "fused head: recomputing backward of a MetaNet layer");
 
     const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
@@ -604,6 +629,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // rows of padding tokens are multiplied by exact zeros in the token-contraction products: they must hold
         // finite numbers from the start (0 * NaN would poison an accumulator)
         for (int i = threadIdx.x; i < 5 * ROWS * LD; i += blockDim.x) sq[i] = 0.f;
+        if constexpr (HEADF) {
+            for (int i = threadIdx.x; i < F * D + hd.n_dense; i += blockDim.x) s_wh[i] = hd.w[i];
+            for (int i = threadIdx.x; i < kFusedBlock * 4 * KT; i += blockDim.x) s_hw[i] = 0.f;
+            for (int i = threadIdx.x; i < 64 * kHeadDenseMax; i += blockDim.x) s_hwd[i] = 0.f;
+            for (int i = threadIdx.x; i < 64; i += blockDim.x) s_dn[i] = 0.f;
+        }
     }
     __syncthreads();
 
@@ -633,6 +664,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     f32x4 acc_wq[KT][KT], acc_wk[KT][KT], acc_wv[KT][KT], acc_wo[KT][KT];
     f32x4 acc_w1q[KT][UT], acc_w2q[UT][KT], acc_w1k[KT][UT], acc_w2k[UT][KT];
     float agq[KT][4], abq[KT][4], agk[KT][4], abk[KT][4], agl[KT][4], abl[KT][4];
+    float head_loss = 0.f, head_gb = 0.f;      // HEADF: loss / dlogit sums of the samples whose (field 0, group 0) lane this is
+    float head_bias = 0.f;
+    if constexpr (HEADF) head_bias = hd.bias[0];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KT; ++i) {
@@ -820,6 +854,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 __builtin_amdgcn_global_load_lds(save_keep + (size_t)first * HF + threadIdx.x, (lds_ptr)(st_keep + 64 * wave), 4, 0, 0);
             }
         }
+        // HEADF: the sample's label and dense columns, consumed in phase C - issued here, raw (see the load pipeline above)
+        float label_pre = 0.f, dense_pre[kHeadDenseMax] = {0.f, 0.f};
+        if constexpr (HEADF) {
+            label_pre = hd.labels[b];
+#pragma unroll
+            for (int j = 0; j < kHeadDenseMax; ++j) dense_pre[j] = hd.dense[(size_t)b * hd.dense_stride + hd.dense_col[j]];
+        }
         const uint32_t key_q = drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b);
         const uint32_t key_k = drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b);
         const uint32_t key_o = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
@@ -950,7 +991,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // the upstream gradient rows of phase C: issued here, a phase ahead (HBM latency under the attention forward); padding
         // lanes read a real row (sample 0 of the tile, field 0) and are masked where the rows are consumed
         float gy_pre[KT][4];
-        if (!has_save) load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy_pre);
+        if constexpr (!HEADF)
+            if (!has_save) load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy_pre);
         // ================= phase B: attention forward; cache numerators, 1/sum and dropout keep bits ===================
         // Scores are staged in the task's row of the numerator cache (pre-scaled by log2(e)/sqrt(d)), keys in chunks of
         // four with all loads of a chunk issued before its results are stored; padding keys of the last chunk read the
@@ -1024,30 +1066,31 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
         STAMP(2);
         // ================= phase C: output block forward + backward ======================================================
+        // out = in x (D x D weight), along the forward direction of the image `f_` or the backward direction (image `b_`)
+        auto prod_dd = [&](float* img, bool back_, const float (&in_)[KT][4], float (&out_)[KT][4]) {
+            if constexpr (PROD) {
+                bf16x8 ih_[KT / 2], il_[KT / 2];
+                split_frag<KT>(in_, ih_, il_);
+                chain_split<KT / 2, KT, KD>(bimg(img) + sl_d, D * KD, ih_, il_, out_);
+            } else if (!back_) {
+                chain<KT, KT, LD>(img + lo_d, in_, out_);
+            } else {
+                if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
+                else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
+            }
+        };
+        float zh[KT][4], gy[KT][4], keep[KT][4];      // normalised output rows, upstream gradient, dropout x ReLU factor of du
+        float rstd_o = 0.f;
+        const float* staged = sDS + ((size_t)(valid ? ls_tok : 0) * F + f) * D + g4;      // (saved attention: this token's dy row)
         if (has_tile) {
-            float o[KT][4], u[KT][4], zh[KT][4], gy[KT][4];
-            const float* staged = sDS + ((size_t)(valid ? ls_tok : 0) * F + f) * D + g4;      // (saved attention: this token's dy row)
+            float o[KT][4], u[KT][4];
             if (has_save) {
                 load_frag<KT>(staged + Tsamp * F * D, o, valid);
                 store_frag<KT>(my_o, o);          // (dWo below reads the wave's o rows from LDS)
             } else {
                 load_frag<KT>(my_o, o);
             }
-            // out = in x (D x D weight), along the forward direction of the image `f_` or the backward direction (image `b_`)
-            auto prod_dd = [&](float* img, bool back_, const float (&in_)[KT][4], float (&out_)[KT][4]) {
-                if constexpr (PROD) {
-                    bf16x8 ih_[KT / 2], il_[KT / 2];
-                    split_frag<KT>(in_, ih_, il_);
-                    chain_split<KT / 2, KT, KD>(bimg(img) + sl_d, D * KD, ih_, il_, out_);
-                } else if (!back_) {
-                    chain<KT, KT, LD>(img + lo_d, in_, out_);
-                } else {
-                    if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
-                    else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
-                }
-            };
             prod_dd(woT, false, o, u);
-            float keep[KT][4];      // multiplicative factor of du: dropout mask times ReLU mask
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1061,13 +1104,89 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     keep[t][r] = kf;
                     u[t][r] = use_res ? val + x[t][r] : val;
                 }
-            float rstd_o;
             layer_norm_keep<KT>(u, zh, rstd_o);
+        }
+        if constexpr (HEADF) {
+            // ---- the head on the rows this tile just recomputed: y = zh gamma + beta is the layer's OUTPUT (satrans.py:98);
+            //      logit_b = sum over the sample's F tokens of y . w_head[f] (+ dense columns + bias), satrans.py:244-255 ----
+            const int ls_c = valid ? ls_tok : 0;
+            if (has_tile) {
+                float pd = 0.f;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 gg = *reinterpret_cast<const float4*>(ln_g + 16 * t + g4);
+                    const float4 bb = *reinterpret_cast<const float4*>(ln_b + 16 * t + g4);
+                    const float4 ww = *reinterpret_cast<const float4*>(s_wh + f * D + 16 * t + g4);
+                    pd = fmaf(zh[t][0] * gg.x + bb.x, ww.x, pd); pd = fmaf(zh[t][1] * gg.y + bb.y, ww.y, pd);
+                    pd = fmaf(zh[t][2] * gg.z + bb.z, ww.z, pd); pd = fmaf(zh[t][3] * gg.w + bb.w, ww.w, pd);
+                }
+                pd = token_sum(pd);
+                if (g == 0) s_dot[row0 + n] = valid ? pd : 0.f;
+                if (hd.n_dense > 0 && valid && f == 0 && g == 0) {
+                    float dn = 0.f;
+#pragma unroll
+                    for (int j = 0; j < kHeadDenseMax; ++j)
+                        if (j < hd.n_dense) dn = fmaf(dense_pre[j], s_wh[F * D + j], dn);
+                    s_dn[ls_c] = dn;
+                }
+            }
+            lds_barrier();
+            if (has_tile) {
+                float z = 0.f;
+                if constexpr (FT != 0) {
+#pragma unroll
+                    for (int f2 = 0; f2 < FT; ++f2) z += s_dot[ls_c * FT + f2];
+                } else {
+                    for (int f2 = 0; f2 < F; ++f2) z += s_dot[ls_c * F + f2];
+                }
+                z = (z + s_dn[ls_c]) + head_bias;
+                const float pr = 1.0f / (1.0f + expf(-z));
+                const float tl = label_pre;
+                const float pq = (1.0f - pr) * pr;
+                float dl, lossv;
+                if (hd.loss_kind == SATRANS_LOSS_MSE) {            // F.mse_loss(reduction='sum')
+                    lossv = (pr - tl) * (pr - tl);
+                    dl = 2.0f * (pr - tl) * pq;
+                } else if (hd.loss_kind == SATRANS_LOSS_MAE) {     // F.l1_loss(reduction='sum')
+                    lossv = fabsf(pr - tl);
+                    dl = (pr > tl ? 1.0f : (pr < tl ? -1.0f : 0.0f)) * pq;
+                } else {                                           // binary_cross_entropy: both logs clamped at -100 (as head_kernel)
+                    const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(logf(1.0f - pr), -100.f);
+                    lossv = -(tl * lp + (1.0f - tl) * lq);
+                    dl = (pr - tl) / fmaxf(pq, 1e-12f) * pq;
+                }
+                if (!valid) dl = 0.f;
+                if (valid && f == 0 && g == 0) {                   // one lane per sample: outputs and the per-workgroup sums
+                    hd.prob[b] = pr;
+                    if (hd.logit) hd.logit[b] = z;
+                    head_loss += lossv;
+                    head_gb += dl;
+#pragma unroll
+                    for (int j = 0; j < kHeadDenseMax; ++j)
+                        if (j < hd.n_dense) s_hwd[ls_c * kHeadDenseMax + j] = fmaf(dl, dense_pre[j], s_hwd[ls_c * kHeadDenseMax + j]);
+                }
+                // dy = dlogit w_head[f] (never leaves the registers); dW_head[f] += dlogit y in this lane's own LDS slots
+                float* hw = s_hw + (size_t)threadIdx.x * 4 * KT;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    const float4 gg = *reinterpret_cast<const float4*>(ln_g + 16 * t + g4);
+                    const float4 bb = *reinterpret_cast<const float4*>(ln_b + 16 * t + g4);
+                    const float4 ww = *reinterpret_cast<const float4*>(s_wh + f * D + 16 * t + g4);
+                    float4 ac = *reinterpret_cast<float4*>(hw + 4 * t);
+                    ac.x = fmaf(dl, zh[t][0] * gg.x + bb.x, ac.x); ac.y = fmaf(dl, zh[t][1] * gg.y + bb.y, ac.y);
+                    ac.z = fmaf(dl, zh[t][2] * gg.z + bb.z, ac.z); ac.w = fmaf(dl, zh[t][3] * gg.w + bb.w, ac.w);
+                    *reinterpret_cast<float4*>(hw + 4 * t) = ac;
+                    gy[t][0] = dl * ww.x; gy[t][1] = dl * ww.y; gy[t][2] = dl * ww.z; gy[t][3] = dl * ww.w;
+                }
+            }
+        } else if (has_tile) {
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gy[t][r] = valid ? gy_pre[t][r] : 0.f;
             if (has_save) load_frag<KT>(staged, gy, valid);
+        }
+        if (has_tile) {
             layer_norm_bwd<KT>(gy, zh, rstd_o, ln_g, g4, agl, abl);          // gy is now dr
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -1469,6 +1588,40 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         flush_ln(agq, abq, 4 * D * D + 2 * D);
         flush_ln(agk, abk, 4 * D * D + 4 * D);
     }
+    if constexpr (HEADF) {
+        // ---- the head's gradients and the loss of this workgroup's samples: one row [g_w (F D + n_dense) | g_b | loss] per
+        //      workgroup, added up in workgroup order by head_reduce_kernel (fixed order: bitwise reproducible) ------------
+        const int ncol = F * D + hd.n_dense;
+        float* prow = hd.partial + (size_t)blockIdx.x * (ncol + 2);
+        if (idle) {
+            for (int c = threadIdx.x; c < ncol + 2; c += kFusedBlock) prow[c] = 0.f;
+        } else {
+            const int tok_ = 16 * wave + n, ls_ = tok_ / F;
+            if (g == 0 && tok_ - ls_ * F == 0 && ls_ < Tsamp) { s_fin[ls_] = head_loss; s_fin[64 + ls_] = head_gb; }
+            __syncthreads();
+            for (int e = threadIdx.x; e < F * D; e += kFusedBlock) {
+                const int f_ = e / D, feat = e - f_ * D;
+                const int t_ = feat >> 4, g_ = (feat & 15) >> 2, r_ = feat & 3;
+                float acc = 0.f;
+                for (int ls = 0; ls < Tsamp; ++ls) {             // the sample slots of a tile, in slot order
+                    const int tk = ls * F + f_;
+                    if (tk < 64) acc += s_hw[(size_t)((tk >> 4) * 64 + g_ * 16 + (tk & 15)) * 4 * KT + 4 * t_ + r_];
+                }
+                prow[e] = acc;
+            }
+            if ((int)threadIdx.x < hd.n_dense) {
+                float acc = 0.f;
+                for (int ls = 0; ls < Tsamp; ++ls) acc += s_hwd[ls * kHeadDenseMax + threadIdx.x];
+                prow[F * D + threadIdx.x] = acc;
+            }
+            if (threadIdx.x == 0) {
+                float gb = 0.f, lsum = 0.f;
+                for (int ls = 0; ls < Tsamp; ++ls) { lsum += s_fin[ls]; gb += s_fin[64 + ls]; }
+                prow[ncol] = gb;
+                prow[ncol + 1] = lsum;
+            }
+        }
+    }
 }
 
 
@@ -1663,14 +1816,16 @@ extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc
 
 namespace satrans {
 
-static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr, bool split = false) {
+static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr, bool split = false, bool head = false) {
     const int LD = D + 4, LU = U + 4;
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
     const int64_t tasks = (int64_t)T * H * F;
     const int copies = (tr || split) ? 2 : 1;         // forward images, and their transposes when they fit
     const int64_t dd = split ? (int64_t)D * (D + 8) : (int64_t)D * LD;
     const int64_t mlp = split ? (int64_t)U * (D + 8) + (int64_t)D * (U + 8) : (int64_t)D * LU + (int64_t)U * LD;
-    return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + 64;
+    // (fused head: head weights, token dots, dense terms, final sums, per-lane and per-slot gradient sums - the kernel's take() calls)
+    const int64_t hd = head ? r4((int64_t)F * D + kHeadDenseMax) + 64 + 64 + 128 + (int64_t)kFusedBlock * 4 * (D / 16) + 64 * kHeadDenseMax : 0;
+    return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + hd + 64;
 }
 
 // MetaNet width the fused kernels are INSTANTIATED with for an embedding dim (U = 2 D; forward-only D = 64: 16).  With a MetaNet
@@ -1685,7 +1840,7 @@ struct FusedBwdPlan {
     bool split;   // split products (both directions of every weight as bf16 hi / lo images)
 };
 
-static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
+static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p, bool head = false) {
     if (!satrans_layer_fused_supported(d) || d->D > 32 || d->F > 32) return false;   // keep bits: one 32-bit word per row
     const bool same_tab = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;   // (as satrans_layer_bwd_fused picks SAME)
     p.T = 64 / d->F;
@@ -1699,24 +1854,26 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p) {
     p.split = product_mode() == 1 && !p.tr && same_tab && d->D == 32 && d->U == 64 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) &&
               (d->flags & (SATRANS_META_Q | SATRANS_META_K)) &&
               (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, false, true) * 4 <= 160 * 1024;
-    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, p.tr, p.split) * 4;
+    if (head) p.split = false;      // the fused-head instantiations are fp32-product ones (split products fill the LDS on their own)
+    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, p.tr, p.split, head) * 4;
     if (p.lds > 160 * 1024) return false;
     const int64_t tiles = ceil_div(d->B, p.T) + d->S;
     p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
     return true;
 }
 
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false, bool HEADF = false>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
-                      hipStream_t stream) {
+                      hipStream_t stream, const FusedHeadArgs* hd = nullptr) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
-    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE><<<p.G, kFusedBlock, p.lds, stream>>>(*d, p.T, dy, dx, slabs);
+    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF><<<p.G, kFusedBlock, p.lds, stream>>>(
+        *d, p.T, dy, dx, slabs, hd ? *hd : FusedHeadArgs{});
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1796,6 +1953,22 @@ extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc*
     return n;
 }
 
+static int launch_fused_reduce(const satrans_layer_desc* d, const FusedBwdPlan& p, float* slabs, float* g_wq, float* g_wk,
+                               float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q, float* g_tab_k,
+                               hipStream_t stream) {
+    const int D = d->D, U = fused_width(d), CSZ = 4 * D * D + 6 * D;      // (record stride: the kernel's template width)
+    float* records = slabs + (size_t)p.G * CSZ;
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K | SATRANS_BILINEAR);
+    const int row_elems = (d->flags & SATRANS_GATE) ? D : ((d->flags & SATRANS_BILINEAR) ? D * (D / d->H) : 2 * D * U);
+    SATRANS_REQUIRE(!meta || g_tab_q, SATRANS_E_BADARG, "layer_bwd: null generated-row gradient");
+    const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(row_elems, 32);
+    fused_reduce_kernel<<<(unsigned)(common_blocks + (meta ? record_blocks * d->S : 0)), 32 * kRG, 0, stream>>>(
+        slabs, records, d->seg, d->S, p.T, p.G, D, U, d->H, d->flags, d->tab_stride, common_blocks, record_blocks, g_wq, g_wk, g_wv,
+        g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
+    SATRANS_CHECK_LAUNCH("fused_reduce_kernel");
+    return SATRANS_OK;
+}
+
 extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
                                        float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk,
                                        float* g_tab_q, float* g_tab_k, void* stream_) {
@@ -1838,17 +2011,63 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
                    : launch_bwd<16, 32, 2, false, false>(d, p, dy, dx, slabs, stream);
     }
     if (rc) return rc;
-    const int D = d->D, U = fused_width(d), CSZ = 4 * D * D + 6 * D;      // (record stride: the kernel's template width)
-    float* records = slabs + (size_t)p.G * CSZ;
-    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K | SATRANS_BILINEAR);
-    const int row_elems = (d->flags & SATRANS_GATE) ? D : ((d->flags & SATRANS_BILINEAR) ? D * (D / d->H) : 2 * D * U);
-    SATRANS_REQUIRE(!meta || g_tab_q, SATRANS_E_BADARG, "layer_bwd: null generated-row gradient");
-    const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(row_elems, 32);
-    fused_reduce_kernel<<<(unsigned)(common_blocks + (meta ? record_blocks * d->S : 0)), 32 * kRG, 0, stream>>>(
-        slabs, records, d->seg, d->S, p.T, p.G, D, U, d->H, d->flags, d->tab_stride, common_blocks, record_blocks, g_wq, g_wk, g_wv,
-        g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k);
-    SATRANS_CHECK_LAUNCH("fused_reduce_kernel");
-    return SATRANS_OK;
+    return launch_fused_reduce(d, p, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
+}
+
+// ---- last layer of a training step with the head fused in (include/satrans_hip.h: satrans_layer_bwd_head) ---------------------
+extern "C" int satrans_head_reduce_partials(const float* partial, int nblk, int ncol, float* g_w, float* g_b, double* loss_sum,
+                                            void* stream);
+
+extern "C" int satrans_layer_bwd_head_fused_supported(const satrans_layer_desc* d, const satrans_head_desc* h) {
+    FusedBwdPlan p;
+    if (!d || !h) return 0;
+    if (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) return 0;
+    if (!(d->D == 32 || d->D == 16)) return 0;
+    if (h->n_dense < 0 || h->n_dense > kHeadDenseMax) return 0;
+    return fused_bwd_plan(d, p, true) ? 1 : 0;
+}
+
+extern "C" int64_t satrans_layer_bwd_head_scratch_floats_fused(const satrans_layer_desc* d, int n_dense) {
+    FusedBwdPlan p;
+    if (!d || !fused_bwd_plan(d, p, true)) return -1;
+    return (int64_t)p.G * ((int64_t)d->F * d->D + n_dense + 2);
+}
+
+extern "C" int satrans_layer_bwd_head_fused(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs,
+                                            float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
+                                            float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FusedBwdPlan p;
+    SATRANS_REQUIRE(dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd_head: null pointer");
+    SATRANS_REQUIRE(h->w && h->bias && h->labels && h->prob && h->loss_sum && h->g_w && h->g_b && h->scratch, SATRANS_E_BADARG,
+                    "layer_bwd_head: null head pointer");
+    SATRANS_REQUIRE(h->n_dense == 0 || (h->dense && h->h_dense_cols), SATRANS_E_BADARG, "layer_bwd_head: dense columns without a matrix");
+    SATRANS_REQUIRE(h->loss_kind >= SATRANS_LOSS_BCE && h->loss_kind <= SATRANS_LOSS_MAE, SATRANS_E_BADARG, "layer_bwd_head: loss kind %d", h->loss_kind);
+    SATRANS_REQUIRE(satrans_layer_bwd_head_fused_supported(d, h) && fused_bwd_plan(d, p, true), SATRANS_E_UNSUPPORTED,
+                    "layer_bwd_head: shape not built");
+    SATRANS_REQUIRE((int64_t)d->B * d->F < ((int64_t)1 << 31), SATRANS_E_UNSUPPORTED, "layer_bwd_head: B * F must stay below 2^31");
+    FusedHeadArgs hd;
+    hd.w = h->w; hd.bias = h->bias; hd.labels = h->labels;
+    hd.dense = h->n_dense ? h->dense : h->labels;               // (n_dense == 0: element 0 of a readable array, multiplied by nothing)
+    hd.dense_stride = h->n_dense ? h->dense_stride : 0;
+    for (int j = 0; j < kHeadDenseMax; ++j) hd.dense_col[j] = h->n_dense ? h->h_dense_cols[std::min(j, h->n_dense - 1)] : 0;
+    hd.n_dense = h->n_dense; hd.loss_kind = h->loss_kind;
+    hd.prob = h->prob; hd.logit = h->logit; hd.partial = h->scratch;
+    const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
+    static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
+    int rc;
+    if (d->D == 32 && same && d->F == 19 && f_const)
+        rc = launch_bwd<32, 64, 4, true, false, 19, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+    else if (d->D == 32)
+        rc = same ? launch_bwd<32, 64, 4, true, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                  : launch_bwd<32, 64, 4, false, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+    else
+        rc = same ? launch_bwd<16, 32, 2, true, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                  : launch_bwd<16, 32, 2, false, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+    if (rc) return rc;
+    rc = launch_fused_reduce(d, p, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
+    if (rc) return rc;
+    return satrans_head_reduce_partials(h->scratch, p.G, d->F * d->D + h->n_dense, h->g_w, h->g_b, h->loss_sum, stream_);
 }
 
 #ifdef SATRANS_STAMPS

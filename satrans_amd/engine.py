@@ -116,6 +116,7 @@ class PathEngine:
         for c in dense:
             dcols += list(range(fi[c.name][0], fi[c.name][1]))
         self.n_dense = len(dcols)
+        self._dense_cols_host = list(dcols)
         self.dense_cols = torch.tensor(dcols, dtype=torch.int32, device=self.dev) if dcols else None
         self.dom_col = fi[m.domain_column_list[0]][0]
         if self.multi:
@@ -179,6 +180,9 @@ class PathEngine:
         # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
         # standalone gather kernel + activation buffer, as in round 1
         self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
+        # the last layer of a training step as one launch with the head fused in (satrans_layer_bwd_head): no forward launch
+        # for that layer, no head launches, no [B,F,D] round trip of its output and gradient; SATRANS_FUSE_HEAD=0: separate calls
+        self.fuse_head = os.environ.get("SATRANS_FUSE_HEAD", "1") != "0"
         # SATRANS_SAVE_ATTENTION=1: the forward of a training step leaves the attention's softmax numerators / statistics /
         # output for its backward, which then copies them into LDS instead of recomputing them.  Measured:
         # backward 216 -> 200 us, forward 63 -> 73 us per layer, the step does not move, +72 MB per layer at B = 8192: off by default.
@@ -268,8 +272,12 @@ class PathEngine:
         n_max = max(n_loc, n_big)
         if "dact" not in ws:                                    # independent of the rank count: allocated once
             ws["dact"] = [torch.empty(B, F, D, **f32) for _ in range(2)]
-            ws["head_scratch"] = torch.empty(int(lib.satrans_head_scratch_floats(B, F * D, self.n_dense)), **f32)
             desc = self._layer_desc(ws, 0, B, None, None, True)
+            # partial rows of the head's weight gradient: one per 8 samples (head_kernel) or one per workgroup of the fused
+            # last-layer step (satrans_layer_bwd_head), whichever is more
+            n_head = max(int(lib.satrans_head_scratch_floats(B, F * D, self.n_dense)),
+                         int(lib.satrans_layer_bwd_head_scratch_floats(C.byref(desc), self.n_dense)))
+            ws["head_scratch"] = torch.empty(n_head, **f32)
             if ws["generic"]:
                 n = int(lib.satrans_layer_generic_saved_floats(C.byref(desc)))
                 while len(ws["gen_saved"]) < self.L:            # one per layer
@@ -446,7 +454,7 @@ class PathEngine:
             raise NotImplementedError("integer id matrix together with dense features: pass inputs.PackedInput(ids, dense)")
         return X
 
-    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False):
+    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False, n_layers=None):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         sx, sidt, sstride, scol = X, idt, X.stride(0), self.dom_col
@@ -467,7 +475,7 @@ class PathEngine:
                                                self.status.data_ptr(), st), "satrans_gather_fwd")
         self._last_X = X
         self._stepped_since_forward = False
-        for l in range(self.L):
+        for l in range(self.L if n_layers is None else n_layers):
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn)
             att = att_list[l].data_ptr() if att_list is not None else None
             with self.phase("layer_fwd"):
@@ -504,6 +512,46 @@ class PathEngine:
                                           ws["prob"].data_ptr(), ws["logit"].data_ptr(), y.data_ptr(),
                                           self.loss_sum.data_ptr(), ws["dact"][0].data_ptr(), gw.data_ptr(), gb.data_ptr(),
                                           ws["head_scratch"].data_ptr(), kind, st), "satrans_head_loss")
+
+    def _head_desc(self, X, ws, y) -> N.HeadDesc:
+        """Head operands of satrans_layer_bwd_head (the last layer of a training step with the head fused in)."""
+        m = self.m
+        h = N.HeadDesc()
+        h.w, h.bias = m.dnn_linear.weight.data_ptr(), m.dnn_linear.bias.data_ptr()
+        h.labels = y.data_ptr() if y is not None else None
+        h.n_dense = self.n_dense
+        h.dense, h.dense_stride, h.h_dense_cols = None, 0, None
+        if self.n_dense:
+            if getattr(self, "_dense_override", None) is not None:
+                h.dense, h.dense_stride = self._dense_override.data_ptr(), self._dense_override.stride(0)
+                cols = list(range(self.n_dense))
+            else:
+                h.dense, h.dense_stride = X.data_ptr(), X.stride(0)
+                cols = self._dense_cols_host
+            self._head_cols_keep = (C.c_int32 * len(cols))(*cols)          # (kept alive until the call returns)
+            h.h_dense_cols = self._head_cols_keep
+        h.loss_kind = {"binary_crossentropy": 0, "mse": 1, "mae": 2}[getattr(m, "loss_func", "binary_crossentropy")]
+        h.prob, h.logit = ws["prob"].data_ptr(), ws["logit"].data_ptr()
+        h.loss_sum = self.loss_sum.data_ptr()
+        if self.flat_g is not None:
+            h.g_w, h.g_b = self._grad_view("dnn_linear.weight").data_ptr(), self._grad_view("dnn_linear.bias").data_ptr()
+        h.scratch = ws["head_scratch"].data_ptr() if "head_scratch" in ws else None
+        return h
+
+    def _fuse_head(self, X, ws, B) -> bool:
+        """Whether this step runs its last layer as ONE launch with the head fused in (satrans_layer_bwd_head): the fused
+        kernels, fp32 products for that layer, at most two dense columns.  SATRANS_FUSE_HEAD=0: the three separate calls."""
+        key = "fuse_head"
+        if key not in ws:
+            ok = self.fuse_head and not ws["generic"] and self.L >= 1
+            if ok:
+                desc = self._layer_desc(ws, self.L - 1, B, None, None, True)
+                ok = bool(self.lib.satrans_layer_bwd_head_supported(C.byref(desc), C.byref(self._head_desc(X, ws, None))))
+                if ok:
+                    need = int(self.lib.satrans_layer_bwd_head_scratch_floats(C.byref(desc), self.n_dense))
+                    ok = 0 <= need <= ws["head_scratch"].numel()
+            ws[key] = ok
+        return ws[key]
 
     def forward(self, X: torch.Tensor, training: bool = False, capture_attention: bool = False) -> torch.Tensor:
         self.flush_lazy()
@@ -665,13 +713,17 @@ class PathEngine:
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
         tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
-        self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready, save_attn=True)
-        with self.phase("head"):
-            self._head(X, ws, y)
+        fuse_head = self._fuse_head(X, ws, B)
+        self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready, save_attn=True,
+                          n_layers=self.L - 1 if fuse_head else None)
+        if not fuse_head:
+            with self.phase("head"):
+                self._head(X, ws, y)
         cur = 0
         for l in reversed(range(self.L)):
+            head_here = fuse_head and l == self.L - 1
             desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather or self._x_src is not None,
-                                    attn_save=True)
+                                    attn_save=not head_here)
             lay = f"domain_int_layers.{l}."
             gq = gk = glnq = glnk = None
             if modulated:
@@ -691,6 +743,16 @@ class PathEngine:
                         self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
                         self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
                         self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd_generic")
+                cur = 1 - cur
+                continue
+            if head_here:
+                # layer L-1 forward (recomputed) + head + loss + their backward: one launch, the layer's output never leaves the CU
+                with self.phase("layer_bwd_head"):
+                    N.check(lib.satrans_layer_bwd_head(
+                        C.byref(desc), C.byref(self._head_desc(X, ws, y)), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),
+                        self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
+                        self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
+                        self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd_head")
                 cur = 1 - cur
                 continue
             with self.phase("layer_bwd"):

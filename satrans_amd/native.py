@@ -42,6 +42,13 @@ class LayerDesc(C.Structure):
     ]
 
 
+class HeadDesc(C.Structure):
+    """Mirror of `satrans_head_desc` (the head operands of satrans_layer_bwd_head)."""
+    _fields_ = [("w", _vp), ("bias", _vp), ("labels", _vp), ("dense", _vp), ("dense_stride", C.c_int64),
+                ("h_dense_cols", C.POINTER(C.c_int32)), ("n_dense", C.c_int32), ("loss_kind", C.c_int32),
+                ("prob", _vp), ("logit", _vp), ("loss_sum", _vp), ("g_w", _vp), ("g_b", _vp), ("scratch", _vp)]
+
+
 class SelfAttDesc(C.Structure):
     """Mirror of `satrans_selfatt_desc`."""
     _fields_ = [("B", C.c_int32), ("F", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("flags", C.c_int32),
@@ -100,6 +107,10 @@ SIGNATURES = {
     "satrans_batch_metrics": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "satrans_layer_bwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp]),
+    "satrans_layer_bwd_head_supported": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(HeadDesc)]),
+    "satrans_layer_bwd_head_scratch_floats": (C.c_int64, [C.POINTER(LayerDesc), C.c_int]),
+    "satrans_layer_bwd_head": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(HeadDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp]),
     "satrans_head_scratch_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "satrans_head": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp]),

@@ -28,14 +28,16 @@ def split_products() -> bool:
     return native.lib().satrans_get_product_mode() == 1
 
 
-def assert_close_but_for_kinks(got, want, rtol, atol, err_msg, frac=5e-4, slack=20.0):
-    """assert_allclose, except that under split products a fraction `frac` of the elements may sit up to `slack` x outside it.
+def assert_close_but_for_kinks(got, want, rtol, atol, err_msg, frac=5e-4, slack=20.0, kinks=None):
+    """assert_allclose, except that a fraction `frac` of the elements may sit up to `slack` x outside it - under split products,
+    and with fp32 products only when the ORACLE saw MetaNet hidden units within fp32 rounding of the ReLU's kink on these very
+    inputs (`kinks` > 0: the count of O.KINK_PROBE; at B = 8,192 a step evaluates 6e7 hidden units and a few of them always are).
     A ReLU whose pre-activation is within the products' error of zero takes the other branch than the oracle's: the gradient
     of the one sample involved then changes by O(1) of that sample's share, which an element-wise bound at 1e-4 of the
     largest entry sees in the table rows that sample touched.  With fp32 products (error ~1e-7) 8,192 samples x 2 x 64 hidden
     units x 19 fields almost never hold such a unit, with split products (~1e-5 near a kink) a handful do: measured 29 of
     259,744 elements of one table's exp_avg, the largest 9e-4 of the tensor's largest entry."""
-    if not split_products():
+    if not split_products() and not kinks:
         np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=err_msg)
         return
     err = np.abs(got - want)
@@ -61,20 +63,33 @@ def softmax_side_floor(key, grads, floor):
     return floor
 
 
-def assert_grad_close_but_for_kinks(got, want, atol, err_msg, frac=0.02, outlier=0.05):
+def oracle_grads_probing_kinks(state, X, y, spec, drop=None, eps=2e-6):
+    """O.loss_and_grads plus the number of MetaNet hidden units whose pre-activation the oracle saw within `eps` (relative to the
+    largest pre-activation of its product) of the ReLU's kink: fp32 products of 32 / 64 terms differ by a few 1e-7 of that
+    scale between two evaluation orders, so only such a unit can take one branch in the kernels and the other in the oracle."""
+    O.KINK_PROBE = {"eps": eps, "near_zero": 0}
+    try:
+        out = O.loss_and_grads(state, X, y, spec, drop)
+        return out, int(O.KINK_PROBE["near_zero"])
+    finally:
+        O.KINK_PROBE = None
+
+
+def assert_grad_close_but_for_kinks(got, want, atol, err_msg, frac=0.02, outlier=0.05, kinks=None):
     """Gradient comparison of a TRAINING-mode step against the oracle (replayed dropout masks).  Element by element within `atol`,
-    except that a MetaNet ReLU on its kink may have taken the other branch than the oracle's: one hidden unit of one token then
+    except where a MetaNet ReLU on its kink may have taken the other branch than the oracle's: one hidden unit of one token then
     contributes - or does not - to the rows / columns of the generated-weight gradient it touches and to everything downstream
     of them (measured: 440 of 131,072 elements of the scenario encoder's weight gradient, the largest 1.5 % of the tensor's
-    largest entry).  Any two evaluation orders do this to each other; with split products (~1e-5 near a kink instead of ~1e-7)
-    a step over 10^5 hidden units holds such a unit more often than not.  So, UNDER SPLIT PRODUCTS ONLY: at most `frac` of a
-    tensor's elements outside `atol`, none of them by more than `outlier` of the tensor's largest entry.  With fp32 products
-    (the default, the reference's arithmetic) the bound is element-wise, as it was before split products existed."""
+    largest entry).  The exception - at most `frac` of a tensor's elements outside `atol`, none of them by more than `outlier`
+    of the tensor's largest entry - is granted
+      * under split products (product error ~1e-5 near a kink: a step over 10^5 hidden units holds such a unit more often than not);
+      * with fp32 products (the default, the reference's arithmetic) ONLY when the oracle itself saw a hidden unit within fp32
+        rounding of the kink on these very inputs (`kinks` = the count of oracle_grads_probing_kinks; None / 0: element-wise)."""
     err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
     bad = err > atol
     if not bad.any():
         return
-    if not split_products():
+    if not split_products() and not kinks:
         np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), rtol=0, atol=atol,
                                    err_msg=err_msg)
     assert float(bad.mean()) <= frac, (err_msg, "fraction outside the bound", float(bad.mean()))
@@ -239,7 +254,9 @@ def _trained_aliccp_model(steps=120, B=8192, rows_cap=20000, seed=5):
 
 # measured on an MI355X (printed by the test; bounds = ~2x the measurement): {mode: (logit bound, gradient bound as a fraction
 # of the tensor's largest entry)}
-TRAINED_BOUNDS = {0: (1e-5, 1e-4), 1: (2e-4, 1e-3)}
+# measured: fp32 products logit 1.6e-6, worst gradient 4.2e-6; split products logit 4.3e-6 on these weights (7.7e-5 on another
+# run's: heavy-tailed), worst gradient 4.4e-4
+TRAINED_BOUNDS = {0: (1e-5, 5e-5), 1: (2e-4, 1e-3)}
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["fp32-products", "split-products"])
@@ -277,7 +294,7 @@ def test_trained_weights_regime_against_the_oracle(mode):
         bce, reg, grads = eng.loss_and_grads(Xb.to(DEV), yb.to(DEV))
         masks = O.dropout_masks(eng.drop_seed, eng.drop_step, B, 19, 32, 4, 3, 0.1)
         sd64 = sd_aliased(model, torch.float64)
-        bce_ref, reg_ref, g_ref = O.loss_and_grads(sd64, Xb, yb, spec, O.Dropper("masks", 0.1, masks))
+        (bce_ref, reg_ref, g_ref), kinks = oracle_grads_probing_kinks(sd64, Xb, yb, spec, O.Dropper("masks", 0.1, masks))
         worst, worst_key = 0.0, None
         for k, g in g_ref.items():
             if k in grads and float(g.abs().max()) > 1e-7:
@@ -293,7 +310,7 @@ def test_trained_weights_regime_against_the_oracle(mode):
             if k in grads:
                 sc = max(1e-6, float(g.abs().max()))
                 assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), gb * sc + softmax_side_floor(k, g_ref, 1e-8),
-                                                f"{k} (trained weights, mode {mode})")
+                                                f"{k} (trained weights, mode {mode})", kinks=kinks)
     _with_product_mode(mode, body)
 
 
@@ -724,7 +741,7 @@ def test_training_mode_gradients_match_oracle_with_same_masks(name):
     bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
     m = c.meta
     masks = O.dropout_masks(eng.drop_seed, eng.drop_step, c.X.shape[0], len(m["fields"]), m["D"], m["H"], m["L"], 0.1)
-    bce_ref, reg_ref, g_ref = O.loss_and_grads(c.tensors("param"), c.X, c.y, c.spec(), O.Dropper("masks", 0.1, masks))
+    (bce_ref, reg_ref, g_ref), kinks = oracle_grads_probing_kinks(c.tensors("param"), c.X, c.y, c.spec(), O.Dropper("masks", 0.1, masks))
     assert bce == pytest.approx(bce_ref, rel=2e-6)
     assert set(grads) <= set(g_ref)
     for k, g in g_ref.items():
@@ -733,7 +750,37 @@ def test_training_mode_gradients_match_oracle_with_same_masks(name):
         scale = max(1e-6, float(g.abs().max()))
         # fp32 products: element by element.  Split products: the same bound but for ReLU kinks (assert_grad_close_but_for_kinks)
         floor = softmax_side_floor(k, g_ref, 1e-9) if split_products() else 1e-9
-        assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), 5e-5 * scale + floor, k)
+        assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), 5e-5 * scale + floor, k, kinks=kinks)
+
+
+@pytest.mark.parametrize("loss", ["binary_crossentropy", "mse", "mae"])
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_qkv", "small_pos_dense", "small_relu", "small_k"])
+def test_fused_last_layer_and_head_equal_the_separate_calls(name, train, loss):
+    """satrans_layer_bwd_head (last layer forward + head + loss + backward in one launch; the default of a training step) against
+    satrans_layer_fwd + satrans_head_loss + satrans_layer_bwd on the same batch, weights and dropout counters: probabilities,
+    loss and every gradient.  The two differ only in the order the logit's F x D terms are added (token dots summed per sample
+    against a lane-strided sum), i.e. by fp32 rounding of the logit.  Covers dense columns (Alimama), D = 16, separate Q / K
+    tables ('pos'), ReLU output, one modulated role, and the three losses of compile()."""
+    c = Case(name)
+    out = []
+    for fuse in (True, False):
+        model = build_model(c, DEV)
+        model.compile("adam", loss)
+        model.train(train)
+        eng = model._require_engine()
+        eng.fuse_head = fuse
+        X, y = c.X.to(DEV), c.y.to(DEV)
+        bce, reg, grads = eng.loss_and_grads(X, y)
+        assert bool(eng._ws[X.shape[0]]["fuse_head"]) == fuse, "the fused last-layer step was expected to take every one of these cases"
+        out.append((bce, eng.last_prob().clone().cpu(), {k: g.cpu() for k, g in grads.items()}))
+    (b1, p1, g1), (b0, p0, g0) = out
+    assert b1 == pytest.approx(b0, rel=2e-6)
+    np.testing.assert_allclose(p1.numpy(), p0.numpy(), rtol=0, atol=3e-7)
+    for k in g0:
+        sc = max(1e-6, float(g0[k].abs().max()))
+        # MAE: d|p - t| / dp = sign(p - t) is discontinuous where p == t; no golden label sits there
+        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=2e-5 * sc + 1e-9, err_msg=k)
 
 
 def test_gather_bit_exact_and_out_of_range_ids():
@@ -1058,14 +1105,14 @@ def test_general_layer_path_matches_golden_and_the_oracle(monkeypatch, name):
         # (the oracle in fp64: W_Query / W_Key gradients are differences of nearly equal softmax terms, 1e-3 of the other tensors'
         # scale, and an fp32 oracle carries as much cancellation noise in them as the kernels do - which of the two a 1e-4 bound
         # then measures depends on the mask realisation)
-        bce_ref, reg_ref, g_ref = O.loss_and_grads(c.tensors("param", torch.float64), X, y, c.spec(), drop)
+        (bce_ref, reg_ref, g_ref), kinks = oracle_grads_probing_kinks(c.tensors("param", torch.float64), X, y, c.spec(), drop)
         assert bce == pytest.approx(bce_ref, rel=5e-6)
         for k, g in g_ref.items():
             if k in grads:
                 scale = max(1e-6, float(g.abs().max()))
                 if train:
                     assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), 1e-4 * scale + softmax_side_floor(k, g_ref, 5e-9),
-                                                    f"{k} B={B} train={train}")
+                                                    f"{k} B={B} train={train} (oracle: {kinks} hidden units on the kink)", kinks=kinks)
                 else:
                     np.testing.assert_allclose(grads[k].cpu().numpy().astype(np.float64), g.numpy(), rtol=0, atol=1e-4 * scale + 5e-9,
                                                err_msg=f"{k} B={B} train={train}")
@@ -1262,7 +1309,13 @@ def test_teacher_forced_step_at_the_baseline_batch_on_full_size_tables():
         if st is not None:
             tr.optim.state[leaf] = dict(step=torch.tensor(2.0), exp_avg=st["exp_avg"].clone(), exp_avg_sq=st["exp_avg_sq"].clone())
     before = {k: leaf.detach().clone() for k, leaf in tr.leaves.items()}
-    bce_ref, reg_ref = tr.step(torch.from_numpy(X[2 * B:]), torch.from_numpy(y[2 * B:]))
+    O.KINK_PROBE = {"eps": 2e-6, "near_zero": 0}      # hidden units of THIS step within fp32 rounding of the ReLU's kink
+    try:
+        bce_ref, reg_ref = tr.step(torch.from_numpy(X[2 * B:]), torch.from_numpy(y[2 * B:]))
+        kinks = int(O.KINK_PROBE["near_zero"])
+    finally:
+        O.KINK_PROBE = None
+    print(f"oracle step at B = {B}: {kinks} MetaNet hidden units within 2e-6 of the kink")
     eng.reset_epoch_sums()
     eng.train_step(Xd[2 * B:], yd[2 * B:])
     bce, reg = eng.epoch_sums()
@@ -1291,9 +1344,9 @@ def test_teacher_forced_step_at_the_baseline_batch_on_full_size_tables():
             if rm.numel() == 0:
                 continue
             assert_close_but_for_kinks(gm.numpy(), rm.numpy(), rtol=1e-5, atol=1e-4 * float(rm.abs().max()) + 1e-30,
-                                       err_msg=f"exp_avg/{k} ({what} rows)")
+                                       err_msg=f"exp_avg/{k} ({what} rows)", kinks=kinks)
             assert_close_but_for_kinks(gv.numpy(), rv.numpy(), rtol=1e-5, atol=2e-4 * float(rv.abs().max()) + 1e-30,
-                                       err_msg=f"exp_avg_sq/{k} ({what} rows)")
+                                       err_msg=f"exp_avg_sq/{k} ({what} rows)", kinks=kinks)
             delta = (got[k][sel] - leaf.detach()[sel]).abs()
             vhat = rv / (1 - 0.999 ** 3)
             ok = vhat.sqrt() > 1e-4 * max(float(vhat.sqrt().max()), 1e-30)
@@ -1934,7 +1987,7 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
         bce, reg, grads = eng.loss_and_grads(Xg.to(DEV), yt.to(DEV))
         assert bool(eng._ws[B]["generic"]) == generic, "unexpected layer path"
         drop = O.Dropper("masks", 0.1, O.dropout_masks(eng.drop_seed, eng.drop_step, B, F, D, H, L, 0.1)) if train else None
-        bce_ref, reg_ref, g_ref = O.loss_and_grads(state, Xt, yt, spec, drop)
+        (bce_ref, reg_ref, g_ref), kinks = oracle_grads_probing_kinks(state, Xt, yt, spec, drop)
         if not train:
             model(Xg.to(DEV))
             _, logit_ref = O.forward(state, Xt, spec)
@@ -1955,7 +2008,8 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
                     assert float(err.max()) <= 10 * grad_tol * scale + 1e-8, (k, train, float(err.max()), scale)
                     continue
                 if train:
-                    assert_grad_close_but_for_kinks(got_g, want_g, grad_tol * scale + softmax_side_floor(k, g_ref, 1e-8), f"{k} train={train}")
+                    assert_grad_close_but_for_kinks(got_g, want_g, grad_tol * scale + softmax_side_floor(k, g_ref, 1e-8),
+                                                    f"{k} train={train} (oracle: {kinks} hidden units on the kink)", kinks=kinks)
                 else:
                     np.testing.assert_allclose(got_g, want_g, rtol=0, atol=grad_tol * scale + 1e-8, err_msg=f"{k} train={train}")
 
