@@ -357,8 +357,11 @@ def main():
     Xd, yd = torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)
     model.train()
 
+    n_res = K + W               # resident batches; a step names the batch that follows it, as `fit` does (engine._prepare_async)
+
     def step(i):
-        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+        j = (i + 1) % n_res
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B], next_X=Xd[j * B:(j + 1) * B])
 
     if world > 1:
         # several ranks, owner form: the exchange sizes of the W + K resident batches in one pass (what `fit` does per epoch),
@@ -447,9 +450,9 @@ def main():
         t1 = time.perf_counter()
         sus_timers = {}
         for i in range(n_sus):
-            j = i % n_distinct
+            j, jn = i % n_distinct, (i + 1) % n_distinct
             eng.timers = sus_timers if (i % 50 == 49 and not args.no_phase_timing) else None   # a phase sample every 50th step
-            eng.train_step(Xsd[j * B:(j + 1) * B], ysd[j * B:(j + 1) * B])
+            eng.train_step(Xsd[j * B:(j + 1) * B], ysd[j * B:(j + 1) * B], next_X=Xsd[jn * B:(jn + 1) * B])
         eng.timers = sus_timers if not args.no_phase_timing else None
         eng.flush_lazy()
         torch.cuda.synchronize()

@@ -519,16 +519,26 @@ class BaseModel(nn.Module):
                 bar = tqdm(iterator)
                 iterator = bar
             step_num = 0
+
+            def resident_batch(step_):
+                lo_, hi_ = step_ * batch_size, min(sample_num, (step_ + 1) * batch_size)
+                if order is None:
+                    return data[lo_:hi_], labels[lo_:hi_]
+                idx = order[lo_:hi_]
+                return data.index_select(0, idx), labels.index_select(0, idx)
+
+            ahead = resident_batch(0) if feeder is None else None      # (resident dataset: batches are cut one step ahead)
             for step in iterator:
                 lo, hi = step * batch_size, min(sample_num, (step + 1) * batch_size)
                 if feeder is not None:
                     xb, yb = next(feeder)
-                elif order is None:
-                    xb, yb = data[lo:hi], labels[lo:hi]
+                    engine.train_step(xb, yb)
                 else:
-                    idx = order[lo:hi]
-                    xb, yb = data.index_select(0, idx), labels.index_select(0, idx)
-                engine.train_step(xb, yb)
+                    xb, yb = ahead
+                    ahead = resident_batch(step + 1) if step + 1 < steps_per_epoch else None
+                    # the next batch's id matrix as a hint: its ids -> rows, sort and scenario bucketing run on a side stream
+                    # underneath this step's tail kernels (engine._prepare_async)
+                    engine.train_step(xb, yb, next_X=ahead[0] if ahead is not None and torch.is_tensor(ahead[0]) else None)
                 if verbose > 0 and self.metrics and device_metrics:
                     # the reference's per-step train metrics (:330-337) evaluated on the device: no sync, read once per epoch
                     prob = engine.last_prob()

@@ -101,6 +101,63 @@ __global__ void segment_bounds_kernel(const uint32_t* __restrict__ sorted_keys, 
     for (int64_t s = prev + 1; s <= cur; ++s) seg[s] = i;
 }
 
+// The whole bucketing as ONE launch for a handful of scenarios (the usual case: AliCCP has 4 scenario rows): a stable counting sort
+// in one workgroup.  Thread t owns the samples [t ipt, (t + 1) ipt); the counts c[s][t] laid out scenario-major ARE the
+// histogram of a stable sort, so the exclusive prefix over that array is the output position of thread t's first sample of
+// scenario s.  (The general path below is extract + a rocPRIM radix sort of six launches + bounds: eight launches of ~5 us.)
+constexpr int kBucketThreads = 1024, kBucketMaxS = 16, kBucketMaxIpt = 64;
+__global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const void* __restrict__ X, int id_dtype, int64_t x_stride,
+                                                                      int col, int B, int S, int32_t* __restrict__ sid,
+                                                                      int32_t* __restrict__ order, int32_t* __restrict__ seg,
+                                                                      int32_t* __restrict__ status) {
+    extern __shared__ int32_t s_pos[];                 // [S][kBucketThreads] counts, then exclusive prefixes
+    __shared__ int32_t s_wave[kBucketThreads / 64];
+    const int t = threadIdx.x;
+    const int ipt = (B + kBucketThreads - 1) / kBucketThreads;
+    const int b0 = t * ipt, b1 = min(B, b0 + ipt);
+    int32_t cnt[kBucketMaxS];
+#pragma unroll
+    for (int s = 0; s < kBucketMaxS; ++s) cnt[s] = 0;
+    bool bad = false;
+    for (int b = b0; b < b1; ++b) {
+        int64_t id = load_id(X, id_dtype, x_stride, b, col);
+        if (id < 0 || id >= S) { bad = true; id = 0; }
+        sid[b] = (int32_t)id;
+#pragma unroll
+        for (int s = 0; s < kBucketMaxS; ++s) cnt[s] += (id == s) ? 1 : 0;
+    }
+    if (bad) atomicOr(status, 1);
+#pragma unroll
+    for (int s = 0; s < kBucketMaxS; ++s)
+        if (s < S) s_pos[s * kBucketThreads + t] = cnt[s];
+    __syncthreads();
+    // exclusive prefix over the S * 1024 counts: thread t scans the S consecutive entries [t S, (t + 1) S) of the flat array
+    int32_t mine = 0;
+    for (int k = 0; k < S; ++k) mine += s_pos[t * S + k];
+    int32_t incl = mine;                               // inclusive scan of `mine` over the workgroup: lanes, then waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t up = __shfl_up(incl, off, 64);
+        if ((t & 63) >= off) incl += up;
+    }
+    if ((t & 63) == 63) s_wave[t >> 6] = incl;
+    __syncthreads();
+    int32_t base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += s_wave[w];
+    int32_t run = base + incl - mine;
+    for (int k = 0; k < S; ++k) {
+        const int32_t c = s_pos[t * S + k];
+        s_pos[t * S + k] = run;
+        run += c;
+    }
+    __syncthreads();
+    if (t <= S) seg[t] = t == S ? B : s_pos[t * kBucketThreads];
+    for (int b = b0; b < b1; ++b) {
+        const int s = sid[b];
+        order[s_pos[s * kBucketThreads + t]++] = b;      // (this thread's own slot: no other thread touches it)
+    }
+}
+
 static int bits_for(int64_t n) {  // number of key bits needed for values in [0, n)
     int bits = 1;
     while (((int64_t)1 << bits) < n) ++bits;
@@ -142,6 +199,19 @@ extern "C" int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_s
     SATRANS_REQUIRE(X && sid && order && seg && status && workspace, SATRANS_E_BADARG, "bucket_scenarios: null pointer");
     SATRANS_REQUIRE(B > 0 && S > 0 && col >= 0, SATRANS_E_BADARG, "bucket_scenarios: bad sizes B=%d S=%d col=%d", B, S, col);
     SATRANS_REQUIRE(id_dtype >= 0 && id_dtype <= 2, SATRANS_E_BADARG, "bucket_scenarios: id_dtype %d", id_dtype);
+    if (S <= kBucketMaxS && B <= kBucketThreads * kBucketMaxIpt) {
+        static bool attr_set = false;
+        if (!attr_set) {      // (S = 16: 64 KB of dynamic LDS next to the static wave sums)
+            hipError_t ea = hipFuncSetAttribute((const void*)bucket_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                kBucketMaxS * kBucketThreads * (int)sizeof(int32_t));
+            SATRANS_REQUIRE(ea == hipSuccess, SATRANS_E_LAUNCH, "bucket_scenarios: LDS attribute: %s", hipGetErrorString(ea));
+            attr_set = true;
+        }
+        bucket_small_kernel<<<1, kBucketThreads, (size_t)S * kBucketThreads * sizeof(int32_t), stream>>>(X, id_dtype, x_stride, col, B, S,
+                                                                                                       sid, order, seg, status);
+        SATRANS_CHECK_LAUNCH("bucket_small_kernel");
+        return SATRANS_OK;
+    }
     const BucketLayout L = bucket_layout(B, S);
     SATRANS_REQUIRE((int64_t)L.total <= workspace_bytes, SATRANS_E_WORKSPACE,
                     "bucket_scenarios: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)L.total);

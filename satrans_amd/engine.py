@@ -183,6 +183,10 @@ class PathEngine:
         # the last layer of a training step as one launch with the head fused in (satrans_layer_bwd_head): no forward launch
         # for that layer, no head launches, no [B,F,D] round trip of its output and gradient; SATRANS_FUSE_HEAD=0: separate calls
         self.fuse_head = os.environ.get("SATRANS_FUSE_HEAD", "1") != "0"
+        # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
+        # (SATRANS_PREFETCH=0: the hint is ignored)
+        self.prefetch = os.environ.get("SATRANS_PREFETCH", "1") != "0"
+        self._prep = None
         # SATRANS_SAVE_ATTENTION=1: the forward of a training step leaves the attention's softmax numerators / statistics /
         # output for its backward, which then copies them into LDS instead of recomputing them.  Measured:
         # backward 216 -> 200 us, forward 63 -> 73 us per layer, the step does not move, +72 MB per layer at B = 8192: off by default.
@@ -454,10 +458,9 @@ class PathEngine:
             raise NotImplementedError("integer id matrix together with dense features: pass inputs.PackedInput(ids, dense)")
         return X
 
-    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False, n_layers=None):
+    def _bucket(self, X, ws):
         lib, B, st = self.lib, X.shape[0], self._stream()
-        idt = N.id_dtype_of(X)
-        sx, sidt, sstride, scol = X, idt, X.stride(0), self.dom_col
+        sx, sidt, sstride, scol = X, N.id_dtype_of(X), X.stride(0), self.dom_col
         if self.multi:   # composite scenario id of every sample (a few elementwise torch ops on [B, k] ids)
             sx = (X.index_select(1, self._multi_cols).long() * self._multi_strides).sum(1).to(torch.int32).contiguous()
             sidt, sstride, scol = N.ID_I32, 1, 0
@@ -465,6 +468,13 @@ class PathEngine:
                                              ws["sid"].data_ptr(), ws["order"].data_ptr(), ws["seg"].data_ptr(),
                                              self.status.data_ptr(), ws["bucket"].data_ptr(), ws["bucket"].numel(), st),
                 "satrans_bucket_scenarios")
+
+    def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False, n_layers=None,
+                     bucket_ready=False):
+        lib, B, st = self.lib, X.shape[0], self._stream()
+        idt = N.id_dtype_of(X)
+        if not bucket_ready:
+            self._bucket(X, ws)
         fuse = self.fuse_gather or self._x_src is not None
         ws["acts0_of"] = None if fuse else X
         if not (fuse and rows_ready):
@@ -701,7 +711,7 @@ class PathEngine:
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
         return h
 
-    def backward(self, X, y, ws, rows_ready=False):
+    def backward(self, X, y, ws, rows_ready=False, bucket_ready=False, after_layers=None):
         """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
         `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
         lib, B, st = self.lib, X.shape[0], self._stream()
@@ -715,7 +725,7 @@ class PathEngine:
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
         fuse_head = self._fuse_head(X, ws, B)
         self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready, save_attn=True,
-                          n_layers=self.L - 1 if fuse_head else None)
+                          n_layers=self.L - 1 if fuse_head else None, bucket_ready=bucket_ready)
         if not fuse_head:
             with self.phase("head"):
                 self._head(X, ws, y)
@@ -762,14 +772,79 @@ class PathEngine:
                     self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
                     self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
             cur = 1 - cur
+        if after_layers is not None:
+            after_layers()                  # (train_step: the next batch's preprocessing goes to the side stream from here)
         if modulated:
             with self.phase("scenario_bwd"):
                 self.scenario_tables_backward(g_tabs)
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
 
-    def train_step(self, X: torch.Tensor, y: torch.Tensor):
-        """One optimizer step of every data-parallel rank, all on the launch stream: ids -> arena rows, sort, [lazy: replay of
+    # ------------------------------------------------------------------------------------------------
+    # next-batch preprocessing on a side stream
+    # ------------------------------------------------------------------------------------------------
+    _PREP_KEYS = ("rows", "sorted_rows", "src", "sid", "order", "seg", "bucket")
+
+    def _prep_key(self, X):
+        return (X.data_ptr(), tuple(X.shape), X.dtype, X.stride(0))
+
+    def _can_prepare(self, X, B) -> bool:
+        return (self.prefetch and torch.is_tensor(X) and X.is_cuda and X.dim() == 2 and X.is_contiguous()
+                and X.dtype in (torch.float32, torch.int32, torch.int64) and not self.multi and self.lazy
+                and self._sort_fields is not None and B <= 8192 and self.fuse_gather and not self.force_split)
+
+    def _prepare_async(self, X_next, ws_cur_B):
+        """Everything of a step that depends on nothing but its id matrix - ids -> arena rows, the per-field sort of the rows,
+        the scenario bucketing (four launches, ~60 us of mostly idle GPU: one workgroup per field / one workgroup) - for the
+        NEXT batch, on a side stream, into the other half of a double buffer.  Called from inside the current step right after
+        its last layer kernel has been queued: the side stream starts there, i.e. underneath the current step's small tail
+        kernels (reductions, scenario-table backward, touched-row Adam, flat Adam), never underneath the persistent layer
+        kernels (they own every CU: a 19-workgroup sort beside them would hold back 19 of their workgroups for its whole
+        duration).  Consumed by the next train_step when it is given the SAME tensor, unchanged; anything else discards it."""
+        B = X_next.shape[0]
+        ws = self.train_workspace(B, 1, False)
+        if "prep_alt" not in ws:
+            ws["prep_alt"] = {k: torch.empty_like(ws[k]) for k in self._PREP_KEYS}
+        alt = ws["prep_alt"]
+        main = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.dev)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self._side.wait_event(fork)
+        with torch.cuda.stream(self._side):
+            st = self._stream()
+            N.check(self.lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(), self.cols.data_ptr(),
+                                                X_next.data_ptr(), N.id_dtype_of(X_next), X_next.stride(0), B, self.F, self.D, None,
+                                                alt["rows"].data_ptr(), self.status.data_ptr(), st), "satrans_gather_fwd(rows, next)")
+            f_, lo_, n_ = self._sort_fields
+            N.check(self.lib.satrans_embed_sort_fields(alt["rows"].data_ptr(), B, self.F, f_, lo_, n_, alt["sorted_rows"].data_ptr(),
+                                                       alt["src"].data_ptr(), st), "satrans_embed_sort_fields(next)")
+            self._bucket(X_next, alt)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._prep = dict(key=self._prep_key(X_next), X=X_next, B=B, done=done)
+
+    def _take_prepared(self, X, ws) -> bool:
+        """True when the preprocessing of exactly this batch is waiting in the other half of the double buffer: the halves
+        swap roles and the launch stream waits for the side stream's event."""
+        prep, self._prep = self._prep, None
+        if prep is None:
+            return False
+        if prep["key"] != self._prep_key(X) or prep["B"] != X.shape[0] or "prep_alt" not in ws:
+            torch.cuda.current_stream(self.dev).wait_event(prep["done"])      # (the discarded work still owns the alt buffers)
+            return False
+        alt = ws["prep_alt"]
+        for k in self._PREP_KEYS:
+            ws[k], alt[k] = alt[k], ws[k]
+        torch.cuda.current_stream(self.dev).wait_event(prep["done"])
+        return True
+
+    def train_step(self, X: torch.Tensor, y: torch.Tensor, next_X: Optional[torch.Tensor] = None):
+        """`next_X` (optional): the id matrix the NEXT call will be given - `fit` knows it; its preprocessing then runs on a side
+        stream underneath this step's tail (_prepare_async).  A hint only: results are the same bits with or without it.
+
+        One optimizer step of every data-parallel rank, all on the launch stream: ids -> arena rows, sort, [lazy: replay of
         the rows this rank is about to read], bucket, gather, forward, head, backward; then the exchange (large-table row ids,
         flat gradient + dense small-table gradient, large-table gradient rows) with the global sort and the replay of the
         other ranks' rows underneath the last all-gather; dense step of the small tables; ordered segmented sums + step over
@@ -828,12 +903,14 @@ class PathEngine:
                 N.check(lib.satrans_sum_f64(reg.data_ptr(), reg.numel(), reg_sum.data_ptr(), 1, self._stream()),
                         "satrans_sum_f64")
 
-        # ---- 1. this batch's arena rows (nothing is moved yet), sorted -----------------------------------------------
-        N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
-                                       N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
-                                       self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
-        with self.phase("embed_sort"):
-            sort(ws["rows"], n_loc, ws["sorted_rows"], ws["src"], None, per_field=True)
+        # ---- 1. this batch's arena rows (nothing is moved yet), sorted - unless the previous step prepared them already ----
+        prepared = (not exch) and self._take_prepared(X, ws)
+        if not prepared:
+            N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
+                                           N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
+                                           self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
+            with self.phase("embed_sort"):
+                sort(ws["rows"], n_loc, ws["sorted_rows"], ws["src"], None, per_field=True)
         self.adam_t += 1
         self._note_lr(cfg["lr"])
         h_emb = self._hparams(l2)
@@ -875,7 +952,11 @@ class PathEngine:
                     side_done.record(self._side)
 
         # ---- 4. forward, loss, backward ---------------------------------------------------------------------------------
-        gemb = self.backward(X, y, ws, rows_ready=True)
+        hook = None
+        if next_X is not None and not exch and self._dense_override is None and self._can_prepare(next_X, next_X.shape[0]) \
+                and next_X.shape[1] >= self.n_cols:
+            hook = lambda: self._prepare_async(next_X, B)
+        gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook)
 
         # ---- 5. small tables: ordered segmented sums into the dense gradient at the tail of the flat gradient buffer -----------
         if n_s > 0:

@@ -783,6 +783,72 @@ def test_fused_last_layer_and_head_equal_the_separate_calls(name, train, loss):
         np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=2e-5 * sc + 1e-9, err_msg=k)
 
 
+@pytest.mark.parametrize("S,B", [(1, 1), (3, 5), (4, 1000), (4, 8192), (16, 8192), (16, 65536), (17, 300), (4, 70000), (4096, 5000)])
+def test_scenario_bucketing_is_a_stable_sort(S, B):
+    """satrans_bucket_scenarios - one counting-sort launch for S <= 16 scenario rows, the rocPRIM radix sort beyond - against a
+    stable argsort: `order` groups the sample indices by scenario in their original order, seg[s] is where scenario s starts."""
+    from satrans_amd import native as N
+    lib = N.lib()
+    rng = np.random.RandomState(S + B)
+    ids = rng.randint(0, S, size=B)
+    if S > 2:
+        ids[ids == 1] = 2                                   # an empty scenario row
+    X = torch.from_numpy(np.stack([rng.rand(B), ids.astype(np.float64)], axis=1).astype(np.float32)).to(DEV)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    sid, order, seg, status = torch.empty(B, **i32), torch.empty(B, **i32), torch.empty(S + 1, **i32), torch.zeros(1, **i32)
+    wsb = torch.empty(int(lib.satrans_bucket_workspace_bytes(B, S)), dtype=torch.uint8, device=DEV)
+    N.check(lib.satrans_bucket_scenarios(X.data_ptr(), N.ID_F32, X.stride(0), 1, B, S, sid.data_ptr(), order.data_ptr(),
+                                         seg.data_ptr(), status.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                                         torch.cuda.current_stream().cuda_stream), "satrans_bucket_scenarios")
+    want = np.argsort(ids, kind="stable")
+    assert np.array_equal(sid.cpu().numpy(), ids)
+    assert np.array_equal(order.cpu().numpy(), want)
+    assert np.array_equal(seg.cpu().numpy(), np.searchsorted(ids[want], np.arange(S + 1)))
+    assert int(status.item()) == 0
+    X[B // 2, 1] = S                                        # an id outside the table: flagged, counted as row 0
+    N.check(lib.satrans_bucket_scenarios(X.data_ptr(), N.ID_F32, X.stride(0), 1, B, S, sid.data_ptr(), order.data_ptr(),
+                                         seg.data_ptr(), status.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                                         torch.cuda.current_stream().cuda_stream), "satrans_bucket_scenarios")
+    assert int(status.item()) == 1 and int(sid[B // 2].item()) == 0
+    assert sorted(order.cpu().tolist()) == list(range(B))
+
+
+def test_next_batch_hint_changes_no_bit():
+    """train_step(X, y, next_X=...) runs the next batch's ids -> rows, per-field sort and scenario bucketing on a side stream under
+    the current step's tail.  Tables, moments and the logged sums after six steps are the same bits with the hint, without it,
+    and with a hint that names the wrong batch (prepared work discarded)."""
+    c = Case("aliccp_sota")
+    rng = np.random.RandomState(4)
+    n = c.X.shape[0]
+    Xs = [c.X[rng.permutation(n)].to(DEV) for _ in range(6)]
+    ys = [c.y[rng.permutation(n)].to(DEV) for _ in range(6)]
+
+    def run(hint):
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        model.train()
+        eng = model._require_engine()
+        eng.reset_epoch_sums()
+        for i in range(6):
+            nxt = None
+            if hint == "right" and i + 1 < 6:
+                nxt = Xs[i + 1]
+            elif hint == "wrong":
+                nxt = Xs[(i + 3) % 6]
+            eng.train_step(Xs[i], ys[i], next_X=nxt)
+        sums = eng.epoch_sums()
+        return sd_to_cpu(model), model.optimizer_state_dict(), sums
+    ref_sd, ref_opt, ref_sums = run(None)
+    for hint in ("right", "wrong"):
+        sd, opt, sums = run(hint)
+        assert sums == ref_sums, hint
+        for k in ref_sd:
+            assert torch.equal(sd[k], ref_sd[k]), (hint, k)
+        for k, st in ref_opt["state"].items():
+            for kind in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(opt["state"][k][kind], st[kind]), (hint, k, kind)
+
+
 def test_gather_bit_exact_and_out_of_range_ids():
     c = Case("aliccp_sota")
     model = build_model(c, DEV)
