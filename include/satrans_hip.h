@@ -335,6 +335,23 @@ int satrans_layer_bwd_head(const satrans_layer_desc* d, const satrans_head_desc*
                            float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
                            float* g_tab_k, void* stream);
 
+/* The same two calls without their reduction launches, and ONE reduction launch for all layers of a step.  satrans_layer_bwd ends
+ * with a fixed-order reduction of per-workgroup slabs (~10 us of a mostly idle GPU per layer); a training step can instead launch
+ * its L backward kernels back to back - a slab buffer of satrans_layer_bwd_slab_floats(d) floats PER LAYER - and reduce them all,
+ * together with the fused head's partial rows, in one launch on whichever stream suits it (the engine runs it on a side stream
+ * underneath the touched-row optimizer kernels).  Same arithmetic and order per layer: the same bits as the per-layer calls.
+ *   h_descs / h_slabs / h_grads   HOST arrays of n entries (n <= 8); the layers must share batch, bucketing, shape and flags
+ *   head                          the descriptor given to satrans_layer_bwd_head_launch, or NULL
+ * Fused kernels only: satrans_layer_bwd_deferred_supported says whether a layer can take this route. */
+typedef struct satrans_layer_grads {
+    float *g_wq, *g_wk, *g_wv, *g_wo, *g_ln, *g_lnq, *g_lnk, *g_tab_q, *g_tab_k;
+} satrans_layer_grads;
+int satrans_layer_bwd_deferred_supported(const satrans_layer_desc* d);
+int satrans_layer_bwd_launch(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, void* stream);
+int satrans_layer_bwd_head_launch(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, void* stream);
+int satrans_layer_bwd_reduce(int n, const satrans_layer_desc* const* h_descs, float* const* h_slabs,
+                             const satrans_layer_grads* h_grads, const satrans_head_desc* head, void* stream);
+
 /* Dense elementwise steps of the optimizers `compile` accepts besides Adam (models/meta_basemodel.py:612-640: torch.optim.SGD
  * lr 0.01, Adagrad lr 0.01 eps 1e-10, RMSprop lr 0.01 alpha 0.99 eps 1e-8), over n floats with the dense gradient g:
  *   SATRANS_OPT_SGD      p -= lr g

@@ -39,6 +39,11 @@ int satrans_layer_bwd_head_fused(const satrans_layer_desc* d, const satrans_head
                                  float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,
                                  float* g_tab_k, void* stream);
 
+int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, void* stream);
+int satrans_layer_bwd_head_launch_fused(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, void* stream);
+int satrans_layer_bwd_reduce_fused(int n, const satrans_layer_desc* const* descs, float* const* slabs,
+                                   const satrans_layer_grads* grads, const satrans_head_desc* head, void* stream);
+
 const char* satrans_last_error(void) { return satrans::g_error; }
 int satrans_abi_version(void) { return SATRANS_ABI_VERSION; }
 
@@ -116,6 +121,37 @@ int satrans_layer_bwd_head(const satrans_layer_desc* d, const satrans_head_desc*
     SATRANS_REQUIRE(satrans_layer_bwd_head_supported(d, h), SATRANS_E_UNSUPPORTED,
                     "layer_bwd_head: not built for this layer / head (use satrans_layer_fwd + satrans_head_loss + satrans_layer_bwd)");
     return satrans_layer_bwd_head_fused(d, h, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
+}
+
+// backward kernels without their reduction launches + one reduction for all layers of a step: fused kernels only
+int satrans_layer_bwd_deferred_supported(const satrans_layer_desc* d) {
+    if (!d || satrans_layer_validate(d, "layer_bwd_launch")) return 0;
+    return satrans_layer_impl() == 0 && satrans_layer_bwd_fused_supported(d);
+}
+
+int satrans_layer_bwd_launch(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, void* stream) {
+    int rc = satrans_layer_validate(d, "layer_bwd_launch");
+    if (rc) return rc;
+    SATRANS_REQUIRE(satrans_layer_bwd_deferred_supported(d), SATRANS_E_UNSUPPORTED, "layer_bwd_launch: fused kernels only (use satrans_layer_bwd)");
+    return satrans_layer_bwd_launch_fused(d, dy, dx, slabs, stream);
+}
+
+int satrans_layer_bwd_head_launch(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, void* stream) {
+    int rc = satrans_layer_validate(d, "layer_bwd_head_launch");
+    if (rc) return rc;
+    SATRANS_REQUIRE(h && satrans_layer_bwd_head_supported(d, h), SATRANS_E_UNSUPPORTED, "layer_bwd_head_launch: not built for this layer / head");
+    return satrans_layer_bwd_head_launch_fused(d, h, dx, slabs, stream);
+}
+
+int satrans_layer_bwd_reduce(int n, const satrans_layer_desc* const* h_descs, float* const* h_slabs,
+                             const satrans_layer_grads* h_grads, const satrans_head_desc* head, void* stream) {
+    SATRANS_REQUIRE(n >= 1 && h_descs && h_slabs && h_grads, SATRANS_E_BADARG, "layer_bwd_reduce: null argument");
+    for (int l = 0; l < n; ++l) {
+        int rc = satrans_layer_validate(h_descs[l], "layer_bwd_reduce");
+        if (rc) return rc;
+        SATRANS_REQUIRE(satrans_layer_bwd_deferred_supported(h_descs[l]), SATRANS_E_UNSUPPORTED, "layer_bwd_reduce: fused kernels only");
+    }
+    return satrans_layer_bwd_reduce_fused(n, h_descs, h_slabs, h_grads, head, stream);
 }
 
 }  // extern "C"

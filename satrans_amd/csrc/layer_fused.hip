@@ -1678,9 +1678,13 @@ __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ co
     if (mk && !shared) g_lnk[r - 4 * D] += t;
 }
 
-__device__ __forceinline__ void fused_records_reduce(const float* __restrict__ records, const int32_t* __restrict__ seg,
+// `n_layers` record sets (one per layer of a step, in the order their backward kernels ran) whose gradients go to generated-weight
+// tables that MAY BE THE SAME MEMORY for every layer (no 'pos' flag: one table for all layers): the block adds them one layer after
+// the other, which is also the order - and hence the bits - of one reduction launch per layer.
+__device__ __forceinline__ void fused_records_reduce(int n_layers, const float* const* records_of, float* const* g_tab_q_of,
+                                                     float* const* g_tab_k_of, const int32_t* __restrict__ seg,
                                                      int S, int T, int G, int D, int U, int H, int flags, int64_t tab_stride,
-                                                     float* g_tab_q, float* g_tab_k, int block, int s) {
+                                                     int block, int s) {
     __shared__ float s_q[kRG][32], s_k[kRG][32];
     // One record per (workgroup, scenario), TSZ = 4 D U floats apart.  What it holds and which elements of the generated row
     // they are:   MetaNet   [W1q | W2q | W1k | W2k]: role r = elements [r * 2DU, (r + 1) * 2DU) = the row itself
@@ -1698,7 +1702,7 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
         total += tiles_of(seg, k, T);
     }
     const int nt = tiles_of(seg, s, T);
-    if (nt == 0) return;
+    if (nt == 0) return;                                        // (uniform over the block)
     const int per = (total + G - 1) / G;
     const int w_lo = pre / per, w_hi = (pre + nt - 1) / per;
     const int share = (w_hi - w_lo + kRG) / kRG;
@@ -1709,26 +1713,33 @@ __device__ __forceinline__ void fused_records_reduce(const float* __restrict__ r
         const int h = e / (d * d), i = (e / d) % d, j = e % d;
         src_q = (h * d + i) * D + h * d + j;
     }
-    float aq = 0.f, ak = 0.f;
-    if (e < half) {
+    for (int l = 0; l < n_layers; ++l) {
+        const float* records = records_of[l];
+        float aq = 0.f, ak = 0.f;
+        if (e < half) {
 #pragma unroll 4
-        for (int w = a; w < b; ++w) {
-            const float* rec = records + (size_t)(w + s) * TSZ;
-            if (mq) aq += rec[src_q];
-            if (mk) ak += rec[src_k];
+            for (int w = a; w < b; ++w) {
+                const float* rec = records + (size_t)(w + s) * TSZ;
+                if (mq) aq += rec[src_q];
+                if (mk) ak += rec[src_k];
+            }
         }
-    }
-    s_q[grp][lane] = aq;
-    s_k[grp][lane] = ak;
-    __syncthreads();
-    if (grp != 0 || e >= half) return;
-    aq = 0.f; ak = 0.f;
-    for (int k = 0; k < kRG; ++k) { aq += s_q[k][lane]; ak += s_k[k][lane]; }
-    if (mq && mk && g_tab_q == g_tab_k) {
-        g_tab_q[(size_t)s * tab_stride + e] += aq + ak;
-    } else {
-        if (mq) g_tab_q[(size_t)s * tab_stride + e] += aq;
-        if (mk) g_tab_k[(size_t)s * tab_stride + e] += ak;
+        s_q[grp][lane] = aq;
+        s_k[grp][lane] = ak;
+        __syncthreads();
+        if (grp == 0 && e < half) {
+            aq = 0.f; ak = 0.f;
+            for (int k = 0; k < kRG; ++k) { aq += s_q[k][lane]; ak += s_k[k][lane]; }
+            float* g_tab_q = g_tab_q_of[l];
+            float* g_tab_k = g_tab_k_of[l];
+            if (mq && mk && g_tab_q == g_tab_k) {
+                g_tab_q[(size_t)s * tab_stride + e] += aq + ak;
+            } else {
+                if (mq) g_tab_q[(size_t)s * tab_stride + e] += aq;
+                if (mk) g_tab_k[(size_t)s * tab_stride + e] += ak;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1742,9 +1753,85 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
         fused_common_reduce(common, G, D, flags, bx, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk);
     } else {
         const int rb = bx - common_blocks;
-        fused_records_reduce(records, seg, S, T, G, D, U, H, flags, tab_stride, g_tab_q, g_tab_k, rb % record_blocks,
-                             rb / record_blocks);
+        const float* recs[1] = {records};
+        float *gq[1] = {g_tab_q}, *gk[1] = {g_tab_k};
+        fused_records_reduce(1, recs, gq, gk, seg, S, T, G, D, U, H, flags, tab_stride, rb % record_blocks, rb / record_blocks);
     }
+}
+
+// ---- all layers of a step in ONE reduction launch (satrans_layer_bwd_reduce): the backward kernels of the step's layers were
+//      launched back to back with a slab buffer each; blocks [l * per_layer, (l + 1) * per_layer) do what fused_reduce_kernel does
+//      for layer l, the blocks behind them add the fused head's partial rows (head_reduce_kernel's arithmetic and order) ----------
+constexpr int kReduceMaxLayers = 8;
+struct ReduceLayers {
+    int n;
+    const float* slabs[kReduceMaxLayers];
+    float* g[kReduceMaxLayers][9];      // g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k
+};
+struct ReduceHead {
+    const float* partial;               // [nblk][ncol + 2] or null
+    int nblk, ncol;
+    float *g_w, *g_b;
+    double* loss_sum;
+};
+__device__ __forceinline__ void head_partials_reduce(const ReduceHead& hd, int block) {
+    __shared__ double s_acc[kRG][32];
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = block * 32 + lane, ncol = hd.ncol;
+    const int share = (hd.nblk + kRG - 1) / kRG;
+    const int lo = grp * share, hi = min(hd.nblk, lo + share);
+    double acc = 0.0;
+    if (c < ncol + 2) {
+        if (c == ncol + 1) {
+            for (int k = lo; k < hi; ++k) acc += (double)hd.partial[(size_t)k * (ncol + 2) + c];
+        } else {
+            float a32 = 0.f;
+#pragma unroll 8
+            for (int k = lo; k < hi; ++k) a32 += hd.partial[(size_t)k * (ncol + 2) + c];
+            acc = (double)a32;
+        }
+    }
+    s_acc[grp][lane] = acc;
+    __syncthreads();
+    if (grp != 0 || c >= ncol + 2) return;
+    if (c == ncol + 1) {
+        double t = 0.0;
+        for (int k = 0; k < kRG; ++k) t += s_acc[k][lane];
+        hd.loss_sum[0] += t;
+        return;
+    }
+    float t = 0.f;
+    for (int k = 0; k < kRG; ++k) t += (float)s_acc[k][lane];
+    if (c < ncol) hd.g_w[c] += t;
+    else hd.g_b[0] += t;
+}
+__global__ __launch_bounds__(32 * kRG) void fused_reduce_all_kernel(ReduceLayers R, ReduceHead hd, const int32_t* __restrict__ seg,
+                                                             int S, int T, int G, int D, int U, int H, int flags,
+                                                             int64_t tab_stride, int common_blocks, int record_blocks,
+                                                             int per_layer) {
+    // blocks: [n x common_blocks: the scenario-independent part of every layer] [record_blocks x S: the generated-weight records of
+    // ALL layers, layer after layer inside the block - their tables may be one and the same] [the fused head's partial rows]
+    int bx = blockIdx.x;
+    if (bx < R.n * common_blocks) {
+        const int l = bx / common_blocks;
+        float* const* g = R.g[l];
+        fused_common_reduce(R.slabs[l], G, D, flags, bx - l * common_blocks, g[0], g[1], g[2], g[3], g[4], g[5], g[6]);
+        return;
+    }
+    bx -= R.n * common_blocks;
+    const int n_rec = per_layer - common_blocks;      // record_blocks * S, or 0 without generated weights
+    if (bx < n_rec) {
+        const float* recs[kReduceMaxLayers];
+        float *gq[kReduceMaxLayers], *gk[kReduceMaxLayers];
+        for (int l = 0; l < R.n; ++l) {
+            recs[l] = R.slabs[l] + (size_t)G * (4 * D * D + 6 * D);
+            gq[l] = R.g[l][7];
+            gk[l] = R.g[l][8];
+        }
+        fused_records_reduce(R.n, recs, gq, gk, seg, S, T, G, D, U, H, flags, tab_stride, bx % record_blocks, bx / record_blocks);
+        return;
+    }
+    head_partials_reduce(hd, bx - n_rec);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1846,10 +1933,8 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p, bool he
     p.T = 64 / d->F;
     // No transposed copies of the weight images: the backward products read the forward images by rows (chain_t).  The
     // four-way bank conflicts of those reads cost nothing measurable, while staging half as many images per workgroup
-    // makes the kernel 4 % faster (0.934 -> 0.895 ms per step) and leaves 37 KB of LDS free.  SATRANS_BWD_TR=1 keeps the
-    // transposed copies where they fit (D = 32 with one shared generated-weight table) for comparison.
-    static const int force_tr = getenv("SATRANS_BWD_TR") ? atoi(getenv("SATRANS_BWD_TR")) : 0;
-    p.tr = force_tr == 1 && same_tab && d->D == 32 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR));
+    // makes the kernel 4 % faster (0.934 -> 0.895 ms per step) and leaves 37 KB of LDS free.
+    p.tr = false;      // (round 1's transposed copies: measured slower, the instantiation is no longer built)
     const int Uw = fused_width(d);
     p.split = product_mode() == 1 && !p.tr && same_tab && d->D == 32 && d->U == 64 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) &&
               (d->flags & (SATRANS_META_Q | SATRANS_META_K)) &&
@@ -1969,12 +2054,12 @@ static int launch_fused_reduce(const satrans_layer_desc* d, const FusedBwdPlan& 
     return SATRANS_OK;
 }
 
-extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
-                                       float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk,
-                                       float* g_tab_q, float* g_tab_k, void* stream_) {
+// the backward kernel alone: its per-workgroup slabs wait in `slabs` for satrans_layer_bwd_fused's own reduction launch or for
+// satrans_layer_bwd_reduce_fused (one launch for all layers of a step)
+extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     FusedBwdPlan p;
-    SATRANS_REQUIRE(dy && dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
+    SATRANS_REQUIRE(dy && dx && slabs, SATRANS_E_BADARG, "layer_bwd: null pointer");
     // (a caller with one table but two LayerNorm vectors gets the two-table instantiation: it stages the table twice, nothing else)
     const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
     int rc;
@@ -2002,16 +2087,25 @@ extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float*
         rc = launch_bwd<32, 64, 4, true, false, 19, 0, 1>(d, p, dy, dx, slabs, stream);
     else if (p.split)
         rc = launch_bwd<32, 64, 4, true, false, 0, 0, 1>(d, p, dy, dx, slabs, stream);
-    else if (d->D == 32 && same && !p.tr && d->F == 19 && f_const)
+    else if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
-    else if (d->D == 32) rc = same ? (p.tr ? launch_bwd<32, 64, 4, true, true>(d, p, dy, dx, slabs, stream)
-                                      : launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream))
-                              : launch_bwd<32, 64, 4, false, false>(d, p, dy, dx, slabs, stream);
+    else if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream)
+                                   : launch_bwd<32, 64, 4, false, false>(d, p, dy, dx, slabs, stream);
     else rc = same ? launch_bwd<16, 32, 2, true, false>(d, p, dy, dx, slabs, stream)
                    : launch_bwd<16, 32, 2, false, false>(d, p, dy, dx, slabs, stream);
     }
+    return rc;
+}
+
+extern "C" int satrans_layer_bwd_fused(const satrans_layer_desc* d, const float* dy, float* dx, float* slabs, float* g_wq,
+                                       float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk,
+                                       float* g_tab_q, float* g_tab_k, void* stream_) {
+    SATRANS_REQUIRE(g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd: null pointer");
+    int rc = satrans_layer_bwd_launch_fused(d, dy, dx, slabs, stream_);
     if (rc) return rc;
-    return launch_fused_reduce(d, p, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
+    FusedBwdPlan p;
+    fused_bwd_plan(d, p);
+    return launch_fused_reduce(d, p, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, (hipStream_t)stream_);
 }
 
 // ---- last layer of a training step with the head fused in (include/satrans_hip.h: satrans_layer_bwd_head) ---------------------
@@ -2033,14 +2127,12 @@ extern "C" int64_t satrans_layer_bwd_head_scratch_floats_fused(const satrans_lay
     return (int64_t)p.G * ((int64_t)d->F * d->D + n_dense + 2);
 }
 
-extern "C" int satrans_layer_bwd_head_fused(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs,
-                                            float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
-                                            float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream_) {
+extern "C" int satrans_layer_bwd_head_launch_fused(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs,
+                                                   void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     FusedBwdPlan p;
-    SATRANS_REQUIRE(dx && slabs && g_wq && g_wk && g_wv && g_wo && g_ln, SATRANS_E_BADARG, "layer_bwd_head: null pointer");
-    SATRANS_REQUIRE(h->w && h->bias && h->labels && h->prob && h->loss_sum && h->g_w && h->g_b && h->scratch, SATRANS_E_BADARG,
-                    "layer_bwd_head: null head pointer");
+    SATRANS_REQUIRE(dx && slabs, SATRANS_E_BADARG, "layer_bwd_head: null pointer");
+    SATRANS_REQUIRE(h->w && h->bias && h->labels && h->prob && h->scratch, SATRANS_E_BADARG, "layer_bwd_head: null head pointer");
     SATRANS_REQUIRE(h->n_dense == 0 || (h->dense && h->h_dense_cols), SATRANS_E_BADARG, "layer_bwd_head: dense columns without a matrix");
     SATRANS_REQUIRE(h->loss_kind >= SATRANS_LOSS_BCE && h->loss_kind <= SATRANS_LOSS_MAE, SATRANS_E_BADARG, "layer_bwd_head: loss kind %d", h->loss_kind);
     SATRANS_REQUIRE(satrans_layer_bwd_head_fused_supported(d, h) && fused_bwd_plan(d, p, true), SATRANS_E_UNSUPPORTED,
@@ -2064,10 +2156,66 @@ extern "C" int satrans_layer_bwd_head_fused(const satrans_layer_desc* d, const s
     else
         rc = same ? launch_bwd<16, 32, 2, true, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
                   : launch_bwd<16, 32, 2, false, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+    return rc;
+}
+
+extern "C" int satrans_layer_bwd_head_fused(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs,
+                                            float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq,
+                                            float* g_lnk, float* g_tab_q, float* g_tab_k, void* stream_) {
+    SATRANS_REQUIRE(g_wq && g_wk && g_wv && g_wo && g_ln && h->loss_sum && h->g_w && h->g_b, SATRANS_E_BADARG, "layer_bwd_head: null pointer");
+    int rc = satrans_layer_bwd_head_launch_fused(d, h, dx, slabs, stream_);
     if (rc) return rc;
-    rc = launch_fused_reduce(d, p, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
+    FusedBwdPlan p;
+    fused_bwd_plan(d, p, true);
+    rc = launch_fused_reduce(d, p, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, (hipStream_t)stream_);
     if (rc) return rc;
     return satrans_head_reduce_partials(h->scratch, p.G, d->F * d->D + h->n_dense, h->g_w, h->g_b, h->loss_sum, stream_);
+}
+
+// One reduction launch for the backward kernels of n layers of ONE step (same batch, same bucketing, same shape and flags: the
+// layers of a model) that were launched with satrans_layer_bwd_launch / _head_launch into a slab buffer each, plus - `head` given -
+// the fused head's partial rows.  Same arithmetic and order per layer as the per-layer reduction: the same bits.
+extern "C" int satrans_layer_bwd_reduce_fused(int n, const satrans_layer_desc* const* descs, float* const* slabs,
+                                              const satrans_layer_grads* grads, const satrans_head_desc* head, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(n >= 1 && n <= kReduceMaxLayers && descs && slabs && grads, SATRANS_E_BADARG, "layer_bwd_reduce: 1..%d layers", kReduceMaxLayers);
+    const satrans_layer_desc* d = descs[0];
+    FusedBwdPlan p;
+    SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd_reduce: shape not built");
+    const int D = d->D, U = fused_width(d), CSZ = 4 * D * D + 6 * D;
+    const bool meta = d->flags & (SATRANS_META_Q | SATRANS_META_K | SATRANS_BILINEAR);
+    const int row_elems = (d->flags & SATRANS_GATE) ? D : ((d->flags & SATRANS_BILINEAR) ? D * (D / d->H) : 2 * D * U);
+    const int common_blocks = (int)ceil_div(CSZ, 32), record_blocks = (int)ceil_div(row_elems, 32);
+    const int per_layer = common_blocks + (meta ? record_blocks * d->S : 0);
+    ReduceLayers R;
+    R.n = n;
+    for (int l = 0; l < n; ++l) {
+        const satrans_layer_desc* e = descs[l];
+        FusedBwdPlan q;
+        SATRANS_REQUIRE(e->B == d->B && e->F == d->F && e->D == d->D && e->U == d->U && e->H == d->H && e->S == d->S &&
+                        e->flags == d->flags && e->seg == d->seg && e->tab_stride == d->tab_stride && fused_bwd_plan(e, q) &&
+                        q.G == p.G && q.T == p.T, SATRANS_E_BADARG, "layer_bwd_reduce: layer %d differs from layer 0 in shape, flags or bucketing", l);
+        const satrans_layer_grads& g = grads[l];
+        SATRANS_REQUIRE(slabs[l] && g.g_wq && g.g_wk && g.g_wv && g.g_wo && g.g_ln && (!meta || g.g_tab_q), SATRANS_E_BADARG,
+                        "layer_bwd_reduce: null pointer (layer %d)", l);
+        R.slabs[l] = slabs[l];
+        float* gp[9] = {g.g_wq, g.g_wk, g.g_wv, g.g_wo, g.g_ln, g.g_lnq, g.g_lnk, g.g_tab_q, g.g_tab_k};
+        for (int k = 0; k < 9; ++k) R.g[l][k] = gp[k];
+    }
+    ReduceHead hd{};
+    int head_blocks = 0;
+    if (head) {
+        SATRANS_REQUIRE(head->scratch && head->g_w && head->g_b && head->loss_sum, SATRANS_E_BADARG, "layer_bwd_reduce: null head pointer");
+        FusedBwdPlan ph;
+        SATRANS_REQUIRE(fused_bwd_plan(d, ph, true), SATRANS_E_UNSUPPORTED, "layer_bwd_reduce: fused head not built for this shape");
+        hd.partial = head->scratch; hd.nblk = ph.G; hd.ncol = d->F * d->D + head->n_dense;
+        hd.g_w = head->g_w; hd.g_b = head->g_b; hd.loss_sum = head->loss_sum;
+        head_blocks = (int)ceil_div(hd.ncol + 2, 32);
+    }
+    fused_reduce_all_kernel<<<(unsigned)(n * common_blocks + (per_layer - common_blocks) + head_blocks), 32 * kRG, 0, stream>>>(
+        R, hd, d->seg, d->S, p.T, p.G, D, U, d->H, d->flags, d->tab_stride, common_blocks, record_blocks, per_layer);
+    SATRANS_CHECK_LAUNCH("fused_reduce_all_kernel");
+    return SATRANS_OK;
 }
 
 #ifdef SATRANS_STAMPS

@@ -186,6 +186,8 @@ class PathEngine:
         # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
         # (SATRANS_PREFETCH=0: the hint is ignored)
         self.prefetch = os.environ.get("SATRANS_PREFETCH", "1") != "0"
+        # one reduction launch for all layers' weight-gradient slabs (satrans_layer_bwd_reduce; SATRANS_DEFER_REDUCE=0: per layer)
+        self.defer_reduce = os.environ.get("SATRANS_DEFER_REDUCE", "1") != "0"
         self._prep = None
         # SATRANS_SAVE_ATTENTION=1: the forward of a training step leaves the attention's softmax numerators / statistics /
         # output for its backward, which then copies them into LDS instead of recomputing them.  Measured:
@@ -711,6 +713,17 @@ class PathEngine:
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
         return h
 
+    def _defer_reduce(self, ws, B) -> bool:
+        if "defer" not in ws:
+            ok = self.defer_reduce and not ws["generic"] and 1 <= self.L <= 8
+            if ok:
+                desc = self._layer_desc(ws, 0, B, None, None, True)
+                ok = bool(self.lib.satrans_layer_bwd_deferred_supported(C.byref(desc)))
+            if ok:
+                ws["slabs_l"] = [ws["slabs"]] + [torch.empty_like(ws["slabs"]) for _ in range(self.L - 1)]
+            ws["defer"] = ok
+        return ws["defer"]
+
     def backward(self, X, y, ws, rows_ready=False, bucket_ready=False, after_layers=None):
         """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
         `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
@@ -729,6 +742,10 @@ class PathEngine:
         if not fuse_head:
             with self.phase("head"):
                 self._head(X, ws, y)
+        # Fused kernels: the L backward kernels back to back, a slab buffer each, and ONE reduction launch for all of them (and the
+        # fused head's partial rows) instead of one ~10 us reduction per layer between them (satrans_layer_bwd_reduce).
+        defer = self._defer_reduce(ws, B)
+        d_descs, d_slabs, d_grads, d_head = [], [], [], None
         cur = 0
         for l in reversed(range(self.L)):
             head_here = fuse_head and l == self.L - 1
@@ -745,38 +762,66 @@ class PathEngine:
                 kname = "K_meta_mlp" if m.domain_int_layers[l].K_meta_mlp is not m.domain_int_layers[l].Q_meta_mlp \
                     else "Q_meta_mlp"
                 glnk = self._grad_view(lay + kname + ".ffn_layer_norm.weight").data_ptr()
+            g_ptrs = (self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
+                      self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
+                      self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk)
             if ws["generic"]:
                 with self.phase("layer_bwd"):
                     N.check(lib.satrans_layer_bwd_generic(
                         C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["gen_saved"][l].data_ptr(),
-                        ws["gen_scratch"].data_ptr(),
-                        self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
-                        self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
-                        self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd_generic")
+                        ws["gen_scratch"].data_ptr(), *g_ptrs, st), "satrans_layer_bwd_generic")
                 cur = 1 - cur
                 continue
+            slabs = ws["slabs_l"][l] if defer else ws["slabs"]
+            if defer:
+                d_descs.append(desc)
+                d_slabs.append(slabs.data_ptr())
+                d_grads.append(g_ptrs)
             if head_here:
                 # layer L-1 forward (recomputed) + head + loss + their backward: one launch, the layer's output never leaves the CU
+                hdesc = self._head_desc(X, ws, y)
                 with self.phase("layer_bwd_head"):
-                    N.check(lib.satrans_layer_bwd_head(
-                        C.byref(desc), C.byref(self._head_desc(X, ws, y)), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),
-                        self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
-                        self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
-                        self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd_head")
+                    if defer:
+                        d_head = hdesc
+                        N.check(lib.satrans_layer_bwd_head_launch(C.byref(desc), C.byref(hdesc), ws["dact"][1 - cur].data_ptr(),
+                                                                  slabs.data_ptr(), st), "satrans_layer_bwd_head_launch")
+                    else:
+                        N.check(lib.satrans_layer_bwd_head(C.byref(desc), C.byref(hdesc), ws["dact"][1 - cur].data_ptr(),
+                                                           slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd_head")
                 cur = 1 - cur
                 continue
             with self.phase("layer_bwd"):
-                N.check(lib.satrans_layer_bwd(
-                    C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(), ws["slabs"].data_ptr(),
-                    self._grad_view(lay + "W_Query").data_ptr(), self._grad_view(lay + "W_Key").data_ptr(),
-                    self._grad_view(lay + "W_Value").data_ptr(), self._grad_view(lay + "Out_linear.weight").data_ptr(),
-                    self._grad_view(lay + "layer_norm.weight").data_ptr(), glnq, glnk, gq, gk, st), "satrans_layer_bwd")
+                if defer:
+                    N.check(lib.satrans_layer_bwd_launch(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
+                                                         slabs.data_ptr(), st), "satrans_layer_bwd_launch")
+                else:
+                    N.check(lib.satrans_layer_bwd(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
+                                                  slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd")
             cur = 1 - cur
+
+        def finish():
+            # what only the dense-parameter step needs: the slab reduction and the scenario-table backward
+            if d_descs:
+                n = len(d_descs)
+                descs_a = (C.POINTER(N.LayerDesc) * n)(*[C.pointer(d_) for d_ in d_descs])
+                slabs_a = (C.c_void_p * n)(*d_slabs)
+                grads_a = (N.LayerGrads * n)()
+                for i_, gp in enumerate(d_grads):
+                    for name_, v_ in zip(("g_wq", "g_wk", "g_wv", "g_wo", "g_ln", "g_lnq", "g_lnk", "g_tab_q", "g_tab_k"), gp):
+                        setattr(grads_a[i_], name_, v_)
+                with self.phase("layer_bwd_reduce"):
+                    N.check(lib.satrans_layer_bwd_reduce(n, descs_a, slabs_a, grads_a, C.byref(d_head) if d_head is not None else None,
+                                                         self._stream()), "satrans_layer_bwd_reduce")
+            if modulated:
+                with self.phase("scenario_bwd"):
+                    self.scenario_tables_backward(g_tabs)
+
+        # (Measured and removed: this tail on the side stream underneath the touched-row kernels.  Every cross-stream dependency
+        #  costs ~15-20 us of wake-up latency on this platform, two more per step ate the overlap and 45 us besides:
+        #  1.265 -> 1.310 ms/step.  Only the next batch's preprocessing - whose join is an event that completed long ago - pays.)
+        finish()
         if after_layers is not None:
             after_layers()                  # (train_step: the next batch's preprocessing goes to the side stream from here)
-        if modulated:
-            with self.phase("scenario_bwd"):
-                self.scenario_tables_backward(g_tabs)
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
 

@@ -49,6 +49,11 @@ class HeadDesc(C.Structure):
                 ("prob", _vp), ("logit", _vp), ("loss_sum", _vp), ("g_w", _vp), ("g_b", _vp), ("scratch", _vp)]
 
 
+class LayerGrads(C.Structure):
+    """Mirror of `satrans_layer_grads`."""
+    _fields_ = [(k, _vp) for k in ("g_wq", "g_wk", "g_wv", "g_wo", "g_ln", "g_lnq", "g_lnk", "g_tab_q", "g_tab_k")]
+
+
 class SelfAttDesc(C.Structure):
     """Mirror of `satrans_selfatt_desc`."""
     _fields_ = [("B", C.c_int32), ("F", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("flags", C.c_int32),
@@ -111,6 +116,11 @@ SIGNATURES = {
     "satrans_layer_bwd_head_scratch_floats": (C.c_int64, [C.POINTER(LayerDesc), C.c_int]),
     "satrans_layer_bwd_head": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(HeadDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
+    "satrans_layer_bwd_deferred_supported": (C.c_int, [C.POINTER(LayerDesc)]),
+    "satrans_layer_bwd_launch": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp, _vp]),
+    "satrans_layer_bwd_head_launch": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(HeadDesc), _vp, _vp, _vp]),
+    "satrans_layer_bwd_reduce": (C.c_int, [C.c_int, C.POINTER(C.POINTER(LayerDesc)), C.POINTER(_vp), C.POINTER(LayerGrads),
+                                           C.POINTER(HeadDesc), _vp]),
     "satrans_head_scratch_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "satrans_head": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp]),

@@ -849,6 +849,28 @@ def test_next_batch_hint_changes_no_bit():
                 assert torch.equal(opt["state"][k][kind], st[kind]), (hint, k, kind)
 
 
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_qkv", "small_gate", "small_bilinear"])
+def test_one_reduction_launch_for_all_layers_is_bitwise_the_per_layer_reductions(name, train):
+    """satrans_layer_bwd_launch x L + satrans_layer_bwd_reduce (one launch for all layers' slabs and the fused head's rows; the
+    default) against satrans_layer_bwd per layer: the same arithmetic in the same order - the layers' generated-weight records,
+    which without 'pos' all go to ONE table, are added layer after layer inside a block - so every gradient is the same bits."""
+    c = Case(name)
+    X, y = c.X.to(DEV), c.y.to(DEV)
+    outs = []
+    for defer in (True, False):
+        model = build_model(c, DEV)
+        model.compile("adam", "binary_crossentropy")
+        model.train(train)
+        eng = model._require_engine()
+        eng.defer_reduce = defer
+        bce, reg, grads = eng.loss_and_grads(X, y)
+        assert bool(eng._ws[X.shape[0]]["defer"]) == defer
+        outs.append((bce, {k: g.cpu() for k, g in grads.items()}))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[1][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
 def test_gather_bit_exact_and_out_of_range_ids():
     c = Case("aliccp_sota")
     model = build_model(c, DEV)
