@@ -68,7 +68,7 @@ def make_config(name, table_rows=None):
 
 CFG = make_config("aliccp")
 
-PMC_SUMMARY = "r03_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
+PMC_SUMMARY = "r04_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
 BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
@@ -363,7 +363,7 @@ def main():
         j = (i + 1) % n_res
         eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B], next_X=Xd[j * B:(j + 1) * B])
 
-    if world > 1:
+    if world > 1 or force_exchange:
         # several ranks, owner form: the exchange sizes of the W + K resident batches in one pass (what `fit` does per epoch),
         # instead of one count read-back per step
         eng.plan_owner_counts(Xd, None, B)
@@ -522,12 +522,16 @@ def main():
                                work=6.0 * (total_rows - uniq * world) * D * 4 / 1e9),   # read p,m,v + write p,m,v
         "layer_bwd": dict(kernel=bwd_kernel, bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=2.0 * fwd_flops / 1e12),
         "layer_fwd": dict(kernel=fwd_kernel, bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=fwd_flops / 1e12),
+        "layer_fwd_gather": dict(kernel=fwd_kernel + " (layer 0: tokens read from the embedding arena, gather fused in)", bound="mfma",
+                                 unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=fwd_flops / 1e12),
         "gather_fwd": dict(kernel="gather_rows_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
                            work=B * F * (D * 4 + 4) / 1e9),                        # read bytes (only timed with SATRANS_FUSE_GATHER=0)
     }
     n_flush = max(1, n_flush_timed)
     n_sep = L - 1 if fused_head else L
-    count = {"layer_fwd": n_sep, "layer_bwd": n_sep, "layer_bwd_head": 1, "lazy_flush": n_flush / K}  # launches per step (the flush runs every
+    gather_fused = "layer_fwd_gather" in phases
+    count = {"layer_fwd": n_sep - (1 if gather_fused else 0), "layer_fwd_gather": 1, "layer_bwd": n_sep, "layer_bwd_head": 1,
+             "lazy_flush": n_flush / K}  # launches per step (the flush runs every
     #                                   SATRANS_LAZY_FLUSH_EVERY = 64 steps and once more at the end of the timed region)
 
     def table(ph, count=count):
@@ -581,7 +585,8 @@ def main():
             from satrans_amd import native as _native
             sha = _native.source_hash()
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
-            rec = next(v for k, v in pmc.items() if k.startswith(roofline["kernel"]))
+            rec = pmc[{"layer_bwd": "layer_bwd_fused_kernel", "layer_bwd_head": "layer_bwd_fused_kernel[head]",
+                       "layer_fwd": "layer_fwd_fused_kernel", "layer_fwd_gather": "layer_fwd_fused_kernel @layer0"}.get(dominant, roofline["kernel"])]
             if pmc.get("_source_sha256") != sha:
                 roofline["traffic_source"] = (f"stale: profiles/{PMC_SUMMARY} was taken on other kernel sources "
                                               f"({str(pmc.get('_source_sha256'))[:12]} vs {sha[:12]})")
@@ -598,6 +603,18 @@ def main():
     # ---- the gather on its own: achieved HBM GB/s at the training batch and at the reference's prediction batch
     #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
     gather = gather_microbench(eng, Xd, B, F, D) if not args.train_only else None
+    if gather is not None and gather_fused and "layer_fwd" in phases:
+        # In the training step no gather kernel runs: layer 0 reads its B x F rows (128-byte random reads) straight from the arena.
+        # What that costs is the difference between layer 0's forward launch and the same kernel on dense [B,F,D] input (layer 1).
+        exposed = phases["layer_fwd_gather"] - phases["layer_fwd"]
+        nbytes = B * F * (D * 4 + 4)
+        gather["fused_into_layer0"] = {
+            "layer0_fwd_ms": round(phases["layer_fwd_gather"], 4), "other_layer_fwd_ms": round(phases["layer_fwd"], 4),
+            "exposed_ms": round(exposed, 4), "algorithmic_read_bytes": nbytes,
+            "hidden": bool(exposed <= 0.002),
+            "read_GBps_if_all_exposed_time_were_the_gather": round(nbytes / 1e9 / (max(exposed, 1e-4) / 1e3), 1),
+            "note": "timed region of the training step, HIP events on every 4th step: the gather's random row reads run underneath "
+                    "layer 0's arithmetic (the kernel is compute-bound); `exposed_ms` is all of it that the step pays for"}
 
     # ---- the evaluation forward alone (predict / evaluate path) at the reference's prediction batch --------------------------
     forward_only = None

@@ -490,7 +490,9 @@ class PathEngine:
         for l in range(self.L if n_layers is None else n_layers):
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn)
             att = att_list[l].data_ptr() if att_list is not None else None
-            with self.phase("layer_fwd"):
+            # (layer 0 reads its tokens straight from the embedding arena - the gather fused in: its own phase name, so that what
+            #  the random row reads cost shows next to the other layers' time)
+            with self.phase("layer_fwd_gather" if (fuse and l == 0 and training) else "layer_fwd"):
                 if ws["generic"] and not (self.fwd_bf16 and not training and att is None
                                           and lib.satrans_layer_fwd_bf16_supported(C.byref(desc))):
                     saved = ws["gen_saved"][l if len(ws["gen_saved"]) > l else 0]
@@ -1111,7 +1113,7 @@ class PathEngine:
         from . import parallel
         self._owner_plan = None
         world = parallel.world_size()
-        if not (parallel.exchange_enabled() and self.dp_mode == "owner" and self.lazy and self.F_small < self.F) or world == 1:
+        if not (parallel.exchange_enabled() and self.dp_mode == "owner" and self.lazy and self.F_small < self.F):
             return
         if ids.dtype not in (torch.float32, torch.int32, torch.int64) or ids.dim() != 2:
             return
