@@ -20,10 +20,6 @@
 
 namespace satrans {
 
-#ifndef SATRANS_FWD_PREFETCH_X
-#define SATRANS_FWD_PREFETCH_X 0
-#endif
-
 // MOD: what modulates q / k - 0 the MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear' (compile time: the main instantiation
 // pays nothing for the other two).  PROD: 0 = fp32 products on v_mfma_f32_16x16x4_f32, 1 = split products (fp32 operands as bf16
 // pairs, three v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block: layer_fused_common.h) - MOD 0 only
@@ -143,18 +139,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
       // The input row of a wave's (first) token tile is fetched one tile ahead, behind the output block of the previous tile:
       // sample index -> row address -> row are two dependent global loads (HBM misses for the first layer, whose rows come
       // straight from the embedding arena), which three waves per SIMD do not hide at the top of phase 1.
-#if SATRANS_FWD_PREFETCH_X
-      float xn[KT][4];
-#endif
       auto fetch_x = [&](int first_, int tt_, float (&dst)[KT][4]) {
           const int tok_ = 16 * tt_ + n, ntok_ = min(Tsamp, hi - first_) * F;
           const bool valid_ = tok_ < ntok_;
           const int ls_ = valid_ ? tok_ / F : 0, f_ = valid_ ? tok_ - ls_ * F : 0;
           load_frag<KT>(layer_x_row(a, a.order[first_ + ls_], f_, F, D) + g4, dst);
       };
-#if SATRANS_FWD_PREFETCH_X
-      if (16 * wave < min(Tsamp, hi - lo) * F) fetch_x(lo, wave, xn);
-#endif
       for (int first = lo; first < hi; first += Tsamp) {
         const int32_t* samp = a.order + first;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
@@ -167,18 +157,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             const int ls = valid ? tok / F : 0, f = valid ? tok - ls * F : 0;
             const int b = samp[ls];
             float x[KT][4], q[KT][4], k[KT][4], v[KT][4];
-#if SATRANS_FWD_PREFETCH_X
-            if (tt == wave) {
-#pragma unroll
-                for (int t = 0; t < KT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[t][r] = xn[t][r];
-            } else {
-                fetch_x(first, tt, x);
-            }
-#else
             fetch_x(first, tt, x);
-#endif
             store_frag<KT>(sx + (size_t)tok * LD + g4, x);
             if constexpr (PROD) {
                 bf16x8 xh[KT / 2], xl[KT / 2];
@@ -453,9 +432,6 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                     *reinterpret_cast<float4*>(yrow + 16 * t) = make_float4(u[t][0], u[t][1], u[t][2], u[t][3]);
             }
         }
-#if SATRANS_FWD_PREFETCH_X
-        if (first + Tsamp < hi && 16 * wave < min(Tsamp, hi - first - Tsamp) * F) fetch_x(first + Tsamp, wave, xn);
-#endif
         __syncthreads();
         STAMP(12);
       }
@@ -484,22 +460,10 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 // keeps the rolled loop over a.F.
 // (measured per loop with -Rpass-analysis: unrolling the exp / P V loop of phase B is what spills - 56 VGPRs on its own - so that
 // one stays rolled; the other four unroll spill-free)
-#ifndef SATRANS_UB1
-#define SATRANS_UB1 1
-#define SATRANS_UB2 0
-#define SATRANS_UD1 1
-#define SATRANS_UD2 1
-#define SATRANS_UE 1
-#endif
-#ifndef SATRANS_DP_REGS
-#define SATRANS_DP_REGS 0      // 1: dP of phase D in registers between its two passes - 60 spilled VGPRs, +10 % (measured)
-#endif
-#ifndef SATRANS_ATTN_SB
-#define SATRANS_ATTN_SB __builtin_amdgcn_sched_barrier(0)
-#endif
+// (dP of phase D in registers between its two passes: 60 spilled VGPRs, +10 % - measured, not built)
 #define ATTN_CHUNKS(VAR, BODY, UNROLL)                                                                          \
     if constexpr (FT != 0 && (UNROLL)) {                                                                                  \
-        _Pragma("unroll") for (int VAR = 0; VAR < FT; VAR += 4) { BODY(VAR); SATRANS_ATTN_SB; } \
+        _Pragma("unroll") for (int VAR = 0; VAR < FT; VAR += 4) { BODY(VAR); __builtin_amdgcn_sched_barrier(0); } \
     } else {                                                                                                    \
         _Pragma("unroll 1") for (int VAR = 0; VAR < F; VAR += 4) BODY(VAR);                                      \
     }
@@ -1021,7 +985,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) prow[(j0 + u) * HF] = sc[u];
             };
-            ATTN_CHUNKS(j0, chunk1, SATRANS_UB1);
+            ATTN_CHUNKS(j0, chunk1, true);
             f32x2 oacc[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) oacc[e] = f32x2{0.f, 0.f};
@@ -1056,7 +1020,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) prow[(j0 + u) * HF] = ex[u];
             };
-            ATTN_CHUNKS(j0, chunk2, SATRANS_UB2);
+            ATTN_CHUNKS(j0, chunk2, false);      // (unrolled, this loop alone spills 56 VGPRs)
             const float inv = 1.0f / sum;
             st_inv[task] = inv;
             st_keep[task] = keep;
@@ -1221,9 +1185,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
             float dot = 0.f;
-            // with the field count a constant both passes are unrolled and dP stays in registers between them
-            constexpr bool kDpRegs = FT != 0 && SATRANS_UD1 && SATRANS_UD2 && SATRANS_DP_REGS;
-            float dpr[kDpRegs ? ((FT + 3) & ~3) : 1];
             auto chunk3 = [&](const int j0) {
                 f32x2 vr[4][d / 2];
                 float pj[4], dp[4];
@@ -1242,12 +1203,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     dot = fmaf(pj[u], dp[u], dot);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if constexpr (kDpRegs) dpr[j0 + u] = dp[u];
-                    else if (j0 + u < F) drow[j0 + u] = dp[u];
-                }
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < F) drow[j0 + u] = dp[u];
             };
-            ATTN_CHUNKS(j0, chunk3, SATRANS_UD1);
+            ATTN_CHUNKS(j0, chunk3, true);
             f32x2 dq[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) dq[e] = f32x2{0.f, 0.f};
@@ -1258,8 +1217,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
                     pj[u] = prow[j * HF];
-                    if constexpr (kDpRegs) ds[u] = dpr[j0 + u];
-                    else ds[u] = drow[j];
+                    ds[u] = drow[j];
                     load_row<d>(kbase + (size_t)j * LD, kr[u]);
                 }
 #pragma unroll
@@ -1274,7 +1232,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) { drow[j0 + u] = ds[u]; prow[(j0 + u) * HF] = pj[u]; }
             };
-            ATTN_CHUNKS(j0, chunk4, SATRANS_UD2);
+            ATTN_CHUNKS(j0, chunk4, true);
             store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
         }
         lds_barrier();
@@ -1308,7 +1266,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     axpy_row<d>(real ? pm[u] : 0.f, gr[u], dv);
                 }
             };
-            ATTN_CHUNKS(i0, chunk5, SATRANS_UE);
+            ATTN_CHUNKS(i0, chunk5, true);
             store_row<d>(sk + (size_t)(tls * F + j) * LD + h * d, dk, 1.0f);
             store_row<d>(sv + (size_t)(tls * F + j) * LD + h * d, dv, 1.0f);
         }
@@ -1353,7 +1311,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, dm);
-                    if constexpr (PROD && !SATRANS_WGRAD_F32) {           // (dm is read and split once for both halves of h)
+                    if constexpr (PROD) {           // (dm is read and split once for both halves of h)
                         bf16x8 av_[NB], gh_[KT], gl_[KT];
                         load_split_g<KT, LD>(wg_g, gh_, gl_);
                         load_split_a<NB, LD>(wg_q, av_);
@@ -1395,7 +1353,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, in0, valid);
-                    if constexpr (PROD && !SATRANS_WGRAD_F32) {           // (in0 once for both halves of dh)
+                    if constexpr (PROD) {           // (in0 once for both halves of dh)
                         bf16x8 av_[KT], gh_[NB], gl_[NB];
                         load_split_a<KT, LD>(wg_g, av_);
                         load_split_g<NB, LD>(wg_q, gh_, gl_);
@@ -1461,7 +1419,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
-            if constexpr (PROD && !SATRANS_WGRAD_F32) {                   // (x once for the three products)
+            if constexpr (PROD) {                   // (x once for the three products)
                 bf16x8 av_[KT], gh_[KT], gl_[KT];
                 load_split_a<KT, LD>(wg_q, av_);
                 load_split_g<KT, LD>(wg_o, gh_, gl_);
@@ -1992,14 +1950,10 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     hipStream_t stream = (hipStream_t)stream_;
     SATRANS_REQUIRE(satrans_layer_fused_supported(d), SATRANS_E_UNSUPPORTED, "layer_fwd(fused): shape not built");
     // D = 32: one 12-wave workgroup per CU (three waves per SIMD at <= 168 VGPRs, one copy of the weight images in LDS for
-    // ten samples per tile) beats two 4-wave workgroups (two waves per SIMD) by 11 % (0.275 vs 0.309 ms per step);
-    // SATRANS_FWD_WAVES = 4 | 8 selects the other builds
-    static const int fwd_waves = getenv("SATRANS_FWD_WAVES") ? atoi(getenv("SATRANS_FWD_WAVES")) : 12;
+    // ten samples per tile) beats two 4-wave workgroups (two waves per SIMD) by 11 % (0.275 vs 0.309 ms per step)
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
     if (mod && d->D == 32) return mod == 1 ? launch_fwd_w<32, 64, 4, 12, 1>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 2>(d, y, att, stream);
     if (mod) return mod == 1 ? launch_fwd_w<16, 32, 2, kFusedWaves, 1>(d, y, att, stream) : launch_fwd_w<16, 32, 2, kFusedWaves, 2>(d, y, att, stream);
-    if (d->D == 32 && fwd_waves == 8) return launch_fwd_w<32, 64, 4, 8>(d, y, att, stream);
-    if (d->D == 32 && fwd_waves == 4) return launch_fwd<32, 64, 4>(d, y, att, stream);
     // split products in the TRAINING forward only: predict / evaluate keep the fp32 instruction - what a user compares with the
     // reference's outputs is exact to fp32 summation order (logits of a trained model: 1.4e-6 from the CPU oracle against
     // 7.7e-5 with split products), what sits under dropout and minibatch noise is fast
@@ -2066,7 +2020,7 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
     {
     SATRANS_REQUIRE(fused_bwd_plan(d, p), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): shape not built");
     SATRANS_REQUIRE((int64_t)d->B * d->F < ((int64_t)1 << 31), SATRANS_E_UNSUPPORTED, "layer_bwd(fused): B * F must stay below 2^31");
-    static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
+    constexpr bool f_const = true;
     // the AliCCP field count as a compile-time constant: -11 % (0.868 -> 0.777 ms over three layers).  The same for the 16
     // fields of the Alimama `sota-pos` shape (separate Q / K tables) spills 34 VGPRs and gains nothing: not instantiated.
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
@@ -2146,7 +2100,7 @@ extern "C" int satrans_layer_bwd_head_launch_fused(const satrans_layer_desc* d, 
     hd.n_dense = h->n_dense; hd.loss_kind = h->loss_kind;
     hd.prob = h->prob; hd.logit = h->logit; hd.partial = h->scratch;
     const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
-    static const bool f_const = !(getenv("SATRANS_BWD_FCONST") && atoi(getenv("SATRANS_BWD_FCONST")) == 0);
+    constexpr bool f_const = true;
     int rc;
     if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);

@@ -142,12 +142,8 @@ __device__ __forceinline__ void chain_t(const float* __restrict__ wl, const floa
 // 1.8e-8, worst gradient 3.6e-5 against 1.3e-5 of the largest entry: tools/experiments/r03_split_products_sim.py).
 // Weights are split ONCE per workgroup while they are staged into LDS; activations on the fly (~3 VALU instructions per value).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef SATRANS_SPLIT_SB
-#define SATRANS_SPLIT_SB __builtin_amdgcn_sched_barrier(0)      // keeps the fragment reads of a chain above its MFMAs
-#endif
-#ifndef SATRANS_SPLIT_TERMS
-#define SATRANS_SPLIT_TERMS 3      // 4 = the a_lo w_lo term as well (one more instruction per block)
-#endif
+// (with the a_lo w_lo term as a fourth instruction: logits 3.3e-8 instead of 4.8e-8 against fp64, +12 % forward time - measured in
+// round 3, not built)
 
 // Image of a weight for split products: rows = output features, RS = K + 8 bf16 per row (16 bytes of padding: the row stride is an
 // odd number of 16-byte slots), the hi image followed by the lo image.  Inside a row the contraction index k sits where the B
@@ -288,16 +284,10 @@ __device__ __forceinline__ void chain_split(const __bf16* __restrict__ hl, int l
             ah[s][mt] = *reinterpret_cast<const bf16x8*>(hl + 16 * mt * RS + 32 * s);
             al[s][mt] = *reinterpret_cast<const bf16x8*>(hl + lo_off + 16 * mt * RS + 32 * s);
         }
-    SATRANS_SPLIT_SB;
+    __builtin_amdgcn_sched_barrier(0);      // keeps the fragment reads of a chain above its MFMAs
 #pragma unroll
     for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the small terms first
-#if SATRANS_SPLIT_TERMS == 4
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][mt], bl[s], acc[mt], 0, 0, 0);
-#endif
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -430,14 +420,11 @@ __device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f3
     mma_split<MT_, NT_, MOFF, NOFF>(av, gh, gl_, acc);
 }
 
-#ifndef SATRANS_WGRAD_F32
-#define SATRANS_WGRAD_F32 0      // 1: keep the token-contraction products on the fp32 instruction in split mode (experiments)
-#endif
 template <int PROD>
 struct wgrad_sel {
     template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
     static __device__ __forceinline__ void run(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
-        if constexpr (PROD && !SATRANS_WGRAD_F32) wgrad_split<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
+        if constexpr (PROD) wgrad_split<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
         else wgrad_r4<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
     }
 };
