@@ -567,9 +567,12 @@ def main():
                     "unit": e["unit"], "frac": e["frac"], "traffic": None,
                     "algorithmic_per_launch": spec["work"], "launch_ms": e["ms_per_launch"],
                     "launches_per_step": count.get(dominant, 1),
-                    "note": "HIP events on the launch stream over the timed region (every 4th step); layer_bwd includes "
-                            "its fixed-order reduction launch; `kernels_serial` repeats the measurement in an extra "
-                            "untimed pass" + ("; `achieved` counts the ALGORITHMIC fp32 FLOPs of the layer, `peak` is the fp32 "
+                    "note": "HIP events on the launch stream over the timed region (every 4th step); " +
+                            ("the weight-gradient slabs of all layers are reduced by ONE launch per step (`layer_bwd_reduce`), "
+                             "so a layer_bwd launch is the backward kernel alone; the last layer runs as `layer_bwd_head` "
+                             "(its forward, the head, the loss and their backward in one launch)" if "layer_bwd_reduce" in phases
+                             else "layer_bwd includes its fixed-order reduction launch") +
+                            "; `kernels_serial` repeats the measurement in an extra untimed pass" + ("; `achieved` counts the ALGORITHMIC fp32 FLOPs of the layer, `peak` is the fp32 "
                             "MFMA peak: the kernel issues them as split bf16 products (3 x 1/16 of the fp32 instruction's "
                             "cycles), so the matrix pipe is ~10 % of its cycles and the fraction is a time-to-solution "
                             "figure against the fp32 roof, not a pipe utilisation" if products == "split" else "")}

@@ -993,20 +993,26 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             uint32_t keep = 0xFFFFFFFFu;
             const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb);
             const uint32_t block0 = drop_attn_elem(h, F, i, 0) >> 2;
-            auto chunk2 = [&](const int j0) {
+            // `guarded`: the chunk may hold keys beyond F (the last, partial chunk).  With the field count a constant the whole
+            // chunks run as a rolled loop WITHOUT guards - unrolled, this loop alone spills 56 VGPRs; rolled with guards, hipcc
+            // turns every `j < F` into a scalar branch around its v_exp (eight taken-or-not branches per iteration at one wave
+            // per SIMD) - and the partial chunk follows as straight-line code with constant guards.
+            auto chunk2 = [&](const int j0, auto guarded_c) {
+                constexpr bool guarded = decltype(guarded_c)::value;
                 f32x2 vr[4][d / 2];
                 float ex[4];
                 const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)(j0 >> 2), dc.thresh) : 0xFu;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int j = min(j0 + u, F - 1);
+                    const int j = guarded ? min(j0 + u, F - 1) : j0 + u;
                     ex[u] = prow[j * HF];
                     load_row<d>(vbase + (size_t)j * LD, vr[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + u;
-                    ex[u] = j < F ? __builtin_amdgcn_exp2f(ex[u] - mx) : 0.f;
+                    ex[u] = __builtin_amdgcn_exp2f(ex[u] - mx);
+                    if (guarded && j >= F) ex[u] = 0.f;
                     sum += ex[u];
                     float pe = ex[u];
                     if (dc.on) {
@@ -1018,9 +1024,17 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) prow[(j0 + u) * HF] = ex[u];
+                    if (!guarded || j0 + u < F) prow[(j0 + u) * HF] = ex[u];
             };
-            ATTN_CHUNKS(j0, chunk2, false);      // (unrolled, this loop alone spills 56 VGPRs)
+            if constexpr (FT != 0) {
+                constexpr int kWhole = FT & ~3;
+#pragma unroll 1
+                for (int j0 = 0; j0 < kWhole; j0 += 4) chunk2(j0, std::false_type{});
+                if constexpr (kWhole < FT) chunk2(kWhole, std::true_type{});
+            } else {
+#pragma unroll 1
+                for (int j0 = 0; j0 < F; j0 += 4) chunk2(j0, std::true_type{});
+            }
             const float inv = 1.0f / sum;
             st_inv[task] = inv;
             st_keep[task] = keep;
