@@ -1608,6 +1608,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 // index order, the group sums are then combined in group order (fixed order => bitwise reproducible).  (8 groups: 32 dependent
 // rounds of loads per thread, 12 us per launch for 4 MB; 32 groups: 8 rounds.)
 constexpr int kRG = 32;
+constexpr int kReduceMaxLayers = 8;      // layers one reduction launch can serve (satrans_layer_bwd_reduce)
 __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ common, int G, int D, int flags, int block,
                                                     float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
                                                     float* g_lnq, float* g_lnk) {
@@ -1685,30 +1686,38 @@ __device__ __forceinline__ void fused_records_reduce(int n_layers, const float* 
         const int h = e / (d * d), i = (e / d) % d, j = e % d;
         src_q = (h * d + i) * D + h * d + j;
     }
-    for (int l = 0; l < n_layers; ++l) {
-        const float* records = records_of[l];
-        float aq = 0.f, ak = 0.f;
-        if (e < half) {
+    // the partial sums of ALL layers first (their loads are independent: one round of memory latency instead of one per layer), then
+    // the group sums layer after layer through LDS
+    float aq[kReduceMaxLayers], ak[kReduceMaxLayers];
+#pragma unroll
+    for (int l = 0; l < kReduceMaxLayers; ++l) {
+        aq[l] = 0.f; ak[l] = 0.f;
+        if (l < n_layers && e < half) {
+            const float* records = records_of[l];
 #pragma unroll 4
             for (int w = a; w < b; ++w) {
                 const float* rec = records + (size_t)(w + s) * TSZ;
-                if (mq) aq += rec[src_q];
-                if (mk) ak += rec[src_k];
+                if (mq) aq[l] += rec[src_q];
+                if (mk) ak[l] += rec[src_k];
             }
         }
-        s_q[grp][lane] = aq;
-        s_k[grp][lane] = ak;
+    }
+#pragma unroll
+    for (int l = 0; l < kReduceMaxLayers; ++l) {
+        if (l >= n_layers) break;
+        s_q[grp][lane] = aq[l];
+        s_k[grp][lane] = ak[l];
         __syncthreads();
         if (grp == 0 && e < half) {
-            aq = 0.f; ak = 0.f;
-            for (int k = 0; k < kRG; ++k) { aq += s_q[k][lane]; ak += s_k[k][lane]; }
+            float tq = 0.f, tk = 0.f;
+            for (int k = 0; k < kRG; ++k) { tq += s_q[k][lane]; tk += s_k[k][lane]; }
             float* g_tab_q = g_tab_q_of[l];
             float* g_tab_k = g_tab_k_of[l];
             if (mq && mk && g_tab_q == g_tab_k) {
-                g_tab_q[(size_t)s * tab_stride + e] += aq + ak;
+                g_tab_q[(size_t)s * tab_stride + e] += tq + tk;
             } else {
-                if (mq) g_tab_q[(size_t)s * tab_stride + e] += aq;
-                if (mk) g_tab_k[(size_t)s * tab_stride + e] += ak;
+                if (mq) g_tab_q[(size_t)s * tab_stride + e] += tq;
+                if (mk) g_tab_k[(size_t)s * tab_stride + e] += tk;
             }
         }
         __syncthreads();
@@ -1734,7 +1743,6 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_kernel(const float* __r
 // ---- all layers of a step in ONE reduction launch (satrans_layer_bwd_reduce): the backward kernels of the step's layers were
 //      launched back to back with a slab buffer each; blocks [l * per_layer, (l + 1) * per_layer) do what fused_reduce_kernel does
 //      for layer l, the blocks behind them add the fused head's partial rows (head_reduce_kernel's arithmetic and order) ----------
-constexpr int kReduceMaxLayers = 8;
 struct ReduceLayers {
     int n;
     const float* slabs[kReduceMaxLayers];

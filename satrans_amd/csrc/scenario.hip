@@ -68,6 +68,49 @@ __global__ __launch_bounds__(256) void scenario_table_bwd_e1_kernel(const float*
     }
 }
 
+// The two kernels above as ONE launch (they are independent; each is at the ~5 us launch floor): blocks [0, n_w) run the weight /
+// bias part, the S * kSlices blocks behind them the first level of the embedding part.
+__global__ __launch_bounds__(256) void scenario_table_bwd_we1_kernel(const float* __restrict__ emb, const float* __restrict__ W,
+                                                                   const float* __restrict__ g_tab, int S, int De, int P,
+                                                                   float* __restrict__ g_W, float* __restrict__ g_bias,
+                                                                   float* __restrict__ partial, int n_w) {
+    extern __shared__ float s_part[];   // [kSub][De]
+    if ((int)blockIdx.x < n_w) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= P * De) return;
+        const int p = i / De, k = i - p * De;
+        float acc = 0.f, accb = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float g = g_tab[(size_t)s * P + p];
+            acc = fmaf(g, fmaxf(emb[(size_t)s * De + k], 0.f), acc);
+            accb += g;
+        }
+        g_W[i] += acc;
+        if (k == 0) g_bias[p] += accb;
+        return;
+    }
+    const int bx = blockIdx.x - n_w;
+    const int s = bx / kSlices, slice = bx - s * kSlices;
+    const int per = 256 / kSub;
+    const int sub = threadIdx.x / per, kk = threadIdx.x % per;
+    const int span = (P + kSlices - 1) / kSlices, sspan = (span + kSub - 1) / kSub;
+    const int p0 = min(P, slice * span + sub * sspan), p1 = min(min(P, (slice + 1) * span), p0 + sspan);
+    for (int k0 = 0; k0 < De; k0 += per) {
+        const int k = k0 + kk;
+        if (k < De) {
+            float acc = 0.f;
+            for (int p = p0; p < p1; ++p) acc = fmaf(g_tab[(size_t)s * P + p], W[(size_t)p * De + k], acc);
+            s_part[sub * De + k] = acc;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < De; k += blockDim.x) {
+        float t = 0.f;
+        for (int sh = 0; sh < kSub; ++sh) t += s_part[sh * De + k];
+        partial[((size_t)s * kSlices + slice) * De + k] = t;
+    }
+}
+
 __global__ void scenario_table_bwd_e2_kernel(const float* __restrict__ emb, const float* __restrict__ partial, int S, int De,
                                              float* __restrict__ g_emb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,10 +282,10 @@ extern "C" int satrans_scenario_table_bwd(const float* emb, const float* W, cons
     SATRANS_REQUIRE(emb && W && g_tab && g_emb && g_W && g_bias && workspace, SATRANS_E_BADARG, "scenario_table_bwd: null pointer");
     SATRANS_REQUIRE(S > 0 && De > 0 && P > 0 && (int64_t)P * De < ((int64_t)1 << 31), SATRANS_E_BADARG,
                     "scenario_table_bwd: S=%d De=%d P=%d", S, De, P);
-    scenario_table_bwd_w_kernel<<<(unsigned)ceil_div((int64_t)P * De, 256), 256, 0, stream>>>(emb, g_tab, S, De, P, g_W, g_bias);
-    SATRANS_CHECK_LAUNCH("scenario_table_bwd_w_kernel");
-    scenario_table_bwd_e1_kernel<<<dim3(S, kSlices), 256, sizeof(float) * kSub * De, stream>>>(W, g_tab, De, P, workspace);
-    SATRANS_CHECK_LAUNCH("scenario_table_bwd_e1_kernel");
+    const int n_w = (int)ceil_div((int64_t)P * De, 256);
+    scenario_table_bwd_we1_kernel<<<(unsigned)(n_w + S * kSlices), 256, sizeof(float) * kSub * De, stream>>>(emb, W, g_tab, S, De, P, g_W,
+                                                                                                          g_bias, workspace, n_w);
+    SATRANS_CHECK_LAUNCH("scenario_table_bwd_we1_kernel");
     scenario_table_bwd_e2_kernel<<<(unsigned)ceil_div(S * De, 256), 256, 0, stream>>>(emb, workspace, S, De, g_emb);
     SATRANS_CHECK_LAUNCH("scenario_table_bwd_e2_kernel");
     return SATRANS_OK;

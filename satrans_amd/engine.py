@@ -909,7 +909,7 @@ class PathEngine:
         world = parallel.world_size()
         exch = parallel.exchange_enabled()            # several ranks (or one rank made to run its collectives: tests)
         if exch and self.dp_mode == "owner" and self.lazy and self.F_small < self.F:
-            return self._train_step_owner(X, y, B, world, self.train_workspace(B, 1, False))
+            return self._train_step_owner(X, y, B, world, self.train_workspace(B, 1, False), next_X)
         if self._owner_world:                          # (a run that switches forms mid-way: bring the replicas together first)
             self.flush_lazy()
             self._owner_world = 0
@@ -1158,7 +1158,7 @@ class PathEngine:
         ws["_owner"] = ow
         return ow
 
-    def _train_step_owner(self, X, y, B, world, ws):
+    def _train_step_owner(self, X, y, B, world, ws, next_X=None):
         """One optimizer step of every data-parallel rank with row OWNERSHIP (reference semantics unchanged: per-GPU batches,
         loss summed over all samples, one dense Adam + L2 step, meta_basemodel.py:272-275,317; main.py:343).
 
@@ -1197,12 +1197,17 @@ class PathEngine:
         if bt is None or bt[0] is not bounds:
             bt = self._owner_bounds_t = (bounds, torch.tensor(bounds[1:-1], dtype=torch.int32, device=self.dev))
 
-        # ---- 1. this batch's arena rows, sorted; the large-table part is N runs, one per owner -----------------------------
-        N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
-                                       N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
-                                       self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
+        # ---- 1. this batch's arena rows, sorted; the large-table part is N runs, one per owner (the previous step may have
+        #         prepared them - ids -> rows, per-field sort, bucketing - on the side stream: _prepare_async) ------------------
+        prepared = self._take_prepared(X, ws)
+        if not prepared:
+            N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
+                                           N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
+                                           self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
         with self.phase("embed_sort"):
-            if self._sort_fields is not None and B <= 8192:
+            if prepared:
+                pass
+            elif self._sort_fields is not None and B <= 8192:
                 f_, lo_, n_ = self._sort_fields
                 N.check(lib.satrans_embed_sort_fields(ws["rows"].data_ptr(), B, self.F, f_, lo_, n_, ws["sorted_rows"].data_ptr(),
                                                       ws["src"].data_ptr(), st), "satrans_embed_sort_fields")
@@ -1263,8 +1268,12 @@ class PathEngine:
             inv[ws["src"].long()] = ws["iota_loc"]
         # ---- 3. forward, loss, backward on the received rows ------------------------------------------------------------------
         self._x_src = (xg, inv)
+        hook = None
+        if next_X is not None and self._dense_override is None and self._can_prepare(next_X, next_X.shape[0]) \
+                and next_X.shape[1] >= self.n_cols:
+            hook = lambda: self._prepare_async(next_X, B)
         try:
-            gemb = self.backward(X, y, ws, rows_ready=True)
+            gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook)
         finally:
             self._x_src = None
         # ---- 4. small tables + dense parameters: one all-reduce; large tables: gradient rows to their owners -------------------
