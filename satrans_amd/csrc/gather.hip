@@ -102,59 +102,73 @@ __global__ void segment_bounds_kernel(const uint32_t* __restrict__ sorted_keys, 
 }
 
 // The whole bucketing as ONE launch for a handful of scenarios (the usual case: AliCCP has 4 scenario rows): a stable counting sort
-// in one workgroup.  Thread t owns the samples [t ipt, (t + 1) ipt); the counts c[s][t] laid out scenario-major ARE the
-// histogram of a stable sort, so the exclusive prefix over that array is the output position of thread t's first sample of
-// scenario s.  (The general path below is extract + a rocPRIM radix sort of six launches + bounds: eight launches of ~5 us.)
-constexpr int kBucketThreads = 1024, kBucketMaxS = 16, kBucketMaxIpt = 64;
+// in one workgroup.  Samples are taken in rounds of 1,024 (thread t of round r owns sample 1024 r + t: coalesced reads); inside a
+// wave the samples of scenario s are ranked by a ballot, so the counts c[s][r][w] (scenario, round, wave - in that order) ARE the
+// histogram of a stable sort, and their exclusive prefix plus the rank inside the wave is a sample's position in `order`.
+// (The general path below is extract + a rocPRIM radix sort of six launches + bounds: eight launches of ~5 us.)
+constexpr int kBucketThreads = 1024, kBucketWaves = kBucketThreads / 64, kBucketMaxS = 16, kBucketMaxRounds = 64;
+__device__ __forceinline__ int lanes_below(uint64_t mask) {      // set bits of `mask` in lanes below this one
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+template <int SP>      // scenario rows, padded to 4 / 8 / 16: the ballots per round
 __global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const void* __restrict__ X, int id_dtype, int64_t x_stride,
                                                                       int col, int B, int S, int32_t* __restrict__ sid,
                                                                       int32_t* __restrict__ order, int32_t* __restrict__ seg,
                                                                       int32_t* __restrict__ status) {
-    extern __shared__ int32_t s_pos[];                 // [S][kBucketThreads] counts, then exclusive prefixes
-    __shared__ int32_t s_wave[kBucketThreads / 64];
-    const int t = threadIdx.x;
-    const int ipt = (B + kBucketThreads - 1) / kBucketThreads;
-    const int b0 = t * ipt, b1 = min(B, b0 + ipt);
-    int32_t cnt[kBucketMaxS];
-#pragma unroll
-    for (int s = 0; s < kBucketMaxS; ++s) cnt[s] = 0;
+    extern __shared__ int32_t s_pos[];                 // [SP][R][kBucketWaves] counts, then exclusive prefixes
+    __shared__ int32_t s_wave[kBucketWaves];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int R = (B + kBucketThreads - 1) / kBucketThreads;
+    const int n = SP * R * kBucketWaves;
     bool bad = false;
-    for (int b = b0; b < b1; ++b) {
-        int64_t id = load_id(X, id_dtype, x_stride, b, col);
-        if (id < 0 || id >= S) { bad = true; id = 0; }
-        sid[b] = (int32_t)id;
+    for (int r = 0; r < R; ++r) {
+        const int b = r * kBucketThreads + t;
+        int id = -1;                                   // (beyond B: no scenario)
+        if (b < B) {
+            int64_t v = load_id(X, id_dtype, x_stride, b, col);
+            if (v < 0 || v >= S) { bad = true; v = 0; }
+            id = (int)v;
+            sid[b] = id;
+        }
 #pragma unroll
-        for (int s = 0; s < kBucketMaxS; ++s) cnt[s] += (id == s) ? 1 : 0;
+        for (int sc = 0; sc < SP; ++sc) {
+            const uint64_t mask = __ballot(id == sc);
+            if (lane == 0) s_pos[(sc * R + r) * kBucketWaves + w] = __popcll(mask);
+        }
     }
     if (bad) atomicOr(status, 1);
-#pragma unroll
-    for (int s = 0; s < kBucketMaxS; ++s)
-        if (s < S) s_pos[s * kBucketThreads + t] = cnt[s];
     __syncthreads();
-    // exclusive prefix over the S * 1024 counts: thread t scans the S consecutive entries [t S, (t + 1) S) of the flat array
+    // exclusive prefix over the n counts: thread t scans the consecutive entries [t per, (t + 1) per)
+    const int per = (n + kBucketThreads - 1) / kBucketThreads;
     int32_t mine = 0;
-    for (int k = 0; k < S; ++k) mine += s_pos[t * S + k];
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) mine += s_pos[k];
     int32_t incl = mine;                               // inclusive scan of `mine` over the workgroup: lanes, then waves
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int32_t up = __shfl_up(incl, off, 64);
-        if ((t & 63) >= off) incl += up;
+        if (lane >= off) incl += up;
     }
-    if ((t & 63) == 63) s_wave[t >> 6] = incl;
+    if (lane == 63) s_wave[w] = incl;
     __syncthreads();
-    int32_t base = 0;
-    for (int w = 0; w < (t >> 6); ++w) base += s_wave[w];
-    int32_t run = base + incl - mine;
-    for (int k = 0; k < S; ++k) {
-        const int32_t c = s_pos[t * S + k];
-        s_pos[t * S + k] = run;
+    int32_t run = incl - mine;
+    for (int ww = 0; ww < w; ++ww) run += s_wave[ww];
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) {
+        const int32_t c = s_pos[k];
+        s_pos[k] = run;
         run += c;
     }
     __syncthreads();
-    if (t <= S) seg[t] = t == S ? B : s_pos[t * kBucketThreads];
-    for (int b = b0; b < b1; ++b) {
-        const int s = sid[b];
-        order[s_pos[s * kBucketThreads + t]++] = b;      // (this thread's own slot: no other thread touches it)
+    if (t <= S) seg[t] = t == S ? B : s_pos[t * R * kBucketWaves];
+    for (int r = 0; r < R; ++r) {
+        const int b = r * kBucketThreads + t;
+        const int id = b < B ? sid[b] : -1;            // (written by this very thread above)
+        uint64_t my_mask = 0;
+#pragma unroll
+        for (int sc = 0; sc < SP; ++sc) {
+            const uint64_t mask = __ballot(id == sc);
+            if (id == sc) my_mask = mask;
+        }
+        if (b < B) order[s_pos[(id * R + r) * kBucketWaves + w] + lanes_below(my_mask)] = b;
     }
 }
 
@@ -199,16 +213,25 @@ extern "C" int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_s
     SATRANS_REQUIRE(X && sid && order && seg && status && workspace, SATRANS_E_BADARG, "bucket_scenarios: null pointer");
     SATRANS_REQUIRE(B > 0 && S > 0 && col >= 0, SATRANS_E_BADARG, "bucket_scenarios: bad sizes B=%d S=%d col=%d", B, S, col);
     SATRANS_REQUIRE(id_dtype >= 0 && id_dtype <= 2, SATRANS_E_BADARG, "bucket_scenarios: id_dtype %d", id_dtype);
-    if (S <= kBucketMaxS && B <= kBucketThreads * kBucketMaxIpt) {
-        static bool attr_set = false;
-        if (!attr_set) {      // (S = 16: 64 KB of dynamic LDS next to the static wave sums)
-            hipError_t ea = hipFuncSetAttribute((const void*)bucket_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                kBucketMaxS * kBucketThreads * (int)sizeof(int32_t));
-            SATRANS_REQUIRE(ea == hipSuccess, SATRANS_E_LAUNCH, "bucket_scenarios: LDS attribute: %s", hipGetErrorString(ea));
-            attr_set = true;
+    if (S <= kBucketMaxS && B <= kBucketThreads * kBucketMaxRounds) {
+        const int R = (int)ceil_div(B, kBucketThreads);
+        const int SP = S <= 4 ? 4 : (S <= 8 ? 8 : 16);
+        const size_t lds = (size_t)SP * R * kBucketWaves * sizeof(int32_t);      // <= 64 KB
+#define SATRANS_BUCKET(SPV)                                                                                                     \
+        bucket_small_kernel<SPV><<<1, kBucketThreads, lds, stream>>>(X, id_dtype, x_stride, col, B, S, sid, order, seg, status)
+        if (SP == 4) SATRANS_BUCKET(4);
+        else if (SP == 8) SATRANS_BUCKET(8);
+        else {
+            static bool attr_set = false;
+            if (!attr_set) {      // (16 scenario rows x 64 rounds: 64 KB of dynamic LDS next to the static wave sums)
+                hipError_t ea = hipFuncSetAttribute((const void*)bucket_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kBucketMaxS * kBucketMaxRounds * kBucketWaves * (int)sizeof(int32_t));
+                SATRANS_REQUIRE(ea == hipSuccess, SATRANS_E_LAUNCH, "bucket_scenarios: LDS attribute: %s", hipGetErrorString(ea));
+                attr_set = true;
+            }
+            SATRANS_BUCKET(16);
         }
-        bucket_small_kernel<<<1, kBucketThreads, (size_t)S * kBucketThreads * sizeof(int32_t), stream>>>(X, id_dtype, x_stride, col, B, S,
-                                                                                                       sid, order, seg, status);
+#undef SATRANS_BUCKET
         SATRANS_CHECK_LAUNCH("bucket_small_kernel");
         return SATRANS_OK;
     }
