@@ -591,7 +591,15 @@ class BaseModel(nn.Module):
             for name, result in train_result.items():
                 if result and torch.is_tensor(result[0]):
                     result = torch.stack(result).cpu().numpy()           # the epoch's only read of the per-step metrics
-                    if name == "auc" and np.isnan(result).any():
+                    one_class = bool(name == "auc" and np.isnan(result).any())
+                    if name == "auc":
+                        # several ranks: every rank must leave the epoch the same way, or the others block in their next
+                        # collective - the flag is agreed on before anybody raises
+                        from . import parallel as _par
+                        if _par.world_size() > 1:
+                            one_class = bool(_par.all_reduce_scalars(torch.tensor([float(one_class)], dtype=torch.float64,
+                                                                                  device=self.device)).item() > 0)
+                    if one_class:
                         # sklearn (the reference's per-step call) raises on such a batch; here it surfaces at the epoch end
                         raise ValueError("Only one class present in y_true of a training batch. ROC AUC score is not "
                                          "defined in that case.")

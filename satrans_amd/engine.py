@@ -683,7 +683,7 @@ class PathEngine:
             self.flat_m.copy_(st["flat_m"].to(self.dev))
             self.flat_v.copy_(st["flat_v"].to(self.dev))
             self.last_step.fill_(self.adam_t)            # the state was taken after a flush: every row is current
-            self._table_lr = self._table_dirty = self._lr_hist = None    # (rows of earlier steps are never replayed again)
+            self._table_lr = self._table_dirty = self._lr_hist = self._lr_starts = None    # (rows of earlier steps are never replayed again)
             self._hp_table = None
         else:
             self._opt_state_arena.copy_(st["acc_arena"].to(self.dev))
@@ -1131,7 +1131,12 @@ class PathEngine:
         for lo in range(0, n, 1 << 22):                                                # (bounded temporaries on 42 M-row datasets)
             hi = min(n, lo + (1 << 22))
             sel = order[lo:hi] if order is not None else slice(lo, hi)
-            rows = ids[sel][:, cols].long() + self.row_span[big, 0][None, :]
+            idv = ids[sel][:, cols].long()
+            size = (self.row_span[big, 1] - self.row_span[big, 0])[None, :]
+            # an id outside its table is recorded as the table's FIRST row by the gather kernel (and flagged: the step raises
+            # IndexError afterwards); the plan must count it where the step will send it, or the all-to-all sizes disagree
+            idv = torch.where((idv < 0) | (idv >= size), torch.zeros_like(idv), idv)
+            rows = idv + self.row_span[big, 0][None, :]
             owner = torch.bucketize(rows, inner, right=True)                              # rows >= a boundary belong to the next owner
             key = step_of[lo:hi, None] * world + owner
             per.view(-1).scatter_add_(0, key.reshape(-1), torch.ones_like(key.reshape(-1)))
@@ -1395,6 +1400,11 @@ class PathEngine:
         prev = getattr(self, "_table_lr", None)
         if prev is None or lr != prev:
             hist[self.adam_t] = lr
+            starts = getattr(self, "_lr_starts", None)
+            if starts is not None and (not starts or self.adam_t > starts[-1]):
+                starts.append(self.adam_t)          # (steps only grow: the sorted key list stays sorted)
+            else:
+                self._lr_starts = None
             self._table_lr = lr
             if self._hp_table is not None:
                 d = getattr(self, "_table_dirty", None)
@@ -1402,12 +1412,21 @@ class PathEngine:
 
     def _rates(self, lo: int, hi: int):
         """Learning rate of the steps [lo, hi) as an fp64 array: the rate of the last change at or before each step (steps before
-        the first recorded change - a resumed run - take the first recorded rate; they are never replayed)."""
+        the first recorded change - a resumed run - take the first recorded rate; they are never replayed).  The history is
+        kept in step order (every `_note_lr` appends), so the segments that matter are found by bisection: a scheduler that
+        changes the rate every step costs O(changes inside [lo, hi)) per call, not O(all changes so far)."""
+        import bisect
         import numpy as np
         hist = getattr(self, "_lr_hist", None) or {0: self.m._adam_cfg["lr"]}
-        starts = sorted(hist)
+        starts = getattr(self, "_lr_starts", None)
+        if starts is None or len(starts) != len(hist):
+            starts = self._lr_starts = sorted(hist)
         out = np.empty(max(0, hi - lo), dtype=np.float64)
-        for i, st in enumerate(starts):
+        i0 = max(0, bisect.bisect_right(starts, lo) - 1)
+        for i in range(i0, len(starts)):
+            st = starts[i]
+            if st >= hi:
+                break
             a_, b_ = max(lo, st if i else 0), (starts[i + 1] if i + 1 < len(starts) else hi)
             if b_ > a_:
                 out[a_ - lo:min(b_, hi) - lo] = hist[st]
