@@ -10,6 +10,13 @@ namespace satrans {
 
 constexpr int kWave = 64;
 
+// Workgroup-range groups of the fixed-order reductions (fused_reduce_kernel / fused_reduce_all_kernel / head_reduce_kernel): a block
+// is 32 elements x kReduceGroups groups, every group adds its contiguous share of the partial rows in index order, the group sums are
+// combined in group order.  ONE constant for all of them: the head's rows are reduced by head_reduce_kernel or inside
+// fused_reduce_all_kernel and must come out the same bits.  (A/B on one box, round 4: 4 / 8 / 16 / 32 groups -> 49 / 30 / 25 / 33 us
+// for the three-layer reduction.)
+constexpr int kReduceGroups = 16;
+
 // thread-local description of the last failure, surfaced by satrans_last_error()
 void set_error(const char* fmt, ...);
 

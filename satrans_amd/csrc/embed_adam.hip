@@ -24,7 +24,7 @@
 
 namespace satrans {
 
-constexpr int kChunk = 32;         // sorted positions per lane group in the touched-row pass
+constexpr int kChunk = 16;         // sorted positions per lane group in the touched-row pass (A/B on one box, round 4: 8 / 16 / 32 / 64 -> 75 / 74 / 81 / 96 us for the five launches)
 constexpr int kStreamBlock = 256;
 constexpr int kStreamBlocks = 2048;  // upper bound of the streaming grid = slots reserved for its partial sums
 
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict_
         };
         // positions in batches of 8: the ids, source positions and the 8 gradient rows of a batch are loaded together
         // (8 independent 16-byte loads in flight per lane), then consumed in position order
-        constexpr int kBatch = 8;
+        constexpr int kBatch = 16;      // (= kChunk: the whole chunk in one round of loads; 4 / 8 / 16 -> 74 / 73 / 69 us for the chain)
         for (int64_t jb = start; jb < end; jb += kBatch) {
             int32_t r[kBatch];
             float4 g[kBatch];

@@ -99,8 +99,7 @@ __global__ __launch_bounds__(kHeadBlock) void head_kernel(const float* __restric
     }
 }
 
-// block = 32 columns x 32 groups of partial rows (contiguous shares, index order), group sums combined in group order
-constexpr int kReduceGroups = 32;
+// block = 32 columns x kReduceGroups (common.h) groups of partial rows (contiguous shares, index order), group sums combined in group order
 __global__ __launch_bounds__(32 * kReduceGroups) void head_reduce_kernel(const float* __restrict__ partial, int nblk, int ncol,
                                                                        float* __restrict__ g_w, float* __restrict__ g_b,
                                                                        double* __restrict__ loss_sum) {

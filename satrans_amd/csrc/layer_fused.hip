@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 // Both use blocks of 32 elements x kRG = 32 groups of workgroups: every group adds its contiguous share of the workgroup range in
 // index order, the group sums are then combined in group order (fixed order => bitwise reproducible).  (8 groups: 32 dependent
 // rounds of loads per thread, 12 us per launch for 4 MB; 32 groups: 8 rounds.)
-constexpr int kRG = 32;
+constexpr int kRG = kReduceGroups;      // (common.h)
 constexpr int kReduceMaxLayers = 8;      // layers one reduction launch can serve (satrans_layer_bwd_reduce)
 __device__ __forceinline__ void fused_common_reduce(const float* __restrict__ common, int G, int D, int flags, int block,
                                                     float* g_wq, float* g_wk, float* g_wv, float* g_wo, float* g_ln,
