@@ -1789,6 +1789,7 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_all_kernel(ReduceLayers
                                                              int S, int T, int G, int D, int U, int H, int flags,
                                                              int64_t tab_stride, int common_blocks, int record_blocks,
                                                              int per_layer) {
+    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD)
     // blocks: [n x common_blocks: the scenario-independent part of every layer] [record_blocks x S: the generated-weight records of
     // ALL layers, layer after layer inside the block - their tables may be one and the same] [the fused head's partial rows]
     int bx = blockIdx.x;
