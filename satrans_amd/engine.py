@@ -826,12 +826,15 @@ class PathEngine:
                 with self.phase("scenario_bwd"):
                     self.scenario_tables_backward(g_tabs)
 
+        # train_step: the next batch's preprocessing forks to the side stream HERE, right behind the last backward kernel and in
+        # front of the reduction (the step timeline showed it starting 48 us later when forked behind `finish`, and the next
+        # step's first kernel waiting 29 us for it: profiles/r04_step_timeline_*.txt)
+        if after_layers is not None:
+            after_layers()
         # (Measured and removed: this tail on the side stream underneath the touched-row kernels.  Every cross-stream dependency
         #  costs ~15-20 us of wake-up latency on this platform, two more per step ate the overlap and 45 us besides:
         #  1.265 -> 1.310 ms/step.  Only the next batch's preprocessing - whose join is an event that completed long ago - pays.)
         finish()
-        if after_layers is not None:
-            after_layers()                  # (train_step: the next batch's preprocessing goes to the side stream from here)
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
 
