@@ -188,6 +188,10 @@ class PathEngine:
         self.prefetch = os.environ.get("SATRANS_PREFETCH", "1") != "0"
         # one reduction launch for all layers' weight-gradient slabs (satrans_layer_bwd_reduce; SATRANS_DEFER_REDUCE=0: per layer)
         self.defer_reduce = os.environ.get("SATRANS_DEFER_REDUCE", "1") != "0"
+        # ... on a stream of its own beside the touched-row kernels, with the scenario-table backward (SATRANS_SIDE_TAIL=0: in line)
+        self.side_tail = os.environ.get("SATRANS_SIDE_TAIL", "1") != "0"
+        self._side_tail = None
+        self._tail_done = None
         self._prep = None
         # SATRANS_SAVE_ATTENTION=1: the forward of a training step leaves the attention's softmax numerators / statistics /
         # output for its backward, which then copies them into LDS instead of recomputing them.  Measured:
@@ -732,7 +736,7 @@ class PathEngine:
             ws["defer"] = ok
         return ws["defer"]
 
-    def backward(self, X, y, ws, rows_ready=False, bucket_ready=False, after_layers=None):
+    def backward(self, X, y, ws, rows_ready=False, bucket_ready=False, after_layers=None, side_tail=False):
         """Forward (training mode as set by the caller) + loss + backward.  Leaves the dense gradients in
         `flat_g` and the gradient of the gathered rows in the returned tensor [B,F,D]."""
         lib, B, st = self.lib, X.shape[0], self._stream()
@@ -831,10 +835,25 @@ class PathEngine:
         # step's first kernel waiting 29 us for it: profiles/r04_step_timeline_*.txt)
         if after_layers is not None:
             after_layers()
-        # (Measured and removed: this tail on the side stream underneath the touched-row kernels.  Every cross-stream dependency
-        #  costs ~15-20 us of wake-up latency on this platform, two more per step ate the overlap and 45 us besides:
-        #  1.265 -> 1.310 ms/step.  Only the next batch's preprocessing - whose join is an event that completed long ago - pays.)
-        finish()
+        # train_step (side_tail): the reduction and the scenario-table backward feed only the flat Adam launch at the very end of
+        # the step, while the five touched-row launches that come first need only the last backward kernel's dx.  On a stream of
+        # their own (NOT the next-batch stream: queued behind each other the two made the next step wait, which is what the first
+        # attempt measured as "45 us slower") they run beside the touched-row chain; the flat Adam waits for `_tail_done`, an
+        # event that has long completed by then.
+        self._tail_done = None
+        if side_tail and d_descs:
+            main = torch.cuda.current_stream(self.dev)
+            if self._side_tail is None:
+                self._side_tail = torch.cuda.Stream(self.dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self._side_tail.wait_event(fork)
+            with torch.cuda.stream(self._side_tail):
+                finish()
+                self._tail_done = torch.cuda.Event()
+                self._tail_done.record(self._side_tail)
+        else:
+            finish()
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
 
@@ -1014,7 +1033,8 @@ class PathEngine:
         if next_X is not None and not exch and self._dense_override is None and self._can_prepare(next_X, next_X.shape[0]) \
                 and next_X.shape[1] >= self.n_cols:
             hook = lambda: self._prepare_async(next_X, B)
-        gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook)
+        gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook,
+                             side_tail=self.side_tail and not exch and not split)
 
         # ---- 5. small tables: ordered segmented sums into the dense gradient at the tail of the flat gradient buffer -----------
         if n_s > 0:
@@ -1072,6 +1092,9 @@ class PathEngine:
             self._since_flush += 1
         self._stepped_since_forward = True
         h_flat = self._hparams(0.0)
+        if self._tail_done is not None:          # the dense gradients were finished on their own stream
+            main.wait_event(self._tail_done)
+            self._tail_done = None
         with self.phase("adam_flat"):
             self._flat_step(h_flat, ws, st)
         if self.lazy and self.flush_every and self._since_flush >= self.flush_every:

@@ -815,19 +815,21 @@ def test_scenario_bucketing_is_a_stable_sort(S, B):
 
 def test_next_batch_hint_changes_no_bit():
     """train_step(X, y, next_X=...) runs the next batch's ids -> rows, per-field sort and scenario bucketing on a side stream under
-    the current step's tail.  Tables, moments and the logged sums after six steps are the same bits with the hint, without it,
-    and with a hint that names the wrong batch (prepared work discarded)."""
+    the current step's tail, and the step's reduction + scenario-table backward run on a stream of their own beside the touched-row
+    kernels.  Tables, moments and the logged sums after six steps are the same bits with everything in line on the launch stream,
+    with the side streams, with the hint, without it, and with a hint that names the wrong batch (prepared work discarded)."""
     c = Case("aliccp_sota")
     rng = np.random.RandomState(4)
     n = c.X.shape[0]
     Xs = [c.X[rng.permutation(n)].to(DEV) for _ in range(6)]
     ys = [c.y[rng.permutation(n)].to(DEV) for _ in range(6)]
 
-    def run(hint):
+    def run(hint, side_tail=True):
         model = build_model(c, DEV)
         model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
         model.train()
         eng = model._require_engine()
+        eng.side_tail = side_tail          # reduction + scenario-table backward on their own stream beside the touched-row kernels
         eng.reset_epoch_sums()
         for i in range(6):
             nxt = None
@@ -838,8 +840,8 @@ def test_next_batch_hint_changes_no_bit():
             eng.train_step(Xs[i], ys[i], next_X=nxt)
         sums = eng.epoch_sums()
         return sd_to_cpu(model), model.optimizer_state_dict(), sums
-    ref_sd, ref_opt, ref_sums = run(None)
-    for hint in ("right", "wrong"):
+    ref_sd, ref_opt, ref_sums = run(None, side_tail=False)      # everything in line on the launch stream
+    for hint in ("right", "wrong", None):
         sd, opt, sums = run(hint)
         assert sums == ref_sums, hint
         for k in ref_sd:
