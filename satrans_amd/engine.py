@@ -743,7 +743,13 @@ class PathEngine:
         m = self.m
         # (one rank without table classes never writes the small tables' dense gradient: only the tail is cleared)
         from . import parallel as _par
-        (self.flat_g_all if (_par.exchange_enabled() or self.force_split) else self._g_step_tail).zero_()
+        g_clear = self.flat_g_all if (_par.exchange_enabled() or self.force_split) else self._g_step_tail
+        # With the reduction deferred to one launch on its own stream nothing writes the dense gradients before that launch: the
+        # clear goes there too, off the launch stream (6 us at the head of every step)
+        # (only with the fused head: the separate head launch adds dnn_linear's gradient in front of the reduction)
+        clear_late = side_tail and self.defer_reduce and ws.get("defer") is True and ws.get("fuse_head") is True
+        if not clear_late:
+            g_clear.zero_()
         training = m.training
         if training:
             self.drop_step += 1
@@ -849,10 +855,14 @@ class PathEngine:
             fork.record(main)
             self._side_tail.wait_event(fork)
             with torch.cuda.stream(self._side_tail):
+                if clear_late:
+                    g_clear.zero_()
                 finish()
                 self._tail_done = torch.cuda.Event()
                 self._tail_done.record(self._side_tail)
         else:
+            if clear_late:
+                g_clear.zero_()
             finish()
         self._last_prob = ws["prob"]
         return ws["dact"][cur]
