@@ -1996,7 +1996,14 @@ extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
 
 extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc* d) {
     FusedBwdPlan p;
-    if (!d || !fused_bwd_plan(d, p) || !p.split) return 0;      // (built for the split-product backward only)
+    // built for the (32, 64, 4) MetaNet shape with one shared table: the split-product backward and (round 4) the fp32-product one
+    if (!d || !fused_bwd_plan(d, p)) return 0;
+    {
+        const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
+        if (!(d->D == 32 && d->U == 64 && same) || (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) ||
+            !(d->flags & (SATRANS_META_Q | SATRANS_META_K)))
+            return 0;
+    }
     const int64_t HF = (int64_t)d->H * d->F;
     // the forward saves from its register-resident score row (F <= 32), the backward copies the numerators 16 bytes at a time
     // ... and stages the tile's dy and saved output rows in the dS cache (T H F F floats): H F >= 2 D
@@ -2064,6 +2071,9 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
         rc = launch_bwd<32, 64, 4, true, false, 19, 0, 1>(d, p, dy, dx, slabs, stream);
     else if (p.split)
         rc = launch_bwd<32, 64, 4, true, false, 0, 0, 1>(d, p, dy, dx, slabs, stream);
+    else if (d->D == 32 && same && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0)
+        rc = d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, 0, true>(d, p, dy, dx, slabs, stream)
+                                   : launch_bwd<32, 64, 4, true, false, 0, 0, 0, true>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream)

@@ -193,10 +193,14 @@ class PathEngine:
         self._side_tail = None
         self._tail_done = None
         self._prep = None
-        # SATRANS_SAVE_ATTENTION=1: the forward of a training step leaves the attention's softmax numerators / statistics /
-        # output for its backward, which then copies them into LDS instead of recomputing them.  Measured:
-        # backward 216 -> 200 us, forward 63 -> 73 us per layer, the step does not move, +72 MB per layer at B = 8192: off by default.
-        self.save_attention = os.environ.get("SATRANS_SAVE_ATTENTION", "0") == "1"
+        # The forward of a training step leaves the attention's softmax numerators / statistics / output for its backward, which
+        # copies them into LDS (global_load_lds) instead of recomputing them - where the fused kernels are built for it (the
+        # (32, 64, 4) MetaNet shape with one shared table; +72 MB per layer at B = 8192).  With fp32 products (round 4): forward
+        # +7 us, backward -23 us per layer (A/B on one box: -13 to -37 us per step); the last layer has no forward launch and
+        # keeps recomputing.  Default: on with fp32 products; the opt-in split-product mode recomputes (measured neutral there in
+        # round 3, and its trajectory bounds were set without it).  SATRANS_SAVE_ATTENTION=0 / 1 forces it off / on in both modes.
+        self._save_attention_env = os.environ.get("SATRANS_SAVE_ATTENTION", "auto")
+        self.save_attention = self._save_attention_env != "0"
         # evaluation forwards (predict / evaluate / model.eval()(X)) with the dense products in bf16 on the matrix pipe
         # (csrc/layer_fwd_bf16.hip; BASELINE.json configs[1]).  Off by default: fp32 is the parity path.  Also
         # model.set_forward_precision("bf16" | "fp32").
@@ -404,7 +408,9 @@ class PathEngine:
         d.seed, d.step = self.drop_seed, self.drop_step & 0xFFFFFFFF
         d.x = N.ptr(x) if x is not None else ws["acts"][l].data_ptr()
         d.x_rows = None
-        d.attn_save = ws["attn_save"][l].data_ptr() if attn_save and ws.get("attn_save") else None
+        use_save = attn_save and ws.get("attn_save") and (self._save_attention_env == "1" or
+                                                          (self._save_attention_env != "0" and self.lib.satrans_get_product_mode() == 0))
+        d.attn_save = ws["attn_save"][l].data_ptr() if use_save else None
         if fuse and l == 0:
             # gather fused into the first layer: token (b, f) is read straight from the embedding arena through the row
             # numbers the rows-only gather launch left in ws["rows"]; [B,F,D] is never written nor read back.

@@ -2185,9 +2185,9 @@ def test_fused_kernels_on_field_counts_without_a_golden_case(F, B):
 
 @pytest.mark.parametrize("train", [False, True])
 def test_saved_attention_backward_equals_the_recomputing_one(monkeypatch, train):
-    """SATRANS_SAVE_ATTENTION=1 (include/satrans_hip.h: satrans_layer_desc.attn_save): the forward leaves softmax numerators,
-    1 / sum, dropout keep words and the attention output per sorted sample position, the split-product backward copies them
-    straight into LDS (global_load_lds) instead of running its attention-forward phase.  Same mathematics: every gradient
+    """Saved attention (the default; SATRANS_SAVE_ATTENTION=0 recomputes; include/satrans_hip.h: satrans_layer_desc.attn_save): the
+    forward leaves softmax numerators, 1 / sum, dropout keep words and the attention output per sorted sample position, the
+    backward (fp32 or split products) copies them straight into LDS (global_load_lds) instead of running its attention-forward phase.  Same mathematics: every gradient
     within rounding of the recomputing backward (the saved numerators come from the forward kernel's q / k, the recomputed
     ones from the backward's - equal up to the last bit), on the golden batch and on a ragged one that leaves partial tiles."""
     c = Case("aliccp_sota")
@@ -2202,7 +2202,7 @@ def test_saved_attention_backward_equals_the_recomputing_one(monkeypatch, train)
         res = []
         for B in (c.X.shape[0], 37):
             bce, reg, grads = eng.loss_and_grads(c.X[:B].to(DEV), c.y[:B].to(DEV))
-            if save == "1" and split_products():        # (built for the split-product backward; fp32 products ignore the switch)
+            if save == "1":
                 assert eng._ws[B].get("attn_save"), "the saved-attention buffers were not allocated"
             res.append((bce, {k: g.cpu() for k, g in grads.items()}))
         outs.append(res)
