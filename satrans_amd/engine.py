@@ -578,6 +578,7 @@ class PathEngine:
         return ws[key]
 
     def forward(self, X: torch.Tensor, training: bool = False, capture_attention: bool = False) -> torch.Tensor:
+        self._join_flat()
         self.flush_lazy()
         X = self._prepare_input(X)
         B = X.shape[0]
@@ -731,6 +732,12 @@ class PathEngine:
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, cfg["eps"], l2
         return h
 
+    def _join_flat(self):
+        """The launch stream waits for the flat Adam launch of the previous step when that ran on the reduction's stream."""
+        ev, self._flat_done = getattr(self, "_flat_done", None), None
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+
     def _defer_reduce(self, ws, B) -> bool:
         if "defer" not in ws:
             ok = self.defer_reduce and not ws["generic"] and 1 <= self.L <= 8
@@ -760,6 +767,7 @@ class PathEngine:
         if training:
             self.drop_step += 1
         modulated = bool(self.flags & (N.META_Q | N.META_K | N.BILINEAR))
+        self._join_flat()
         tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
         fuse_head = self._fuse_head(X, ws, B)
@@ -1108,11 +1116,29 @@ class PathEngine:
             self._since_flush += 1
         self._stepped_since_forward = True
         h_flat = self._hparams(0.0)
-        if self._tail_done is not None:          # the dense gradients were finished on their own stream
-            main.wait_event(self._tail_done)
+        if self._tail_done is not None:
+            # The dense gradients were finished on their own stream: the flat Adam launch follows them THERE (a join here would
+            # cost the launch stream ~14 us of wake-up latency for an event that completes about when the touched-row chain
+            # does), the launch stream only adds up the step's regulariser partial sums.  The next reader of the flat
+            # parameters - the next step's scenario tables, behind its replay launch - waits for `_flat_done`, long complete.
             self._tail_done = None
-        with self.phase("adam_flat"):
-            self._flat_step(h_flat, ws, st)
+            with torch.cuda.stream(self._side_tail):
+                with self.phase("adam_flat"):
+                    N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                                  self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat),
+                                                  self._stream()), "satrans_adam_flat")
+                self._flat_done = torch.cuda.Event()
+                self._flat_done.record(self._side_tail)
+            N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(), 1, st),
+                    "satrans_sum_f64")
+            if next_X is None:
+                # no next step announced (a caller outside a fit-style loop): the launch stream joins right here, so that whatever
+                # it does next - reading a parameter tensor directly, for instance - sees the finished step, as with any torch op.
+                # A pipelined caller (fit, bench: `next_X` given) joins where the next step first reads the flat parameters.
+                self._join_flat()
+        else:
+            with self.phase("adam_flat"):
+                self._flat_step(h_flat, ws, st)
         if self.lazy and self.flush_every and self._since_flush >= self.flush_every:
             self.flush_lazy()
 
@@ -1513,6 +1539,7 @@ class PathEngine:
         """Bring every table row (owner form: every row this rank owns) to the current step - a no-op when nothing is pending -
         and, with `sync`, make the replicas of all ranks identical again (owner form: collective; every rank reaches the flush
         points - epoch end, evaluation forward, state_dict, optimizer_state - together, as it reaches the steps together)."""
+        self._join_flat()
         if self.lazy and self._lazy_pending:
             m = self.m
             h = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
