@@ -515,6 +515,8 @@ def main():
     # the last layer of a step as ONE launch with the head fused in (satrans_layer_bwd_head): its recomputed forward IS the
     # layer's forward (no forward launch exists for it), so the launch carries forward + backward = 3 x the forward's FLOPs
     fused_head = bool(eng._ws.get(B, {}).get("fuse_head"))
+    saved_attn = bool(eng._ws.get(B, {}).get("attn_save")) and eng._save_attention_env != "0" and \
+        (eng._save_attention_env == "1" or eng.lib.satrans_get_product_mode() == 0)
     per_launch = {
         "layer_bwd_head": dict(kernel=bwd_kernel + " (HEADF instantiation: last layer forward + head + loss + backward)",
                                bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=3.0 * fwd_flops / 1e12),
@@ -567,6 +569,13 @@ def main():
                     "unit": e["unit"], "frac": e["frac"], "traffic": None,
                     "algorithmic_per_launch": spec["work"], "launch_ms": e["ms_per_launch"],
                     "launches_per_step": count.get(dominant, 1),
+                    # HBM bytes the launch has to move (what `traffic` is to be read against): layer input, upstream gradient and
+                    # input gradient [B,F,D] each - plus, when the forward handed its attention state over (the default with fp32
+                    # products: softmax numerators H F F, 1 / sum and keep word H F, attention output F D per sample), that state,
+                    # which the backward reads INSTEAD of recomputing it: bytes traded for VALU time in a compute-bound kernel
+                    "algorithmic_bytes_per_launch": (3 * B * F * D * 4 + (B * (CFG["H"] * F * F + 2 * CFG["H"] * F + F * D) * 4
+                                                                         if (dominant == "layer_bwd" and saved_attn) else 0))
+                                                    if dominant in ("layer_bwd", "layer_bwd_head") else None,
                     "note": "HIP events on the launch stream over the timed region (every 4th step); " +
                             ("the weight-gradient slabs of all layers are reduced by ONE launch per step (`layer_bwd_reduce`), "
                              "so a layer_bwd launch is the backward kernel alone; the last layer runs as `layer_bwd_head` "

@@ -187,14 +187,30 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
 #pragma unroll
                     for (int r = 0; r < 4; ++r) q[t][r] = qb[t][r];
             }
+            // SAVE: the normalised MetaNet rows and their 1 / std go to the backward of this step as well (it then skips the two W2
+            // products and the LayerNorm statistics of its recomputation): [sorted position][field][role][D] behind the attention
+            // state, then 1 / std [sorted position][field][role]
+            float zsave[KT][4];
+            float* save_z = nullptr;
+            float* save_r = nullptr;
+            if constexpr (SAVE) {
+                const size_t pos = (size_t)(first + ls) * F + f;
+                float* z_all = a.attn_save + (size_t)a.B * ((size_t)F * H * F + 2 * H * F + (size_t)F * D);
+                save_z = z_all + pos * 2 * D + g4;
+                save_r = z_all + (size_t)a.B * F * 2 * D + pos * 2;
+            }
             if (mlp_q) {                                                                  // satrans.py:60-66
                 float h[UT][4], o[KT][4];
                 if constexpr (PROD)
                     metanet_frag_split<D, U>(bimg(W.w1q) + sl_d, bimg(W.w2q) + sl_u, W.lnq_g, W.lnq_b, g4, dc,
-                                             drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, o, mean, rstd);
+                                             drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, o, mean, rstd, SAVE ? zsave : nullptr);
                 else
                 metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
-                                   drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd);
+                                   drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd, SAVE ? zsave : nullptr);
+                if (SAVE && valid) {
+                    store_frag<KT>(save_z, zsave);
+                    if (g == 0) save_r[0] = rstd;
+                }
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -204,10 +220,14 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 float h[UT][4], o[KT][4];
                 if constexpr (PROD)
                     metanet_frag_split<D, U>(bimg(W.w1k) + sl_d, bimg(W.w2k) + sl_u, W.lnk_g, W.lnk_b, g4, dc,
-                                             drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, o, mean, rstd);
+                                             drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, o, mean, rstd, SAVE ? zsave : nullptr);
                 else
                 metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
-                                   drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd);
+                                   drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd, SAVE ? zsave : nullptr);
+                if (SAVE && valid) {
+                    store_frag<KT>(save_z + D, zsave);
+                    if (g == 0) save_r[1] = rstd;
+                }
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -622,6 +642,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const float* save_inv = a.attn_save + (size_t)a.B * F * HF;
     const float* save_keep = save_inv + (size_t)a.B * HF;
     const float* save_o = save_keep + (size_t)a.B * HF;
+    const float* save_z = save_o + (size_t)a.B * F * D;
+    const float* save_r = save_z + (size_t)a.B * F * 2 * D;
     using lds_ptr = __attribute__((address_space(3))) void*;
 
     // ---- register accumulators of the weight gradients (whole kernel) ----------------------------------------------
@@ -782,6 +804,18 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       if (has_save) copy_samples_of(t0);
       int xrow_next = row_of(t0, b_next);
       load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
+      // saved MetaNet rows: zh of both roles and their 1 / std of this lane's token, straight by sorted position - fetched where
+      // the input row is, a tile ahead (padding lanes read the tile's first token)
+      float zq_next[KT][4], zk_next[KT][4], rq_next = 0.f, rk_next = 0.f;
+      auto fetch_z = [&](int tile_) {
+          const int first_ = lo + tile_ * Tsamp;
+          const size_t pos = (size_t)first_ * F + (tok < min(Tsamp, hi - first_) * F ? tok : 0);
+          load_frag<KT>(save_z + pos * 2 * D + g4, zq_next);
+          load_frag<KT>(save_z + pos * 2 * D + D + g4, zk_next);
+          rq_next = save_r[pos * 2];
+          rk_next = save_r[pos * 2 + 1];
+      };
+      if (has_save) fetch_z(t0);
       for (int tile = t0; tile < t1; ++tile) {
         const int first = lo + tile * Tsamp;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
@@ -877,12 +911,19 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             chain<KT, KT, LD>(wv + lo_d, x, v);
             }
             if (mlp_q) {
-                float m[KT][4];
                 fwd_w1(w1q, q0, hq);
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hq[t][r] = fmaxf(hq[t][r], 0.f);
+                if (has_save) {      // the forward of this step left the normalised rows: no W2 product, no statistics
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zhq[t][r] = zq_next[t][r];
+                    rstd_q = rq_next;
+                } else {
+                float m[KT][4];
                 fwd_w2(w2q, hq, m);
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
@@ -893,6 +934,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         m[t][r] = mm + q0[t][r];
                     }
                 layer_norm_keep<KT>(m, zhq, rstd_q);
+                }
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
                     const float4 gg = *reinterpret_cast<const float4*>(lnq_g + 16 * t + g4);
@@ -912,12 +954,19 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
             }
             if (mlp_k) {
-                float m[KT][4];
                 fwd_w1(w1k, k0, hk);
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hk[t][r] = fmaxf(hk[t][r], 0.f);
+                if (has_save) {
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zhk[t][r] = zk_next[t][r];
+                    rstd_k = rk_next;
+                } else {
+                float m[KT][4];
                 fwd_w2(w2k, hk, m);
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
@@ -928,6 +977,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         m[t][r] = mm + k0[t][r];
                     }
                 layer_norm_keep<KT>(m, zhk, rstd_k);
+                }
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
                     const float4 gg = *reinterpret_cast<const float4*>(lnk_g + 16 * t + g4);
@@ -1477,6 +1527,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
         load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
+        if (has_save) fetch_z(tile_n);
         lds_barrier();
         STAMP(6);
       }
@@ -2008,7 +2059,9 @@ extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc
     // the forward saves from its register-resident score row (F <= 32), the backward copies the numerators 16 bytes at a time
     // ... and stages the tile's dy and saved output rows in the dS cache (T H F F floats): H F >= 2 D
     if (d->F > 32 || (d->F * HF) % 4 != 0 || HF < 2 * d->D) return 0;
-    return (int64_t)d->B * (d->F * HF + 2 * HF + (int64_t)d->F * d->D);
+    // numerators [B][F][HF] | 1 / sum [B][HF] | keep words [B][HF] | attention output [B][F][D] | normalised MetaNet rows
+    // [B][F][role][D] | their 1 / std [B][F][role]
+    return (int64_t)d->B * (d->F * HF + 2 * HF + (int64_t)d->F * d->D + (int64_t)d->F * (2 * d->D + 2));
 }
 
 extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d) {

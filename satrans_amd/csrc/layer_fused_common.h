@@ -589,13 +589,44 @@ __device__ __forceinline__ void stage_image_batch(const ImageJob (&jobs)[NJ]) {
     }
 }
 
+// layer_norm_frag that also hands back the normalised rows zh = (v - mean) rstd (v = zh gamma + beta: the same bits as above)
+template <int KT_>
+__device__ __forceinline__ void layer_norm_frag_z(float (&v)[KT_][4], float (&zh)[KT_][4], const float* gam, const float* bet, int g4,
+                                                  float& mean, float& rstd) {
+    constexpr float invD = 1.0f / (16 * KT_);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    mean = token_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = v[t][r] - mean;
+            q = fmaf(e, e, q);
+        }
+    rstd = 1.0f / sqrtf(token_sum(q) * invD + 1e-6f);
+#pragma unroll
+    for (int t = 0; t < KT_; ++t) {
+        const float4 gg = *reinterpret_cast<const float4*>(gam + 16 * t + g4);
+        const float4 bb = *reinterpret_cast<const float4*>(bet + 16 * t + g4);
+        const float gm[4] = {gg.x, gg.y, gg.z, gg.w}, bt[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zh[t][r] = (v[t][r] - mean) * rstd;
+            v[t][r] = zh[t][r] * gm[r] + bt[r];
+        }
+    }
+}
+
 // MetaNet of one role on a D-layout fragment: out = LN(drop(relu(in W1) W2) + in)     submodules.py:77-103
 // Also hands back the hidden activations, the pre-norm rows and the statistics for the backward pass.
 template <int D, int U>
 __device__ __forceinline__ void metanet_frag(const float* w1l, const float* w2l, const float* gam, const float* bet,
                                              int g4, const FusedDrop& dc, int site, uint32_t sample_key, int f,
                                              const float (&in)[D / 16][4], float (&h)[U / 16][4],
-                                             float (&out)[D / 16][4], float& mean, float& rstd) {
+                                             float (&out)[D / 16][4], float& mean, float& rstd, float (*zh)[4] = nullptr) {
     constexpr int KT = D / 16, UT = U / 16;
     chain<KT, UT, U + 4>(w1l, in, h);
 #pragma unroll
@@ -612,14 +643,16 @@ __device__ __forceinline__ void metanet_frag(const float* w1l, const float* w2l,
             if (dc.on) m = (kb >> (4 * t + r)) & 1u ? m * dc.scale : 0.f;
             out[t][r] = m + in[t][r];
         }
-    layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
+    if (zh) layer_norm_frag_z<KT>(out, *reinterpret_cast<float (*)[KT][4]>(zh), gam, bet, g4, mean, rstd);
+    else layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
 }
 
 // metanet_frag on split products (images of W1 [U][D + 8] and W2 [D][U + 8], see stage_split)
 template <int D, int U>
 __device__ __forceinline__ void metanet_frag_split(const __bf16* w1l, const __bf16* w2l, const float* gam, const float* bet,
                                                    int g4, const FusedDrop& dc, uint32_t sample_key, int f,
-                                                   const float (&in)[D / 16][4], float (&out)[D / 16][4], float& mean, float& rstd) {
+                                                   const float (&in)[D / 16][4], float (&out)[D / 16][4], float& mean, float& rstd,
+                                                   float (*zh)[4] = nullptr) {
     constexpr int KT = D / 16, UT = U / 16;
     float h[UT][4];
     bf16x8 ih[KT / 2], il[KT / 2], hh[UT / 2], hl_[UT / 2];
@@ -640,7 +673,8 @@ __device__ __forceinline__ void metanet_frag_split(const __bf16* w1l, const __bf
             if (dc.on) m = (kb >> (4 * t + r)) & 1u ? m * dc.scale : 0.f;
             out[t][r] = m + in[t][r];
         }
-    layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
+    if (zh) layer_norm_frag_z<KT>(out, *reinterpret_cast<float (*)[KT][4]>(zh), gam, bet, g4, mean, rstd);
+    else layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
 }
 
 struct SlabOffF {
