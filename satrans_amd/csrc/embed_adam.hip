@@ -728,6 +728,23 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
     p[i] = pp; m[i] = mm; v[i] = vv;
 }
 
+// vals[threadIdx.x], vals[threadIdx.x + 1024], ... added in index order (a workgroup of 1024 lanes); eight loads in flight per
+// lane - the same bits as one load at a time, without paying the memory latency once per element (13.5 -> ~4 us for the 40 k
+// partial sums of a step)
+__device__ __forceinline__ double strided_sum_1024(const double* __restrict__ vals, int64_t count) {
+    double acc = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < count; i += 8 * 1024) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = vals[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; i < count; i += 1024) acc += vals[i];
+    return acc;
+}
+
 // flat Adam and the step's regulariser sum in one launch: the last block adds the partial sums in a fixed order
 __global__ __launch_bounds__(1024) void adam_flat_sum_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, AdamK k,
@@ -743,17 +760,14 @@ __global__ __launch_bounds__(1024) void adam_flat_sum_kernel(float* __restrict__
         p[i] = pp; m[i] = mm; v[i] = vv;
         return;
     }
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += 1024) acc += vals[i];
-    const double total = block_sum(acc, s_red);
+    const double total = block_sum(strided_sum_1024(vals, count), s_red);
     if (threadIdx.x == 0) out[0] += total;
 }
 
 __global__ __launch_bounds__(1024) void sum_f64_kernel(const double* __restrict__ vals, int64_t count,
                                                       double* __restrict__ out, int accumulate) {
     __shared__ double s_red[1024];
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < count; i += 1024) acc += vals[i];
+    const double acc = strided_sum_1024(vals, count);
     const double total = block_sum(acc, s_red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + total : total;
 }

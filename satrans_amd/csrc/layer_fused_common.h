@@ -436,10 +436,17 @@ struct wgrad_sel {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // sum over the D features of each token: registers, then the four lane groups
+// (v + the lane 16 away, then + the lane 32 away.  gfx950's v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / wave
+// halves of two registers in the VALU: given the same value twice they return (own, partner) - the sum of the two is the
+// __shfl_xor form's bits, addition commutes, without the two dependent trips through the LDS crossbar (ds_bpermute), whose
+// latency nothing hides at one wave per SIMD)
 __device__ __forceinline__ float token_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // LayerNorm over features of a D-layout fragment (torch: biased variance, eps = 1e-6 inside the sqrt).

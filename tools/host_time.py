@@ -13,11 +13,11 @@ X, y = bench.synth_batches(60 * B, 5)
 Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
 model.train()
 for i in range(5):
-    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B], Xd[(i + 1) * B:(i + 2) * B])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(5, 55):
-    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B], Xd[(i + 1) * B:(i + 2) * B])
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
@@ -25,6 +25,6 @@ print(f"host enqueue {1e3 * (t1 - t0) / 50:.3f} ms/step ; wall incl. GPU drain {
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for i in range(5, 25):
-    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+    eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B], Xd[(i + 1) * B:(i + 2) * B])
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
