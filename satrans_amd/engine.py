@@ -513,9 +513,33 @@ class PathEngine:
                 else:
                     N.check(lib.satrans_layer_fwd(C.byref(desc), ws["acts"][l + 1].data_ptr(), att, st), "satrans_layer_fwd")
 
+    def after_step(self, fn, *tensors) -> None:
+        """Launches that only READ what the step just produced - the probabilities of `last_prob()`, the labels: `fit`'s per-step
+        metrics - go on the stream of the step's tail kernels (reduction, scenario-table backward, flat Adam), beside the
+        touched-row chain, instead of between two steps of the launch stream.  `fn()` is called with that stream current;
+        `tensors` are the caller's operands, kept from being recycled while that stream uses them.  The next launch that
+        overwrites the probabilities waits for it (`_join_prob_readers`).  Without such a stream (several ranks, the fused head
+        switched off) `fn()` simply runs on the launch stream."""
+        st = self._side_tail
+        if st is None or getattr(self, "_flat_done", None) is None or not self.side_tail:
+            fn()
+            return
+        with torch.cuda.stream(st):
+            fn()
+            self._prob_read = torch.cuda.Event()
+            self._prob_read.record(st)
+        for t in tensors:
+            t.record_stream(st)
+
+    def _join_prob_readers(self) -> None:
+        ev, self._prob_read = getattr(self, "_prob_read", None), None
+        if ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+
     def _head(self, X, ws, y=None, train_ws=None):
         lib, B, st = self.lib, X.shape[0], self._stream()
         m = self.m
+        self._join_prob_readers()
         dense_ptr = X.data_ptr() if self.n_dense else None
         dcols = self.dense_cols.data_ptr() if self.n_dense else None
         dstride = X.stride(0)
@@ -814,6 +838,7 @@ class PathEngine:
             if head_here:
                 # layer L-1 forward (recomputed) + head + loss + their backward: one launch, the layer's output never leaves the CU
                 hdesc = self._head_desc(X, ws, y)
+                self._join_prob_readers()
                 with self.phase("layer_bwd_head"):
                     if defer:
                         d_head = hdesc
