@@ -571,9 +571,10 @@ def main():
                     "launches_per_step": count.get(dominant, 1),
                     # HBM bytes the launch has to move (what `traffic` is to be read against): layer input, upstream gradient and
                     # input gradient [B,F,D] each - plus, when the forward handed its attention state over (the default with fp32
-                    # products: softmax numerators H F F, 1 / sum and keep word H F, attention output F D per sample), that state,
-                    # which the backward reads INSTEAD of recomputing it: bytes traded for VALU time in a compute-bound kernel
-                    "algorithmic_bytes_per_launch": (3 * B * F * D * 4 + (B * (CFG["H"] * F * F + 2 * CFG["H"] * F + F * D) * 4
+                    # products: softmax numerators H F F, 1 / sum and keep word H F, attention output F D, the normalised MetaNet
+                    # rows of both roles 2 F D and their 1 / std 2 F per sample), that state, which the backward reads INSTEAD of
+                    # recomputing it: bytes traded for matrix-pipe and VALU time in a compute-bound kernel
+                    "algorithmic_bytes_per_launch": (3 * B * F * D * 4 + (B * (CFG["H"] * F * F + 2 * CFG["H"] * F + F * D + F * (2 * D + 2)) * 4
                                                                          if (dominant == "layer_bwd" and saved_attn) else 0))
                                                     if dominant in ("layer_bwd", "layer_bwd_head") else None,
                     "note": "HIP events on the launch stream over the timed region (every 4th step); " +

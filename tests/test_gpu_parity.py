@@ -780,7 +780,10 @@ def test_fused_last_layer_and_head_equal_the_separate_calls(name, train, loss):
     for k in g0:
         sc = max(1e-6, float(g0[k].abs().max()))
         # MAE: d|p - t| / dp = sign(p - t) is discontinuous where p == t; no golden label sits there
-        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=2e-5 * sc + 1e-9, err_msg=k)
+        # (opt-in split products: the fused launch exists with fp32 products only, the separate calls run the last layer's
+        #  backward on split products - two arithmetics for one layer, ~16 significant bits apart)
+        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=(1e-4 if split_products() else 2e-5) * sc + 1e-9,
+                                   err_msg=k)
 
 
 @pytest.mark.parametrize("S,B", [(1, 1), (3, 5), (4, 1000), (4, 8192), (16, 8192), (16, 65536), (17, 300), (4, 70000), (4096, 5000)])
