@@ -251,16 +251,16 @@ __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict_
 // All three finishing kernels (this one, the superchunk and the spans kernel) have a second mode: with G != nullptr the
 // finished sum of a row is STORED into the dense gradient buffer G[row] instead of being applied (small tables, whose
 // gradient is all-reduced as a dense buffer across data-parallel ranks).
+// (`bid`: the block's index among the blocks of THIS body - the three stepping bodies share one launch, see touched_step_kernel;
+//  `s_red`: the launch's 256 doubles of LDS)
 template <int LPR>
-__global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__ P, float4* __restrict__ M,
-                                                           float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
-                                                           int64_t n, const float4* __restrict__ rowsum,
-                                                           const int32_t* __restrict__ head_of, AdamK k,
-                                                           double* __restrict__ reg_partials, float4* __restrict__ G,
-                                                           int32_t* __restrict__ last, int t) {
-    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
-    __shared__ double s_red[256];
-    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+__device__ __forceinline__ void touched_apply_body(int64_t bid, double* s_red, float4* __restrict__ P, float4* __restrict__ M,
+                                                   float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
+                                                   int64_t n, const float4* __restrict__ rowsum,
+                                                   const int32_t* __restrict__ head_of, const AdamK& k,
+                                                   double* __restrict__ reg_partials, float4* __restrict__ G,
+                                                   int32_t* __restrict__ last, int t) {
+    const int64_t j = (bid * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
     double reg = 0.0;
     if (j < n && head_of[j] == 1) {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void touched_apply_kernel(float4* __restrict__
         }
     }
     const double total = block_sum(reg, s_red);
-    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+    if (threadIdx.x == 0) reg_partials[bid] = total;
 }
 
 // Second level: a run that crosses chunk boundaries is the ordered sum  trail(c0) + lead(c0+1) + ... + lead(c1).
@@ -354,15 +354,13 @@ __global__ __launch_bounds__(256) void touched_super_kernel(int64_t chunks,
 
 // the runs the superchunk kernel finished, one lane group per chunk (at most one run ends in a chunk that began in an earlier one)
 template <int LPR>
-__global__ __launch_bounds__(256) void touched_finish_kernel(float4* __restrict__ P, float4* __restrict__ M,
-                                                            float4* __restrict__ V, int64_t chunks,
-                                                            const float4* __restrict__ done_sum,
-                                                            const int32_t* __restrict__ done_row, AdamK k,
-                                                            double* __restrict__ reg_partials, float4* __restrict__ G,
-                                                            int32_t* __restrict__ last, int t) {
-    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
-    __shared__ double s_red[256];
-    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+__device__ __forceinline__ void touched_finish_body(int64_t bid, double* s_red, float4* __restrict__ P, float4* __restrict__ M,
+                                                    float4* __restrict__ V, int64_t chunks,
+                                                    const float4* __restrict__ done_sum,
+                                                    const int32_t* __restrict__ done_row, const AdamK& k,
+                                                    double* __restrict__ reg_partials, float4* __restrict__ G,
+                                                    int32_t* __restrict__ last, int t) {
+    const int64_t c = (bid * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
     double reg = 0.0;
     if (c < chunks) {
@@ -380,21 +378,19 @@ __global__ __launch_bounds__(256) void touched_finish_kernel(float4* __restrict_
         }
     }
     const double total = block_sum(reg, s_red);
-    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+    if (threadIdx.x == 0) reg_partials[bid] = total;
 }
 
 // third level: one lane group per superchunk that owns a trail piece walks the following superchunks' lead pieces in order
 template <int LPR>
-__global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__ P, float4* __restrict__ M,
-                                                           float4* __restrict__ V, int64_t chunks,
-                                                           const float4* __restrict__ partial,
-                                                           const int32_t* __restrict__ info,
-                                                           const int32_t* __restrict__ trail_row, AdamK k,
-                                                           double* __restrict__ reg_partials, float4* __restrict__ G,
-                                                           int32_t* __restrict__ last, int t) {
-    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
-    __shared__ double s_red[256];
-    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+__device__ __forceinline__ void touched_spans_body(int64_t bid, double* s_red, float4* __restrict__ P, float4* __restrict__ M,
+                                                   float4* __restrict__ V, int64_t chunks,
+                                                   const float4* __restrict__ partial,
+                                                   const int32_t* __restrict__ info,
+                                                   const int32_t* __restrict__ trail_row, const AdamK& k,
+                                                   double* __restrict__ reg_partials, float4* __restrict__ G,
+                                                   int32_t* __restrict__ last, int t) {
+    const int64_t group = (bid * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
     double reg = 0.0;
     if (group < chunks && (info[group] & 1)) {
@@ -417,7 +413,36 @@ __global__ __launch_bounds__(256) void touched_spans_kernel(float4* __restrict__
         }
     }
     const double total = block_sum(reg, s_red);
-    if (threadIdx.x == 0) reg_partials[blockIdx.x] = total;
+    if (threadIdx.x == 0) reg_partials[bid] = total;
+}
+
+// The three stepping bodies - per-position runs (apply), the runs a superchunk finished (finish), the walk over superchunks
+// (spans) - touch disjoint rows and need nothing from each other, only the chunk kernel's and the superchunk kernel's output: ONE
+// launch behind the superchunk kernel instead of three in a line.  The few long-running blocks of the walk come first in the grid
+// (resident from the start), the many short ones fill the chip around them.  chunks -> super -> [spans | finish | apply]: two
+// dependent launches less on the critical path of every step.  (apply merged with the SUPERCHUNK kernel instead, which would make
+// the chain a diamond, was measured: that kernel's 80 preloaded registers halve the occupancy the random row reads of apply live
+// on - 41 us for the pair against 19 + 16 in a line.)
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_step_kernel(int64_t sblocks, int64_t cblocks, float4* __restrict__ P,
+                                                          float4* __restrict__ M, float4* __restrict__ V, AdamK k,
+                                                          float4* __restrict__ G, int32_t* __restrict__ last, int t,
+                                                          const int32_t* __restrict__ sorted_rows, int64_t n,
+                                                          const float4* __restrict__ rowsum, const int32_t* __restrict__ head_of,
+                                                          double* __restrict__ reg_apply, int64_t chunks,
+                                                          const float4* __restrict__ done_sum, const int32_t* __restrict__ done_row,
+                                                          double* __restrict__ reg_finish, int64_t supers,
+                                                          const float4* __restrict__ partial2, const int32_t* __restrict__ info2,
+                                                          const int32_t* __restrict__ trail_row2, double* __restrict__ reg_spans) {
+    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
+    __shared__ double s_red[256];
+    const int64_t b = blockIdx.x;
+    if (b < sblocks)
+        touched_spans_body<LPR>(b, s_red, P, M, V, supers, partial2, info2, trail_row2, k, reg_spans, G, last, t);
+    else if (b < sblocks + cblocks)
+        touched_finish_body<LPR>(b - sblocks, s_red, P, M, V, chunks, done_sum, done_row, k, reg_finish, G, last, t);
+    else
+        touched_apply_body<LPR>(b - sblocks - cblocks, s_red, P, M, V, sorted_rows, n, rowsum, head_of, k, reg_apply, G, last, t);
 }
 
 // Dense step over the arena rows [row0, row0 + rows) with a dense gradient buffer G [rows, D] (small tables: every row
@@ -971,10 +996,6 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
                         (float4*)arena, (float4*)m, (float4*)v, sorted_rows, src, n, (const float4*)gemb, partial, info,
                         trail_row, rowsum, head_of)));
     SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
-    DISPATCH_LPR(D, (touched_apply_kernel<LPR><<<(unsigned)blocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, n, (const float4*)rowsum, head_of, k, reg_a,
-                        (float4*)G, last, t)));
-    SATRANS_CHECK_LAUNCH("touched_apply_kernel");
     const int64_t supers = ceil_div(chunks, kSuper);
     int64_t off2 = off + n * D + n;
     off2 = (off2 + 3) & ~(int64_t)3;
@@ -990,14 +1011,11 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
     DISPATCH_LPR(D, (touched_super_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
                         chunks, (const float4*)partial, info, trail_row, partial2, info2, trail_row2, done_sum, done_row)));
     SATRANS_CHECK_LAUNCH("touched_super_kernel");
-    DISPATCH_LPR(D, (touched_finish_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, chunks, (const float4*)done_sum, done_row, k, reg_b,
-                        (float4*)G, last, t)));
-    SATRANS_CHECK_LAUNCH("touched_finish_kernel");
-    DISPATCH_LPR(D, (touched_spans_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, supers, (const float4*)partial2, info2, trail_row2, k, reg_c,
-                        (float4*)G, last, t)));
-    SATRANS_CHECK_LAUNCH("touched_spans_kernel");
+    DISPATCH_LPR(D, (touched_step_kernel<LPR><<<(unsigned)(sblocks + cblocks + blocks), 256, 0, stream>>>(
+                        sblocks, cblocks, (float4*)arena, (float4*)m, (float4*)v, k, (float4*)G, last, t, sorted_rows, n,
+                        (const float4*)rowsum, head_of, reg_a, chunks, (const float4*)done_sum, done_row, reg_b, supers,
+                        (const float4*)partial2, info2, trail_row2, reg_c)));
+    SATRANS_CHECK_LAUNCH("touched_step_kernel");
     return SATRANS_OK;
 }
 
