@@ -558,7 +558,10 @@ def test_lr_schedule_needs_no_flush_and_stays_bitwise(monkeypatch):
                 sched.step()                      # a new rate for the next step
         if lazy == "1":
             assert getattr(eng, "flush_count", 0) == flushes, "a learning-rate change must not flush the postponed steps"
+            assert len(eng._lr_hist) == steps                  # one entry per rate change while the steps are postponed ...
         res = sd_to_cpu(m)
+        if lazy == "1":
+            assert len(eng._lr_hist) == 1, "... and only the rate in force once a flush (state_dict) made every row current"
         for k, st_ in m.optimizer_state_dict()["state"].items():
             res["exp_avg/" + k], res["exp_avg_sq/" + k] = st_["exp_avg"], st_["exp_avg_sq"]
         results[lazy] = res
