@@ -409,6 +409,13 @@ int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_rows, int32
  * SATRANS_E_UNSUPPORTED.  Output identical to satrans_embed_sort's. */
 int satrans_embed_sort_fields(const int32_t* rows, int B, int F, const int32_t* seg_field, const int32_t* seg_lo,
                               const int32_t* seg_rows, int32_t* sorted_rows, int32_t* src, void* stream);
+/* ... and with the ids -> rows translation of satrans_gather_fwd(out = NULL, rows_out = rows) in the same launch (meta_basemodel.py:
+ * 533-535, the lookup's index arithmetic): `rows` [B, F] is an OUTPUT; X / id_dtype / x_stride / cols / row_span / status as for
+ * satrans_gather_fwd (an id outside its table sets bit 0 of *status and is recorded as the table's first row); seg_lo[k] must be
+ * row_span[2 * seg_field[k]]. */
+int satrans_embed_rows_sort_fields(const void* X, int id_dtype, int64_t x_stride, const int32_t* cols, const int64_t* row_span,
+                                   int32_t* rows, int B, int F, const int32_t* seg_field, const int32_t* seg_lo,
+                                   const int32_t* seg_rows, int32_t* sorted_rows, int32_t* src, int32_t* status, void* stream);
 int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D);
 /* last / t: optional (lazy form): last[row] = t for every row stepped */
 int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,

@@ -908,19 +908,51 @@ struct SortFields {
     int32_t bits[kSortFieldsMax];    // key bits of its local ids
 };
 
-template <int ITEMS>
+// IDS: the keys come straight from the id matrix (satrans_embed_rows_sort_fields) - ids -> arena rows exactly as the gather kernel
+// translates them (gather.hip: an id outside its table is flagged in `status` and recorded as the table's first row) - and the
+// [B, F] row matrix is written on the way: the launch that used to produce it is gone from the front of every sort.
+struct SortIds {
+    const void* X;
+    int id_dtype;
+    int64_t x_stride;
+    const int32_t* cols;
+    const int64_t* row_span;
+    int32_t* rows_out;
+    int32_t* status;
+};
+
+template <int ITEMS, bool IDS = false>
 __global__ __launch_bounds__(1024) void sort_fields_kernel(const int32_t* __restrict__ rows, int B, int F, SortFields sf,
-                                                          int32_t* __restrict__ sorted_rows, int32_t* __restrict__ src) {
+                                                          int32_t* __restrict__ sorted_rows, int32_t* __restrict__ src,
+                                                          SortIds ids) {
     using Sort = rocprim::block_radix_sort<uint32_t, 1024, ITEMS, int32_t, 1, 1, SATRANS_SORT_RADIX_BITS>;
     __shared__ typename Sort::storage_type storage;
     const int seg = blockIdx.x, f = sf.field[seg], lo = sf.lo[seg];
     uint32_t keys[ITEMS];
     int32_t vals[ITEMS];
+    int col = 0;
+    int64_t span = 0;
+    if constexpr (IDS) {
+        col = ids.cols[f];
+        span = ids.row_span[2 * f + 1] - ids.row_span[2 * f];      // (row_span[2 f] == lo: checked by the launcher's caller contract)
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int b = (int)threadIdx.x * ITEMS + i;           // blocked arrangement: sample order = position order
         const bool in = b < B;
-        keys[i] = in ? (uint32_t)(rows[(size_t)b * F + f] - lo) : 0xFFFFFFFFu;      // padding sorts to the end
+        if constexpr (IDS) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (in) {
+                const int64_t id = load_id(ids.X, ids.id_dtype, ids.x_stride, b, col);
+                const bool bad = id < 0 || id >= span;
+                key = bad ? 0u : (uint32_t)id;
+                ids.rows_out[(size_t)b * F + f] = lo + (int32_t)key;
+                if (bad) atomicOr(ids.status, 1);
+            }
+            keys[i] = key;
+        } else {
+            keys[i] = in ? (uint32_t)(rows[(size_t)b * F + f] - lo) : 0xFFFFFFFFu;      // padding sorts to the end
+        }
         vals[i] = in ? b * F + f : -1;
     }
     // padding keys need the top bit: sort one bit more than the ids use when the batch does not fill the block
@@ -953,11 +985,43 @@ extern "C" int satrans_embed_sort_fields(const int32_t* rows, int B, int F, cons
         sf.bits[k] = bits_for(seg_rows[k]);
     }
     for (int k = F; k < kSortFieldsMax; ++k) { sf.field[k] = 0; sf.lo[k] = 0; sf.bits[k] = 1; }
-    if (B <= 1024) sort_fields_kernel<1><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src);
-    else if (B <= 2048) sort_fields_kernel<2><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src);
-    else if (B <= 4096) sort_fields_kernel<4><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src);
-    else sort_fields_kernel<8><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src);
+    const SortIds none{};
+    if (B <= 1024) sort_fields_kernel<1><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src, none);
+    else if (B <= 2048) sort_fields_kernel<2><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src, none);
+    else if (B <= 4096) sort_fields_kernel<4><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src, none);
+    else sort_fields_kernel<8><<<F, 1024, 0, stream>>>(rows, B, F, sf, sorted_rows, src, none);
     SATRANS_CHECK_LAUNCH("sort_fields_kernel");
+    return SATRANS_OK;
+}
+
+// satrans_gather_fwd(out = NULL, rows_out = rows) + satrans_embed_sort_fields(rows, ...) in one launch: `rows` [B, F] is an OUTPUT.
+// row_span / cols: the device arrays satrans_gather_fwd takes; seg_lo[k] must be row_span[2 seg_field[k]] (the field's own table).
+extern "C" int satrans_embed_rows_sort_fields(const void* X, int id_dtype, int64_t x_stride, const int32_t* cols,
+                                              const int64_t* row_span, int32_t* rows, int B, int F, const int32_t* seg_field,
+                                              const int32_t* seg_lo, const int32_t* seg_rows, int32_t* sorted_rows, int32_t* src,
+                                              int32_t* status, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(X && cols && row_span && rows && seg_field && seg_lo && seg_rows && sorted_rows && src && status, SATRANS_E_BADARG,
+                    "embed_rows_sort_fields: null pointer");
+    SATRANS_REQUIRE(id_dtype == SATRANS_ID_F32 || id_dtype == SATRANS_ID_I32 || id_dtype == SATRANS_ID_I64, SATRANS_E_BADARG,
+                    "embed_rows_sort_fields: id_dtype %d", id_dtype);
+    SATRANS_REQUIRE(B > 0 && B <= 8192 && F > 0 && F <= kSortFieldsMax, SATRANS_E_UNSUPPORTED,
+                    "embed_rows_sort_fields: B=%d F=%d (B <= 8192, F <= %d)", B, F, kSortFieldsMax);
+    SortFields sf;
+    for (int k = 0; k < F; ++k) {
+        SATRANS_REQUIRE(seg_field[k] >= 0 && seg_field[k] < F && seg_rows[k] > 0 && (k == 0 || seg_lo[k] >= seg_lo[k - 1] + seg_rows[k - 1]),
+                        SATRANS_E_BADARG, "embed_rows_sort_fields: segment %d is not a table of its own behind segment %d", k, k - 1);
+        sf.field[k] = seg_field[k];
+        sf.lo[k] = seg_lo[k];
+        sf.bits[k] = bits_for(seg_rows[k]);
+    }
+    for (int k = F; k < kSortFieldsMax; ++k) { sf.field[k] = 0; sf.lo[k] = 0; sf.bits[k] = 1; }
+    const SortIds ids{X, id_dtype, x_stride, cols, row_span, rows, status};
+    if (B <= 1024) sort_fields_kernel<1, true><<<F, 1024, 0, stream>>>(nullptr, B, F, sf, sorted_rows, src, ids);
+    else if (B <= 2048) sort_fields_kernel<2, true><<<F, 1024, 0, stream>>>(nullptr, B, F, sf, sorted_rows, src, ids);
+    else if (B <= 4096) sort_fields_kernel<4, true><<<F, 1024, 0, stream>>>(nullptr, B, F, sf, sorted_rows, src, ids);
+    else sort_fields_kernel<8, true><<<F, 1024, 0, stream>>>(nullptr, B, F, sf, sorted_rows, src, ids);
+    SATRANS_CHECK_LAUNCH("sort_fields_kernel(ids)");
     return SATRANS_OK;
 }
 

@@ -944,12 +944,13 @@ class PathEngine:
         self._side.wait_event(fork)
         with torch.cuda.stream(self._side):
             st = self._stream()
-            N.check(self.lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(), self.cols.data_ptr(),
-                                                X_next.data_ptr(), N.id_dtype_of(X_next), X_next.stride(0), B, self.F, self.D, None,
-                                                alt["rows"].data_ptr(), self.status.data_ptr(), st), "satrans_gather_fwd(rows, next)")
+            # ids -> rows and the per-field sort of the rows in ONE launch (the row matrix is written on the way)
             f_, lo_, n_ = self._sort_fields
-            N.check(self.lib.satrans_embed_sort_fields(alt["rows"].data_ptr(), B, self.F, f_, lo_, n_, alt["sorted_rows"].data_ptr(),
-                                                       alt["src"].data_ptr(), st), "satrans_embed_sort_fields(next)")
+            N.check(self.lib.satrans_embed_rows_sort_fields(X_next.data_ptr(), N.id_dtype_of(X_next), X_next.stride(0),
+                                                            self.cols.data_ptr(), self.row_span.data_ptr(), alt["rows"].data_ptr(),
+                                                            B, self.F, f_, lo_, n_, alt["sorted_rows"].data_ptr(),
+                                                            alt["src"].data_ptr(), self.status.data_ptr(), st),
+                    "satrans_embed_rows_sort_fields(next)")
             # two events: the next step's first launch (the replay) needs the sorted rows only; the bucketing is waited for
             # behind it, in front of the first layer (13 us + a launch gap that the step's start does not wait for)
             sorted_ev = torch.cuda.Event()
@@ -1046,7 +1047,14 @@ class PathEngine:
 
         # ---- 1. this batch's arena rows (nothing is moved yet), sorted - unless the previous step prepared them already ----
         prepared = (not exch) and self._take_prepared(X, ws)
-        if not prepared:
+        if not prepared and self._sort_fields is not None and B <= 8192:
+            f_, lo_, n_ = self._sort_fields           # ids -> rows + per-field sort, one launch
+            with self.phase("embed_sort"):
+                N.check(lib.satrans_embed_rows_sort_fields(X.data_ptr(), N.id_dtype_of(X), X.stride(0), self.cols.data_ptr(),
+                                                           self.row_span.data_ptr(), ws["rows"].data_ptr(), B, self.F, f_, lo_, n_,
+                                                           ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(),
+                                                           self.status.data_ptr(), st), "satrans_embed_rows_sort_fields")
+        elif not prepared:
             N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
                                            N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
                                            self.status.data_ptr(), st), "satrans_gather_fwd(rows)")

@@ -151,6 +151,8 @@ SIGNATURES = {
     "satrans_embed_adam_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, _vp, C.POINTER(AdamHParams),
                                           C.c_int, _vp, _vp]),
     "satrans_embed_pack_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp, _vp]),
+    "satrans_embed_rows_sort_fields": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
     "satrans_embed_sort_fields": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             _vp, _vp, _vp]),
     "satrans_embed_lazy_reg_partials": (C.c_int64, [C.c_int64, C.c_int]),

@@ -2260,3 +2260,28 @@ def test_per_field_sort_equals_the_device_wide_sort(B):
     N.check(lib.satrans_embed_sort(rows.data_ptr(), n, total, ref_r.data_ptr(), ref_s.data_ptr(), None, ws.data_ptr(), ws.numel(),
                                    None, st), "sort")
     assert torch.equal(out_r, ref_r) and torch.equal(out_s, ref_s)
+    # ... and from the id matrix itself (satrans_embed_rows_sort_fields: ids -> rows as satrans_gather_fwd translates them, written
+    # on the way, one launch), in the three id dtypes, with the columns permuted and a few ids outside their tables
+    cols = torch.randperm(F + 2, generator=g)[:F].to(torch.int32)
+    span = torch.tensor([[lo[f], lo[f] + sizes[f]] for f in range(F)], dtype=torch.int64, device=DEV)
+    for dt in (torch.int64, torch.int32, torch.float32):
+        bad_ids = ids.clone()
+        bad_ids[0, 1], bad_ids[B - 1, 3] = -1, sizes[3]                 # out of range: flagged, recorded as the table's first row
+        X = torch.zeros(B, F + 2, dtype=dt)
+        X[:, cols.long()] = bad_ids.to(dt)
+        X = X.to(DEV)
+        arena = torch.zeros(4, 16, device=DEV)                           # (rows-only mode never reads it)
+        want_rows_m = torch.empty(B, F, dtype=torch.int32, device=DEV)
+        status0 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        N.check(lib.satrans_gather_fwd(arena.data_ptr(), span.data_ptr(), cols.to(DEV).data_ptr(), X.data_ptr(), N.id_dtype_of(X),
+                                       X.stride(0), B, F, 16, None, want_rows_m.data_ptr(), status0.data_ptr(), st), "gather_fwd(rows)")
+        N.check(lib.satrans_embed_sort_fields(want_rows_m.data_ptr(), B, F, Arr(*order), Arr(*[lo[f] for f in order]),
+                                              Arr(*[sizes[f] for f in order]), ref_r.data_ptr(), ref_s.data_ptr(), st), "sort_fields")
+        got_rows_m = torch.full((B, F), -7, dtype=torch.int32, device=DEV)
+        status1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        N.check(lib.satrans_embed_rows_sort_fields(X.data_ptr(), N.id_dtype_of(X), X.stride(0), cols.to(DEV).data_ptr(), span.data_ptr(),
+                                                   got_rows_m.data_ptr(), B, F, Arr(*order), Arr(*[lo[f] for f in order]),
+                                                   Arr(*[sizes[f] for f in order]), out_r.data_ptr(), out_s.data_ptr(),
+                                                   status1.data_ptr(), st), "rows_sort_fields")
+        assert torch.equal(got_rows_m, want_rows_m) and int(status1.item()) == int(status0.item()) == 1, dt
+        assert torch.equal(out_r, ref_r) and torch.equal(out_s, ref_s), dt
