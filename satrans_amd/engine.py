@@ -882,8 +882,13 @@ class PathEngine:
         # train_step: the next batch's preprocessing forks to the side stream HERE, right behind the last backward kernel and in
         # front of the reduction (the step timeline showed it starting 48 us later when forked behind `finish`, and the next
         # step's first kernel waiting 29 us for it: profiles/r04_step_timeline_*.txt)
+        # (ONE fork event for both side streams: every event recorded on the launch stream is a marker its next kernel waits behind)
+        fork = None
+        if after_layers is not None or (side_tail and d_descs):
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(self.dev))
         if after_layers is not None:
-            after_layers()
+            after_layers(fork)
         # train_step (side_tail): the reduction and the scenario-table backward feed only the flat Adam launch at the very end of
         # the step, while the five touched-row launches that come first need only the last backward kernel's dx.  On a stream of
         # their own (NOT the next-batch stream: queued behind each other the two made the next step wait, which is what the first
@@ -894,8 +899,6 @@ class PathEngine:
             main = torch.cuda.current_stream(self.dev)
             if self._side_tail is None:
                 self._side_tail = torch.cuda.Stream(self.dev)
-            fork = torch.cuda.Event()
-            fork.record(main)
             self._side_tail.wait_event(fork)
             with torch.cuda.stream(self._side_tail):
                 if clear_late:
@@ -923,7 +926,7 @@ class PathEngine:
                 and X.dtype in (torch.float32, torch.int32, torch.int64) and not self.multi and self.lazy
                 and self._sort_fields is not None and B <= 8192 and self.fuse_gather and not self.force_split)
 
-    def _prepare_async(self, X_next, ws_cur_B):
+    def _prepare_async(self, X_next, ws_cur_B, fork=None):
         """Everything of a step that depends on nothing but its id matrix - ids -> arena rows, the per-field sort of the rows,
         the scenario bucketing (four launches, ~60 us of mostly idle GPU: one workgroup per field / one workgroup) - for the
         NEXT batch, on a side stream, into the other half of a double buffer.  Called from inside the current step right after
@@ -939,8 +942,9 @@ class PathEngine:
         main = torch.cuda.current_stream(self.dev)
         if self._side is None:
             self._side = torch.cuda.Stream(self.dev)
-        fork = torch.cuda.Event()
-        fork.record(main)
+        if fork is None:
+            fork = torch.cuda.Event()
+            fork.record(main)
         self._side.wait_event(fork)
         with torch.cuda.stream(self._side):
             st = self._stream()
@@ -1104,7 +1108,7 @@ class PathEngine:
         hook = None
         if next_X is not None and not exch and self._dense_override is None and self._can_prepare(next_X, next_X.shape[0]) \
                 and next_X.shape[1] >= self.n_cols:
-            hook = lambda: self._prepare_async(next_X, B)
+            hook = lambda fork: self._prepare_async(next_X, B, fork)
         gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook,
                              side_tail=self.side_tail and not exch and not split)
 
@@ -1400,7 +1404,7 @@ class PathEngine:
         hook = None
         if next_X is not None and self._dense_override is None and self._can_prepare(next_X, next_X.shape[0]) \
                 and next_X.shape[1] >= self.n_cols:
-            hook = lambda: self._prepare_async(next_X, B)
+            hook = lambda fork: self._prepare_async(next_X, B, fork)
         try:
             gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook)
         finally:
