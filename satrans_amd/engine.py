@@ -186,6 +186,10 @@ class PathEngine:
         # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
         # (SATRANS_PREFETCH=0: the hint is ignored)
         self.prefetch = os.environ.get("SATRANS_PREFETCH", "1") != "0"
+        # ... forked in FRONT of the last backward kernel, on a stream of the lowest priority: its workgroups find no room beside
+        # that kernel's and start as its CUs come free, without the ~14 us a fork behind the kernel costs (SATRANS_PREP_EARLY=0:
+        # behind it; 1.137 -> 1.119 ms/step over 256 steps, three A/B rounds on one box)
+        self.prep_early = os.environ.get("SATRANS_PREP_EARLY", "1") != "0"
         # one reduction launch for all layers' weight-gradient slabs (satrans_layer_bwd_reduce; SATRANS_DEFER_REDUCE=0: per layer)
         self.defer_reduce = os.environ.get("SATRANS_DEFER_REDUCE", "1") != "0"
         # ... on a stream of its own beside the touched-row kernels, with the scenario-table backward (SATRANS_SIDE_TAIL=0: in line)
@@ -853,6 +857,13 @@ class PathEngine:
                                                            slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd_head")
                 cur = 1 - cur
                 continue
+            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer:
+                # the next batch's preprocessing forks in front of the LAST backward kernel, on a low-priority stream - its workgroups
+                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.dev))
+                after_layers(ev)
+                after_layers = None
             with self.phase("layer_bwd"):
                 if defer:
                     N.check(lib.satrans_layer_bwd_launch(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
@@ -926,6 +937,26 @@ class PathEngine:
                 and X.dtype in (torch.float32, torch.int32, torch.int64) and not self.multi and self.lazy
                 and self._sort_fields is not None and B <= 8192 and self.fuse_gather and not self.force_split)
 
+    def _low_priority_stream(self):
+        """A HIP stream of the lowest priority the device offers (torch only hands out priorities <= 0, i.e. normal and above),
+        wrapped for torch: when its kernels and the launch stream's become ready together, the launch stream's are dispatched
+        first."""
+        try:
+            hip = C.CDLL("libamdhip64.so")          # (the runtime torch itself is linked against: already in the process)
+            least, greatest = C.c_int(0), C.c_int(0)
+            handle = C.c_void_p()
+            with torch.cuda.device(self.dev):
+                rc = hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest))
+                if rc == 0 and least.value > greatest.value:          # (numerically larger = lower priority)
+                    rc = hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(least.value))      # 1 = hipStreamNonBlocking
+            if rc == 0 and handle.value:
+                return torch.cuda.ExternalStream(handle.value, device=self.dev)
+        except OSError:
+            pass
+        # no priorities on this device / runtime: an early fork would race the last backward kernel for the CUs - fork behind it
+        self.prep_early = False
+        return torch.cuda.Stream(self.dev)
+
     def _prepare_async(self, X_next, ws_cur_B, fork=None):
         """Everything of a step that depends on nothing but its id matrix - ids -> arena rows, the per-field sort of the rows,
         the scenario bucketing (four launches, ~60 us of mostly idle GPU: one workgroup per field / one workgroup) - for the
@@ -941,7 +972,7 @@ class PathEngine:
         alt = ws["prep_alt"]
         main = torch.cuda.current_stream(self.dev)
         if self._side is None:
-            self._side = torch.cuda.Stream(self.dev)
+            self._side = self._low_priority_stream() if self.prep_early else torch.cuda.Stream(self.dev)
         if fork is None:
             fork = torch.cuda.Event()
             fork.record(main)
@@ -1181,6 +1212,9 @@ class PathEngine:
                                                   self._stream()), "satrans_adam_flat")
                 self._flat_done = torch.cuda.Event()
                 self._flat_done.record(self._side_tail)
+            # (the step's regulariser partial sums on that stream as well, behind an event of the touched-row chain and with two
+            #  alternating sets of partial sums: 1.116-1.119 -> 1.120-1.122 ms/step, three A/B rounds - the sum is not what the next
+            #  step's first launch waits for)
             N.check(lib.satrans_sum_f64(ws["reg_partials"].data_ptr(), ws["reg_partials"].numel(), self.reg_sum.data_ptr(), 1, st),
                     "satrans_sum_f64")
             if next_X is None:

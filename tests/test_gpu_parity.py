@@ -830,12 +830,13 @@ def test_next_batch_hint_changes_no_bit():
     Xs = [c.X[rng.permutation(n)].to(DEV) for _ in range(6)]
     ys = [c.y[rng.permutation(n)].to(DEV) for _ in range(6)]
 
-    def run(hint, side_tail=True):
+    def run(hint, side_tail=True, early=True):
         model = build_model(c, DEV)
         model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
         model.train()
         eng = model._require_engine()
         eng.side_tail = side_tail          # reduction + scenario-table backward on their own stream beside the touched-row kernels
+        eng.prep_early = early             # the next batch forked in front of the last backward kernel (low-priority stream) / behind it
         eng.reset_epoch_sums()
         for i in range(6):
             nxt = None
@@ -847,8 +848,8 @@ def test_next_batch_hint_changes_no_bit():
         sums = eng.epoch_sums()
         return sd_to_cpu(model), model.optimizer_state_dict(), sums
     ref_sd, ref_opt, ref_sums = run(None, side_tail=False)      # everything in line on the launch stream
-    for hint in ("right", "wrong", None):
-        sd, opt, sums = run(hint)
+    for hint in ("right", "wrong", None, "late fork"):
+        sd, opt, sums = run(hint) if hint != "late fork" else run("right", early=False)
         assert sums == ref_sums, hint
         for k in ref_sd:
             assert torch.equal(sd[k], ref_sd[k]), (hint, k)
