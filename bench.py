@@ -231,6 +231,25 @@ def gather_microbench(eng, Xd, B, F, D, launches=48):
     return out
 
 
+LAYER_PHASES = ("layer_fwd_gather", "layer_fwd", "layer_bwd_head", "layer_bwd")      # one fused kernel each (fused path)
+
+
+def read_dispatch_ms(lib):
+    """Mean duration of the fused layer kernels' dispatches since the last read (satrans_kernel_timing: HIP events that the
+    dispatch packet itself signals with its begin / end timestamps - the kernel alone, on the stream it runs on): phase name -> ms.
+    A step's launches arrive in order [layer 0 forward, other forwards ..., last layer + head, backward L-2 .. 0]."""
+    import ctypes as C
+    kinds, ms = (C.c_int * 512)(), (C.c_float * 512)()
+    n = lib.satrans_kernel_timing_read(kinds, ms, 512)
+    acc, prev = {}, None
+    for i in range(max(0, n)):
+        k = kinds[i]
+        name = {1: "layer_bwd", 2: "layer_bwd_head"}.get(k) or ("layer_fwd_gather" if prev != 0 else "layer_fwd")
+        acc.setdefault(name, []).append(ms[i])
+        prev = k
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
 def launch_ranks(n: int) -> int:
     """Start `n` ranks of this script on the GPUs of this node (one process per GPU, RCCL) and wait for them."""
     import socket
@@ -375,14 +394,19 @@ def main():
     # per-phase HIP events are recorded on every 4th step of the timed region: ~40 event records per step cost
     # ~0.4 ms/step (measured 2.13 vs 1.69 ms/step), which would distort the very number being reported
     timers = {} if not args.no_phase_timing else None
+    if not bool(eng._ws.get(B, {}).get("generic")):
+        eng.untimed_phases = frozenset(LAYER_PHASES)      # their durations come from the dispatches themselves (read_dispatch_ms)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     flushes_before = getattr(eng, "flush_count", 0)
     t0 = time.perf_counter()
     for i in range(W, W + K):
-        eng.timers = timers if (timers is not None and (i - W) % 4 == 0) else None
+        sampled = timers is not None and (i - W) % 4 == 0
+        eng.timers = timers if sampled else None
+        eng.lib.satrans_kernel_timing(1 if sampled else 0)      # the fused layer kernels' own durations on the sampled steps
         step(i)
+    eng.lib.satrans_kernel_timing(0)
     eng.timers = timers
     # lazy-exact Adam: every postponed row update of the K steps is paid inside the timed region.  (Several ranks, owner form:
     # each rank flushes the rows it owns - that IS the work of the K steps; bringing the replicas together again, 2.5 GB of
@@ -418,6 +442,7 @@ def main():
                               "note": "replica synchronisation at flush points, outside the timed region"}
     eng.raise_if_bad_ids()
     phases = eng.phase_ms() if eng.timers is not None else {}
+    dispatch = read_dispatch_ms(eng.lib) if eng.timers is not None else {}
     eng.timers = None
 
     # Extra, untimed pass with the streaming Adam back on the main stream: clean per-kernel durations (in the timed
@@ -536,17 +561,25 @@ def main():
              "lazy_flush": n_flush / K}  # launches per step (the flush runs every
     #                                   SATRANS_LAZY_FLUSH_EVERY = 64 steps and once more at the end of the timed region)
 
-    def table(ph, count=count):
+    def table(ph, count=count, disp=None):
+        # `disp`: phase -> the kernel's own duration (events signalled by the dispatch, read_dispatch_ms): the fused layer kernels,
+        # which are then NOT bracketed by recorded events (two markers less per launch in the queue: `timed_by` says which)
         rows, dom, dom_time = {}, None, -1.0
-        for name, ms in ph.items():
+        order = [n for n in LAYER_PHASES if disp and n in disp and n not in ph] + list(ph)
+        for name in order:
+            ms = ph[name] if name in ph else disp[name]
             per_step = ms * count.get(name, 1)
             entry = {"ms_per_launch": round(ms, 4), "ms_per_step": round(per_step, 4)}
+            if name not in ph:
+                entry["timed_by"] = "dispatch"
+            elif disp and name in disp:
+                entry["kernel_ms"] = round(disp[name], 4)
             if name == "lazy_flush":
                 entry["note"] = (f"all {total_rows:,} rows brought up to date {n_flush} time(s) inside the timed region of {K} steps "
                                  f"(every {eng.flush_every} steps and at its end)")
             if name in per_launch:
                 spec = per_launch[name]
-                ach = spec["work"] / (ms / 1e3)
+                ach = spec["work"] / (entry.get("kernel_ms", ms) / 1e3)
                 entry.update(bound=spec["bound"], achieved=round(ach, 2), peak=spec["peak"], unit=spec["unit"],
                              frac=round(ach / spec["peak"], 4))
                 if per_step > dom_time:
@@ -559,7 +592,7 @@ def main():
     split_applies = D == 32 and args.config != "c5" and not ("gate" in args.flag or "bilinear" in args.flag)
     split_on = eng.lib.satrans_get_product_mode() == 1 and split_applies
     products = "f32" if not split_on else ("split" if (args.config == "aliccp" and "pos" not in args.flag) else "split forward, f32 backward")
-    kernels, dominant = table(phases)
+    kernels, dominant = table(phases, disp=dispatch)
     phase_sum = sum(v["ms_per_step"] for v in kernels.values())
     kernels_serial, _ = table(phases_serial)
     roofline = None
@@ -567,7 +600,8 @@ def main():
         e, spec = kernels[dominant], per_launch[dominant]
         roofline = {"kernel": spec["kernel"], "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"],
                     "unit": e["unit"], "frac": e["frac"], "traffic": None,
-                    "algorithmic_per_launch": spec["work"], "launch_ms": e["ms_per_launch"],
+                    "algorithmic_per_launch": spec["work"], "launch_ms": e.get("kernel_ms", e["ms_per_launch"]),
+                    "timed_by": e.get("timed_by", "recorded events"),
                     "launches_per_step": count.get(dominant, 1),
                     # HBM bytes the launch has to move (what `traffic` is to be read against): layer input, upstream gradient and
                     # input gradient [B,F,D] each - plus, when the forward handed its attention state over (the default with fp32
@@ -577,7 +611,10 @@ def main():
                     "algorithmic_bytes_per_launch": (3 * B * F * D * 4 + (B * (CFG["H"] * F * F + 2 * CFG["H"] * F + F * D + F * (2 * D + 2)) * 4
                                                                          if (dominant == "layer_bwd" and saved_attn) else 0))
                                                     if dominant in ("layer_bwd", "layer_bwd_head") else None,
-                    "note": "HIP events on the launch stream over the timed region (every 4th step); " +
+                    "note": "timed_by dispatch: `launch_ms` is the kernel's own duration - HIP events that its dispatch signals with its "
+                            "begin / end timestamps (hipExtLaunchKernelGGL through satrans_kernel_timing), on the stream it runs on, "
+                            "every 4th step of the timed region (two events RECORDED around a launch add the dispatch latency on "
+                            "either side, 5-15 us here, and two markers to the queue); the other phases are timed by recorded events; " +
                             ("the weight-gradient slabs of all layers are reduced by ONE launch per step (`layer_bwd_reduce`), "
                              "so a layer_bwd launch is the backward kernel alone; the last layer runs as `layer_bwd_head` "
                              "(its forward, the head, the loss and their backward in one launch)" if "layer_bwd_reduce" in phases
@@ -710,21 +747,25 @@ def main():
             fl0 = getattr(eng, "flush_count", 0)
             t1 = time.perf_counter()
             for i in range(W, W + K):
-                eng.timers = tm if (tm is not None and (i - W) % 4 == 0) else None
+                smp = tm is not None and (i - W) % 4 == 0
+                eng.timers = tm if smp else None
+                eng.lib.satrans_kernel_timing(1 if smp else 0)
                 step(i)
+            eng.lib.satrans_kernel_timing(0)
             eng.timers = tm
             eng.flush_lazy(sync=False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             ph = eng.phase_ms() if tm is not None else {}
+            disp_o = read_dispatch_ms(eng.lib) if tm is not None else {}
             eng.timers = None
             cnt = dict(count, lazy_flush=max(1, getattr(eng, "flush_count", 0) - fl0) / K)
-            kern_o, dom_o = table(ph, cnt)
+            kern_o, dom_o = table(ph, cnt, disp_o)
             roof_o = None
             if dom_o:
                 e, spec = kern_o[dom_o], per_launch[dom_o]
                 roof_o = {"kernel": spec["kernel"], "bound": e["bound"], "achieved": e["achieved"], "unit": e["unit"],
-                          "launch_ms": e["ms_per_launch"], "algorithmic_per_launch": spec["work"],
+                          "launch_ms": e.get("kernel_ms", e["ms_per_launch"]), "algorithmic_per_launch": spec["work"],
                           "peak_fp32_mfma": FP32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": round(e["achieved"] / FP32_PEAK_TFLOPS, 4)}
                 if other == 1:
                     roof_o.update({"peak_bf16_mfma_dense": BF16_PEAK_TFLOPS,

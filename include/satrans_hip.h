@@ -157,6 +157,14 @@ typedef struct satrans_layer_desc {
                             * Fused kernels only (others ignore it)                                                    */
 } satrans_layer_desc;
 
+/* Measurement aid (bench.py: `roofline.launch_ms`).  While armed (on != 0), every launch of the fused layer kernels is issued with a
+ * pair of HIP events that the dispatch itself signals with its begin / end timestamps; satrans_kernel_timing_read waits for the
+ * recorded launches, returns how many there were (<= max reported; at most 512 are kept between reads) with their kind - 0 layer
+ * forward, 1 layer backward, 2 last layer + head in one launch (satrans_layer_bwd_head) - and duration in ms, and forgets them.
+ * satrans_kernel_timing returns the previous state.  Process-wide, not thread-safe: for a single measuring thread. */
+int satrans_kernel_timing(int on);
+int satrans_kernel_timing_read(int* kinds, float* ms, int max);
+
 /* Floats of `attn_save` for this layer (B samples), 0 when the kernels that would run it do not use one. */
 int64_t satrans_layer_attn_save_floats(const satrans_layer_desc* d);
 

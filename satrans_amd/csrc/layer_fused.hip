@@ -16,9 +16,32 @@
 //     (sample, head, query row), keys/values read as LDS broadcasts, two passes (max, then exp / sum / PV), nothing
 //     of size F x F is stored;
 //   * shapes are template parameters (D, U, H): no runtime division in any inner loop.
+#include <hip/hip_ext.h>
+
 #include "layer_fused_common.h"
 
 namespace satrans {
+
+// satrans_kernel_timing: while armed, every launch of the fused layer kernels carries a pair of HIP events that the dispatch packet
+// itself signals with its begin / end timestamps (hipExtLaunchKernelGGL) - the kernel's own duration on the stream it runs on,
+// without the dispatch latency that events recorded around a launch include (5-15 us here, measured against rocprofv3).
+struct KernelTimer {
+    static constexpr int kPairs = 512;
+    struct Pair { hipEvent_t start, stop; int kind; };
+    Pair pairs[kPairs];
+    int made = 0, used = 0;
+    bool armed = false;
+    Pair* next(int kind) {          // kind: 0 layer forward, 1 layer backward, 2 last layer + head in one launch
+        if (!armed || used >= kPairs) return nullptr;
+        if (used >= made) {
+            if (hipEventCreate(&pairs[made].start) != hipSuccess || hipEventCreate(&pairs[made].stop) != hipSuccess) return nullptr;
+            ++made;
+        }
+        pairs[used].kind = kind;
+        return &pairs[used++];
+    }
+};
+static KernelTimer g_ktimer;
 
 // MOD: what modulates q / k - 0 the MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear' (compile time: the main instantiation
 // pays nothing for the other two).  PROD: 0 = fp32 products on v_mfma_f32_16x16x4_f32, 1 = split products (fp32 operands as bf16
@@ -1918,6 +1941,10 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int64_t tiles = ceil_div(d->B, best);                        // (the kernel splits the batch by samples)
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
+    if (KernelTimer::Pair* tp = g_ktimer.next(0))      // (satrans_kernel_timing: the dispatch's own begin / end timestamps)
+        hipExtLaunchKernelGGL((layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE>), dim3(gx), dim3(64 * WAVES), lds, stream,
+                              tp->start, tp->stop, 0, *d, best, y, att);
+    else
     layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
@@ -1989,6 +2016,10 @@ static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const 
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
+    if (KernelTimer::Pair* tp = g_ktimer.next(HEADF ? 2 : 1))
+        hipExtLaunchKernelGGL((layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF>), dim3(p.G), dim3(kFusedBlock),
+                              p.lds, stream, tp->start, tp->stop, 0, *d, p.T, dy, dx, slabs, hd ? *hd : FusedHeadArgs{});
+    else
     layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF><<<p.G, kFusedBlock, p.lds, stream>>>(
         *d, p.T, dy, dx, slabs, hd ? *hd : FusedHeadArgs{});
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
@@ -2268,3 +2299,30 @@ extern "C" int satrans_debug_read_stamps(unsigned long long* h_out, int reset) {
     return 0;
 }
 #endif
+
+extern "C" int satrans_kernel_timing(int on) {
+    const int was = satrans::g_ktimer.armed ? 1 : 0;
+    satrans::g_ktimer.armed = on != 0;
+    return was;
+}
+
+extern "C" int satrans_kernel_timing_read(int* kinds, float* ms, int max) {
+    using namespace satrans;
+    int n = 0;
+    for (int i = 0; i < g_ktimer.used; ++i) {
+        float t = 0.f;
+        if (hipEventSynchronize(g_ktimer.pairs[i].stop) != hipSuccess ||
+            hipEventElapsedTime(&t, g_ktimer.pairs[i].start, g_ktimer.pairs[i].stop) != hipSuccess) {
+            set_error("kernel_timing_read: %s", hipGetErrorString(hipGetLastError()));
+            g_ktimer.used = 0;
+            return SATRANS_E_LAUNCH;
+        }
+        if (n < max) {
+            if (kinds) kinds[n] = g_ktimer.pairs[i].kind;
+            if (ms) ms[n] = t;
+            ++n;
+        }
+    }
+    g_ktimer.used = 0;
+    return n;
+}

@@ -186,6 +186,9 @@ class PathEngine:
         # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
         # (SATRANS_PREFETCH=0: the hint is ignored)
         self.prefetch = os.environ.get("SATRANS_PREFETCH", "1") != "0"
+        # phases that `phase()` does not bracket with recorded events even while `timers` is set (bench.py: the fused layer kernels,
+        # whose own durations come from satrans_kernel_timing without a marker in the queue)
+        self.untimed_phases = frozenset()
         # ... forked in FRONT of the last backward kernel, on a stream of the lowest priority: its workgroups find no room beside
         # that kernel's and start as its CUs come free, without the ~14 us a fork behind the kernel costs (SATRANS_PREP_EARLY=0:
         # behind it; 1.137 -> 1.119 ms/step over 256 steps, three A/B rounds on one box)
@@ -225,12 +228,13 @@ class PathEngine:
             self.eng, self.name = eng, name
 
         def __enter__(self):
-            if self.eng.timers is not None:
+            self.on = self.eng.timers is not None and self.name not in self.eng.untimed_phases
+            if self.on:
                 self.t0 = torch.cuda.Event(enable_timing=True)
                 self.t0.record(torch.cuda.current_stream(self.eng.dev))
 
         def __exit__(self, *exc):
-            if self.eng.timers is not None:
+            if self.on:
                 t1 = torch.cuda.Event(enable_timing=True)
                 t1.record(torch.cuda.current_stream(self.eng.dev))
                 self.eng.timers.setdefault(self.name, []).append((self.t0, t1))
@@ -857,9 +861,12 @@ class PathEngine:
                                                            slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd_head")
                 cur = 1 - cur
                 continue
-            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer:
+            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer and \
+                    (self.timers is None or "layer_bwd" in self.untimed_phases):
                 # the next batch's preprocessing forks in front of the LAST backward kernel, on a low-priority stream - its workgroups
-                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`)
+                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`).  Not on steps whose backward
+                # launches are bracketed by recorded events: a marker between the two backward kernels holds the second one back
+                # for a few us, which is all the head start the sort needs to take 19 CUs first (+48 us for that kernel).
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.dev))
                 after_layers(ev)

@@ -78,6 +78,8 @@ class AdamHParams(C.Structure):
 SIGNATURES = {
     "satrans_last_error": (C.c_char_p, []),
     "satrans_abi_version": (C.c_int, []),
+    "satrans_kernel_timing": (C.c_int, [C.c_int]),
+    "satrans_kernel_timing_read": (C.c_int, [_vp, _vp, C.c_int]),
     "satrans_bucket_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "satrans_bucket_scenarios": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                            _vp, C.c_int64, _vp]),
