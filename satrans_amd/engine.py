@@ -861,12 +861,12 @@ class PathEngine:
                                                            slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd_head")
                 cur = 1 - cur
                 continue
-            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer and \
-                    (self.timers is None or "layer_bwd" in self.untimed_phases):
+            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer and self.timers is None:
                 # the next batch's preprocessing forks in front of the LAST backward kernel, on a low-priority stream - its workgroups
-                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`).  Not on steps whose backward
-                # launches are bracketed by recorded events: a marker between the two backward kernels holds the second one back
-                # for a few us, which is all the head start the sort needs to take 19 CUs first (+48 us for that kernel).
+                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`).  Not on steps that are being
+                # timed: a marker between the two backward kernels - an event recorded there, or the start event of a launch under
+                # satrans_kernel_timing - holds the second one back for a few us, which is all the head start the sort needs to
+                # take 19 CUs first (measured: that kernel 203 -> 240-255 us on such steps).
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.dev))
                 after_layers(ev)
