@@ -817,6 +817,7 @@ class PathEngine:
         defer = self._defer_reduce(ws, B)
         d_descs, d_slabs, d_grads, d_head = [], [], [], None
         cur = 0
+        early_ev = None
         for l in reversed(range(self.L)):
             head_here = fuse_head and l == self.L - 1
             desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather or self._x_src is not None,
@@ -867,10 +868,8 @@ class PathEngine:
                 # timed: a marker between the two backward kernels - an event recorded there, or the start event of a launch under
                 # satrans_kernel_timing - holds the second one back for a few us, which is all the head start the sort needs to
                 # take 19 CUs first (measured: that kernel 203 -> 240-255 us on such steps).
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.dev))
-                after_layers(ev)
-                after_layers = None
+                early_ev = torch.cuda.Event()
+                early_ev.record(torch.cuda.current_stream(self.dev))
             with self.phase("layer_bwd"):
                 if defer:
                     N.check(lib.satrans_layer_bwd_launch(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
@@ -878,6 +877,10 @@ class PathEngine:
                 else:
                     N.check(lib.satrans_layer_bwd(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
                                                   slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd")
+            if early_ev is not None:
+                # (queued by the host BEHIND the kernel it must not overtake, waiting for the event recorded in front of it)
+                after_layers(early_ev)
+                after_layers, early_ev = None, None
             cur = 1 - cur
 
         def finish():
