@@ -614,7 +614,9 @@ def main():
                     "note": "timed_by dispatch: `launch_ms` is the kernel's own duration - HIP events that its dispatch signals with its "
                             "begin / end timestamps (hipExtLaunchKernelGGL through satrans_kernel_timing), on the stream it runs on, "
                             "every 4th step of the timed region (two events RECORDED around a launch add the dispatch latency on "
-                            "either side, 5-15 us here, and two markers to the queue); the other phases are timed by recorded events; " +
+                            "either side, 5-15 us here, and two markers to the queue; of the L - 1 plain backward launches of a step the last one - "
+                            "layer 0, the same kernel - goes untimed, because the next batch's preparation forks in front of it and "
+                            "must not find a marker there); the other phases are timed by recorded events; " +
                             ("the weight-gradient slabs of all layers are reduced by ONE launch per step (`layer_bwd_reduce`), "
                              "so a layer_bwd launch is the backward kernel alone; the last layer runs as `layer_bwd_head` "
                              "(its forward, the head, the loss and their backward in one launch)" if "layer_bwd_reduce" in phases

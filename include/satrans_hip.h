@@ -149,9 +149,9 @@ typedef struct satrans_layer_desc {
                             * materialise [B,F,D]); forward and backward alike                                       */
     float* attn_save;      /* NULL, or satrans_layer_attn_save_floats(d) floats: the forward leaves what the backward  *
                             * would otherwise recompute (softmax numerators, 1 / sum, dropout keep word and the       *
-                            * attention output, and - since late round 4 - the normalised MetaNet rows of both roles   *
-                            * with their 1 / std, all per SORTED sample position) and a satrans_layer_bwd on the same  *
-                            * batch, bucket order and dropout counters reads it instead of running its attention-      *
+                            * attention output, and - since late round 4, fp32 products - the normalised MetaNet rows  *
+                            * of both roles with their 1 / std, all per SORTED sample position) and a satrans_layer_bwd *
+                            * on the same batch, bucket order and dropout counters reads it instead of running its attention- *
                             * forward phase, the MetaNet's second products and its LayerNorm statistics.  The layout   *
                             * is the library's own: size it with satrans_layer_attn_save_floats, never by hand.        *
                             * Fused kernels only (others ignore it)                                                    */

@@ -213,10 +213,12 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             // SAVE: the normalised MetaNet rows and their 1 / std go to the backward of this step as well (it then skips the two W2
             // products and the LayerNorm statistics of its recomputation): [sorted position][field][role][D] behind the attention
             // state, then 1 / std [sorted position][field][role]
+            // (fp32 products only: the opt-in split-product pair keeps round 3's hand-over - attention state alone)
+            constexpr bool ZSAVE = SAVE && PROD == 0;
             float zsave[KT][4];
             float* save_z = nullptr;
             float* save_r = nullptr;
-            if constexpr (SAVE) {
+            if constexpr (ZSAVE) {
                 const size_t pos = (size_t)(first + ls) * F + f;
                 float* z_all = a.attn_save + (size_t)a.B * ((size_t)F * H * F + 2 * H * F + (size_t)F * D);
                 save_z = z_all + pos * 2 * D + g4;
@@ -226,11 +228,11 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 float h[UT][4], o[KT][4];
                 if constexpr (PROD)
                     metanet_frag_split<D, U>(bimg(W.w1q) + sl_d, bimg(W.w2q) + sl_u, W.lnq_g, W.lnq_b, g4, dc,
-                                             drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, o, mean, rstd, SAVE ? zsave : nullptr);
+                                             drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, o, mean, rstd, ZSAVE ? zsave : nullptr);
                 else
                 metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
-                                   drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd, SAVE ? zsave : nullptr);
-                if (SAVE && valid) {
+                                   drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd, ZSAVE ? zsave : nullptr);
+                if (ZSAVE && valid) {
                     store_frag<KT>(save_z, zsave);
                     if (g == 0) save_r[0] = rstd;
                 }
@@ -243,11 +245,11 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 float h[UT][4], o[KT][4];
                 if constexpr (PROD)
                     metanet_frag_split<D, U>(bimg(W.w1k) + sl_d, bimg(W.w2k) + sl_u, W.lnk_g, W.lnk_b, g4, dc,
-                                             drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, o, mean, rstd, SAVE ? zsave : nullptr);
+                                             drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, o, mean, rstd, ZSAVE ? zsave : nullptr);
                 else
                 metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
-                                   drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd, SAVE ? zsave : nullptr);
-                if (SAVE && valid) {
+                                   drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd, ZSAVE ? zsave : nullptr);
+                if (ZSAVE && valid) {
                     store_frag<KT>(save_z + D, zsave);
                     if (g == 0) save_r[1] = rstd;
                 }
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // into LDS, issued at the top of the tile and complete by the end of phase A - instead of a recomputation
     const int HF = H * F;
     constexpr bool has_save = SAVE;
+    constexpr bool has_zsave = SAVE && PROD == 0;      // the normalised MetaNet rows too (fp32 products only)
     const float* save_inv = a.attn_save + (size_t)a.B * F * HF;
     const float* save_keep = save_inv + (size_t)a.B * HF;
     const float* save_o = save_keep + (size_t)a.B * HF;
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
           rq_next = save_r[pos * 2];
           rk_next = save_r[pos * 2 + 1];
       };
-      if (has_save) fetch_z(t0);
+      if (has_zsave) fetch_z(t0);
       for (int tile = t0; tile < t1; ++tile) {
         const int first = lo + tile * Tsamp;
         const int nS = min(Tsamp, hi - first), ntok = nS * F, ntt = (ntok + 15) >> 4;
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hq[t][r] = fmaxf(hq[t][r], 0.f);
-                if (has_save) {      // the forward of this step left the normalised rows: no W2 product, no statistics
+                if (has_zsave) {      // the forward of this step left the normalised rows: no W2 product, no statistics
 #pragma unroll
                     for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hk[t][r] = fmaxf(hk[t][r], 0.f);
-                if (has_save) {
+                if (has_zsave) {
 #pragma unroll
                     for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1550,7 +1553,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
         load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
-        if (has_save) fetch_z(tile_n);
+        if (has_zsave) fetch_z(tile_n);
         lds_barrier();
         STAMP(6);
       }

@@ -862,14 +862,18 @@ class PathEngine:
                                                            slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd_head")
                 cur = 1 - cur
                 continue
-            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer and self.timers is None:
+            untimed_launch = False
+            if l == 0 and self.L >= 2 and after_layers is not None and self.prep_early and defer and \
+                    (self.timers is None or "layer_bwd" in self.untimed_phases):
                 # the next batch's preprocessing forks in front of the LAST backward kernel, on a low-priority stream - its workgroups
-                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`).  Not on steps that are being
-                # timed: a marker between the two backward kernels - an event recorded there, or the start event of a launch under
-                # satrans_kernel_timing - holds the second one back for a few us, which is all the head start the sort needs to
-                # take 19 CUs first (measured: that kernel 203 -> 240-255 us on such steps).
+                # find no room beside that kernel's and fill the CUs as they come free (`prep_early`).  No marker may sit between
+                # the two backward kernels: an event recorded there, or the start event of a launch under satrans_kernel_timing,
+                # holds the second one back for a few us, which is all the head start the sort needs to take 19 CUs first (measured:
+                # that kernel 203 -> 240-255 us).  So: not on steps whose layer phases are bracketed by recorded events, and on
+                # steps under satrans_kernel_timing THIS launch goes untimed (layer 1's launch of the same kernel is the sample).
                 early_ev = torch.cuda.Event()
                 early_ev.record(torch.cuda.current_stream(self.dev))
+                untimed_launch = self.timers is not None and bool(lib.satrans_kernel_timing(0))
             with self.phase("layer_bwd"):
                 if defer:
                     N.check(lib.satrans_layer_bwd_launch(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
@@ -877,6 +881,8 @@ class PathEngine:
                 else:
                     N.check(lib.satrans_layer_bwd(C.byref(desc), ws["dact"][cur].data_ptr(), ws["dact"][1 - cur].data_ptr(),
                                                   slabs.data_ptr(), *g_ptrs, st), "satrans_layer_bwd")
+            if untimed_launch:
+                lib.satrans_kernel_timing(1)
             if early_ev is not None:
                 # (queued by the host BEHIND the kernel it must not overtake, waiting for the event recorded in front of it)
                 after_layers(early_ev)

@@ -814,7 +814,8 @@ def test_kernel_timing_brackets_every_fused_launch_and_changes_no_bit():
         kinds, ms = (C.c_int * 64)(), (C.c_float * 64)()
         n = lib.satrans_kernel_timing_read(kinds, ms, 64)
         if armed:
-            assert [kinds[i] for i in range(n)] == [0, 0, 2, 1, 1], [kinds[i] for i in range(n)]
+            fused = bool(eng._ws[X.shape[0]]["fuse_head"])          # (SATRANS_FUSE_HEAD=0: three forwards, three plain backwards)
+            assert [kinds[i] for i in range(n)] == ([0, 0, 2, 1, 1] if fused else [0, 0, 0, 1, 1, 1]), [kinds[i] for i in range(n)]
             assert all(0.0 < ms[i] < 50.0 for i in range(n)), [ms[i] for i in range(n)]
             assert lib.satrans_kernel_timing_read(kinds, ms, 64) == 0      # read forgets
         else:
@@ -2253,7 +2254,9 @@ def test_saved_attention_backward_equals_the_recomputing_one(monkeypatch, train)
         assert bce0 == pytest.approx(bce1, rel=1e-6)
         for k in g0:
             scale = max(1e-6, float(g0[k].abs().max()))
-            np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=2e-5 * scale + softmax_side_floor(k, g0, 1e-9),
+            # (opt-in split products: the numerators' last-bit differences pass through products that carry ~16 significant bits)
+            np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0,
+                                       atol=(5e-5 if split_products() else 2e-5) * scale + softmax_side_floor(k, g0, 1e-9),
                                        err_msg=f"{k} train={train}")
 
 
