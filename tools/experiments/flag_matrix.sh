@@ -2,6 +2,7 @@
 # The GPU parity suite under every switch the engine reads from the environment (each path that can be turned off must stay green).
 cd "$(dirname "$0")/../.." || exit 1
 o=gpurun_out/flags; mkdir -p $o
+# (split_save: the pair split products + forced saved attention misses the 2e-4 trajectory bound of test_parity_gates_hold_in_both_product_modes by 20 % - why the saved attention is on by default only with fp32 products)
 run() { name=$1; shift; env "$@" python -m pytest tests -m gpu -q -x > $o/$name.log 2>&1; echo "$name rc=$? $(tail -1 $o/$name.log)"; }
 for spec in "save_off SATRANS_SAVE_ATTENTION=0" "split SATRANS_PRODUCTS=split" "split_save SATRANS_PRODUCTS=split SATRANS_SAVE_ATTENTION=1" \
             "no_fuse_head SATRANS_FUSE_HEAD=0" "no_prefetch SATRANS_PREFETCH=0" "late_fork SATRANS_PREP_EARLY=0" \
