@@ -197,6 +197,7 @@ class PathEngine:
         self.defer_reduce = os.environ.get("SATRANS_DEFER_REDUCE", "1") != "0"
         # ... on a stream of its own beside the touched-row kernels, with the scenario-table backward (SATRANS_SIDE_TAIL=0: in line)
         self.side_tail = os.environ.get("SATRANS_SIDE_TAIL", "1") != "0"
+        self.preclear = os.environ.get("SATRANS_PRECLEAR", "1") != "0"      # the next step's gradient clear behind this step's flat Adam
         self._side_tail = None
         self._tail_done = None
         self._prep = None
@@ -794,10 +795,14 @@ class PathEngine:
         # clear goes there too, off the launch stream (6 us at the head of every step)
         # (only with the fused head: the separate head launch adds dnn_linear's gradient in front of the reduction)
         clear_late = side_tail and self.defer_reduce and ws.get("defer") is True and ws.get("fuse_head") is True
-        # (the NEXT step's clear behind this step's flat Adam on that stream instead - measured: 1.145-1.158 against 1.134-1.139
-        #  ms/step, three A/B rounds on one box; the fill delays the event the next step's first forward waits for)
+        # ... or the previous step has done it already, behind its flat Adam launch on that stream and behind the event the next
+        # forward waits for (`_precleared`; in front of that event it cost 12 us per step: the fill delays the event)
+        pre, self._precleared = getattr(self, "_precleared", None), None
+        precleared = pre is not None and g_clear is self._g_step_tail
         if not clear_late:
             self._join_flat()          # (the previous step's flat Adam may still be reading what is cleared here)
+            if pre is not None:
+                torch.cuda.current_stream(self.dev).wait_event(pre)      # (... and its clear must not land on what this step writes)
             g_clear.zero_()
         training = m.training
         if training:
@@ -928,13 +933,13 @@ class PathEngine:
                 self._side_tail = torch.cuda.Stream(self.dev)
             self._side_tail.wait_event(fork)
             with torch.cuda.stream(self._side_tail):
-                if clear_late:
+                if clear_late and not precleared:
                     g_clear.zero_()
                 finish()
                 self._tail_done = torch.cuda.Event()
                 self._tail_done.record(self._side_tail)
         else:
-            if clear_late:
+            if clear_late and not precleared:
                 g_clear.zero_()
             finish()
         self._last_prob = ws["prob"]
@@ -1228,6 +1233,11 @@ class PathEngine:
                                                   self._stream()), "satrans_adam_flat")
                 self._flat_done = torch.cuda.Event()
                 self._flat_done.record(self._side_tail)
+                if self.preclear and not split:
+                    # the NEXT step's gradient clear, behind the event: 6 us and a launch gap off the head of that step's reduction
+                    self._g_step_tail.zero_()
+                    self._precleared = torch.cuda.Event()
+                    self._precleared.record(self._side_tail)
             # (the step's regulariser partial sums on that stream as well, behind an event of the touched-row chain and with two
             #  alternating sets of partial sums: 1.116-1.119 -> 1.120-1.122 ms/step, three A/B rounds - the sum is not what the next
             #  step's first launch waits for)
