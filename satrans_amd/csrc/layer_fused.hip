@@ -1363,6 +1363,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         lds_barrier();
 
         STAMP(5);
+        // the next tile's input row (and what the forward saved of its MetaNet): issued HERE, a whole phase F ahead of their use at
+        // the top of the next tile (at the end of phase F the dropout hashing of that top covered a few hundred cycles of an HBM
+        // round trip, the rest was waited for)
+        load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
+        if (has_zsave) fetch_z(tile_n);
         // ================= phase F: MetaNet and projection backward, weight gradients, dx ==================================
         if (has_tile) {
             float gq[KT][4], gk[KT][4];
@@ -1552,8 +1557,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
-        load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
-        if (has_zsave) fetch_z(tile_n);
         lds_barrier();
         STAMP(6);
       }
