@@ -795,7 +795,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
       //   top of tile t      sample indices of tile t + 1 (token lane: b_next; attention task lane: tb_next)
       //   after phase A      the upstream gradient rows dy of tile t (consumed in phase C)
       //   after phase C      row id of the input row of tile t + 1 (first layer with the gather fused in: x_rows[b f])
-      //   end of phase F     the input row of tile t + 1 (consumed behind the dropout hashing at the top of that tile)
+      //   start of phase F   the input row of tile t + 1 and what the forward saved of its MetaNet (a whole phase of products ahead
+      //                      of their use at the top of that tile; at the END of phase F - round 3 - the top of the tile waited)
       // Tile t1 - 1 "prefetches" itself again (clamped index): a few wasted loads instead of a branch.
       const int tok = row0 + n;
       const int ls_tok = tok / F, f_tok = tok - ls_tok * F;      // this lane's (sample, field) inside any tile that holds it
