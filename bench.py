@@ -68,10 +68,9 @@ def make_config(name, table_rows=None):
 
 CFG = make_config("aliccp")
 
-PMC_SUMMARY = "r04_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
+PMC_SUMMARY = "r05_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
-BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 
 
 def synth_batches(n_rows, seed, ids="uniform", cfg=None):
@@ -132,8 +131,10 @@ def cpu_model_name():
 def cpu_baseline(state, X, y, batch, lr, flag='sota', timed=10, warm=2, timed_verbose=5):
     """The reference's training step restated op for op (oracle/satrans_oracle.py: per-sample generated weights, torch CPU
     dropout, dense L2 over all rows, dense torch.optim.Adam), timed on this box's host cores with the protocol of SURVEY
-    §8d / BASELINE.md §3: thread count chosen by a one-step sweep, `warm` untimed steps, MEDIAN of `timed` steps; then a
-    second leg with the per-step sklearn log_loss / roc_auc_score of `fit(verbose=1)` (what reference main.py does)."""
+    §8d / BASELINE.md §3: thread count chosen by a sweep that takes the MEDIAN of three steps per candidate (a one-step sweep
+    picked 8 threads on one box and 32 on another of the same kind: a 35 % spread in the stated baseline), `warm`
+    untimed steps, MEDIAN of `timed` steps; then a second leg with the per-step sklearn log_loss / roc_auc_score of
+    `fit(verbose=1)` (what reference main.py does)."""
     from oracle import satrans_oracle as O
     from sklearn.metrics import log_loss, roc_auc_score
     ncpu = os.cpu_count()
@@ -160,7 +161,7 @@ def cpu_baseline(state, X, y, batch, lr, flag='sota', timed=10, warm=2, timed_ve
     sweep = {}
     for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
         torch.set_num_threads(th)
-        sweep[th] = one()
+        sweep[th] = sorted(one() for _ in range(3))[1]
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     for _ in range(max(0, warm - 1)):
@@ -296,6 +297,7 @@ def main():
     ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
                     help="id distribution of the synthetic batches (uniform = HBM worst case, the reported configuration)")
     args = ap.parse_args()
+    import satrans_amd  # noqa: F401  (before the first GPU call: its import sets the HIP runtime's stream-queue default)
     global CFG
     CFG = make_config(args.config, args.table_rows)
     if args.flag is None:
@@ -483,10 +485,17 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         sus_ph = eng.phase_ms() if eng.timers is not None else {}
+        n_fl = len((eng.timers or {}).get("lazy_flush", []))
         eng.timers = None
         sustained = {"steps": n_sus, "distinct_batches": n_distinct, "ms_per_step": round(dt / n_sus * 1e3, 4),
                      "samples_per_s": round(n_sus * B / dt, 1), "wall_s": round(dt, 2),
                      "phase_ms_per_launch": {k: round(v, 4) for k, v in sus_ph.items()},
+                     "lazy_flush": {"ms_per_launch": round(sus_ph.get("lazy_flush", 0.0), 4), "every_steps": eng.flush_every,
+                                    "ms_per_step": round(sus_ph.get("lazy_flush", 0.0) / max(1, eng.flush_every), 4),
+                                    "launches_timed": n_fl,
+                                    "note": "a flush replays flush_every postponed steps of every row not gathered since (the "
+                                            "headline's one flush replays its K = 20 steps: a third of the work per launch, the "
+                                            "same work per step)"},
                      "note": "same step as `value`, lazy flush inside the timed region, one rank; phases sampled every 50th step "
                              "(a row's postponed optimizer steps are replayed when it is next gathered: the replay chains are "
                              "longer here than in the 20-step headline)"}
@@ -509,7 +518,15 @@ def main():
             hist = model.fit(x=xf, y=yf, batch_size=B, epochs=1, verbose=1, shuffle=True)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
+            # the same call with two epochs: the second one finds the dataset resident (no packing, no upload)
+            t2 = time.perf_counter()
+            model.fit(x=xf, y=yf, batch_size=B, epochs=2, verbose=1, shuffle=True)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            warm = max(dt2 - dt, 1e-9)
             fit_leg = {"rows": int(n_fit * B), "batch_size": B, "wall_s": round(dt, 3), "samples_per_s": round(n_fit * B / dt, 1),
+                       "warm_epoch": {"wall_s": round(warm, 3), "samples_per_s": round(n_fit * B / warm, 1),
+                                      "note": "a two-epoch fit minus the one-epoch fit: an epoch over the already resident dataset"},
                        "epoch_loss": float(hist.history["loss"][-1]) if hist.history.get("loss") else None,
                        "note": "model.fit(x=dict, y, batch_size, epochs=1, verbose=1, shuffle=True): host packing + upload of "
                                "the epoch's rows, per-epoch shuffle, per-step train metrics (binary_crossentropy, auc), History"}
@@ -540,8 +557,7 @@ def main():
     # the last layer of a step as ONE launch with the head fused in (satrans_layer_bwd_head): its recomputed forward IS the
     # layer's forward (no forward launch exists for it), so the launch carries forward + backward = 3 x the forward's FLOPs
     fused_head = bool(eng._ws.get(B, {}).get("fuse_head"))
-    saved_attn = bool(eng._ws.get(B, {}).get("attn_save")) and eng._save_attention_env != "0" and \
-        (eng._save_attention_env == "1" or eng.lib.satrans_get_product_mode() == 0)
+    saved_attn = any(t is not None for t in (eng._ws.get(B, {}).get("attn_save") or []))
     per_launch = {
         "layer_bwd_head": dict(kernel=bwd_kernel + " (HEADF instantiation: last layer forward + head + loss + backward)",
                                bound="mfma", unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=3.0 * fwd_flops / 1e12),
@@ -552,11 +568,11 @@ def main():
         "layer_fwd_gather": dict(kernel=fwd_kernel + " (layer 0: tokens read from the embedding arena, gather fused in)", bound="mfma",
                                  unit="TFLOP/s", peak=FP32_PEAK_TFLOPS, work=fwd_flops / 1e12),
         "gather_fwd": dict(kernel="gather_rows_kernel", bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS,
-                           work=B * F * (D * 4 + 4) / 1e9),                        # read bytes (only timed with SATRANS_FUSE_GATHER=0)
+                           work=B * F * (D * 4 + 4) / 1e9),                        # read bytes (only timed with engine.fuse_gather off)
     }
     n_flush = max(1, n_flush_timed)
     n_sep = L - 1 if fused_head else L
-    gather_fused = "layer_fwd_gather" in phases
+    gather_fused = "layer_fwd_gather" in phases or "layer_fwd_gather" in dispatch
     count = {"layer_fwd": n_sep - (1 if gather_fused else 0), "layer_fwd_gather": 1, "layer_bwd": n_sep, "layer_bwd_head": 1,
              "lazy_flush": n_flush / K}  # launches per step (the flush runs every
     #                                   SATRANS_LAZY_FLUSH_EVERY = 64 steps and once more at the end of the timed region)
@@ -587,11 +603,6 @@ def main():
             rows[name] = entry
         return rows, dom
 
-    # split products: the training forward of every D = 32 MetaNet layer on the fused kernels; the backward only with ONE generated
-    # table for both roles (no 'pos') and within the LDS budget (F <= 19)
-    split_applies = D == 32 and args.config != "c5" and not ("gate" in args.flag or "bilinear" in args.flag)
-    split_on = eng.lib.satrans_get_product_mode() == 1 and split_applies
-    products = "f32" if not split_on else ("split" if (args.config == "aliccp" and "pos" not in args.flag) else "split forward, f32 backward")
     kernels, dominant = table(phases, disp=dispatch)
     phase_sum = sum(v["ms_per_step"] for v in kernels.values())
     kernels_serial, _ = table(phases_serial)
@@ -603,11 +614,12 @@ def main():
                     "algorithmic_per_launch": spec["work"], "launch_ms": e.get("kernel_ms", e["ms_per_launch"]),
                     "timed_by": e.get("timed_by", "recorded events"),
                     "launches_per_step": count.get(dominant, 1),
-                    # HBM bytes the launch has to move (what `traffic` is to be read against): layer input, upstream gradient and
-                    # input gradient [B,F,D] each - plus, when the forward handed its attention state over (the default with fp32
-                    # products: softmax numerators H F F, 1 / sum and keep word H F, attention output F D, the normalised MetaNet
-                    # rows of both roles 2 F D and their 1 / std 2 F per sample), that state, which the backward reads INSTEAD of
-                    # recomputing it: bytes traded for matrix-pipe and VALU time in a compute-bound kernel
+                    # HBM bytes the launch has to move (what `traffic` is to be read against).  `_min`: layer input, upstream
+                    # gradient and input gradient [B,F,D] each - what a backward that recomputes everything moves.  `_per_launch`
+                    # adds the state the forward handed over (softmax numerators H F F, 1 / sum and keep word H F, attention
+                    # output F D, the normalised MetaNet rows of both roles 2 F D and their 1 / std 2 F per sample), which the
+                    # backward reads INSTEAD of recomputing it: bytes traded for matrix-pipe and VALU time in a compute-bound kernel
+                    "algorithmic_bytes_min": 3 * B * F * D * 4 if dominant in ("layer_bwd", "layer_bwd_head") else None,
                     "algorithmic_bytes_per_launch": (3 * B * F * D * 4 + (B * (CFG["H"] * F * F + 2 * CFG["H"] * F + F * D + F * (2 * D + 2)) * 4
                                                                          if (dominant == "layer_bwd" and saved_attn) else 0))
                                                     if dominant in ("layer_bwd", "layer_bwd_head") else None,
@@ -621,10 +633,7 @@ def main():
                              "so a layer_bwd launch is the backward kernel alone; the last layer runs as `layer_bwd_head` "
                              "(its forward, the head, the loss and their backward in one launch)" if "layer_bwd_reduce" in phases
                              else "layer_bwd includes its fixed-order reduction launch") +
-                            "; `kernels_serial` repeats the measurement in an extra untimed pass" + ("; `achieved` counts the ALGORITHMIC fp32 FLOPs of the layer, `peak` is the fp32 "
-                            "MFMA peak: the kernel issues them as split bf16 products (3 x 1/16 of the fp32 instruction's "
-                            "cycles), so the matrix pipe is ~10 % of its cycles and the fraction is a time-to-solution "
-                            "figure against the fp32 roof, not a pipe utilisation" if products == "split" else "")}
+                            "; `kernels_serial` repeats the measurement in an extra untimed pass"}
 
     # HBM bytes per launch of that kernel from the PMC passes under profiles/ (tools/pmc_passes.sh: FETCH_SIZE and WRITE_SIZE
     # in separate passes of `bench.py --train-only`, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The
@@ -642,11 +651,13 @@ def main():
             if pmc.get("_source_sha256") != sha:
                 roofline["traffic_source"] = (f"stale: profiles/{PMC_SUMMARY} was taken on other kernel sources "
                                               f"({str(pmc.get('_source_sha256'))[:12]} vs {sha[:12]})")
-            elif pmc.get("_config") != args.config or args.flag != CFG["flag"] or pmc.get("_products", "f32") != products:
-                roofline["traffic_source"] = (f"none: profiles/{PMC_SUMMARY} is of config {pmc.get('_config')!r}, default flag, "
-                                              f"{pmc.get('_products', 'f32')} products")
+            elif pmc.get("_config") != args.config or args.flag != CFG["flag"]:
+                roofline["traffic_source"] = f"none: profiles/{PMC_SUMMARY} is of config {pmc.get('_config')!r}, default flag"
             else:
                 roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)
+                if roofline.get("algorithmic_bytes_min"):
+                    roofline["traffic_ratio_min"] = round(roofline["traffic"] / roofline["algorithmic_bytes_min"], 3)
+                    roofline["traffic_ratio"] = round(roofline["traffic"] / roofline["algorithmic_bytes_per_launch"], 3)
                 roofline["traffic_source"] = (f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc of these kernel sources, bytes per "
                                               f"launch: 2 x FETCH_SIZE + WRITE_SIZE)")
         except (OSError, StopIteration, KeyError):
@@ -655,13 +666,16 @@ def main():
     # ---- the gather on its own: achieved HBM GB/s at the training batch and at the reference's prediction batch
     #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
     gather = gather_microbench(eng, Xd, B, F, D) if not args.train_only else None
-    if gather is not None and gather_fused and "layer_fwd" in phases:
+    fwd_ms = {**dispatch, **phases}
+    if gather is not None and gather_fused and "layer_fwd" in fwd_ms:
         # In the training step no gather kernel runs: layer 0 reads its B x F rows (128-byte random reads) straight from the arena.
         # What that costs is the difference between layer 0's forward launch and the same kernel on dense [B,F,D] input (layer 1).
-        exposed = phases["layer_fwd_gather"] - phases["layer_fwd"]
+        exposed = fwd_ms["layer_fwd_gather"] - fwd_ms["layer_fwd"]
         nbytes = B * F * (D * 4 + 4)
+        # (the training step's answer first: what the step pays for the gather)
+        gather = {"exposed_us_in_training_step": round(1e3 * exposed, 2), **gather}
         gather["fused_into_layer0"] = {
-            "layer0_fwd_ms": round(phases["layer_fwd_gather"], 4), "other_layer_fwd_ms": round(phases["layer_fwd"], 4),
+            "layer0_fwd_ms": round(fwd_ms["layer_fwd_gather"], 4), "other_layer_fwd_ms": round(fwd_ms["layer_fwd"], 4),
             "exposed_ms": round(exposed, 4), "algorithmic_read_bytes": nbytes,
             "hidden": bool(exposed <= 0.002),
             "read_GBps_if_all_exposed_time_were_the_gather": round(nbytes / 1e9 / (max(exposed, 1e-4) / 1e3), 1),
@@ -728,64 +742,6 @@ def main():
         except Exception:
             pass
 
-    # ---- the OTHER product mode, as a named secondary object: the headline runs in the library's mode (default: fp32 products,
-    #      the reference's arithmetic); the opt-in split mode (fp32 operands as bf16 pairs) gets the same protocol -
-    #      W warm-up steps, flush, K timed steps over the same resident batches with the lazy flush inside, per-phase HIP events on
-    #      every 4th step - and its own kernel table and roofline, priced against BOTH roofs ----------------------------------------
-    other_leg, other_key = None, None
-    mode_now = eng.lib.satrans_get_product_mode()
-    if world == 1 and not args.train_only and split_applies:
-        other = 1 - mode_now
-        other_key = "split_products" if other == 1 else "fp32_products"
-        eng.lib.satrans_set_product_mode(other)
-        try:
-            model.train()
-            eng.timers = None
-            for i in range(W):
-                step(i)
-            eng.flush_lazy()
-            torch.cuda.synchronize()
-            tm = {} if not args.no_phase_timing else None
-            fl0 = getattr(eng, "flush_count", 0)
-            t1 = time.perf_counter()
-            for i in range(W, W + K):
-                smp = tm is not None and (i - W) % 4 == 0
-                eng.timers = tm if smp else None
-                eng.lib.satrans_kernel_timing(1 if smp else 0)
-                step(i)
-            eng.lib.satrans_kernel_timing(0)
-            eng.timers = tm
-            eng.flush_lazy(sync=False)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            ph = eng.phase_ms() if tm is not None else {}
-            disp_o = read_dispatch_ms(eng.lib) if tm is not None else {}
-            eng.timers = None
-            cnt = dict(count, lazy_flush=max(1, getattr(eng, "flush_count", 0) - fl0) / K)
-            kern_o, dom_o = table(ph, cnt, disp_o)
-            roof_o = None
-            if dom_o:
-                e, spec = kern_o[dom_o], per_launch[dom_o]
-                roof_o = {"kernel": spec["kernel"], "bound": e["bound"], "achieved": e["achieved"], "unit": e["unit"],
-                          "launch_ms": e.get("kernel_ms", e["ms_per_launch"]), "algorithmic_per_launch": spec["work"],
-                          "peak_fp32_mfma": FP32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": round(e["achieved"] / FP32_PEAK_TFLOPS, 4)}
-                if other == 1:
-                    roof_o.update({"peak_bf16_mfma_dense": BF16_PEAK_TFLOPS,
-                                   "frac_of_bf16_mfma_peak_3_instructions": round(3.0 * e["achieved"] / BF16_PEAK_TFLOPS, 4),
-                                   "note": "`achieved` = ALGORITHMIC fp32 FLOPs of the layer / launch time.  The kernel issues each "
-                                           "product as three bf16 instructions, so the bf16 pipe carries 3 x that rate: that is "
-                                           "the second fraction (the kernel is bound by VALU issue and latency, not by the pipe)"})
-            other_leg = {"dtype": "bf16x3 (fp32 operands as bf16 pairs hi + lo; a_lo w_hi + a_hi w_lo + a_hi w_hi on "
-                                  "v_mfma_f32_16x16x32_bf16, fp32 accumulation)" if other == 1 else "f32",
-                         "ms_per_step": round(dt / K * 1e3, 4), "samples_per_s": round(B * K / dt, 1), "steps": K, "warmup": W,
-                         "kernels": kern_o, "roofline": roof_o,
-                         "note": ("opt-in fast mode (SATRANS_PRODUCTS=split / satrans_set_product_mode(1)): NOT the reference's "
-                                  "arithmetic - operands carry ~16 significant bits; on trained weights the training forward is "
-                                  "outside the 1e-5 logit bar (tests: test_trained_weights_regime_against_the_oracle)")
-                                 if other == 1 else "the reference's arithmetic (v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain)"}
-        finally:
-            eng.lib.satrans_set_product_mode(mode_now)
-
     # ---- parity figure the metric asks for: forward logits vs the CPU oracle on identical inputs -------------
     err = err_train = logit_scale = None
     try:
@@ -799,7 +755,7 @@ def main():
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         _, ref_logit = O.forward(sd, torch.from_numpy(X[:nb]), oracle_spec(args.flag))
         err = float((gpu_logit - ref_logit).abs().max())
-        # the same inputs through the TRAINING forward (split products unless SATRANS_PRODUCTS=f32) with its dropouts switched off
+        # the same inputs through the TRAINING forward (the kernels of the training step) with its dropouts switched off
         model.train()
         keep_p, eng.drop_p = eng.drop_p, 0.0
         try:
@@ -816,18 +772,18 @@ def main():
     cpu = None
     if do_cpu:
         t_cpu = time.time()
-        n_need = 1 + 5 + 2 + args.cpu_steps + 5 + 2
+        n_need = 1 + 3 * 5 + 2 + args.cpu_steps + 5 + 2      # first step, thread sweep (3 per candidate), warm-up, timed, verbose
         # bounded sample: the same step at a smaller batch where one CPU step of the full batch would take minutes (c5)
         Bc = B if args.config != "c5" else min(B, 512)
         timed_c = args.cpu_steps if args.config != "c5" else min(args.cpu_steps, 3)
         Xc, yc = synth_batches(n_need * Bc, seed=7, cfg=cpu_cfg)
         r = cpu_baseline(state_cpu, Xc, yc, Bc, args.lr, args.flag, timed=timed_c, timed_verbose=5 if args.config != "c5" else 2)
-        cpu = {"value": round(r["value"], 1), "unit": "samples/s", "cores": r["threads"], "kind": "port",
+        cpu = {"value": round(r["value"], 1), "unit": "samples/s", "cores": r["threads"], "threads": r["threads"], "kind": "port",
                "cpu_model": cpu_model_name(), "host_cores": os.cpu_count(),
                "value_verbose1": round(r["value_verbose1"], 1),
                "thread_sweep_s_per_step": r["sweep_s_per_step"],
                "sample": f"median of {r['timed']} training steps of B={Bc} after 2 untimed ones at the best thread count of a "
-                         f"one-step sweep (dropout on, dense L2 + dense torch Adam over all {n_cpu_rows:,} rows; `value` = verbose=0, "
+                         f"sweep (median of 3 steps per candidate; dropout on, dense L2 + dense torch Adam over all {n_cpu_rows:,} rows; `value` = verbose=0, "
                          f"`value_verbose1` = median of {r['timed_verbose']} steps with the per-step sklearn log_loss + "
                          f"roc_auc_score of fit(verbose=1), what reference main.py runs); {time.time() - t_cpu:.0f}s wall"}
 
@@ -839,23 +795,17 @@ def main():
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        # the arithmetic type the path computes its products in: the library's product mode decides, nothing is hard-coded
-        "dtype": "f32" if products == "f32" else "bf16x3 split products (fp32 storage and accumulation)", "data": "synthetic",
-        "products": (products + (": fp32 operands as bf16 pairs hi + lo, a product = a_lo w_hi + a_hi w_lo + a_hi w_hi on "
-                                 "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fused kernels of the (32, 64, 4) MetaNet shape): "
-                                 "the opt-in fast mode, NOT the reference's arithmetic (operands carry ~16 significant bits)"
-                                 if products.startswith("split") else ": v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain)")),
+        "dtype": "f32", "data": "synthetic",
+        "products": "f32: v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain)",
         "config": {"workload": f"{CFG['label']}, {model.embedding_arena.shape[0]:,} table rows "
                                f"({model.embedding_arena.numel() * 4 / 1e6:,.0f} MB fp32), {args.ids} ids, dropout on, "
                                f"dense-Adam+L2 semantics over all rows",
                    "batch_per_gpu": B, "global_batch": B * world, "embedding_dim": D, "layers": L, "heads": CFG["H"],
                    "fields": F, "parallelism": f"dp{world}"},
         "fwd_logit_max_abs_err_vs_cpu_oracle": err,
-        **({other_key: other_leg} if other_key else {}),
         "fwd_logit": {"max_abs_err_vs_cpu_oracle": err, "training_forward_dropout_off_max_abs_err": err_train,
                       "max_abs_logit": logit_scale, "samples": 2048,
-                      "note": "weights as they are after this run's training steps; evaluation forward = fp32 products, "
-                              f"training forward = {products} products"},
+                      "note": "weights as they are after this run's training steps; evaluation and training forward"},
         "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
         "fit_samples_per_s": fit_leg["samples_per_s"] if fit_leg else None, "fit": fit_leg,
         "phase_sum_ms_per_step": round(phase_sum, 4), "phase_sum_frac_of_step": round(phase_sum / (elapsed / K * 1e3), 4),

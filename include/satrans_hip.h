@@ -30,7 +30,7 @@ extern "C" {
 /* 4: satrans_layer_desc gained the trailing `attn_save` field and satrans_set_layer_bwd8 left the library (round 3; the number
  *    was bumped one round late); round 4 added satrans_layer_bwd_head (a new entry point, no struct changed).  A caller built against an
  *    older header passes a shorter struct: satrans_abi_version() must be compared with this constant before any other call. */
-#define SATRANS_ABI_VERSION 4
+#define SATRANS_ABI_VERSION 5
 
 /* error codes */
 #define SATRANS_OK 0
@@ -55,6 +55,12 @@ extern "C" {
 
 const char* satrans_last_error(void);
 int satrans_abi_version(void);
+
+/* A non-blocking HIP stream of the LOWEST priority the current device offers, for work that must yield to the caller's launch
+ * stream whenever both have a kernel ready (the engine's next-batch preparation; torch only hands out normal and higher).
+ * SATRANS_E_UNSUPPORTED on a device with one priority level.  The caller owns the handle. */
+int satrans_stream_create_low_priority(void** stream_out);
+int satrans_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Scenario bucketing.  Reads the scenario id column of X (reference satrans.py:203:
@@ -183,21 +189,10 @@ int satrans_set_layer_impl(int impl);
  * between this path and the general one (satrans_layer_generic_supported). */
 int satrans_layer_fused_supported(const satrans_layer_desc* d);
 
-/* How the fused kernels evaluate the weight products (projections, MetaNet, Out_linear; satrans.py:55-57,60-73,91) of the
- * (D,U,H) = (32,64,4) MetaNet shape:
- * 0 = fp32: v_mfma_f32_16x16x4_f32, bit for bit a chain of fmaf - what torch's CPU matmul computes up to summation order;
- * 1 = split: every fp32 operand as a bf16 pair hi + lo, a product as a_lo w_hi + a_hi w_lo + a_hi w_hi on
- *     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what is dropped is <= 2^-16 of a term; measured ~2.6x the error of plain
- *     fp32 products against an fp64 evaluation of the same graph).  Weights are split once per workgroup, activations on the fly.
- * Mode 1 applies to the TRAINING step - the forward with SATRANS_TRAIN set and the backward; a forward without SATRANS_TRAIN
- * (predict / evaluate) always runs fp32 products: outputs that are compared with the reference's stay exact to fp32 summation
- * order (logits of a trained AliCCP-shaped model: 1.4e-6 from the CPU oracle; 7.7e-5 through split products).
- * The library starts in mode 0 - the reference's arithmetic, and the mode every reported headline number is measured in;
- * SATRANS_PRODUCTS=split in the environment (or this call) selects mode 1, an opt-in fast mode.  Layers of other shapes, the
- * gate / bilinear variants and separate Q / K tables (flag 'pos') always run fp32 products.  Returns SATRANS_E_BADARG for any
- * other mode. */
-int satrans_set_product_mode(int mode);
-int satrans_get_product_mode(void);
+/* Every product of the fused layer kernels (projections, MetaNet, Out_linear; satrans.py:55-57,60-73,91) runs on
+ * v_mfma_f32_16x16x4_f32: bit for bit a chain of fmaf - what torch's CPU matmul computes up to summation order.  (ABI 4 had an
+ * opt-in mode that split fp32 operands into bf16 pairs, satrans_set_product_mode; retired in ABI 5: outside the fp32 tolerance on
+ * trained weights - tools/experiments/README.md.) */
 
 /* y [B,F,D]; att optional [H,B,F,F] (`normalized_att_scores`, satrans.py:87) */
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream);
@@ -424,6 +419,14 @@ int satrans_embed_sort_fields(const int32_t* rows, int B, int F, const int32_t* 
 int satrans_embed_rows_sort_fields(const void* X, int id_dtype, int64_t x_stride, const int32_t* cols, const int64_t* row_span,
                                    int32_t* rows, int B, int F, const int32_t* seg_field, const int32_t* seg_lo,
                                    const int32_t* seg_rows, int32_t* sorted_rows, int32_t* src, int32_t* status, void* stream);
+/* The same sort when `ids` [n] is W sorted runs back to back (owner form of the data-parallel step: what W ranks sent an owner;
+ * each run ascending, equal rows in position order): ONE launch, every element ranks itself by W - 1 binary searches.  h_run_start:
+ * HOST array of W + 1 boundaries (h_run_start[0] = 0, h_run_start[W] = n), W <= 64.  Output identical to
+ * satrans_embed_sort(ids, positions = 0..n-1): src[j] = the index in `ids` of sorted element j. */
+int satrans_embed_merge_runs(const int32_t* ids, int64_t n, const int64_t* h_run_start, int W, int32_t* sorted_rows, int32_t* src,
+                             void* stream);
+/* inv[src[i]] = i for i < n: the inverse of a sort's source positions */
+int satrans_embed_inverse_positions(const int32_t* src, int64_t n, int32_t* inv, void* stream);
 int64_t satrans_embed_reg_partials(int64_t total_rows, int64_t n, int D);
 /* last / t: optional (lazy form): last[row] = t for every row stepped */
 int satrans_embed_adam_touched(float* arena, float* m, float* v, int D, const int32_t* sorted_rows,

@@ -190,7 +190,7 @@ class BaseModel(nn.Module):
         eng = getattr(self, "_engine", None)
         carried = getattr(self, "_pending_opt_state", None)
         if eng is not None:
-            eng.flush_lazy()          # postponed optimizer steps must land before the storage is rebuilt
+            eng.flush_lazy(sync="local")          # postponed optimizer steps must land before the storage is rebuilt
             if eng.adam_t > 0:
                 carried = eng.optimizer_state()
         out = super()._apply(fn, *args, **kwargs)
@@ -213,7 +213,7 @@ class BaseModel(nn.Module):
                 return {}
             raw = pend
         else:
-            eng.flush_lazy()
+            eng.flush_lazy(sync="local")
             raw = eng.optimizer_state()
         kind = raw.get("kind", "adam")
         out = {"kind": kind, "step": int(raw["adam_t"]), "drop_step": int(raw["drop_step"]), "state": {}}
@@ -276,7 +276,9 @@ class BaseModel(nn.Module):
                 only_lr = new.get("kind") == "adam" and old.get("kind") == "adam" and \
                     {k: v for k, v in new.items() if k != "lr"} == {k: v for k, v in old.items() if k != "lr"}
                 if not only_lr:
-                    self._flush_engine()
+                    eng = getattr(self, "_engine", None)
+                    if eng is not None:
+                        eng.flush_lazy(sync=False)      # (the rows this rank steps; replicas of other owners' rows are not read)
                 self._adam_cfg = new
         return self._adam_cfg
 
@@ -475,16 +477,12 @@ class BaseModel(nn.Module):
         if stream is None:
             stream = _os.environ.get("SATRANS_STREAM_INPUT", "0") == "1" or sample_num * n_cols * 4 > (8 << 30)
         data = labels = None
-        # The first epoch's sample order (a seeded CPU randperm, 11 ns per row: the reference's DataLoader order) is drawn in a
-        # thread while the columns are uploaded and assembled on the device - neither touches the other's state, and the global
-        # RNG sees the same draws in the same order as before.
-        first_order = None
-        if shuffle and not stream and initial_epoch < epochs:
-            import threading
-            box = {}
-            th = threading.Thread(target=lambda: box.setdefault("order", self._epoch_order(sample_num, True, on_host=True)))
-            th.start()
-            first_order = (th, box)
+        # Resident dataset: the columns are uploaded and assembled on the device by a worker thread while this thread runs the
+        # callbacks and draws the first epoch's sample order (a seeded CPU randperm, 11 ns per row) - the order is drawn HERE, in
+        # this thread, at the point where the reference's DataLoader iterator draws it (after on_epoch_begin): a callback that
+        # seeds or reads the global RNG sees what it sees in the reference.  The worker touches no RNG; its exception, if any,
+        # is re-raised where the data is first needed.
+        upload = None
         if stream:
             packed = np.concatenate(cols, axis=-1)
             if any(np.issubdtype(c.dtype, np.integer) and c.size and int(c.max()) >= (1 << 24) for c in cols) and \
@@ -492,8 +490,19 @@ class BaseModel(nn.Module):
                 packed = np.concatenate([c.astype(np.float64) for c in cols], axis=-1)   # (as _pack)
             host_ids, host_dense = self._host_matrices(packed)
         else:
-            data = self._device_matrix_from_columns(cols)     # whole training set resident in HBM, assembled there
-            labels = torch.from_numpy(y).to(self.device)
+            import threading
+            box = {}
+
+            def _upload():
+                try:
+                    if str(self.device).startswith("cuda"):
+                        torch.cuda.set_device(self.device)
+                    box["data"] = self._device_matrix_from_columns(cols)     # whole training set resident in HBM, assembled there
+                    box["labels"] = torch.from_numpy(y).to(self.device)
+                except BaseException as ex:                                   # noqa: BLE001 - handed to the caller's thread
+                    box["error"] = ex
+            upload = threading.Thread(target=_upload)
+            upload.start()
         self.train()
 
         # SATRANS_HOST_METRICS=1: per-step train metrics through sklearn on host copies, as the reference does
@@ -517,12 +526,15 @@ class BaseModel(nn.Module):
             fused_buf = None
             if verbose > 0 and self.metrics and device_metrics and str(self.device).startswith("cuda"):
                 fused_buf = torch.full((steps_per_epoch, 2), float("nan"), dtype=torch.float64, device=self.device)
+            order = self._epoch_order(sample_num, shuffle, on_host=upload is not None)
+            if upload is not None:
+                upload.join()
+                upload = None
+                if "error" in box:
+                    raise box["error"]
+                data, labels = box["data"], box["labels"]
+                order = order.to(self.device) if order is not None else None
             engine.reset_epoch_sums()
-            if first_order is not None:
-                first_order[0].join()
-                order, first_order = first_order[1]["order"].to(self.device), None
-            else:
-                order = self._epoch_order(sample_num, shuffle)
             if not stream and torch.is_tensor(data):
                 engine.plan_owner_counts(data, order, batch_size)      # several ranks, owner form: the epoch's exchange sizes at once
             feeder = None
@@ -630,6 +642,8 @@ class BaseModel(nn.Module):
             cbs.on_epoch_end(epoch, epoch_logs)
             if self.stop_training:
                 break
+        if upload is not None:                                   # (no epoch ran: initial_epoch >= epochs)
+            upload.join()
         cbs.on_train_end()
         return self.history
 
@@ -725,6 +739,15 @@ class BaseModel(nn.Module):
         raise NotImplementedError
 
     def _flush_engine(self):
+        """Postponed optimizer steps land; single-rank entry points (state_dict, get_regularization_loss): never a collective."""
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng.flush_lazy(sync="local")
+
+    def synchronize(self):
+        """Data-parallel runs (owner form): bring this rank's postponed optimizer steps and every rank's copy of the embedding
+        tables up to date.  COLLECTIVE: call it on every rank (fit / predict / evaluate do so themselves at their flush points;
+        this is for a checkpoint in the middle of an epoch).  One rank: the same as the flush state_dict() performs."""
         eng = getattr(self, "_engine", None)
         if eng is not None:
             eng.flush_lazy()

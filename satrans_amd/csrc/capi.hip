@@ -47,6 +47,29 @@ int satrans_layer_bwd_reduce_fused(int n, const satrans_layer_desc* const* descs
 const char* satrans_last_error(void) { return satrans::g_error; }
 int satrans_abi_version(void) { return SATRANS_ABI_VERSION; }
 
+// A non-blocking HIP stream of the LOWEST priority the current device offers (host frameworks only hand out normal and higher).
+// SATRANS_E_UNSUPPORTED when the device has a single priority level.  The caller owns the handle (satrans_stream_destroy).
+int satrans_stream_create_low_priority(void** out) {
+    SATRANS_REQUIRE(out, SATRANS_E_BADARG, "stream_create_low_priority: null pointer");
+    *out = nullptr;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "stream_create_low_priority: %s", hipGetErrorString(e));
+    SATRANS_REQUIRE(least > greatest, SATRANS_E_UNSUPPORTED, "stream_create_low_priority: one priority level only");   // (numerically larger = lower)
+    hipStream_t st = nullptr;
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "stream_create_low_priority: %s", hipGetErrorString(e));
+    *out = (void*)st;
+    return SATRANS_OK;
+}
+
+int satrans_stream_destroy(void* stream) {
+    if (!stream) return SATRANS_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "stream_destroy: %s", hipGetErrorString(e));
+    return SATRANS_OK;
+}
+
 // 0 = automatic: register-chained MFMA kernels (layer_fused.hip) for the shapes they are built for, else the LDS
 //     kernels with MFMA products, else the LDS kernels with scalar FMA loops;
 // 1 = LDS kernels, scalar FMA loops;  2 = LDS kernels, MFMA products.     Initial value from SATRANS_LAYER_IMPL.

@@ -893,6 +893,89 @@ extern "C" int satrans_embed_sort(const int32_t* rows, int64_t n, int64_t total_
     return SATRANS_OK;
 }
 
+// ---- W sorted runs back to back -> one sorted list (the owner form: what W ranks sent an owner is W sorted runs) ---------------------
+// Output identical to satrans_embed_sort(ids, positions = 0..n-1): ascending rows, equal rows in position order - positions grow
+// with (run, index inside the run), and a run is itself sorted that way.  One lane per element: its final position is its index
+// inside its run + for every EARLIER run the number of elements <= it + for every LATER run the number of elements < it (W - 1
+// binary searches over L2-resident runs, eight of them in flight at a time) - one launch instead of the device-wide sort's block
+// sort + ~10 merge passes.
+constexpr int kMergeRunsMax = 64;
+struct MergeRuns {
+    int32_t start[kMergeRunsMax + 1];
+};
+__global__ __launch_bounds__(256) void merge_runs_kernel(const int32_t* __restrict__ ids, int n, int W, MergeRuns R,
+                                                         int32_t* __restrict__ sorted_rows, int32_t* __restrict__ src) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t x = ids[i];
+    int r = 0;
+    while (r + 1 < W && i >= R.start[r + 1]) ++r;      // (W <= 64: a short scan over kernel arguments)
+    int pos = i - R.start[r];
+    for (int q0 = 0; q0 < W; q0 += 8) {
+        int lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = q0 + k;
+            const bool on = q < W && q != r;
+            lo[k] = on ? R.start[q] : 0;
+            hi[k] = on ? R.start[q + 1] : 0;
+        }
+        bool more = true;
+        while (more) {
+            more = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (lo[k] < hi[k]) {
+                    const int mid = (lo[k] + hi[k]) >> 1;
+                    const int32_t v = ids[mid];
+                    // earlier run: count elements <= x (upper bound); later run: elements < x (lower bound)
+                    const bool right = (q0 + k < r) ? (v <= x) : (v < x);
+                    if (right) lo[k] = mid + 1; else hi[k] = mid;
+                    more = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = q0 + k;
+            if (q < W && q != r) pos += lo[k] - R.start[q];
+        }
+    }
+    sorted_rows[pos] = x;
+    src[pos] = i;
+}
+
+// h_run_start: HOST array of W + 1 ints, run q = ids[h_run_start[q], h_run_start[q + 1]); W <= 64
+extern "C" int satrans_embed_merge_runs(const int32_t* ids, int64_t n, const int64_t* h_run_start, int W, int32_t* sorted_rows,
+                                        int32_t* src, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SATRANS_REQUIRE(ids && h_run_start && sorted_rows && src, SATRANS_E_BADARG, "embed_merge_runs: null pointer");
+    SATRANS_REQUIRE(W >= 1 && W <= kMergeRunsMax, SATRANS_E_UNSUPPORTED, "embed_merge_runs: %d runs (1..%d)", W, kMergeRunsMax);
+    SATRANS_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && h_run_start[0] == 0 && h_run_start[W] == n, SATRANS_E_BADARG,
+                    "embed_merge_runs: run boundaries do not cover [0, %lld)", (long long)n);
+    MergeRuns R;
+    for (int q = 0; q <= kMergeRunsMax; ++q) R.start[q] = (int32_t)h_run_start[std::min(q, W)];
+    for (int q = 0; q < W; ++q)
+        SATRANS_REQUIRE(R.start[q] <= R.start[q + 1], SATRANS_E_BADARG, "embed_merge_runs: run %d has a negative length", q);
+    if (n == 0) return SATRANS_OK;
+    merge_runs_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(ids, (int)n, W, R, sorted_rows, src);
+    SATRANS_CHECK_LAUNCH("merge_runs_kernel");
+    return SATRANS_OK;
+}
+
+// inv[src[i]] = i: the inverse of a sort's source positions (token (b, f) -> its place in the sorted list)
+__global__ __launch_bounds__(256) void inverse_positions_kernel(const int32_t* __restrict__ src, int n, int32_t* __restrict__ inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[src[i]] = i;
+}
+extern "C" int satrans_embed_inverse_positions(const int32_t* src, int64_t n, int32_t* inv, void* stream_) {
+    SATRANS_REQUIRE(src && inv && n >= 0 && n < ((int64_t)1 << 31), SATRANS_E_BADARG, "embed_inverse_positions: bad argument");
+    if (n == 0) return SATRANS_OK;
+    inverse_positions_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream_>>>(src, (int)n, inv);
+    SATRANS_CHECK_LAUNCH("inverse_positions_kernel");
+    return SATRANS_OK;
+}
+
 // ---- the same sort for the rows of ONE batch when every field has a table of its own ---------------------------------------------
 // rows [B, F] (position = b F + f).  The tables lie back to back in the arena, so the globally sorted list is the fields' own
 // sorted lists in arena order: one workgroup per field sorts its B (row, position) pairs in LDS (rocPRIM block radix sort, stable,
@@ -1154,31 +1237,16 @@ extern "C" int satrans_embed_adam_untouched(float* arena, float* m, float* v, in
     // Grid: measured on MI355X (tools/adam_sweep.sh, 841 MB x 3 arrays): 512-768 persistent blocks of 256 threads reach
     // 5.3-5.4 TB/s, 2048 blocks 4.7 TB/s, 256 blocks 3.8 TB/s; the contiguous-slice-per-block form is 6 % slower than the
     // grid-wide stride.  512 also leaves wave slots to the layer kernels when the call runs on a side stream.
-    // grid_blocks / SATRANS_ADAM_BLOCKS override; partial-sum slots beyond the grid are cleared.
-    static const int env_blocks = getenv("SATRANS_ADAM_BLOCKS") ? atoi(getenv("SATRANS_ADAM_BLOCKS")) : 0;
-    const int want_blocks = env_blocks > 0 ? env_blocks : grid_blocks;
-    const int blocks = want_blocks > 0 ? std::min(want_blocks, kStreamBlocks) : 512;
+    // grid_blocks overrides; partial-sum slots beyond the grid are cleared.
+    const int blocks = grid_blocks > 0 ? std::min(grid_blocks, kStreamBlocks) : 512;
     if (blocks < kStreamBlocks) {
         hipError_t e = hipMemsetAsync(reg_partials + blocks, 0, sizeof(double) * (kStreamBlocks - blocks), stream);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "embed_adam_untouched: memset: %s", hipGetErrorString(e));
     }
-    // tuning knob for experiments: SATRANS_ADAM_VARIANT = 0 (UNR 4, non-temporal; default) | 1 (UNR 8, nt) | 2 (UNR 4,
-    // cached) | 3 (UNR 8, cached) | 4 (UNR 2, nt)
-    static const int variant = getenv("SATRANS_ADAM_VARIANT") ? atoi(getenv("SATRANS_ADAM_VARIANT")) : 0;
-#define LAUNCH_ADAM(UNR_, NT_, ...)                                                                              \
-    DISPATCH_LPR(D, (adam_untouched_kernel<LPR, UNR_, NT_, ##__VA_ARGS__><<<blocks, kStreamBlock, 0, stream>>>(  \
-                        (float4*)arena, (float4*)m, (float4*)v, first4, n4, touched, k, reg_partials)))
-    switch (variant) {
-        case 1: LAUNCH_ADAM(8, true); break;
-        case 2: LAUNCH_ADAM(4, false); break;
-        case 3: LAUNCH_ADAM(8, false); break;
-        case 4: LAUNCH_ADAM(2, true); break;
-        case 5: LAUNCH_ADAM(4, true, true); break;
-        case 6: LAUNCH_ADAM(8, true, true); break;
-        case 7: LAUNCH_ADAM(2, true, true); break;
-        default: LAUNCH_ADAM(4, true); break;
-    }
-#undef LAUNCH_ADAM
+    // four 16-byte elements in flight per lane, non-temporal accesses (tools/adam_sweep.sh, round 1: 8 in flight, cached
+    // accesses and the contiguous-slice form all measured slower)
+    DISPATCH_LPR(D, (adam_untouched_kernel<LPR, 4, true><<<blocks, kStreamBlock, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, first4, n4, touched, k, reg_partials)));
     SATRANS_CHECK_LAUNCH("adam_untouched_kernel");
     return SATRANS_OK;
 }

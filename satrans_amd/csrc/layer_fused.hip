@@ -44,17 +44,14 @@ struct KernelTimer {
 static KernelTimer g_ktimer;
 
 // MOD: what modulates q / k - 0 the MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear' (compile time: the main instantiation
-// pays nothing for the other two).  PROD: 0 = fp32 products on v_mfma_f32_16x16x4_f32, 1 = split products (fp32 operands as bf16
-// pairs, three v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block: layer_fused_common.h) - MOD 0 only
-// SAVE: leave the attention's numerators / statistics / output in a.attn_save for the backward of this step
-template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, int PROD = 0, bool SAVE = false>
+// pays nothing for the other two).  Every product runs on v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain).
+// SAVE: leave the attention's numerators / statistics / output (and the normalised MetaNet rows) in a.attn_save for the backward
+// of this step
+template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, bool SAVE = false>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                       float* __restrict__ y, float* __restrict__ att) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
-    constexpr int KD = D + 8, KU = U + 8;                 // row lengths (bf16) of the split-product images
-    static_assert(!PROD || (MOD == 0 && KT % 2 == 0 && UT % 2 == 0), "split products: MetaNet shapes with D, U multiples of 32");
-    // floats of LDS per image: [K][LD]-style fp32 images, or a hi + lo pair of [OUT][K + 8] bf16 images
-    constexpr int SZ_DD = PROD ? D * KD : D * LD, SZ_W1 = PROD ? U * KD : D * LU, SZ_W2 = PROD ? D * KU : U * LD;
+    constexpr int SZ_DD = D * LD, SZ_W1 = D * LU, SZ_W2 = U * LD;      // floats of LDS per [K][LD]-style image
     extern __shared__ __align__(16) float lds[];
     const int F = a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,13 +79,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     float* sv = take(rows * LD);
     float* sx = take(rows * LD);      // the tile's input rows: read from global memory ONCE (phase 1), re-read here for the residual
 
-    auto bimg = [](float* f_) { return reinterpret_cast<__bf16*>(f_); };
-    if constexpr (PROD) {
-        const SplitJob jobs[4] = {{a.w_query, bimg(W.wq), D, D, KD, true}, {a.w_key, bimg(W.wk), D, D, KD, true},
-                                  {a.w_value, bimg(W.wv), D, D, KD, true},
-                                  {a.w_out, bimg(W.woT), D, D, KD, false}};      // nn.Linear [out][in]: y = x @ Wo^T
-        stage_split_batch<4, (D * D / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
-    } else {
+    {
         const ImageJob jobs[4] = {{a.w_query, W.wq, D, D, LD, false}, {a.w_key, W.wk, D, D, LD, false}, {a.w_value, W.wv, D, D, LD, false},
                                   {a.w_out, W.woT, D, D, LD, true}};      // woT[i][o] = Wo[o][i]  (nn.Linear: y = x @ Wo^T)
         stage_image_batch<4, (D * D / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
@@ -108,8 +99,6 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     const float* w2q_l = W.w2q + g4 * LD + wl;
     const float* w1k_l = W.w1k + g4 * LU + wl;
     const float* w2k_l = W.w2k + g4 * LD + wl;
-    // split products: this lane's 16-byte fragment of a row (chunk g, flipped for rows 4..11 of a tile) in images of D / U inputs
-    const int sl_d = n * KD + ((8 * g) ^ split_flip(n)), sl_u = n * KU + ((8 * g) ^ split_flip(n));
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);   // scores * (1/sqrt d): within 1 ulp of the reference's true division
     // Work split by SAMPLES, not by tiles: workgroup w owns the sorted sample positions [B w / G, B (w+1) / G) and walks its share
@@ -126,24 +115,13 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
       // ---- this scenario's generated MetaNet weights (the previous tile loop ended on a barrier) ------------------
       if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
-          if constexpr (PROD) {
-              const SplitJob jobs[2] = {{row, bimg(W.w1q), U, D, KD, true},               // W1 [D][U]: in-major, K = D
-                                        {row + D * U, bimg(W.w2q), D, U, KU, true}};      // W2 [U][D]: in-major, K = U
-              stage_split_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
-          } else {
-              const ImageJob jobs[2] = {{row, W.w1q, D, U, LU, false}, {row + D * U, W.w2q, U, D, LD, false}};
-              stage_image_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
-          }
+          const ImageJob jobs[2] = {{row, W.w1q, D, U, LU, false}, {row + D * U, W.w2q, U, D, LD, false}};
+          stage_image_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
       }
       if (mlp_k && (!same_tab || !mlp_q)) {
           const float* row = a.tab_k + (size_t)scen * a.tab_stride;
-          if constexpr (PROD) {
-              const SplitJob jobs[2] = {{row, bimg(W.w1k), U, D, KD, true}, {row + D * U, bimg(W.w2k), D, U, KU, true}};
-              stage_split_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES)>(jobs);
-          } else {
-              const ImageJob jobs[2] = {{row, W.w1k, D, U, LU, false}, {row + D * U, W.w2k, U, D, LD, false}};
-              stage_image_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
-          }
+          const ImageJob jobs[2] = {{row, W.w1k, D, U, LU, false}, {row + D * U, W.w2k, U, D, LD, false}};
+          stage_image_batch<2, (D * U / 4 + 64 * WAVES - 1) / (64 * WAVES), false>(jobs);
       }
       if (gate) {
           for (int i = threadIdx.x; i < D; i += blockDim.x) {
@@ -182,17 +160,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             float x[KT][4], q[KT][4], k[KT][4], v[KT][4];
             fetch_x(first, tt, x);
             store_frag<KT>(sx + (size_t)tok * LD + g4, x);
-            if constexpr (PROD) {
-                bf16x8 xh[KT / 2], xl[KT / 2];
-                split_frag<KT>(x, xh, xl);
-                chain_split<KT / 2, KT, KD>(bimg(W.wq) + sl_d, D * KD, xh, xl, q);             // satrans.py:55-57
-                chain_split<KT / 2, KT, KD>(bimg(W.wk) + sl_d, D * KD, xh, xl, k);
-                chain_split<KT / 2, KT, KD>(bimg(W.wv) + sl_d, D * KD, xh, xl, v);
-            } else {
-                chain<KT, KT, LD>(wq_l, x, q);                                               // satrans.py:55-57
-                chain<KT, KT, LD>(wk_l, x, k);
-                chain<KT, KT, LD>(wv_l, x, v);
-            }
+            chain<KT, KT, LD>(wq_l, x, q);                                               // satrans.py:55-57
+            chain<KT, KT, LD>(wk_l, x, k);
+            chain<KT, KT, LD>(wv_l, x, v);
             float mean, rstd;
             if (gate) {                                                                    // satrans.py:61-62,68-69
 #pragma unroll
@@ -213,8 +183,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             // SAVE: the normalised MetaNet rows and their 1 / std go to the backward of this step as well (it then skips the two W2
             // products and the LayerNorm statistics of its recomputation): [sorted position][field][role][D] behind the attention
             // state, then 1 / std [sorted position][field][role]
-            // (fp32 products only: the opt-in split-product pair keeps round 3's hand-over - attention state alone)
-            constexpr bool ZSAVE = SAVE && PROD == 0;
+            constexpr bool ZSAVE = SAVE;
             float zsave[KT][4];
             float* save_z = nullptr;
             float* save_r = nullptr;
@@ -226,10 +195,6 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             }
             if (mlp_q) {                                                                  // satrans.py:60-66
                 float h[UT][4], o[KT][4];
-                if constexpr (PROD)
-                    metanet_frag_split<D, U>(bimg(W.w1q) + sl_d, bimg(W.w2q) + sl_u, W.lnq_g, W.lnq_b, g4, dc,
-                                             drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, o, mean, rstd, ZSAVE ? zsave : nullptr);
-                else
                 metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
                                    drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd, ZSAVE ? zsave : nullptr);
                 if (ZSAVE && valid) {
@@ -243,10 +208,6 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             }
             if (mlp_k) {                                                                  // satrans.py:67-73
                 float h[UT][4], o[KT][4];
-                if constexpr (PROD)
-                    metanet_frag_split<D, U>(bimg(W.w1k) + sl_d, bimg(W.w2k) + sl_u, W.lnk_g, W.lnk_b, g4, dc,
-                                             drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, o, mean, rstd, ZSAVE ? zsave : nullptr);
-                else
                 metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
                                    drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd, ZSAVE ? zsave : nullptr);
                 if (ZSAVE && valid) {
@@ -445,13 +406,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 const float4 ov = *reinterpret_cast<const float4*>(orow + 16 * t);
                 o[t][0] = ov.x; o[t][1] = ov.y; o[t][2] = ov.z; o[t][3] = ov.w;
             }
-            if constexpr (PROD) {
-                bf16x8 oh[KT / 2], ol[KT / 2];
-                split_frag<KT>(o, oh, ol);
-                chain_split<KT / 2, KT, KD>(bimg(W.woT) + sl_d, D * KD, oh, ol, u);
-            } else {
-                chain<KT, KT, LD>(wo_l, o, u);
-            }
+            chain<KT, KT, LD>(wo_l, o, u);
             const float* xrow = sx + (size_t)tok * LD + g4;
             const uint32_t skey = drop_sample_key(dc.key[kSiteOut], (uint32_t)b);
             const uint32_t kb = dc.on ? token_keep_bits<KT>(skey, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
@@ -514,13 +469,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     }
 
 // FT: the field count as a constant (0 = a.F).  MOD: 0 MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear'.
-// PROD: 0 = fp32 products, 1 = split products for the token-wise chains (forward recomputation and the gradients of the
-// activations; the token-contraction products of the weight gradients stay on the fp32 instruction).  Split products read one
-// image per DIRECTION of a weight (a fragment is 8 consecutive contraction indices of one output row), so both orientations of
-// every weight live in LDS as hi / lo bf16 pairs: SAME tables, MOD 0, no TR only.
-// token-contraction products: on the fp32 instruction, or (PROD) on split operands
-#define WGRAD wgrad_sel<PROD>::template run
-// SAVE: a.attn_save holds what the forward of this step left of the attention (split-product instantiations only)
+// token-contraction products (weight gradients) with conflict-free operand reads
+#define WGRAD wgrad_r4
+// SAVE: a.attn_save holds what the forward of this step left of the attention and of the MetaNet LayerNorms
 // HEADF: the LAST layer of a training step with the head fused in (satrans_layer_bwd_head): the output rows y this kernel
 // recomputes anyway ARE the layer's forward, a tile holds whole samples, and flatten + Linear + sigmoid + loss + their backward
 // (satrans.py:244-255, meta_basemodel.py:317) are sample-local - so the step needs neither a forward launch for this layer nor
@@ -538,7 +489,7 @@ struct FusedHeadArgs {
     float* partial;            // [G][F D + n_dense + 2]: per-workgroup g_w | g_b | loss (rows of head_reduce_kernel)
 };
 constexpr int kHeadDenseMax = 2;      // dense columns the fused head carries (Alimama: 1); more -> the separate head launches
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false, bool HEADF = false>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, bool SAVE = false, bool HEADF = false>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                          const float* __restrict__ dy,
                                                                          float* __restrict__ dx,
@@ -549,9 +500,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     static_assert(HB <= 2 && UT == HB * NB, "MetaNet hidden width must be D/.. or 2*D for the fused backward");
     static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
     static_assert(64 * H <= kFusedBlock, "one attention task per thread: a tile holds at most 64 tokens x H heads");
-    static_assert(!PROD || (SAME && !TR && MOD == 0 && KT % 2 == 0 && UT % 2 == 0), "split products: one shared MetaNet table, D and U multiples of 32");
-    constexpr int KD = D + 8, KU = U + 8;                 // row lengths (bf16) of the split-product images
-    constexpr int SZ_DD = PROD ? D * KD : D * LD, SZ_W1 = PROD ? U * KD : D * LU, SZ_W2 = PROD ? D * KU : U * LD;
+    constexpr int SZ_DD = D * LD, SZ_W1 = D * LU, SZ_W2 = U * LD;
     extern __shared__ __align__(16) float lds[];
     const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -571,19 +520,17 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // ---- LDS: forward images, transposed images, LN vectors, 5 row buffers, softmax cache ------------------------
     float* p = lds;
     auto take = [&](int cnt) { float* r = p; p += (cnt + 3) & ~3; return r; };
-    auto bimg = [](float* f_) { return reinterpret_cast<__bf16*>(f_); };
     float* wq = take(SZ_DD); float* wk = take(SZ_DD); float* wv = take(SZ_DD); float* woT = take(SZ_DD);
     float* w1q = take(SZ_W1); float* w2q = take(SZ_W2);
     float* w1k = same_tab ? w1q : take(SZ_W1);
     float* w2k = same_tab ? w2q : take(SZ_W2);
-    // transposed copies (TR), the images of the backward direction (PROD) or, without either, the forward images again (read by
-    // rows: chain_t)
-    constexpr bool TWO = TR || PROD;
+    // transposed copies (TR) or, without them, the forward images again (read by rows: chain_t)
+    constexpr bool TWO = TR;
     float* wqT = TWO ? take(SZ_DD) : wq; float* wkT = TWO ? take(SZ_DD) : wk; float* wvT = TWO ? take(SZ_DD) : wv;
     float* wo = TWO ? take(SZ_DD) : woT;
-    // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]   (PROD: rows = the weight's input index, [D][KU] for W1 and [U][KD] for W2)
-    float* w1qT = PROD ? take(D * KU) : (TR ? take(U * LD) : w1q);
-    float* w2qT = PROD ? take(U * KD) : (TR ? take(D * LU) : w2q);
+    // w1T[u][i] = W1[i][u];  w2T[o][u] = W2[u][o]
+    float* w1qT = TR ? take(U * LD) : w1q;
+    float* w2qT = TR ? take(D * LU) : w2q;
     float* w1kT = TWO ? (same_tab ? w1qT : take(U * LD)) : w1k;
     float* w2kT = TWO ? (same_tab ? w2qT : take(D * LU)) : w2k;
     float* lnq_g = take(D); float* lnk_g = take(D); float* ln_g = take(D);
@@ -612,17 +559,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
     if (!idle) {
         // (without transposed copies the images are swizzled: by-columns AND by-rows reads conflict-free, layer_fused_common.h)
-        if constexpr (PROD) {
-            // forward direction: rows = the weight's output index; backward direction: rows = its input index
-            const SplitJob jobs[8] = {{a.w_query, bimg(wq), D, D, KD, true}, {a.w_query, bimg(wqT), D, D, KD, false},
-                                      {a.w_key, bimg(wk), D, D, KD, true},   {a.w_key, bimg(wkT), D, D, KD, false},
-                                      {a.w_value, bimg(wv), D, D, KD, true}, {a.w_value, bimg(wvT), D, D, KD, false},
-                                      {a.w_out, bimg(woT), D, D, KD, false}, {a.w_out, bimg(wo), D, D, KD, true}};   // nn.Linear [out][in]
-            stage_split_batch<8, (D * D / 4 + kFusedBlock - 1) / kFusedBlock>(jobs);
-        } else {
-        const ImageJob jobs[4] = {{a.w_query, wq, D, D, LD, false}, {a.w_key, wk, D, D, LD, false}, {a.w_value, wv, D, D, LD, false},
-                                  {a.w_out, woT, D, D, LD, true}};
-        stage_image_batch<4, (D * D / 4 + kFusedBlock - 1) / kFusedBlock, !TR>(jobs);
+        {
+            const ImageJob jobs[4] = {{a.w_query, wq, D, D, LD, false}, {a.w_key, wk, D, D, LD, false}, {a.w_value, wv, D, D, LD, false},
+                                      {a.w_out, woT, D, D, LD, true}};
+            stage_image_batch<4, (D * D / 4 + kFusedBlock - 1) / kFusedBlock, !TR>(jobs);
         }
         if constexpr (TR) {
             stage_image(a.w_query, wqT, D, D, LD, true);
@@ -652,8 +592,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const int fl_g = (!TR && (g == 1 || g == 2)) ? 4 : 0, fl_n = (!TR && n >= 4 && n < 12) ? 1 : 0;
     const int lo_d = g4 * LD + (n ^ fl_g), lo_u = g4 * LU + (n ^ fl_g);
     const int lt_d = n * LD + 4 * (g ^ fl_n), lt_u = n * LU + 4 * (g ^ fl_n);
-    // split products: this lane's 16-byte fragment of an image row of D / U contraction indices
-    const int sl_d = n * KD + ((8 * g) ^ split_flip(n)), sl_u = n * KU + ((8 * g) ^ split_flip(n));
     // (sample, head, row) of this thread's attention task - the same in every tile and every attention phase
     const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
@@ -664,7 +602,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // into LDS, issued at the top of the tile and complete by the end of phase A - instead of a recomputation
     const int HF = H * F;
     constexpr bool has_save = SAVE;
-    constexpr bool has_zsave = SAVE && PROD == 0;      // the normalised MetaNet rows too (fp32 products only)
+    constexpr bool has_zsave = SAVE;                   // ... and the normalised MetaNet rows with their 1 / std
     const float* save_inv = a.attn_save + (size_t)a.B * F * HF;
     const float* save_keep = save_inv + (size_t)a.B * HF;
     const float* save_o = save_keep + (size_t)a.B * HF;
@@ -753,16 +691,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
               w1q[r * LD + (TR ? c : c ^ img_flip(r))] = (r / d == c / d) ? row[(r / d) * d * d + (r % d) * d + (c % d)] : 0.f;
           }
       }
-      if constexpr (PROD) {
-          if (mlp_q || mlp_k) {                      // (SAME: one table for both roles)
-              const float* row = (mlp_q ? a.tab_q : a.tab_k) + (size_t)scen * a.tab_stride;
-              const SplitJob jobs[4] = {{row, bimg(w1q), U, D, KD, true},              // W1 [D][U]: rows = hidden unit, K = D
-                                        {row + D * U, bimg(w2q), D, U, KU, true},      // W2 [U][D]: rows = output feature, K = U
-                                        {row, bimg(w1qT), D, U, KU, false},            // backward through W1: rows = its input, K = U
-                                        {row + D * U, bimg(w2qT), U, D, KD, false}};   // backward through W2: rows = hidden unit, K = D
-              stage_split_batch<4, (D * U / 4 + kFusedBlock - 1) / kFusedBlock>(jobs);
-          }
-      } else {
       if (mlp_q) {
           const float* row = a.tab_q + (size_t)scen * a.tab_stride;
           {
@@ -784,7 +712,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
               stage_image(row, w1kT, D, U, LD, true);
               stage_image(row + D * U, w2kT, U, D, LU, true);
           }
-      }
       }
       __syncthreads();
       const int lo = a.seg[scen], hi = a.seg[scen + 1];
@@ -907,36 +834,16 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[t][r] = x_next[t][r];
             float v[KT][4], q[KT][4], k[KT][4];
-            // out = in x weight along the forward direction of an image (PROD: split operands)
+            // out = in x weight along the forward direction of an image
             auto fwd_w1 = [&](float* img, const float (&in_)[KT][4], float (&out_)[UT][4]) {
-                if constexpr (PROD) {
-                    bf16x8 ih_[KT / 2], il_[KT / 2];
-                    split_frag<KT>(in_, ih_, il_);
-                    chain_split<KT / 2, UT, KD>(bimg(img) + sl_d, U * KD, ih_, il_, out_);
-                } else {
-                    chain<KT, UT, LU>(img + lo_u, in_, out_);
-                }
+                chain<KT, UT, LU>(img + lo_u, in_, out_);
             };
             auto fwd_w2 = [&](float* img, const float (&in_)[UT][4], float (&out_)[KT][4]) {
-                if constexpr (PROD) {
-                    bf16x8 ih_[UT / 2], il_[UT / 2];
-                    split_frag<UT>(in_, ih_, il_);
-                    chain_split<UT / 2, KT, KU>(bimg(img) + sl_u, D * KU, ih_, il_, out_);
-                } else {
-                    chain<UT, KT, LD>(img + lo_d, in_, out_);
-                }
+                chain<UT, KT, LD>(img + lo_d, in_, out_);
             };
-            if constexpr (PROD) {
-                bf16x8 xh[KT / 2], xl[KT / 2];
-                split_frag<KT>(x, xh, xl);
-                chain_split<KT / 2, KT, KD>(bimg(wq) + sl_d, D * KD, xh, xl, q0);
-                chain_split<KT / 2, KT, KD>(bimg(wk) + sl_d, D * KD, xh, xl, k0);
-                chain_split<KT / 2, KT, KD>(bimg(wv) + sl_d, D * KD, xh, xl, v);
-            } else {
             chain<KT, KT, LD>(wq + lo_d, x, q0);
             chain<KT, KT, LD>(wk + lo_d, x, k0);
             chain<KT, KT, LD>(wv + lo_d, x, v);
-            }
             if (mlp_q) {
                 fwd_w1(w1q, q0, hq);
 #pragma unroll
@@ -970,7 +877,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     q[t][2] = zhq[t][2] * gg.z + bb.z; q[t][3] = zhq[t][3] * gg.w + bb.w;
                 }
             } else if (bilin) {
-                if constexpr (!PROD) chain<KT, KT, LD>(w1q + lo_d, q0, q);     // q_h = q0_h M[s, h]
+                chain<KT, KT, LD>(w1q + lo_d, q0, q);     // q_h = q0_h M[s, h]
             } else {
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
@@ -1123,11 +1030,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // ================= phase C: output block forward + backward ======================================================
         // out = in x (D x D weight), along the forward direction of the image `f_` or the backward direction (image `b_`)
         auto prod_dd = [&](float* img, bool back_, const float (&in_)[KT][4], float (&out_)[KT][4]) {
-            if constexpr (PROD) {
-                bf16x8 ih_[KT / 2], il_[KT / 2];
-                split_frag<KT>(in_, ih_, il_);
-                chain_split<KT / 2, KT, KD>(bimg(img) + sl_d, D * KD, ih_, il_, out_);
-            } else if (!back_) {
+            if (!back_) {
                 chain<KT, KT, LD>(img + lo_d, in_, out_);
             } else {
                 if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
@@ -1407,27 +1310,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, dm);
-                    if constexpr (PROD) {           // (dm is read and split once for both halves of h)
-                        bf16x8 av_[NB], gh_[KT], gl_[KT];
-                        load_split_g<KT, LD>(wg_g, gh_, gl_);
-                        load_split_a<NB, LD>(wg_q, av_);
-                        mma_split<NB, KT, 0, 0>(av_, gh_, gl_, acc_w2);
-                        if constexpr (HB == 2) {
-                            load_split_a<NB, LD>(wg_o, av_);
-                            mma_split<NB, KT, NB, 0>(av_, gh_, gl_, acc_w2);
-                        }
-                    } else {
                     WGRAD<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
                     if constexpr (HB == 2) WGRAD<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
-                    }
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
-                if constexpr (PROD) {
-                    bf16x8 ih_[KT / 2], il_[KT / 2];
-                    split_frag<KT>(dm, ih_, il_);
-                    chain_split<KT / 2, UT, KD>(bimg(const_cast<float*>(w2T)) + sl_d, U * KD, ih_, il_, dh);
-                } else if constexpr (TR) chain<KT, UT, LU>(w2T + lo_u, dm, dh);
+                if constexpr (TR) chain<KT, UT, LU>(w2T + lo_u, dm, dh);
                 else chain_t<KT, UT, LD>(w2T + lt_d, dm, dh);              // w2T is then the forward image W2 [U][LD]
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
@@ -1449,27 +1337,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, in0, valid);
-                    if constexpr (PROD) {           // (in0 once for both halves of dh)
-                        bf16x8 av_[KT], gh_[NB], gl_[NB];
-                        load_split_a<KT, LD>(wg_g, av_);
-                        load_split_g<NB, LD>(wg_q, gh_, gl_);
-                        mma_split<KT, NB, 0, 0>(av_, gh_, gl_, acc_w1);
-                        if constexpr (HB == 2) {
-                            load_split_g<NB, LD>(wg_o, gh_, gl_);
-                            mma_split<KT, NB, 0, NB>(av_, gh_, gl_, acc_w1);
-                        }
-                    } else {
                     WGRAD<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
                     if constexpr (HB == 2) WGRAD<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
-                    }
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
-                if constexpr (PROD) {
-                    bf16x8 ih_[UT / 2], il_[UT / 2];
-                    split_frag<UT>(dh, ih_, il_);
-                    chain_split<UT / 2, KT, KU>(bimg(const_cast<float*>(w1T)) + sl_u, D * KU, ih_, il_, back);
-                } else if constexpr (TR) chain<UT, KT, LD>(w1T + lo_d, dh, back);
+                if constexpr (TR) chain<UT, KT, LD>(w1T + lo_d, dh, back);
                 else chain_t<UT, KT, LU>(w1T + lt_u, dh, back);            // ... the forward image W1 [D][LU]
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
@@ -1495,7 +1368,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 store_frag<KT>(my_o, gq);
                 WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_w1q);
                 float back[KT][4];
-                if constexpr (!PROD) chain_t<KT, KT, LD>(w1q + lt_d, gq, back);   // (by rows of the one image, with or without TR)
+                chain_t<KT, KT, LD>(w1q + lt_d, gq, back);   // (by rows of the one image, with or without TR)
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1515,30 +1388,14 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
-            if constexpr (PROD) {                   // (x once for the three products)
-                bf16x8 av_[KT], gh_[KT], gl_[KT];
-                load_split_a<KT, LD>(wg_q, av_);
-                load_split_g<KT, LD>(wg_o, gh_, gl_);
-                mma_split<KT, KT, 0, 0>(av_, gh_, gl_, acc_wq);
-                store_frag<KT>(my_o, gk);
-                load_split_g<KT, LD>(wg_o, gh_, gl_);
-                mma_split<KT, KT, 0, 0>(av_, gh_, gl_, acc_wk);
-                load_split_g<KT, LD>(wg_v, gh_, gl_);
-                mma_split<KT, KT, 0, 0>(av_, gh_, gl_, acc_wv);
-            } else {
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
             store_frag<KT>(my_o, gk);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
-            }
             float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
             auto back_dd = [&](float* img, const float (&in_)[KT][4], float (&out_)[KT][4]) {
-                if constexpr (PROD) {
-                    bf16x8 ih_[KT / 2], il_[KT / 2];
-                    split_frag<KT>(in_, ih_, il_);
-                    chain_split<KT / 2, KT, KD>(bimg(img) + sl_d, D * KD, ih_, il_, out_);
-                } else if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
+                if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
                 else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
             };
             back_dd(wqT, gq, back);
@@ -1900,27 +1757,15 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_all_kernel(ReduceLayers
 // host side
 // -------------------------------------------------------------------------------------------------------------------
 
-// How the fused kernels evaluate the weight products of the D = 32 MetaNet shapes: 0 = fp32 (v_mfma_f32_16x16x4_f32, bit for bit an
-// fmaf chain), 1 = split (fp32 operands as bf16 pairs, three v_mfma_f32_16x16x32_bf16 per block; layer_fused_common.h).
-// The library starts in mode 0 (the reference's arithmetic); SATRANS_PRODUCTS=split starts it in mode 1 (the opt-in fast mode),
-// satrans_set_product_mode changes it (tests run both).
-static int g_product_mode = -1;
-static int product_mode() {
-    if (g_product_mode < 0) {
-        const char* e = getenv("SATRANS_PRODUCTS");
-        g_product_mode = (e && !strcmp(e, "split")) ? 1 : 0;      // fp32 products unless the fast mode is asked for
-    }
-    return g_product_mode;
-}
-static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab, bool split = false) {
+static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
     const int64_t rows = (((int64_t)T * F + 15) / 16) * 16;
-    const int64_t dd = split ? (int64_t)D * (D + 8) : (int64_t)D * LD;
-    const int64_t mlp = split ? (int64_t)U * (D + 8) + (int64_t)D * (U + 8) : (int64_t)D * LU + (int64_t)U * LD;
+    const int64_t dd = (int64_t)D * LD;
+    const int64_t mlp = (int64_t)D * LU + (int64_t)U * LD;
     return 4 * dd + (same_tab ? 1 : 2) * mlp + 6 * D + 4 * rows * LD + 64;
 }
 
-template <int D, int U, int H, int WAVES, int MOD = 0, int PROD = 0, bool SAVE = false>
+template <int D, int U, int H, int WAVES, int MOD = 0, bool SAVE = false>
 static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipStream_t stream) {
     const bool same_tab = d->tab_q == d->tab_k;
     // samples per tile: as many as keep `per_cu` workgroups per CU, preferring tiles that fill their 16-token MFMA rows
@@ -1929,7 +1774,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int budgets[2] = {WAVES > 4 ? 156 * 1024 : 78 * 1024, 156 * 1024};   // two 4-wave workgroups per CU if any tile fits
     for (int budget : budgets) {
         for (int t = 1; t <= 4 * WAVES; ++t) {
-            if (fused_fwd_lds_floats(t, d->F, D, U, same_tab, PROD) * 4 > budget) break;
+            if (fused_fwd_lds_floats(t, d->F, D, U, same_tab) * 4 > budget) break;
             const int tok = t * d->F, ntt = (tok + 15) / 16;
             const double eff = (double)tok / (16.0 * ntt) * (double)ntt / (double)(ceil_div(ntt, WAVES) * WAVES);
             if (eff >= best_eff) { best_eff = eff; best = t; }
@@ -1937,10 +1782,10 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
         if (best) break;
     }
     SATRANS_REQUIRE(best > 0, SATRANS_E_UNSUPPORTED, "layer_fwd(fused): F=%d does not fit LDS", d->F);
-    const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab, PROD) * 4;
+    const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab) * 4;
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
@@ -1949,10 +1794,10 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
     if (KernelTimer::Pair* tp = g_ktimer.next(0))      // (satrans_kernel_timing: the dispatch's own begin / end timestamps)
-        hipExtLaunchKernelGGL((layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE>), dim3(gx), dim3(64 * WAVES), lds, stream,
+        hipExtLaunchKernelGGL((layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE>), dim3(gx), dim3(64 * WAVES), lds, stream,
                               tp->start, tp->stop, 0, *d, best, y, att);
     else
-    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, PROD, SAVE><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
+    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -1969,13 +1814,13 @@ extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc
 
 namespace satrans {
 
-static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr, bool split = false, bool head = false) {
+static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same_tab, bool tr, bool head = false) {
     const int LD = D + 4, LU = U + 4;
     auto r4 = [](int64_t v) { return (v + 3) & ~(int64_t)3; };
     const int64_t tasks = (int64_t)T * H * F;
-    const int copies = (tr || split) ? 2 : 1;         // forward images, and their transposes when they fit
-    const int64_t dd = split ? (int64_t)D * (D + 8) : (int64_t)D * LD;
-    const int64_t mlp = split ? (int64_t)U * (D + 8) + (int64_t)D * (U + 8) : (int64_t)D * LU + (int64_t)U * LD;
+    const int copies = tr ? 2 : 1;         // forward images, and their transposes when asked for
+    const int64_t dd = (int64_t)D * LD;
+    const int64_t mlp = (int64_t)D * LU + (int64_t)U * LD;
     // (fused head: head weights, token dots, dense terms, final sums, per-lane and per-slot gradient sums - the kernel's take() calls)
     const int64_t hd = head ? r4((int64_t)F * D + kHeadDenseMax) + 64 + 64 + 128 + (int64_t)kFusedBlock * 4 * (D / 16) + 64 * kHeadDenseMax : 0;
     return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + hd + 64;
@@ -1990,7 +1835,6 @@ struct FusedBwdPlan {
     int T, G;
     size_t lds;
     bool tr;      // transposed weight images in LDS
-    bool split;   // split products (both directions of every weight as bf16 hi / lo images)
 };
 
 static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p, bool head = false) {
@@ -2002,32 +1846,28 @@ static bool fused_bwd_plan(const satrans_layer_desc* d, FusedBwdPlan& p, bool he
     // makes the kernel 4 % faster (0.934 -> 0.895 ms per step) and leaves 37 KB of LDS free.
     p.tr = false;      // (round 1's transposed copies: measured slower, the instantiation is no longer built)
     const int Uw = fused_width(d);
-    p.split = product_mode() == 1 && !p.tr && same_tab && d->D == 32 && d->U == 64 && !(d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) &&
-              (d->flags & (SATRANS_META_Q | SATRANS_META_K)) &&
-              (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, false, true) * 4 <= 160 * 1024;
-    if (head) p.split = false;      // the fused-head instantiations are fp32-product ones (split products fill the LDS on their own)
-    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, p.tr, p.split, head) * 4;
+    p.lds = (size_t)fused_bwd_lds_floats(p.T, d->F, d->D, Uw, d->H, same_tab, p.tr, head) * 4;
     if (p.lds > 160 * 1024) return false;
     const int64_t tiles = ceil_div(d->B, p.T) + d->S;
     p.G = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, cu_count()));      // one workgroup per CU, one round
     return true;
 }
 
-template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, int PROD = 0, bool SAVE = false, bool HEADF = false>
+template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, bool SAVE = false, bool HEADF = false>
 static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const float* dy, float* dx, float* slabs,
                       hipStream_t stream, const FusedHeadArgs* hd = nullptr) {
     static size_t attr_set = 0;
     if (p.lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, SAVE, HEADF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_bwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = p.lds;
     }
     if (KernelTimer::Pair* tp = g_ktimer.next(HEADF ? 2 : 1))
-        hipExtLaunchKernelGGL((layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF>), dim3(p.G), dim3(kFusedBlock),
+        hipExtLaunchKernelGGL((layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, SAVE, HEADF>), dim3(p.G), dim3(kFusedBlock),
                               p.lds, stream, tp->start, tp->stop, 0, *d, p.T, dy, dx, slabs, hd ? *hd : FusedHeadArgs{});
     else
-    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, PROD, SAVE, HEADF><<<p.G, kFusedBlock, p.lds, stream>>>(
+    layer_bwd_fused_kernel<D, U, H, SAME, TR, FT, MOD, SAVE, HEADF><<<p.G, kFusedBlock, p.lds, stream>>>(
         *d, p.T, dy, dx, slabs, hd ? *hd : FusedHeadArgs{});
     SATRANS_CHECK_LAUNCH("layer_bwd_fused_kernel");
     return SATRANS_OK;
@@ -2036,13 +1876,6 @@ static int launch_bwd(const satrans_layer_desc* d, const FusedBwdPlan& p, const 
 }  // namespace satrans
 
 using namespace satrans;
-
-extern "C" int satrans_set_product_mode(int mode) {
-    if (mode != 0 && mode != 1) return SATRANS_E_BADARG;
-    satrans::g_product_mode = mode;
-    return SATRANS_OK;
-}
-extern "C" int satrans_get_product_mode(void) { return product_mode(); }
 
 // 1 when the fused kernels are built for this shape
 extern "C" int satrans_layer_fused_supported(const satrans_layer_desc* d) {
@@ -2066,13 +1899,8 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
     if (mod && d->D == 32) return mod == 1 ? launch_fwd_w<32, 64, 4, 12, 1>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 2>(d, y, att, stream);
     if (mod) return mod == 1 ? launch_fwd_w<16, 32, 2, kFusedWaves, 1>(d, y, att, stream) : launch_fwd_w<16, 32, 2, kFusedWaves, 2>(d, y, att, stream);
-    // split products in the TRAINING forward only: predict / evaluate keep the fp32 instruction - what a user compares with the
-    // reference's outputs is exact to fp32 summation order (logits of a trained model: 1.4e-6 from the CPU oracle against
-    // 7.7e-5 with split products), what sits under dropout and minibatch noise is fast
     const bool save = d->attn_save && d->D == 32 && d->F <= 32 && satrans_layer_attn_save_floats_fused(d) > 0;   // (as the backward decides)
-    if (d->D == 32 && product_mode() == 1 && (d->flags & SATRANS_TRAIN))
-        return save ? launch_fwd_w<32, 64, 4, 12, 0, 1, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 0, 1>(d, y, att, stream);
-    if (d->D == 32) return save ? launch_fwd_w<32, 64, 4, 12, 0, 0, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
+    if (d->D == 32) return save ? launch_fwd_w<32, 64, 4, 12, 0, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
     if (d->D == 16) return launch_fwd<16, 32, 2>(d, y, att, stream);
     return launch_fwd<64, 16, 4>(d, y, att, stream);
 }
@@ -2085,7 +1913,7 @@ extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
 
 extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc* d) {
     FusedBwdPlan p;
-    // built for the (32, 64, 4) MetaNet shape with one shared table: the split-product backward and (round 4) the fp32-product one
+    // built for the (32, 64, 4) MetaNet shape with one shared table
     if (!d || !fused_bwd_plan(d, p)) return 0;
     {
         const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
@@ -2155,16 +1983,9 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
                                 : launch_bwd<32, 64, 4, false, false, 0, 2>(d, p, dy, dx, slabs, stream))
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
                                 : launch_bwd<16, 32, 2, false, false, 0, 2>(d, p, dy, dx, slabs, stream));
-    else if (p.split && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0)
-        rc = d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, 1, true>(d, p, dy, dx, slabs, stream)
-                                   : launch_bwd<32, 64, 4, true, false, 0, 0, 1, true>(d, p, dy, dx, slabs, stream);
-    else if (p.split && d->F == 19 && f_const)
-        rc = launch_bwd<32, 64, 4, true, false, 19, 0, 1>(d, p, dy, dx, slabs, stream);
-    else if (p.split)
-        rc = launch_bwd<32, 64, 4, true, false, 0, 0, 1>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32 && same && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0)
-        rc = d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, 0, true>(d, p, dy, dx, slabs, stream)
-                                   : launch_bwd<32, 64, 4, true, false, 0, 0, 0, true>(d, p, dy, dx, slabs, stream);
+        rc = d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, true>(d, p, dy, dx, slabs, stream)
+                                   : launch_bwd<32, 64, 4, true, false, 0, 0, true>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream)
@@ -2227,13 +2048,13 @@ extern "C" int satrans_layer_bwd_head_launch_fused(const satrans_layer_desc* d, 
     constexpr bool f_const = true;
     int rc;
     if (d->D == 32 && same && d->F == 19 && f_const)
-        rc = launch_bwd<32, 64, 4, true, false, 19, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+        rc = launch_bwd<32, 64, 4, true, false, 19, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
     else if (d->D == 32)
-        rc = same ? launch_bwd<32, 64, 4, true, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
-                  : launch_bwd<32, 64, 4, false, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+        rc = same ? launch_bwd<32, 64, 4, true, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                  : launch_bwd<32, 64, 4, false, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
     else
-        rc = same ? launch_bwd<16, 32, 2, true, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
-                  : launch_bwd<16, 32, 2, false, false, 0, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+        rc = same ? launch_bwd<16, 32, 2, true, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                  : launch_bwd<16, 32, 2, false, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
     return rc;
 }
 

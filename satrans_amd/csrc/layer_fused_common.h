@@ -133,179 +133,6 @@ __device__ __forceinline__ void chain_t(const float* __restrict__ wl, const floa
     }
 }
 
-// ---- split products: fp32 operands as bf16 pairs on the bf16 matrix instruction -------------------------------------------------
-// v = hi + lo + O(2^-17 |v|) with hi = bf16(v), lo = bf16(v - hi) (both round-to-nearest-even); a product of two such operands is
-// evaluated as  a_lo w_hi + a_hi w_lo + a_hi w_hi  (each bf16 x bf16 product is exact in fp32, the sums accumulate in fp32 inside
-// v_mfma_f32_16x16x32_bf16): three instructions of 16 cycles for a 16 x 16 x 32 block against eight v_mfma_f32_16x16x4_f32 of 32
-// cycles.  What is dropped is a_lo w_lo (<= 2^-16 of a term) and the rounding of the lo parts (<= 2^-17): measured against the
-// same graph in fp64, the AliCCP-shaped golden case loses 2.6x the accuracy plain fp32 products have (logits 4.8e-8 against
-// 1.8e-8, worst gradient 3.6e-5 against 1.3e-5 of the largest entry: tools/experiments/r03_split_products_sim.py).
-// Weights are split ONCE per workgroup while they are staged into LDS; activations on the fly (~3 VALU instructions per value).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// (with the a_lo w_lo term as a fourth instruction: logits 3.3e-8 instead of 4.8e-8 against fp64, +12 % forward time - measured in
-// round 3, not built)
-
-// Image of a weight for split products: rows = output features, RS = K + 8 bf16 per row (16 bytes of padding: the row stride is an
-// odd number of 16-byte slots), the hi image followed by the lo image.  Inside a row the contraction index k sits where the B
-// operand of a CHAINED product presents it: K-step s = k / 32, then lane group g, element j with k % 32 = 16 (j / 4) + 4 g + j % 4
-// (the accumulator layout of the previous product), so an A fragment is ONE 16-byte read; the 16-byte chunk index carries the XOR
-// flip of img_flip (rows 4..11 of every 16 swap chunks g and g ^ 1), which makes the reads of a service group of 16 lanes hit 16
-// different slots.
-__device__ __forceinline__ int split_pos(int k) {
-    const int s = k >> 5, kk = k & 31;
-    const int t = kk >> 4, g = (kk & 15) >> 2, r = kk & 3;
-    return 32 * s + 8 * g + 4 * t + r;
-}
-__device__ __forceinline__ int split_flip(int row) { return ((row & 15) >= 4 && (row & 15) < 12) ? 8 : 0; }   // in bf16 elements
-
-// global fp32 weight -> hi / lo images [OUT][RS].  in_major: g[k * OUT + o] (W[in][out]); else g[o * K + k] (nn.Linear [out][in]).
-// transpose = the image of W^T (the backward products): roles of the two indices swapped.
-__device__ __forceinline__ void stage_split(const float* __restrict__ g, __bf16* __restrict__ hi, int OUT, int K, int RS, bool in_major) {
-    __bf16* lo = hi + OUT * RS;
-    // one unit = four consecutive contraction indices of one output row: they sit next to each other in the image (split_pos:
-    // ... + r), so a unit is two 8-byte LDS stores; in_major: threads run over the output index (coalesced 4-byte loads), else one
-    // 16-byte load per unit
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    const int K4 = K >> 2;
-    for (int u = threadIdx.x; u < OUT * K4; u += blockDim.x) {
-        int o, k;
-        float v[4];
-        if (in_major) {
-            const int k4 = u / OUT;
-            o = u - k4 * OUT;
-            k = 4 * k4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = g[(size_t)(k + j) * OUT + o];
-        } else {
-            o = u / K4;
-            k = 4 * (u - o * K4);
-            const float4 t = *reinterpret_cast<const float4*>(g + (size_t)o * K + k);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        }
-        bf16x4 h4, l4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 h = (__bf16)v[j];
-            h4[j] = h;
-            l4[j] = (__bf16)(v[j] - (float)h);
-        }
-        const int at = o * RS + (split_pos(k) ^ split_flip(o));
-        *reinterpret_cast<bf16x4*>(hi + at) = h4;
-        *reinterpret_cast<bf16x4*>(lo + at) = l4;
-    }
-}
-
-// Several images at once: ALL global loads first, then the conversions and the LDS stores.  One stage_split call is a loop of
-// load -> wait -> store; eight of them in a row are eight memory latencies with one wave per SIMD and nothing to hide them
-// (measured: the backward's prologue and per-scenario staging were ~5 % of the kernel).  UPT: units per thread and image,
-// >= ceil(OUT K / 4 / blockDim) of the largest image.
-struct SplitJob {
-    const float* g;
-    __bf16* hi;
-    int OUT, K, RS;
-    bool in_major;
-};
-template <int NJ, int UPT>
-__device__ __forceinline__ void stage_split_batch(const SplitJob (&jobs)[NJ]) {
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    float v[NJ][UPT][4];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const SplitJob& jb = jobs[j];
-        const int K4 = jb.K >> 2;
-#pragma unroll
-        for (int p = 0; p < UPT; ++p) {
-            const int u = (int)threadIdx.x + p * (int)blockDim.x;
-            if (u < jb.OUT * K4) {
-                if (jb.in_major) {
-                    const int k4 = u / jb.OUT, o = u - k4 * jb.OUT;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[j][p][q] = jb.g[(size_t)(4 * k4 + q) * jb.OUT + o];
-                } else {
-                    const float4 t = *reinterpret_cast<const float4*>(jb.g + 4 * (size_t)u);     // o K + k = 4 u
-                    v[j][p][0] = t.x; v[j][p][1] = t.y; v[j][p][2] = t.z; v[j][p][3] = t.w;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const SplitJob& jb = jobs[j];
-        const int K4 = jb.K >> 2;
-        __bf16* lo = jb.hi + jb.OUT * jb.RS;
-#pragma unroll
-        for (int p = 0; p < UPT; ++p) {
-            const int u = (int)threadIdx.x + p * (int)blockDim.x;
-            if (u < jb.OUT * K4) {
-                int o, k;
-                if (jb.in_major) { const int k4 = u / jb.OUT; o = u - k4 * jb.OUT; k = 4 * k4; }
-                else { o = u / K4; k = 4 * (u - o * K4); }
-                bf16x4 h4, l4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const __bf16 h = (__bf16)v[j][p][q];
-                    h4[q] = h;
-                    l4[q] = (__bf16)(v[j][p][q] - (float)h);
-                }
-                const int at = o * jb.RS + (split_pos(k) ^ split_flip(o));
-                *reinterpret_cast<bf16x4*>(jb.hi + at) = h4;
-                *reinterpret_cast<bf16x4*>(lo + at) = l4;
-            }
-        }
-    }
-}
-
-// a D-layout fragment (16 KT_ features of 16 tokens) as the hi / lo B operands of KT_ / 2 K-steps
-template <int KT_>
-__device__ __forceinline__ void split_frag(const float (&in)[KT_][4], bf16x8 (&bh)[KT_ / 2], bf16x8 (&bl)[KT_ / 2]) {
-    static_assert(KT_ % 2 == 0, "a K-step of the bf16 MFMA spans two 16-feature tiles");
-#pragma unroll
-    for (int s = 0; s < KT_ / 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = in[2 * s + (j >> 2)][j & 3];
-            const __bf16 h = (__bf16)v;
-            bh[s][j] = h;
-            bl[s][j] = (__bf16)(v - (float)h);
-        }
-}
-
-// out[mt] (16 output features x 16 tokens, D-layout) = sum over the 32 * KS input features of the split operand.
-// hl: hi image + n * RS + (8 g ^ split_flip(n)); lo_off: distance of the lo image (OUT * RS elements)
-template <int KS, int MT_, int RS>
-__device__ __forceinline__ void chain_split(const __bf16* __restrict__ hl, int lo_off, const bf16x8 (&bh)[KS], const bf16x8 (&bl)[KS],
-                                            float (&out)[MT_][4]) {
-    f32x4 acc[MT_];
-    bf16x8 ah[KS][MT_], al[KS][MT_];
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) {
-            ah[s][mt] = *reinterpret_cast<const bf16x8*>(hl + 16 * mt * RS + 32 * s);
-            al[s][mt] = *reinterpret_cast<const bf16x8*>(hl + lo_off + 16 * mt * RS + 32 * s);
-        }
-    __builtin_amdgcn_sched_barrier(0);      // keeps the fragment reads of a chain above its MFMAs
-#pragma unroll
-    for (int mt = 0; mt < MT_; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the small terms first
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][mt], bh[s], acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][mt], bl[s], acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][mt], bh[s], acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < MT_; ++mt) {
-        out[mt][0] = acc[mt][0]; out[mt][1] = acc[mt][1]; out[mt][2] = acc[mt][2]; out[mt][3] = acc[mt][3];
-    }
-}
-
 // ---- conflict-free operand paths of the backward kernel (PMC of round 2: SQ_LDS_BANK_CONFLICT 62 % of its LDS-active cycles) ----
 // Weight images carry an XOR swizzle: the 16-byte chunk c of row k is stored at chunk c ^ [4 <= k mod 16 < 12].  A by-rows
 // 16-byte read of a transposed product (chain_t: lane (n, g) reads row n, chunk g) is serviced in the lane groups
@@ -355,79 +182,6 @@ __device__ __forceinline__ void wgrad_r4(const float* al, const float* gl, f32x4
             for (int nt = 0; nt < NT_; ++nt)
                 acc[MOFF + mt][NOFF + nt] = mfma4(av[ks][mt], gv[ks][nt], acc[MOFF + mt][NOFF + nt]);
 }
-
-// wgrad_r4 on split operands: the SAME four fp32 reads per operand tile (lane group g: token rows 4 g .. 4 g + 3), split in
-// registers, and the 32 contraction slots of v_mfma_f32_16x16x32_bf16 hold the wave's 16 tokens twice: slots 0-3 of a lane
-// group carry the hi parts of its four tokens, slots 4-7 the lo parts on the A side; the B side carries g_hi in both halves for
-// one instruction and g_lo in both halves for the other, so the two instructions add up to (a_hi + a_lo)(g_hi + g_lo): all four
-// cross terms, 32 cycles instead of the 128 of four fp32 instructions.
-__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, __bf16 (&h)[4], __bf16 (&l)[4]) {
-    const float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = (__bf16)v[j];
-        l[j] = (__bf16)(v[j] - (float)h[j]);
-    }
-}
-// the A side of a token-contraction product: MT_ tiles of 16 features, [hi | lo] of the lane group's four tokens
-template <int MT_, int LDA>
-__device__ __forceinline__ void load_split_a(const float* al, bf16x8 (&av)[MT_]) {
-    float ar[4][MT_];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT_; ++mt) ar[ks][mt] = al[ks * LDA + 16 * mt];
-#pragma unroll
-    for (int mt = 0; mt < MT_; ++mt) {
-        __bf16 h[4], l[4];
-        split4(ar[0][mt], ar[1][mt], ar[2][mt], ar[3][mt], h, l);
-        av[mt] = bf16x8{h[0], h[1], h[2], h[3], l[0], l[1], l[2], l[3]};
-    }
-}
-// the B side: [hi | hi] and [lo | lo]
-template <int NT_, int LDG>
-__device__ __forceinline__ void load_split_g(const float* gl, bf16x8 (&gh)[NT_], bf16x8 (&gl_)[NT_]) {
-    float gr[4][NT_];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int nt = 0; nt < NT_; ++nt) gr[ks][nt] = gl[ks * LDG + 16 * nt];
-#pragma unroll
-    for (int nt = 0; nt < NT_; ++nt) {
-        __bf16 h[4], l[4];
-        split4(gr[0][nt], gr[1][nt], gr[2][nt], gr[3][nt], h, l);
-        gh[nt] = bf16x8{h[0], h[1], h[2], h[3], h[0], h[1], h[2], h[3]};
-        gl_[nt] = bf16x8{l[0], l[1], l[2], l[3], l[0], l[1], l[2], l[3]};
-    }
-}
-template <int MT_, int NT_, int MOFF, int NOFF, int MFULL, int NFULL>
-__device__ __forceinline__ void mma_split(const bf16x8 (&av)[MT_], const bf16x8 (&gh)[NT_], const bf16x8 (&gl_)[NT_],
-                                          f32x4 (&acc)[MFULL][NFULL]) {
-#pragma unroll
-    for (int mt = 0; mt < MT_; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT_; ++nt) {
-            f32x4 c = acc[MOFF + mt][NOFF + nt];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], gl_[nt], c, 0, 0, 0);
-            acc[MOFF + mt][NOFF + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], gh[nt], c, 0, 0, 0);
-        }
-}
-template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
-__device__ __forceinline__ void wgrad_split(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
-    bf16x8 av[MT_], gh[NT_], gl_[NT_];
-    load_split_a<MT_, LDA>(al, av);
-    load_split_g<NT_, LDG>(gl, gh, gl_);
-    mma_split<MT_, NT_, MOFF, NOFF>(av, gh, gl_, acc);
-}
-
-template <int PROD>
-struct wgrad_sel {
-    template <int MT_, int NT_, int MOFF, int NOFF, int LDA, int LDG, int MFULL, int NFULL>
-    static __device__ __forceinline__ void run(const float* al, const float* gl, f32x4 (&acc)[MFULL][NFULL]) {
-        if constexpr (PROD) wgrad_split<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
-        else wgrad_r4<MT_, NT_, MOFF, NOFF, LDA, LDG>(al, gl, acc);
-    }
-};
 
 // Workgroup barrier for LDS hand-offs inside a tile loop.  __syncthreads() makes hipcc wait for EVERY outstanding memory
 // operation (s_waitcnt vmcnt(0)) in front of s_barrier, which stalls the waves on global loads that are meant to fly across
@@ -551,8 +305,9 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ g, float* 
     }
 }
 
-// Several fp32 images at once (stage_image / stage_image_sw with all global loads first - see stage_split_batch).  SW: the
-// swizzled layout of the backward.  UPT >= ceil(R C / 4 / blockDim) of the largest image.
+// Several fp32 images at once (stage_image / stage_image_sw with ALL global loads first, then the LDS stores: one stage_image call
+// is a loop of load -> wait -> store, eight of them in a row are eight memory latencies with one wave per SIMD and nothing to hide
+// them - measured: the backward's prologue and per-scenario staging were ~5 % of the kernel).  SW: the swizzled layout of the backward.  UPT >= ceil(R C / 4 / blockDim) of the largest image.
 struct ImageJob {
     const float* g;
     float* s;
@@ -641,36 +396,6 @@ __device__ __forceinline__ void metanet_frag(const float* w1l, const float* w2l,
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
     chain<UT, KT, D + 4>(w2l, h, out);
-    const uint32_t kb = dc.on ? token_keep_bits<KT>(sample_key, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float m = out[t][r];
-            if (dc.on) m = (kb >> (4 * t + r)) & 1u ? m * dc.scale : 0.f;
-            out[t][r] = m + in[t][r];
-        }
-    if (zh) layer_norm_frag_z<KT>(out, *reinterpret_cast<float (*)[KT][4]>(zh), gam, bet, g4, mean, rstd);
-    else layer_norm_frag<KT>(out, gam, bet, g4, mean, rstd);
-}
-
-// metanet_frag on split products (images of W1 [U][D + 8] and W2 [D][U + 8], see stage_split)
-template <int D, int U>
-__device__ __forceinline__ void metanet_frag_split(const __bf16* w1l, const __bf16* w2l, const float* gam, const float* bet,
-                                                   int g4, const FusedDrop& dc, uint32_t sample_key, int f,
-                                                   const float (&in)[D / 16][4], float (&out)[D / 16][4], float& mean, float& rstd,
-                                                   float (*zh)[4] = nullptr) {
-    constexpr int KT = D / 16, UT = U / 16;
-    float h[UT][4];
-    bf16x8 ih[KT / 2], il[KT / 2], hh[UT / 2], hl_[UT / 2];
-    split_frag<KT>(in, ih, il);
-    chain_split<KT / 2, UT, D + 8>(w1l, U * (D + 8), ih, il, h);
-#pragma unroll
-    for (int t = 0; t < UT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
-    split_frag<UT>(h, hh, hl_);
-    chain_split<UT / 2, KT, U + 8>(w2l, D * (U + 8), hh, hl_, out);
     const uint32_t kb = dc.on ? token_keep_bits<KT>(sample_key, f, D, g4, dc.thresh) : 0xFFFFFFFFu;
 #pragma unroll
     for (int t = 0; t < KT; ++t)

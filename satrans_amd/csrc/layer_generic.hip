@@ -1507,8 +1507,8 @@ static int gen_metanet_fused_fwd(hipStream_t st, const satrans_layer_desc* d, co
     const int M = d->B * d->F, D = d->D, U = d->U;
     const GenDrop dc = gen_drop(d, site);
     // 4 waves per workgroup (two workgroups = two waves per SIMD under the 78 KB of weight planes): 264 us per launch at the
-    // configs[4] shape; 8 waves (four per SIMD, SATRANS_MN_WAVES=8) 290 us - more waves do not help, the kernel is bound by issue
-    static const int wv = getenv("SATRANS_MN_WAVES") ? atoi(getenv("SATRANS_MN_WAVES")) : 4;
+    // configs[4] shape; 8 waves (four per SIMD) 290 us - more waves do not help, the kernel is bound by issue
+    constexpr int wv = 4;
     const int rows = 128 * (wv == 8 ? 8 : 4);
     const dim3 grid((unsigned)ceil_div(M, rows), (unsigned)(d->seg ? d->S : 1));
     const size_t lds = sizeof(float) * 4 * ((size_t)g2_plane_floats(D, U) + (size_t)g2_plane_floats(U, D));
@@ -1715,7 +1715,7 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
         float* C[3] = {q0, k0, v};
                 if ((rc = gen_gemm<false, 0>(st, 3, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
     }
-    static const bool fuse_metanet = !(getenv("SATRANS_GENERIC_FUSED_METANET") && atoi(getenv("SATRANS_GENERIC_FUSED_METANET")) == 0);
+    constexpr bool fuse_metanet = true;
     auto metanet = [&](const float* z0, float* h, float* m, float* t, float* out, const float* tab, const float* gam,
                        const float* bet, int site) -> int {      // submodules.py:77-103
         if (fuse_metanet && gen_metanet_fused_ok(D, U))          // one pass: h and t saved for the backward, m never materialised
@@ -1810,7 +1810,7 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     // ---- MetaNet backward of one role: g (gradient of the role's output rows) becomes the gradient of z0 -------------------------
     auto metanet_bwd = [&](float* g, const float* z0, const float* h, const float* t, const float* tab, const float* gam,
                            float* g_ln_role, float* g_tab, int site) -> int {
-        static const bool fuse = !(getenv("SATRANS_GENERIC_FUSED_METANET") && atoi(getenv("SATRANS_GENERIC_FUSED_METANET")) == 0);
+        constexpr bool fuse = true;
         if (fuse && gen_metanet_fused_ok(D, U)) {
             // data gradients in one pass (g <- dz0; dm, dh written for the two weight-gradient products), then dW2, dW1
             float* mn_part = scratch + L.mn_part;

@@ -156,8 +156,8 @@ class PathEngine:
         self._last_prob = None
         # optional per-phase timing with HIP events recorded on the launch stream (bench.py): name -> [(start, end)]
         self.timers: Optional[Dict[str, list]] = None
-        # run the streaming Adam of untouched rows on a side stream under the layer kernels (SATRANS_OVERLAP=0: serial)
-        self.overlap = os.environ.get("SATRANS_OVERLAP", "1") != "0"
+        # streaming form only: the every-row step of untouched rows runs on a side stream under the layer kernels
+        self.overlap = True
         self._side = None
         # Lazy-exact dense Adam (default): the regulariser-only steps of rows that are not gathered are postponed and
         # replayed - same arithmetic, same result bit for bit - when a row is next gathered, or for all rows by
@@ -177,27 +177,29 @@ class PathEngine:
         self._owner_world = 0            # > 0: large-table rows outside this rank's slice may be stale until _sync_replicas()
         self._replicas_stale = False
         self.reg_small = torch.zeros(1, dtype=torch.float64, device=self.dev)
-        # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output); SATRANS_FUSE_GATHER=0:
-        # standalone gather kernel + activation buffer, as in round 1
-        self.fuse_gather = os.environ.get("SATRANS_FUSE_GATHER", "1") != "0"
+        # The step's structure.  These are attributes, not environment switches: the shipped values are the ones below; the
+        # parity tests flip them to hold the fused forms against the plain ones bit for bit.
+        # the first layer reads its tokens straight from the embedding arena (no [B,F,D] gather output)
+        self.fuse_gather = True
         # the last layer of a training step as one launch with the head fused in (satrans_layer_bwd_head): no forward launch
-        # for that layer, no head launches, no [B,F,D] round trip of its output and gradient; SATRANS_FUSE_HEAD=0: separate calls
-        self.fuse_head = os.environ.get("SATRANS_FUSE_HEAD", "1") != "0"
+        # for that layer, no head launches, no [B,F,D] round trip of its output and gradient
+        self.fuse_head = True
         # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
-        # (SATRANS_PREFETCH=0: the hint is ignored)
-        self.prefetch = os.environ.get("SATRANS_PREFETCH", "1") != "0"
+        self.prefetch = True
         # phases that `phase()` does not bracket with recorded events even while `timers` is set (bench.py: the fused layer kernels,
         # whose own durations come from satrans_kernel_timing without a marker in the queue)
         self.untimed_phases = frozenset()
         # ... forked in FRONT of the last backward kernel, on a stream of the lowest priority: its workgroups find no room beside
-        # that kernel's and start as its CUs come free, without the ~14 us a fork behind the kernel costs (SATRANS_PREP_EARLY=0:
-        # behind it; 1.137 -> 1.119 ms/step over 256 steps, three A/B rounds on one box)
-        self.prep_early = os.environ.get("SATRANS_PREP_EARLY", "1") != "0"
-        # one reduction launch for all layers' weight-gradient slabs (satrans_layer_bwd_reduce; SATRANS_DEFER_REDUCE=0: per layer)
-        self.defer_reduce = os.environ.get("SATRANS_DEFER_REDUCE", "1") != "0"
-        # ... on a stream of its own beside the touched-row kernels, with the scenario-table backward (SATRANS_SIDE_TAIL=0: in line)
-        self.side_tail = os.environ.get("SATRANS_SIDE_TAIL", "1") != "0"
-        self.preclear = os.environ.get("SATRANS_PRECLEAR", "1") != "0"      # the next step's gradient clear behind this step's flat Adam
+        # that kernel's and start as its CUs come free, without the ~14 us a fork behind the kernel costs
+        self.prep_early = True
+        # one reduction launch for all layers' weight-gradient slabs (satrans_layer_bwd_reduce)
+        self.defer_reduce = True
+        # ... on a stream of its own beside the touched-row kernels, with the scenario-table backward
+        self.side_tail = True
+        # a PIPELINED step (train_step(next_X=...)) clears the next step's gradient buffer behind its own flat Adam launch;
+        # param.grad is then not readable after the step (documented in train_step).  A step without `next_X` never does this:
+        # its gradients stay in place until the next step, as the reference's do until the next zero_grad()
+        self.preclear = True
         self._side_tail = None
         self._tail_done = None
         self._prep = None
@@ -205,10 +207,8 @@ class PathEngine:
         # copies them into LDS (global_load_lds) instead of recomputing them - where the fused kernels are built for it (the
         # (32, 64, 4) MetaNet shape with one shared table; +72 MB per layer at B = 8192).  With fp32 products (round 4): forward
         # +7 us, backward -23 us per layer (A/B on one box: -13 to -37 us per step); the last layer has no forward launch and
-        # keeps recomputing.  Default: on with fp32 products; the opt-in split-product mode recomputes (measured neutral there in
-        # round 3, and its trajectory bounds were set without it).  SATRANS_SAVE_ATTENTION=0 / 1 forces it off / on in both modes.
-        self._save_attention_env = os.environ.get("SATRANS_SAVE_ATTENTION", "auto")
-        self.save_attention = self._save_attention_env != "0"
+        # keeps recomputing.  (Attribute; False = every backward recomputes: tests.)
+        self.save_attention = True
         # evaluation forwards (predict / evaluate / model.eval()(X)) with the dense products in bf16 on the matrix pipe
         # (csrc/layer_fwd_bf16.hip; BASELINE.json configs[1]).  Off by default: fp32 is the parity path.  Also
         # model.set_forward_precision("bf16" | "fp32").
@@ -311,8 +311,8 @@ class PathEngine:
                 ws["slabs"] = torch.empty(int(lib.satrans_layer_bwd_slab_floats(C.byref(desc))), **f32)
                 # what the forward leaves for the backward of the same step (softmax numerators, 1 / sum, keep words, attention
                 # output): the backward then skips its attention-forward phase.  One buffer per layer (72 MB at B = 8192).
-                n_save = int(lib.satrans_layer_attn_save_floats(C.byref(desc))) if self.save_attention else 0
-                ws["attn_save"] = [torch.empty(n_save, **f32) for _ in range(self.L)] if n_save > 0 else None
+                ws["attn_save_floats"] = int(lib.satrans_layer_attn_save_floats(C.byref(desc)))
+                ws["attn_save"] = [None] * self.L
             ws["sorted_rows"] = torch.empty(n_loc, **i32)       # this rank's rows, sorted, and their source positions
             ws["src"] = torch.empty(n_loc, **i32)
             ws["touched"] = torch.empty((self.total_rows + 31) // 32, **i32)
@@ -417,9 +417,13 @@ class PathEngine:
         d.seed, d.step = self.drop_seed, self.drop_step & 0xFFFFFFFF
         d.x = N.ptr(x) if x is not None else ws["acts"][l].data_ptr()
         d.x_rows = None
-        use_save = attn_save and ws.get("attn_save") and (self._save_attention_env == "1" or
-                                                          (self._save_attention_env != "0" and self.lib.satrans_get_product_mode() == 0))
-        d.attn_save = ws["attn_save"][l].data_ptr() if use_save else None
+        d.attn_save = None
+        if attn_save and self.save_attention and ws.get("attn_save_floats", 0) > 0:
+            # one buffer per layer that HAS a forward launch in a training step, allocated when that layer first asks (with the
+            # head fused in the last layer never does: 113 MB less at B = 8192)
+            if ws["attn_save"][l] is None:
+                ws["attn_save"][l] = torch.empty(ws["attn_save_floats"], dtype=torch.float32, device=self.dev)
+            d.attn_save = ws["attn_save"][l].data_ptr()
         if fuse and l == 0:
             # gather fused into the first layer: token (b, f) is read straight from the embedding arena through the row
             # numbers the rows-only gather launch left in ws["rows"]; [B,F,D] is never written nor read back.
@@ -597,7 +601,7 @@ class PathEngine:
 
     def _fuse_head(self, X, ws, B) -> bool:
         """Whether this step runs its last layer as ONE launch with the head fused in (satrans_layer_bwd_head): the fused
-        kernels, fp32 products for that layer, at most two dense columns.  SATRANS_FUSE_HEAD=0: the three separate calls."""
+        kernels, at most two dense columns.  (`fuse_head` False: the three separate calls.)"""
         key = "fuse_head"
         if key not in ws:
             ok = self.fuse_head and not ws["generic"] and self.L >= 1
@@ -647,7 +651,7 @@ class PathEngine:
                 # NOT be the input that forward saw
                 raise RuntimeError("layer_outputs() after train_step(): att_input was never materialised (gather fused into "
                                    "the first layer) and the tables have been updated since; call forward() / "
-                                   "loss_and_grads() first, or set SATRANS_FUSE_GATHER=0")
+                                   "loss_and_grads() first, or set engine.fuse_gather = False")
             X = self._last_X
             N.check(self.lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
                                                 self.cols.data_ptr(), X.data_ptr(), N.id_dtype_of(X), X.stride(0), B, self.F,
@@ -741,6 +745,7 @@ class PathEngine:
         self._lazy_pending = False
 
     def reset_epoch_sums(self):
+        self._join_flat()          # (a pipelined step's slab reduction adds to loss_sum on the tail stream)
         self.loss_sum.zero_()
         self.reg_sum.zero_()
         self.reg_small.zero_()
@@ -798,11 +803,12 @@ class PathEngine:
         # ... or the previous step has done it already, behind its flat Adam launch on that stream and behind the event the next
         # forward waits for (`_precleared`; in front of that event it cost 12 us per step: the fill delays the event)
         pre, self._precleared = getattr(self, "_precleared", None), None
-        precleared = pre is not None and g_clear is self._g_step_tail
+        pre_ev, pre_buf = pre if pre is not None else (None, None)
+        precleared = pre_ev is not None and pre_buf is g_clear
         if not clear_late:
             self._join_flat()          # (the previous step's flat Adam may still be reading what is cleared here)
-            if pre is not None:
-                torch.cuda.current_stream(self.dev).wait_event(pre)      # (... and its clear must not land on what this step writes)
+            if pre_ev is not None:
+                torch.cuda.current_stream(self.dev).wait_event(pre_ev)   # (... and its clear must not land on what this step writes)
             g_clear.zero_()
         training = m.training
         if training:
@@ -960,25 +966,28 @@ class PathEngine:
 
     def _low_priority_stream(self):
         """A HIP stream of the lowest priority the device offers (torch only hands out priorities <= 0, i.e. normal and above),
-        wrapped for torch: when its kernels and the launch stream's become ready together, the launch stream's are dispatched
-        first."""
-        try:
-            hip = C.CDLL("libamdhip64.so")          # (the runtime torch itself is linked against: already in the process)
-            least, greatest = C.c_int(0), C.c_int(0)
-            handle = C.c_void_p()
-            with torch.cuda.device(self.dev):
-                rc = hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest))
-                if rc == 0 and least.value > greatest.value:          # (numerically larger = lower priority)
-                    rc = hip.hipStreamCreateWithPriority(C.byref(handle), C.c_uint(1), C.c_int(least.value))      # 1 = hipStreamNonBlocking
-            if rc == 0 and handle.value:
-                return torch.cuda.ExternalStream(handle.value, device=self.dev)
-        except OSError:
-            pass
+        created by libsatrans_hip.so - which is linked against the HIP runtime this process already uses - and wrapped for torch:
+        when its kernels and the launch stream's become ready together, the launch stream's are dispatched first.  Lives as long
+        as the engine (destroyed in __del__)."""
+        handle = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            rc = self.lib.satrans_stream_create_low_priority(C.byref(handle))
+        if rc == 0 and handle.value:
+            self._low_prio_handle = handle.value
+            return torch.cuda.ExternalStream(handle.value, device=self.dev)
         # no priorities on this device / runtime: an early fork would race the last backward kernel for the CUs - fork behind it
         self.prep_early = False
         return torch.cuda.Stream(self.dev)
 
-    def _prepare_async(self, X_next, ws_cur_B, fork=None):
+    def __del__(self):
+        h, self._low_prio_handle = getattr(self, "_low_prio_handle", None), None
+        if h:
+            try:
+                self.lib.satrans_stream_destroy(C.c_void_p(h))
+            except Exception:
+                pass
+
+    def _prepare_async(self, X_next, ws_cur_B, fork=None, defer_bucket=False):
         """Everything of a step that depends on nothing but its id matrix - ids -> arena rows, the per-field sort of the rows,
         the scenario bucketing (four launches, ~60 us of mostly idle GPU: one workgroup per field / one workgroup) - for the
         NEXT batch, on a side stream, into the other half of a double buffer.  Called from inside the current step right after
@@ -1011,9 +1020,11 @@ class PathEngine:
             # behind it, in front of the first layer (13 us + a launch gap that the step's start does not wait for)
             sorted_ev = torch.cuda.Event()
             sorted_ev.record(self._side)
-            self._bucket(X_next, alt)
-            done = torch.cuda.Event()
-            done.record(self._side)
+            done = None
+            if not defer_bucket:      # (owner form: the id exchange goes first, _prepare_owner_async finishes the preparation)
+                self._bucket(X_next, alt)
+                done = torch.cuda.Event()
+                done.record(self._side)
         self._prep = dict(key=self._prep_key(X_next), X=X_next, B=B, done=done, sorted=sorted_ev)
 
     def _take_prepared(self, X, ws) -> bool:
@@ -1023,14 +1034,14 @@ class PathEngine:
         if prep is None:
             return False
         if prep["key"] != self._prep_key(X) or prep["B"] != X.shape[0] or "prep_alt" not in ws:
-            torch.cuda.current_stream(self.dev).wait_event(prep["done"])      # (the discarded work still owns the alt buffers)
+            torch.cuda.current_stream(self.dev).wait_event(prep["done"] or prep["sorted"])      # (the discarded work still owns the alt buffers)
             return False
         alt = ws["prep_alt"]
         for k in self._PREP_KEYS:
             ws[k], alt[k] = alt[k], ws[k]
         # (one event for both, waited for here: 1.141 against 1.130 ms/step, four A/B rounds on one box)
         torch.cuda.current_stream(self.dev).wait_event(prep["sorted"])
-        self._prep_rest = prep["done"]          # (waited for by _join_prepared, in front of the first reader of the bucketing)
+        self._prep_rest = prep["done"] or prep["sorted"]      # (waited for by _join_prepared, in front of the first reader of the bucketing)
         return True
 
     def _join_prepared(self) -> None:
@@ -1040,7 +1051,11 @@ class PathEngine:
 
     def train_step(self, X: torch.Tensor, y: torch.Tensor, next_X: Optional[torch.Tensor] = None):
         """`next_X` (optional): the id matrix the NEXT call will be given - `fit` knows it; its preprocessing then runs on a side
-        stream underneath this step's tail (_prepare_async).  A hint only: results are the same bits with or without it.
+        stream underneath this step's tail (_prepare_async).  A hint only: parameters and optimizer state are the same bits
+        with or without it.  One visible difference: a step called WITH `next_X` is pipelined into the next one - its dense
+        gradient buffer (the `param.grad` views) is cleared for the next step behind its own flat Adam launch, so `.grad` is not
+        meaningful after such a step; a step called without `next_X` leaves its gradients in place until the next step
+        (the reference keeps them until the next zero_grad()).
 
         One optimizer step of every data-parallel rank, all on the launch stream: ids -> arena rows, sort, [lazy: replay of
         the rows this rank is about to read], bucket, gather, forward, head, backward; then the exchange (large-table row ids,
@@ -1233,11 +1248,12 @@ class PathEngine:
                                                   self._stream()), "satrans_adam_flat")
                 self._flat_done = torch.cuda.Event()
                 self._flat_done.record(self._side_tail)
-                if self.preclear and not split:
+                if self.preclear and not split and next_X is not None:
                     # the NEXT step's gradient clear, behind the event: 6 us and a launch gap off the head of that step's reduction
+                    # (pipelined callers only: without `next_X` the gradients stay readable - ADVICE r04)
                     self._g_step_tail.zero_()
-                    self._precleared = torch.cuda.Event()
-                    self._precleared.record(self._side_tail)
+                    self._precleared = (torch.cuda.Event(), self._g_step_tail)
+                    self._precleared[0].record(self._side_tail)
             # (the step's regulariser partial sums on that stream as well, behind an event of the touched-row chain and with two
             #  alternating sets of partial sums: 1.116-1.119 -> 1.120-1.122 ms/step, three A/B rounds - the sum is not what the next
             #  step's first launch waits for)
@@ -1333,10 +1349,12 @@ class PathEngine:
         self._owner_plan = dict(counts=allc.reshape(world, steps, world).permute(1, 0, 2).contiguous().cpu(), step=0,
                                 batch=batch_size, last=n - (steps - 1) * batch_size)
 
-    def _owner_ws(self, ws: dict, n_b: int, need: int) -> dict:
-        """Buffers for the lists an owner receives.  Their length depends on the ids of the step (about n_b with uniform ids, up
-        to world * n_b when every rank gathers from one slice): capacity doubles when a step outgrows it."""
-        ow = ws.get("_owner")
+    def _owner_ws(self, ws: dict, half: int, n_b: int, need: int) -> dict:
+        """Buffers for the lists an owner receives, one set per half of the next-batch double buffer.  Their length depends on the
+        ids of the step (about n_b with uniform ids, up to world * n_b when every rank gathers from one slice): capacity doubles
+        when a step outgrows it."""
+        halves = ws.setdefault("_owner", [None, None])
+        ow = halves[half]
         if ow is not None and ow["cap"] >= need:
             return ow
         lib, D, dev = self.lib, self.D, self.dev
@@ -1344,12 +1362,96 @@ class PathEngine:
         i32 = dict(dtype=torch.int32, device=dev)
         n_reg = int(lib.satrans_embed_reg_partials(self.total_rows, cap, D))
         ow = dict(cap=cap, n_reg=n_reg,
+                  ids=torch.empty(cap, **i32),                                     # the row ids as received (rank-major)
                   sorted=torch.empty(cap, **i32), src=torch.empty(cap, **i32), iota=torch.arange(cap, **i32),
                   sort_ws=torch.empty(int(lib.satrans_embed_sort_workspace_bytes(cap, self.total_rows)), dtype=torch.uint8, device=dev),
                   partial_ws=torch.empty(int(lib.satrans_embed_partial_ws_floats(cap, D)), dtype=torch.float32, device=dev),
-                  reg=torch.zeros(n_reg + (cap * D + 255) // 256, dtype=torch.float64, device=dev))
-        ws["_owner"] = ow
+                  vals=torch.empty(cap, D, dtype=torch.float32, device=dev),       # values out / gradient rows in
+                  reg=torch.zeros(n_reg + (cap * D + 255) // 256, dtype=torch.float64, device=dev),
+                  inv=(ow or {}).get("inv"))                                       # [B F]: (b, f) -> its row of the sorted value buffer
+        halves[half] = ow
         return ow
+
+    def _owner_counts(self, B: int, big_sorted, n_b: int, world: int, bt, peek: bool):
+        """[N, N] split sizes of this step's (peek: the NEXT step's) row-id exchange: from the epoch plan (plan_owner_counts: no
+        read-back, the launch queue stays full), else - not for a peek - gathered and read back now."""
+        from . import parallel
+        plan = getattr(self, "_owner_plan", None)
+        if plan is not None:
+            i = plan["step"]
+            steps = plan["counts"].shape[0]
+            if i < steps and B == (plan["last"] if i == steps - 1 else plan["batch"]):
+                if not peek:
+                    plan["step"] = i + 1
+                return plan["counts"][i]
+            if not peek:
+                self._owner_plan = None
+        if peek:
+            return None
+        cut = torch.searchsorted(big_sorted, bt[1]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
+        edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n_b)])
+        return parallel.gather_counts(edges[1:] - edges[:-1])        # [N, N] on the host: the step's one read-back
+
+    def _owner_exchange_ids(self, ws, half, bufs, counts, B, group=None):
+        """Everything of an owner-form step that depends on nothing but the batch's ids: the large-table part of the sorted rows
+        to their owners (all-to-all, int32), the owner-side sort of what arrived (rank-major, then position: the order of the
+        replicated form, hence its bits), the inverse of the batch's own sort (token (b, f) -> its row of the sorted value
+        buffer).  On the CURRENT stream: the launch stream at the top of a step, or - the next batch's - the side stream under
+        the previous step's tail (_prepare_owner_async).  `bufs`: the half of the double buffer holding the batch's rows."""
+        from . import parallel
+        lib, st = self.lib, self._stream()
+        rank = parallel.rank()
+        n_loc, n_s = B * self.F, B * self.F_small
+        n_b = n_loc - n_s
+        send, recv = counts[rank].tolist(), counts[:, rank].tolist()
+        n_recv = int(sum(recv))
+        ow = self._owner_ws(ws, half, n_b, max(n_recv, 1))
+        ow["reg"].zero_()                                                        # (slot counts follow n_recv: no stale partials)
+        big_sorted = bufs["sorted_rows"][n_s:]
+        parallel.all_to_all_rows(big_sorted, send, recv, "all_to_all_row_ids_i32", out=ow["ids"], group=group)
+        if n_recv:
+            # what arrived is one sorted run per sending rank: ONE ranking launch merges them (the device-wide sort of the same
+            # list: a block sort + ~10 merge passes, 48-61 us)
+            starts = [0]
+            for c in recv:
+                starts.append(starts[-1] + int(c))
+            if len(recv) <= 64:
+                N.check(lib.satrans_embed_merge_runs(ow["ids"].data_ptr(), n_recv, (C.c_int64 * len(starts))(*starts), len(recv),
+                                                     ow["sorted"].data_ptr(), ow["src"].data_ptr(), st), "satrans_embed_merge_runs")
+            else:
+                N.check(lib.satrans_embed_sort(ow["ids"].data_ptr(), n_recv, self.total_rows, ow["sorted"].data_ptr(),
+                                               ow["src"].data_ptr(), None, ow["sort_ws"].data_ptr(), ow["sort_ws"].numel(),
+                                               ow["iota"].data_ptr(), st), "satrans_embed_sort(owner)")
+        if ow["inv"] is None or ow["inv"].numel() != n_loc:
+            ow["inv"] = torch.empty(n_loc, dtype=torch.int32, device=self.dev)
+        N.check(lib.satrans_embed_inverse_positions(bufs["src"].data_ptr(), n_loc, ow["inv"].data_ptr(), st),
+                "satrans_embed_inverse_positions")
+        return dict(ow=ow, send=send, recv=recv, n_recv=n_recv, B=B, half=half)
+
+    def _prepare_owner_async(self, X_next, world, bt):
+        """The id exchange of the NEXT step on the side stream, behind that batch's sort (_prepare_async), on a process group of
+        its own (parallel.prefetch_group) - issued by the host AFTER this step's gradient collectives, so that every rank issues
+        its collectives in the same order.  Only with an epoch plan (the split sizes are then known without a read-back)."""
+        from . import parallel
+        prep = self._prep
+        if prep is None or prep.get("owner") is not None or self._side is None:
+            return
+        B = prep["B"]
+        ws = self.train_workspace(B, 1, False)        # (the NEXT batch's workspace: a ragged last batch has one of its own)
+        n_b = B * (self.F - self.F_small)
+        counts = self._owner_counts(B, None, n_b, world, bt, peek=True)
+        with torch.cuda.stream(self._side):
+            if counts is not None:
+                half = 1 - ws.get("_own_half", 0)
+                with self.phase("owner_ids_next"):
+                    own = self._owner_exchange_ids(ws, half, ws["prep_alt"], counts, B, group=parallel.prefetch_group())
+                own["done"] = torch.cuda.Event()
+                own["done"].record(self._side)
+                prep["owner"] = own
+            if prep["done"] is None:                   # the bucketing, deferred behind the exchange (_prepare_async)
+                self._bucket(prep["X"], ws["prep_alt"])
+                prep["done"] = torch.cuda.Event()
+                prep["done"].record(self._side)
 
     def _train_step_owner(self, X, y, B, world, ws, next_X=None):
         """One optimizer step of every data-parallel rank with row OWNERSHIP (reference semantics unchanged: per-GPU batches,
@@ -1358,19 +1460,24 @@ class PathEngine:
         Rank o owns a contiguous 1/N slice of the large tables' rows - values, both Adam moments and the lazy form's `last` -
         and is the only rank that reads or writes them during training:
           ids      every rank sorts its batch's rows; the large-table part splits into N runs by owner   all-to-all (int32)
+                   -> the owner sorts what it received          [both a step AHEAD, on the side stream: _prepare_owner_async]
           values   the owner replays the postponed steps of the requested rows, reads them               all-to-all back (fp32)
                    -> layer 0 reads its tokens from the received rows (plus the replicated small tables)
           grads    gradient rows of the large tables, packed in sorted order                             all-to-all (fp32)
-                   -> the owner sorts what it received (rank-major, then position: the order of the replicated form, hence the
-                      same bits), ordered segmented sums, Adam on its slice
+                   -> ordered segmented sums over the owner's sorted list (rank-major, then position: the order of the
+                      replicated form, hence the same bits), Adam on its slice
           small tables and dense parameters: one SUM all-reduce of the flat gradient buffer, dense step on every rank
         Per rank and step: ~n_b rows received and stepped, 2 x n_b x D x 4 bytes moved each way (8.4 MB at B = 8192) instead
         of N x n_b rows sorted, replayed and stepped and N x 8.4 MB received; the flush of the postponed steps covers 1/N of
         the rows.  The replicas of rows a rank does not own go stale; flush_lazy() brings them together again (slice broadcasts)
-        before anything reads the tables as a whole."""
+        before anything reads the tables as a whole.
+
+        What sits on the launch stream between two steps' layer kernels: replay -> pack values -> all-to-all -> [layers] ->
+        pack gradient rows -> all-to-all -> touched-row Adam.  Beside it, on the tail stream: slab reduction + scenario-table
+        backward + small-table sums -> all-reduce -> dense step of the small tables + flat Adam; on the side stream: the next
+        batch's sort, bucketing, id exchange and owner-side sort."""
         from . import parallel
         lib, m, D, st = self.lib, self.m, self.D, self._stream()
-        rank = parallel.rank()
         n_loc, n_s = B * self.F, B * self.F_small
         n_b = n_loc - n_s
         l2 = m.l2_reg_embedding
@@ -1380,126 +1487,132 @@ class PathEngine:
             self.flush_lazy()                         # (first owner-form step: everything current and identical everywhere)
             self._owner_bounds = None
             self._owner_world = world
+            parallel.prefetch_group()                 # (collective: every rank is here)
         bounds = self._owner_ranges(world, B)
         if "xg" not in ws:
             ws["xg"] = torch.empty(n_loc, D, dtype=torch.float32, device=self.dev)
-            ws["inv"] = torch.empty(n_loc, dtype=torch.int32, device=self.dev)
-            ws["iota_loc"] = torch.arange(n_loc, dtype=torch.int32, device=self.dev)
             ws["packed_o"] = torch.empty(max(n_b, 1), D, dtype=torch.float32, device=self.dev)
         bt = getattr(self, "_owner_bounds_t", None)
         if bt is None or bt[0] is not bounds:
             bt = self._owner_bounds_t = (bounds, torch.tensor(bounds[1:-1], dtype=torch.int32, device=self.dev))
+        main = torch.cuda.current_stream(self.dev)
 
-        # ---- 1. this batch's arena rows, sorted; the large-table part is N runs, one per owner (the previous step may have
-        #         prepared them - ids -> rows, per-field sort, bucketing - on the side stream: _prepare_async) ------------------
+        # ---- 1. this batch's arena rows, sorted, and their exchange with the owners - prepared by the previous step on the
+        #         side stream (_prepare_async + _prepare_owner_async), else here ---------------------------------------------
+        own = (self._prep or {}).get("owner")
         prepared = self._take_prepared(X, ws)
         if not prepared:
+            if own is not None:
+                main.wait_event(own["done"])      # (the discarded exchange still owns its half of the buffers)
+            own = None
             N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
                                            N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
                                            self.status.data_ptr(), st), "satrans_gather_fwd(rows)")
-        with self.phase("embed_sort"):
-            if prepared:
-                pass
-            elif self._sort_fields is not None and B <= 8192:
-                f_, lo_, n_ = self._sort_fields
-                N.check(lib.satrans_embed_sort_fields(ws["rows"].data_ptr(), B, self.F, f_, lo_, n_, ws["sorted_rows"].data_ptr(),
-                                                      ws["src"].data_ptr(), st), "satrans_embed_sort_fields")
-            else:
-                N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_loc, self.total_rows, ws["sorted_rows"].data_ptr(),
-                                               ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
-                                               ws["iota"].data_ptr(), st), "satrans_embed_sort")
+            with self.phase("embed_sort"):
+                if self._sort_fields is not None and B <= 8192:
+                    f_, lo_, n_ = self._sort_fields
+                    N.check(lib.satrans_embed_sort_fields(ws["rows"].data_ptr(), B, self.F, f_, lo_, n_, ws["sorted_rows"].data_ptr(),
+                                                          ws["src"].data_ptr(), st), "satrans_embed_sort_fields")
+                else:
+                    N.check(lib.satrans_embed_sort(ws["rows"].data_ptr(), n_loc, self.total_rows, ws["sorted_rows"].data_ptr(),
+                                                   ws["src"].data_ptr(), None, ws["sort_ws"].data_ptr(), ws["sort_ws"].numel(),
+                                                   ws["iota"].data_ptr(), st), "satrans_embed_sort")
         self.adam_t += 1
         self._note_lr(m._adam_cfg["lr"])
         h_emb = self._hparams(l2)
         big_sorted, big_src = ws["sorted_rows"][n_s:], ws["src"][n_s:]
-        with self.phase("owner_ids"):
-            counts = None
-            plan = getattr(self, "_owner_plan", None)
-            if plan is not None:                      # an epoch plan (plan_owner_counts): no read-back, the queue stays full
-                i = plan["step"]
-                steps = plan["counts"].shape[0]
-                if i < steps and B == (plan["last"] if i == steps - 1 else plan["batch"]):
-                    counts = plan["counts"][i]
-                    plan["step"] = i + 1
-                else:
-                    self._owner_plan = None
-            if counts is None:
-                cut = torch.searchsorted(big_sorted, bt[1]) if world > 1 else big_sorted.new_zeros(0, dtype=torch.int64)
-                edges = torch.cat([cut.new_zeros(1), cut, cut.new_full((1,), n_b)])
-                counts = parallel.gather_counts(edges[1:] - edges[:-1])        # [N, N] on the host: the step's one read-back
-            send, recv = counts[rank].tolist(), counts[:, rank].tolist()
-            n_recv = int(sum(recv))
-            o_rows = parallel.all_to_all_rows(big_sorted, send, recv, "all_to_all_row_ids_i32")
-        ow = self._owner_ws(ws, n_b, max(n_recv, 1))
-        ow["reg"].zero_()                                                        # (slot counts follow n_recv: no stale partials)
-        # ---- 2. the owner's side: sort what was asked for, replay the postponed steps of exactly those rows, answer ---------
-        if n_recv:
-            with self.phase("embed_sort_global"):
-                N.check(lib.satrans_embed_sort(o_rows.data_ptr(), n_recv, self.total_rows, ow["sorted"].data_ptr(),
-                                               ow["src"].data_ptr(), None, ow["sort_ws"].data_ptr(), ow["sort_ws"].numel(),
-                                               ow["iota"].data_ptr(), st), "satrans_embed_sort(owner)")
-            if self.adam_t > 1:
-                with self.phase("lazy_replay"):
-                    table, h = self._table(self.adam_t), self._hparams(l2)
-                    N.check(lib.satrans_embed_lazy_replay(arena, am, av, self.last_step.data_ptr(), D, ow["sorted"].data_ptr(),
-                                                          n_recv, self.adam_t - 1, table.data_ptr(), C.byref(h),
-                                                          ow["reg"][ow["n_reg"]:].data_ptr(), st), "satrans_embed_lazy_replay")
+        if own is not None and own["B"] == B:
+            ws["_own_half"] = own["half"]
+            self._owner_counts(B, big_sorted, n_b, world, bt, peek=False)      # (the plan moves on: these are the counts `own` used)
+            main.wait_event(own["done"])
+        else:
+            with self.phase("owner_ids"):
+                counts = self._owner_counts(B, big_sorted, n_b, world, bt, peek=False)
+                half = ws.get("_own_half", 0)
+                own = self._owner_exchange_ids(ws, half, ws, counts, B)
+        ow, send, recv, n_recv = own["ow"], own["send"], own["recv"], own["n_recv"]
+        # ---- 2. the owner's side: replay the postponed steps of exactly the rows that were asked for, answer ----------------
+        if n_recv and self.adam_t > 1:
+            with self.phase("lazy_replay"):
+                table, h = self._table(self.adam_t), self._hparams(l2)
+                N.check(lib.satrans_embed_lazy_replay(arena, am, av, self.last_step.data_ptr(), D, ow["sorted"].data_ptr(),
+                                                      n_recv, self.adam_t - 1, table.data_ptr(), C.byref(h),
+                                                      ow["reg"][ow["n_reg"]:].data_ptr(), st), "satrans_embed_lazy_replay")
         with self.phase("owner_rows"):
-            vals = torch.empty(n_recv, D, dtype=torch.float32, device=self.dev)
+            # the batch's rows in sorted order: replicated small tables from the arena, large tables from their owners (straight
+            # into their part of the buffer); token (b, f) is row inv[b, f] of that buffer
+            xg, inv = ws["xg"], ow["inv"]
             if n_recv:
-                N.check(lib.satrans_embed_pack_rows(o_rows.data_ptr(), n_recv, arena, D, vals.data_ptr(), st),
+                N.check(lib.satrans_embed_pack_rows(ow["ids"].data_ptr(), n_recv, arena, D, ow["vals"].data_ptr(), st),
                         "satrans_embed_pack_rows(values)")
-            got = parallel.all_to_all_rows(vals, recv, send, "all_to_all_rows_f32")      # [n_b, D], in big_sorted order
-            # the batch's rows in sorted order: replicated small tables from the arena, large tables from their owners; token
-            # (b, f) is row inv[b, f] of that buffer
-            xg, inv = ws["xg"], ws["inv"]
+            parallel.all_to_all_rows(ow["vals"][:n_recv], recv, send, "all_to_all_rows_f32", out=xg[n_s:])
             if n_s:
+                self._join_flat()          # (the previous step's dense step of the small tables ran on the tail stream)
                 N.check(lib.satrans_embed_pack_rows(ws["sorted_rows"].data_ptr(), n_s, arena, D, xg.data_ptr(), st),
                         "satrans_embed_pack_rows(small)")
-            if n_b:
-                xg[n_s:].copy_(got)
-            inv[ws["src"].long()] = ws["iota_loc"]
-        # ---- 3. forward, loss, backward on the received rows ------------------------------------------------------------------
+        # ---- 3. forward, loss, backward on the received rows; the slab reduction and the scenario-table backward go to the tail
+        #         stream (backward(side_tail=True)), the next batch's sort and bucketing to the side stream ----------------------
         self._x_src = (xg, inv)
         hook = None
         if next_X is not None and self._dense_override is None and self._can_prepare(next_X, next_X.shape[0]) \
                 and next_X.shape[1] >= self.n_cols:
-            hook = lambda fork: self._prepare_async(next_X, B, fork)
+            hook = lambda fork: self._prepare_async(next_X, B, fork, defer_bucket=True)
         try:
-            gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook)
+            gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook, side_tail=self.side_tail)
         finally:
             self._x_src = None
-        # ---- 4. small tables + dense parameters: one all-reduce; large tables: gradient rows to their owners -------------------
-        if n_s > 0:
-            with self.phase("adam_small"):
-                N.check(lib.satrans_embed_segment_sums(ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(), n_s, gemb.data_ptr(), D,
-                                                       ws["partial_ws"].data_ptr(), ws["reg_unused"].data_ptr(),
-                                                       self.g_small.data_ptr(), st), "satrans_embed_segment_sums")
-        parallel.all_reduce_flat(self.g_exchange)
+        tail = self._side_tail if self._tail_done is not None else None
+        self._tail_done = None
+        # ---- 4. large tables, launch stream: gradient rows to their owners, ordered sums + Adam on the owner's slice ------------
         with self.phase("owner_grads"):
             if n_b:
                 N.check(lib.satrans_embed_pack_rows(big_src.data_ptr(), n_b, gemb.data_ptr(), D, ws["packed_o"].data_ptr(), st),
                         "satrans_embed_pack_rows(grads)")
-            recv_g = parallel.all_to_all_rows(ws["packed_o"][:n_b], send, recv, "all_to_all_grad_rows_f32")
-        if self.small_rows > 0:
-            with self.phase("adam_small"):
-                N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, self.small_rows, D,
-                                                    self.g_small.data_ptr(), C.byref(h_emb), self.adam_t,
-                                                    ws["reg_rows"].data_ptr(), st), "satrans_embed_adam_rows")
-                N.check(lib.satrans_sum_f64(ws["reg_rows"].data_ptr(), ws["reg_rows"].numel(), self.reg_small.data_ptr(), 1, st),
-                        "satrans_sum_f64")
+            recv_g = parallel.all_to_all_rows(ws["packed_o"][:n_b], send, recv, "all_to_all_grad_rows_f32", out=ow["vals"])
+        # ---- 5. small tables + dense parameters, tail stream (beside 4): ordered sums, ONE all-reduce, dense steps --------------
+        with (torch.cuda.stream(tail) if tail is not None else contextlib.nullcontext()):
+            st_t = self._stream()
+            if n_s > 0:
+                with self.phase("adam_small"):
+                    N.check(lib.satrans_embed_segment_sums(ws["sorted_rows"].data_ptr(), ws["src"].data_ptr(), n_s, gemb.data_ptr(), D,
+                                                           ws["partial_ws"].data_ptr(), ws["reg_unused"].data_ptr(),
+                                                           self.g_small.data_ptr(), st_t), "satrans_embed_segment_sums")
+            parallel.all_reduce_flat(self.g_exchange)
+            if self.small_rows > 0:
+                with self.phase("adam_small"):
+                    N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, self.small_rows, D,
+                                                        self.g_small.data_ptr(), C.byref(h_emb), self.adam_t,
+                                                        ws["reg_rows"].data_ptr(), st_t), "satrans_embed_adam_rows")
+                    N.check(lib.satrans_sum_f64(ws["reg_rows"].data_ptr(), ws["reg_rows"].numel(), self.reg_small.data_ptr(), 1,
+                                                st_t), "satrans_sum_f64")
+            h_flat = self._hparams(0.0)
+            with self.phase("adam_flat"):
+                N.check(lib.satrans_adam_flat(m.flat_params.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                              self.flat_v.data_ptr(), m.flat_params.numel(), C.byref(h_flat), st_t),
+                        "satrans_adam_flat")
+            if tail is not None:
+                self._flat_done = torch.cuda.Event()
+                self._flat_done.record(tail)
+                if self.preclear and next_X is not None:
+                    self.flat_g_all.zero_()      # the NEXT step's gradient clear (pipelined callers only: train_step's docstring)
+                    self._precleared = (torch.cuda.Event(), self.flat_g_all)
+                    self._precleared[0].record(tail)
+        # (the next batch's id exchange: issued behind this step's two gradient collectives - the same order on every rank)
+        if hook is not None:
+            self._prepare_owner_async(next_X, world, bt)
         if n_recv:
             with self.phase("adam_touched"):
                 N.check(lib.satrans_embed_adam_touched(arena, am, av, D, ow["sorted"].data_ptr(), ow["src"].data_ptr(), n_recv,
                                                        recv_g.data_ptr(), ow["partial_ws"].data_ptr(), C.byref(h_emb),
                                                        ow["reg"].data_ptr(), self.last_step.data_ptr(), self.adam_t, st),
                         "satrans_embed_adam_touched")
+        N.check(lib.satrans_sum_f64(ow["reg"].data_ptr(), ow["reg"].numel(), self.reg_sum.data_ptr(), 1, st), "satrans_sum_f64")
         self._lazy_pending = True
         self._replicas_stale = True
         self._since_flush += 1
         self._stepped_since_forward = True
-        with self.phase("adam_flat"):
-            self._flat_step(self._hparams(0.0), {"reg_partials": ow["reg"]}, st)
+        if tail is None or next_X is None:
+            self._join_flat()              # (a caller outside a fit-style loop sees the finished step, as with any torch op)
         if self.flush_every and self._since_flush >= self.flush_every:
             self.flush_lazy(sync=False)               # own slice only: nobody reads the other replicas during training
 
@@ -1662,8 +1775,11 @@ class PathEngine:
 
     def flush_lazy(self, sync: bool = True):
         """Bring every table row (owner form: every row this rank owns) to the current step - a no-op when nothing is pending -
-        and, with `sync`, make the replicas of all ranks identical again (owner form: collective; every rank reaches the flush
-        points - epoch end, evaluation forward, state_dict, optimizer_state - together, as it reaches the steps together)."""
+        and, with `sync`, make the replicas of all ranks identical again (owner form: COLLECTIVE - slice broadcasts; every rank
+        reaches the flush points that `fit` / `predict` / `evaluate` contain together, as it reaches the steps together).
+        `sync="local"` is for entry points a single rank may call on its own (state_dict, optimizer_state_dict, `.to()`): with
+        stale replicas it raises instead of starting a collective the other ranks never join (a rank-0-only
+        checkpoint in the middle of an epoch would hang); `model.synchronize()` on every rank first makes it legal."""
         self._join_flat()
         if self.lazy and self._lazy_pending:
             m = self.m
@@ -1677,6 +1793,11 @@ class PathEngine:
             self.flush_count = getattr(self, "flush_count", 0) + 1
             self._prune_lr_history()
         if sync and self._replicas_stale:
+            from . import parallel
+            if sync == "local" and parallel.world_size() > 1:
+                raise RuntimeError("the embedding tables of this rank are stale outside the slice it owns (data-parallel owner "
+                                   "form, mid-epoch): call model.synchronize() on EVERY rank first - it is a collective - or read "
+                                   "the model at an epoch boundary (fit() leaves the replicas identical)")
             self._sync_replicas()
 
     def _flush_launches(self, m, h, st, table):

@@ -14,9 +14,16 @@ from typing import Optional
 
 import torch
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise.  The
+# data-parallel step runs five (launch stream, next-batch stream, tail stream, two RCCL communicator streams): on four queues
+# its tail chains - gradient rows to their owners beside the slab reduction and the all-reduce - ran one after the other
+# (measured, one rank through RCCL: 1.324 -> 1.214 ms/step with 8 queues; the one-GPU step is unchanged).  A default only: it has
+# no effect when the caller's environment sets it, or when the HIP runtime was initialised before this import.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SATRANS_LIB_PATH") or os.path.join(_HERE, "libsatrans_hip.so")   # (override: kernel experiments)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ID_F32, ID_I32, ID_I64 = 0, 1, 2
 META_Q, META_K, RELU_OUT, NO_RES, TRAIN, GATE, BILINEAR = 1, 2, 4, 8, 16, 32, 64
@@ -78,6 +85,8 @@ class AdamHParams(C.Structure):
 SIGNATURES = {
     "satrans_last_error": (C.c_char_p, []),
     "satrans_abi_version": (C.c_int, []),
+    "satrans_stream_create_low_priority": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "satrans_stream_destroy": (C.c_int, [C.c_void_p]),
     "satrans_kernel_timing": (C.c_int, [C.c_int]),
     "satrans_kernel_timing_read": (C.c_int, [_vp, _vp, C.c_int]),
     "satrans_bucket_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
@@ -89,8 +98,6 @@ SIGNATURES = {
     "satrans_gather_read_probe": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
     "satrans_set_layer_impl": (C.c_int, [C.c_int]),
     "satrans_layer_fused_supported": (C.c_int, [C.POINTER(LayerDesc)]),
-    "satrans_set_product_mode": (C.c_int, [C.c_int]),
-    "satrans_get_product_mode": (C.c_int, []),
     "satrans_layer_fwd": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp, _vp]),
 "satrans_layer_fwd_bf16_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "satrans_layer_fwd_bf16": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
@@ -155,6 +162,8 @@ SIGNATURES = {
     "satrans_embed_pack_rows": (C.c_int, [_vp, C.c_int64, _vp, C.c_int, _vp, _vp]),
     "satrans_embed_rows_sort_fields": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
+    "satrans_embed_merge_runs": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64), C.c_int, _vp, _vp, _vp]),
+    "satrans_embed_inverse_positions": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "satrans_embed_sort_fields": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             _vp, _vp, _vp]),
     "satrans_embed_lazy_reg_partials": (C.c_int64, [C.c_int64, C.c_int]),

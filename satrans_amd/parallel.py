@@ -129,12 +129,31 @@ def gather_counts(counts: torch.Tensor) -> torch.Tensor:
     return out.reshape(w, -1).cpu()
 
 
-def all_to_all_rows(inp: torch.Tensor, send_splits, recv_splits, name: str) -> torch.Tensor:
+_PREFETCH_GROUP = None
+
+
+def prefetch_group():
+    """A second process group (its own RCCL communicator and stream) for the exchange a step issues AHEAD - the next batch's row
+    ids to their owners, on the engine's side stream under the current step's tail: on the default group it would queue behind
+    the current step's gradient collectives, whose inputs are ready later.  Created on first use: COLLECTIVE (every rank takes
+    its first owner-form step at the same point of the program)."""
+    global _PREFETCH_GROUP
+    if _PREFETCH_GROUP is None and dist.is_available() and dist.is_initialized():
+        _PREFETCH_GROUP = dist.new_group()
+    return _PREFETCH_GROUP
+
+
+def all_to_all_rows(inp: torch.Tensor, send_splits, recv_splits, name: str, out: torch.Tensor = None, group=None) -> torch.Tensor:
     """Uneven all-to-all along dim 0: rows [sum(send_splits), ...] -> [sum(recv_splits), ...]; chunk o of `inp` goes to rank o,
-    chunk r of the result came from rank r.  RCCL: grouped point-to-point over xGMI (every pair has its own link)."""
+    chunk r of the result came from rank r.  RCCL: grouped point-to-point over xGMI (every pair has its own link).
+    `out`: a caller-owned buffer of at least sum(recv_splits) rows (its head is filled and returned); `group`: the process group
+    (default: the world)."""
     send_splits, recv_splits = [int(v) for v in send_splits], [int(v) for v in recv_splits]
     inp = inp.contiguous()
-    out = torch.empty((sum(recv_splits),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    if out is None:
+        out = torch.empty((sum(recv_splits),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    else:
+        out = out[:sum(recv_splits)]
     row_bytes = inp.element_size()
     for dim in inp.shape[1:]:
         row_bytes *= int(dim)
@@ -144,10 +163,10 @@ def all_to_all_rows(inp: torch.Tensor, send_splits, recv_splits, name: str) -> t
         return out
     if _host_staged(inp):
         h_out = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(h_out, inp.cpu(), recv_splits, send_splits)
+        dist.all_to_all_single(h_out, inp.cpu(), recv_splits, send_splits, group=group)
         out.copy_(h_out)
     else:
-        dist.all_to_all_single(out, inp, recv_splits, send_splits)
+        dist.all_to_all_single(out, inp, recv_splits, send_splits, group=group)
     return out
 
 

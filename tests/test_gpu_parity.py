@@ -16,28 +16,14 @@ DEV = "cuda:0"
 LOGIT_ATOL = 1e-5
 
 
-def split_products() -> bool:
-    """True when the TRAINING step of the fused kernels (forward with dropout, backward) evaluates the weight products of the
-    (D, U, H) = (32, 64, 4) MetaNet shape as split products (fp32 operands as bf16 pairs, three bf16 MFMAs per block -
-    include/satrans_hip.h: satrans_set_product_mode; opt-in, SATRANS_PRODUCTS=split) rather than on the fp32 instruction
-    (the library's default and the reference's arithmetic; evaluation forwards always use it).  Split products carry ~2.6x the error of plain fp32
-    products against an fp64 evaluation of the same graph (test_product_modes_against_the_fp64_oracle): the golden gates (1e-5
-    on logits, 5e-5 of the largest entry on gradients) hold in both modes; the few bounds below that were set at the fp32
-    kernels' own noise floor are stated per mode."""
-    from satrans_amd import native
-    return native.lib().satrans_get_product_mode() == 1
-
-
 def assert_close_but_for_kinks(got, want, rtol, atol, err_msg, frac=5e-4, slack=20.0, kinks=None):
-    """assert_allclose, except that a fraction `frac` of the elements may sit up to `slack` x outside it - under split products,
-    and with fp32 products only when the ORACLE saw MetaNet hidden units within fp32 rounding of the ReLU's kink on these very
-    inputs (`kinks` > 0: the count of O.KINK_PROBE; at B = 8,192 a step evaluates 6e7 hidden units and a few of them always are).
+    """assert_allclose, except that a fraction `frac` of the elements may sit up to `slack` x outside it - only when the ORACLE saw
+    MetaNet hidden units within fp32 rounding of the ReLU's kink on these very inputs (`kinks` > 0: the count of O.KINK_PROBE; at B = 8,192 a step evaluates 6e7 hidden units and a few of them always are).
     A ReLU whose pre-activation is within the products' error of zero takes the other branch than the oracle's: the gradient
     of the one sample involved then changes by O(1) of that sample's share, which an element-wise bound at 1e-4 of the
     largest entry sees in the table rows that sample touched.  With fp32 products (error ~1e-7) 8,192 samples x 2 x 64 hidden
-    units x 19 fields almost never hold such a unit, with split products (~1e-5 near a kink) a handful do: measured 29 of
-    259,744 elements of one table's exp_avg, the largest 9e-4 of the tensor's largest entry."""
-    if not split_products() and not kinks:
+    units x 19 fields almost never hold such a unit."""
+    if not kinks:
         np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=err_msg)
         return
     err = np.abs(got - want)
@@ -81,15 +67,13 @@ def assert_grad_close_but_for_kinks(got, want, atol, err_msg, frac=0.02, outlier
     contributes - or does not - to the rows / columns of the generated-weight gradient it touches and to everything downstream
     of them (measured: 440 of 131,072 elements of the scenario encoder's weight gradient, the largest 1.5 % of the tensor's
     largest entry).  The exception - at most `frac` of a tensor's elements outside `atol`, none of them by more than `outlier`
-    of the tensor's largest entry - is granted
-      * under split products (product error ~1e-5 near a kink: a step over 10^5 hidden units holds such a unit more often than not);
-      * with fp32 products (the default, the reference's arithmetic) ONLY when the oracle itself saw a hidden unit within fp32
-        rounding of the kink on these very inputs (`kinks` = the count of oracle_grads_probing_kinks; None / 0: element-wise)."""
+    of the tensor's largest entry - is granted ONLY when the oracle itself saw a hidden unit within fp32 rounding of the kink on
+    these very inputs (`kinks` = the count of oracle_grads_probing_kinks; None / 0: element-wise)."""
     err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64))
     bad = err > atol
     if not bad.any():
         return
-    if not split_products() and not kinks:
+    if not kinks:
         np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), rtol=0, atol=atol,
                                    err_msg=err_msg)
     assert float(bad.mean()) <= frac, (err_msg, "fraction outside the bound", float(bad.mean()))
@@ -154,75 +138,41 @@ def test_gradients_match_reference_golden(name):
         np.testing.assert_allclose(grads[k].cpu().numpy(), g, rtol=0, atol=rel * scale + floor, err_msg=k)
 
 
-def _with_product_mode(mode, fn):
-    from satrans_amd import native
-    lib = native.lib()
-    before = lib.satrans_get_product_mode()
-    assert lib.satrans_set_product_mode(mode) == 0
-    try:
-        return fn()
-    finally:
-        lib.satrans_set_product_mode(before)
+def test_gradients_are_the_same_bits_run_to_run():
+    """Same inputs, same weights: the same bits (no float atomics anywhere on the path; every reduction in a fixed order)."""
+    c = Case("aliccp_sota")
+    outs = []
+    for _ in range(2):
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+        model.eval()
+        _, _, grads = model._require_engine().loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+        outs.append({k: g.cpu() for k, g in grads.items()})
+    assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["fp32-products", "split-products"])
-def test_parity_gates_hold_in_both_product_modes(mode):
-    """The golden forward, the golden gradients, the replayed-mask training gradients, the step-by-step Adam trajectory and the
-    run-to-run bit identity of the AliCCP-shaped case under fp32 products AND under split products, whichever of the two the
-    library starts in (satrans_set_product_mode; SATRANS_PRODUCTS)."""
-    from satrans_amd import native
-    assert native.lib().satrans_set_product_mode(2) != 0, "an unknown mode must be refused"
-
-    def body():
-        test_forward_matches_reference_golden("aliccp_sota")
-        test_gradients_match_reference_golden("aliccp_sota")
-        test_training_mode_gradients_match_oracle_with_same_masks("small_qkv")
-        # D = 32, F = 19, meta_mode QK: the instantiation of the headline step (layer_bwd_fused_kernel<32,64,4,true,false,19,0,PROD>)
-        # in TRAINING mode, masks replayed through the oracle - the split-product backward is only reachable at this shape
-        test_training_mode_gradients_match_oracle_with_same_masks("aliccp_sota")
-        test_adam_trajectory_step_by_step_against_the_oracle("aliccp_sota")
-        c = Case("aliccp_sota")
-        outs = []
-        for _ in range(2):                                  # same inputs, same weights: the same bits
-            model = build_model(c, DEV)
-            model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
-            model.eval()
-            _, _, grads = model._require_engine().loss_and_grads(c.X.to(DEV), c.y.to(DEV))
-            outs.append({k: g.cpu() for k, g in grads.items()})
-        assert all(torch.equal(outs[0][k], outs[1][k]) for k in outs[0])
-    _with_product_mode(mode, body)
-
-
-def test_product_modes_against_the_fp64_oracle():
-    """How much accuracy split products cost, measured: logits and every gradient of the AliCCP-shaped golden case in both modes
-    against the SAME graph evaluated in fp64 by the oracle.  Recorded on an MI355X: logits 1.4e-8 (fp32 products) and 4.8e-8
-    (split) on values of ~0.1; worst gradient 1.8e-5 / 5.0e-5 of the tensor's largest entry (the cancellation-dominated
-    W_Query / W_Key gradients) - the CPU simulation of tools/experiments/r03_split_products_sim.py says 1.3e-5 / 3.6e-5 with
-    fp64 accumulation."""
+def test_fp32_products_against_the_fp64_oracle():
+    """The kernels' products are v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain): logits and every gradient of the
+    AliCCP-shaped golden case against the SAME graph evaluated in fp64 by the oracle.  Recorded on an MI355X: logits 1.4e-8 on
+    values of ~0.1; worst gradient 1.8e-5 of the tensor's largest entry (the cancellation-dominated W_Query / W_Key gradients)."""
     c = Case("aliccp_sota")
     spec = c.spec()
     P64 = c.tensors("param", torch.float64)
     _, logit64 = O.forward(P64, c.X, spec)
     _, _, ref = O.loss_and_grads(P64, c.X, c.y, spec)             # BCE(sum) + regulariser, as loss_and_grads of the engine
-
-    def run():
-        model = build_model(c, DEV)
-        model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
-        model.eval()
-        eng = model._require_engine()
-        model(c.X.to(DEV))
-        logit_err = float((eng.last_logit().cpu().double().reshape(-1) - logit64.detach().reshape(-1)).abs().max())
-        _, _, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
-        worst = 0.0
-        for k, g in grads.items():
-            if k in ref and float(ref[k].abs().max()) > 1e-7:
-                worst = max(worst, float((g.cpu().double() - ref[k]).abs().max() / ref[k].abs().max()))
-        return logit_err, worst
-    (l32, g32), (lsp, gsp) = _with_product_mode(0, run), _with_product_mode(1, run)
-    print(f"fp32 products: logit {l32:.2e} gradient {g32:.2e} | split products: logit {lsp:.2e} gradient {gsp:.2e}")
-    assert l32 <= 2e-7 and lsp <= 5e-7, (l32, lsp)
-    assert g32 <= 3e-5 and gsp <= 1e-4, (g32, gsp)
-    assert gsp <= 5.0 * g32 + 1e-6, "split products are expected within a small factor of plain fp32 products"
+    model = build_model(c, DEV)
+    model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
+    model.eval()
+    eng = model._require_engine()
+    model(c.X.to(DEV))
+    logit_err = float((eng.last_logit().cpu().double().reshape(-1) - logit64.detach().reshape(-1)).abs().max())
+    _, _, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+    worst = 0.0
+    for k, g in grads.items():
+        if k in ref and float(ref[k].abs().max()) > 1e-7:
+            worst = max(worst, float((g.cpu().double() - ref[k]).abs().max() / ref[k].abs().max()))
+    print(f"fp32 products against fp64: logit {logit_err:.2e} gradient {worst:.2e}")
+    assert logit_err <= 2e-7 and worst <= 3e-5, (logit_err, worst)
 
 
 def _trained_aliccp_model(steps=120, B=8192, rows_cap=20000, seed=5):
@@ -252,66 +202,59 @@ def _trained_aliccp_model(steps=120, B=8192, rows_cap=20000, seed=5):
     return model, spec, X[steps * B:], y[steps * B:]
 
 
-# measured on an MI355X (printed by the test; bounds = ~2x the measurement): {mode: (logit bound, gradient bound as a fraction
-# of the tensor's largest entry)}
-# measured: fp32 products logit 1.6e-6, worst gradient 4.2e-6; split products logit 4.3e-6 on these weights (7.7e-5 on another
-# run's: heavy-tailed), worst gradient 4.4e-4
-TRAINED_BOUNDS = {0: (1e-5, 5e-5), 1: (2e-4, 1e-3)}
+# measured on an MI355X (printed by the test; bounds = ~2x the measurement): logit 1.6e-6, worst gradient 4.2e-6 of the tensor's
+# largest entry
+TRAINED_BOUNDS = (1e-5, 5e-5)
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["fp32-products", "split-products"])
-def test_trained_weights_regime_against_the_oracle(mode):
-    """VERDICT r03 item 1b.  After 120 training steps at B = 8,192 (trained weights, |logit| of order 1):
+def test_trained_weights_regime_against_the_oracle():
+    """After 120 training steps at B = 8,192 (trained weights, |logit| of order 1):
       (a) the TRAINING forward (the kernels of the training step, dropouts switched off) on 2,048 fresh samples against the CPU
-          oracle on the same weights: fp32 products within the 1e-5 bar of SURVEY 8c; split products within the bound stated in
-          TRAINED_BOUNDS (they are NOT within 1e-5 here - which is why they are an opt-in fast mode and not the headline);
+          oracle on the same weights: within the 1e-5 bar of SURVEY 8c;
       (b) one training-mode step's gradients (dropout on, masks replayed through the oracle in fp64) at B = 1,024: every
-          tensor within the stated fraction of its largest entry - fp32 products element by element, split products but for
-          ReLU kinks."""
-    def body():
-        model, spec, X, y = _trained_aliccp_model()
-        eng = model._require_engine()
-        sd = sd_to_cpu(model)
-        nb = 2048
-        Xt = torch.from_numpy(X[:nb])
-        _, logit_ref = O.forward(sd, Xt, spec)
-        model.eval()
+          tensor within the stated fraction of its largest entry, element by element."""
+    model, spec, X, y = _trained_aliccp_model()
+    eng = model._require_engine()
+    sd = sd_to_cpu(model)
+    nb = 2048
+    Xt = torch.from_numpy(X[:nb])
+    _, logit_ref = O.forward(sd, Xt, spec)
+    model.eval()
+    model(Xt.to(DEV))
+    err_eval = float((eng.last_logit().cpu() - logit_ref).abs().max())
+    model.train()
+    keep_p, eng.drop_p = eng.drop_p, 0.0
+    try:
         model(Xt.to(DEV))
-        err_eval = float((eng.last_logit().cpu() - logit_ref).abs().max())
-        model.train()
-        keep_p, eng.drop_p = eng.drop_p, 0.0
-        try:
-            model(Xt.to(DEV))
-            err_train = float((eng.last_logit().cpu() - logit_ref).abs().max())
-        finally:
-            eng.drop_p = keep_p
-        scale_logit = float(logit_ref.abs().max())
-        assert scale_logit > 1.0, f"the model did not train (max |logit| {scale_logit})"
-        assert err_eval <= 1e-5, ("evaluation forward (always fp32 products)", err_eval)
-        # (b) gradients of a training-mode step, masks replayed
-        B = 1024
-        Xb, yb = torch.from_numpy(X[:B]), torch.from_numpy(y[:B])
-        bce, reg, grads = eng.loss_and_grads(Xb.to(DEV), yb.to(DEV))
-        masks = O.dropout_masks(eng.drop_seed, eng.drop_step, B, 19, 32, 4, 3, 0.1)
-        sd64 = sd_aliased(model, torch.float64)
-        (bce_ref, reg_ref, g_ref), kinks = oracle_grads_probing_kinks(sd64, Xb, yb, spec, O.Dropper("masks", 0.1, masks))
-        worst, worst_key = 0.0, None
-        for k, g in g_ref.items():
-            if k in grads and float(g.abs().max()) > 1e-7:
-                e = float((grads[k].cpu().double() - g).abs().max() / g.abs().max())
-                if e > worst:
-                    worst, worst_key = e, k
-        print(f"trained weights, products mode {mode}: max |logit| {scale_logit:.2f}; logit err eval {err_eval:.2e} train {err_train:.2e}; "
-              f"worst gradient {worst:.2e} of the tensor's largest entry ({worst_key})")
-        lb, gb = TRAINED_BOUNDS[mode]
-        assert err_train <= lb, (mode, err_train)
-        assert bce == pytest.approx(bce_ref, rel=1e-5 if mode == 0 else 1e-4)
-        for k, g in g_ref.items():
-            if k in grads:
-                sc = max(1e-6, float(g.abs().max()))
-                assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), gb * sc + softmax_side_floor(k, g_ref, 1e-8),
-                                                f"{k} (trained weights, mode {mode})", kinks=kinks)
-    _with_product_mode(mode, body)
+        err_train = float((eng.last_logit().cpu() - logit_ref).abs().max())
+    finally:
+        eng.drop_p = keep_p
+    scale_logit = float(logit_ref.abs().max())
+    assert scale_logit > 1.0, f"the model did not train (max |logit| {scale_logit})"
+    assert err_eval <= 1e-5, ("evaluation forward", err_eval)
+    # (b) gradients of a training-mode step, masks replayed
+    B = 1024
+    Xb, yb = torch.from_numpy(X[:B]), torch.from_numpy(y[:B])
+    bce, reg, grads = eng.loss_and_grads(Xb.to(DEV), yb.to(DEV))
+    masks = O.dropout_masks(eng.drop_seed, eng.drop_step, B, 19, 32, 4, 3, 0.1)
+    sd64 = sd_aliased(model, torch.float64)
+    (bce_ref, reg_ref, g_ref), kinks = oracle_grads_probing_kinks(sd64, Xb, yb, spec, O.Dropper("masks", 0.1, masks))
+    worst, worst_key = 0.0, None
+    for k, g in g_ref.items():
+        if k in grads and float(g.abs().max()) > 1e-7:
+            e = float((grads[k].cpu().double() - g).abs().max() / g.abs().max())
+            if e > worst:
+                worst, worst_key = e, k
+    print(f"trained weights: max |logit| {scale_logit:.2f}; logit err eval {err_eval:.2e} train {err_train:.2e}; "
+          f"worst gradient {worst:.2e} of the tensor's largest entry ({worst_key})")
+    lb, gb = TRAINED_BOUNDS
+    assert err_train <= lb, err_train
+    assert bce == pytest.approx(bce_ref, rel=1e-5)
+    for k, g in g_ref.items():
+        if k in grads:
+            sc = max(1e-6, float(g.abs().max()))
+            assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), gb * sc + softmax_side_floor(k, g_ref, 1e-8),
+                                            f"{k} (trained weights)", kinks=kinks)
 
 
 def test_gate_layer_with_a_metanet_width_that_is_not_2d():
@@ -443,8 +386,8 @@ def test_adam_trajectory_step_by_step_against_the_oracle(name):
                 continue                                  # mathematically-zero gradient: rounding noise
             m, v = gopt["state"][k]["exp_avg"], gopt["state"][k]["exp_avg_sq"]
             # (1e-4 / 2e-4 of the largest element is where the fp32 kernels' own rounding sits for the cancellation-heavy
-            # tensors - the scenario embeddings: 128 numbers that sum every token of the batch; split products carry 2.7x that)
-            wide = 3.0 if split_products() else 1.0
+            # tensors - the scenario embeddings: 128 numbers that sum every token of the batch)
+            wide = 1.0
             np.testing.assert_allclose(m.numpy(), ref_m.numpy(), rtol=1e-5, atol=wide * 1e-4 * float(ref_m.abs().max()),
                                        err_msg=f"step {step} exp_avg/{k}")
             np.testing.assert_allclose(v.numpy(), ref_v.numpy(), rtol=1e-5, atol=wide * 2e-4 * float(ref_v.abs().max()),
@@ -454,9 +397,8 @@ def test_adam_trajectory_step_by_step_against_the_oracle(name):
             delta = (got[k] - leaf.detach()).abs()
             vhat = ref_v / (1 - 0.999 ** (step + 1))
             ok = vhat.sqrt() > 1e-4 * max(float(vhat.sqrt().max()), 1e-30)
-            # (split products: an element at 1e-4 of the largest gradient sees 2.6x the relative error: 4e-2 of a step)
             if bool(ok.any()):
-                bound = (4e-2 if split_products() else 2e-2) * lr
+                bound = 2e-2 * lr
                 assert float(delta[ok].max()) <= bound, (step, k, float(delta[ok].max()))
             assert float(delta.max()) <= 2.0 * lr + 1e-6, (step, k)
 
@@ -734,8 +676,8 @@ def test_training_mode_dropout_matches_oracle_with_same_masks():
 @pytest.mark.parametrize("name", ["small_qkv", "aliccp_sota"])
 def test_training_mode_gradients_match_oracle_with_same_masks(name):
     """Training-mode step (four dropout sites per layer on) against the oracle with the kernels' masks replayed.  `small_qkv` is
-    D = 16 (never on the split path); `aliccp_sota` is the headline shape (D = 32, U = 64, H = 4, F = 19, meta_mode QK): the fused
-    backward instantiation of the benchmark, in whichever product mode the library is in."""
+    D = 16; `aliccp_sota` is the headline shape (D = 32, U = 64, H = 4, F = 19, meta_mode QK): the fused backward instantiation
+    of the benchmark."""
     c = Case(name)
     model = build_model(c, DEV)
     model.compile("adam", "binary_crossentropy")
@@ -751,8 +693,7 @@ def test_training_mode_gradients_match_oracle_with_same_masks(name):
         if k not in grads:                           # alias keys of the oracle (K_/V_meta_mlp, domain_map_dnn_K/V)
             continue
         scale = max(1e-6, float(g.abs().max()))
-        # fp32 products: element by element.  Split products: the same bound but for ReLU kinks (assert_grad_close_but_for_kinks)
-        floor = softmax_side_floor(k, g_ref, 1e-9) if split_products() else 1e-9
+        floor = 1e-9
         assert_grad_close_but_for_kinks(grads[k].cpu().numpy(), g.numpy(), 5e-5 * scale + floor, k, kinks=kinks)
 
 
@@ -783,11 +724,7 @@ def test_fused_last_layer_and_head_equal_the_separate_calls(name, train, loss):
     for k in g0:
         sc = max(1e-6, float(g0[k].abs().max()))
         # MAE: d|p - t| / dp = sign(p - t) is discontinuous where p == t; no golden label sits there
-        # (opt-in split products: the fused launch exists with fp32 products only, the separate calls run the last layer's
-        #  forward AND backward on split products - two arithmetics for one layer, ~16 significant bits apart in every product, which
-        #  the loss derivative multiplies into every gradient: measured up to 6e-4 of a tensor's largest entry)
-        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=(2e-3 if split_products() else 2e-5) * sc + 1e-9,
-                                   err_msg=k)
+        np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0, atol=2e-5 * sc + 1e-9, err_msg=k)
 
 
 def test_kernel_timing_brackets_every_fused_launch_and_changes_no_bit():
@@ -814,7 +751,7 @@ def test_kernel_timing_brackets_every_fused_launch_and_changes_no_bit():
         kinds, ms = (C.c_int * 64)(), (C.c_float * 64)()
         n = lib.satrans_kernel_timing_read(kinds, ms, 64)
         if armed:
-            fused = bool(eng._ws[X.shape[0]]["fuse_head"])          # (SATRANS_FUSE_HEAD=0: three forwards, three plain backwards)
+            fused = bool(eng._ws[X.shape[0]]["fuse_head"])          # (fuse_head off: three forwards, three plain backwards)
             assert [kinds[i] for i in range(n)] == ([0, 0, 2, 1, 1] if fused else [0, 0, 0, 1, 1, 1]), [kinds[i] for i in range(n)]
             assert all(0.0 < ms[i] < 50.0 for i in range(n)), [ms[i] for i in range(n)]
             assert lib.satrans_kernel_timing_read(kinds, ms, 64) == 0      # read forgets
@@ -2228,35 +2165,34 @@ def test_fused_kernels_on_field_counts_without_a_golden_case(F, B):
 
 
 @pytest.mark.parametrize("train", [False, True])
-def test_saved_attention_backward_equals_the_recomputing_one(monkeypatch, train):
-    """Saved attention (the default; SATRANS_SAVE_ATTENTION=0 recomputes; include/satrans_hip.h: satrans_layer_desc.attn_save): the
+def test_saved_attention_backward_equals_the_recomputing_one(train):
+    """Saved attention (the default; engine.save_attention = False recomputes; include/satrans_hip.h: satrans_layer_desc.attn_save): the
     forward leaves softmax numerators, 1 / sum, dropout keep words and the attention output per sorted sample position, the
-    backward (fp32 or split products) copies them straight into LDS (global_load_lds) instead of running its attention-forward phase.  Same mathematics: every gradient
+    backward copies them straight into LDS (global_load_lds) instead of running its attention-forward phase.  Same mathematics: every gradient
     within rounding of the recomputing backward (the saved numerators come from the forward kernel's q / k, the recomputed
     ones from the backward's - equal up to the last bit), on the golden batch and on a ragged one that leaves partial tiles."""
     c = Case("aliccp_sota")
     outs = []
-    for save in ("0", "1"):
-        monkeypatch.setenv("SATRANS_SAVE_ATTENTION", save)
+    for save in (False, True):
         model = build_model(c, DEV)
         model.compile(torch.optim.Adam(model.parameters(), lr=c.meta["lr"]), "binary_crossentropy")
         model.train(train)
         eng = model._require_engine()
-        assert eng.save_attention == (save == "1")
+        eng.save_attention = save
         res = []
         for B in (c.X.shape[0], 37):
             bce, reg, grads = eng.loss_and_grads(c.X[:B].to(DEV), c.y[:B].to(DEV))
-            if save == "1":
-                assert eng._ws[B].get("attn_save"), "the saved-attention buffers were not allocated"
+            held = [t is not None for t in eng._ws[B]["attn_save"]]
+            # (the last layer runs with the head fused in: no forward launch, nothing saved for it)
+            assert held == ([True] * (eng.L - 1) + [False] if save else [False] * eng.L), held
             res.append((bce, {k: g.cpu() for k, g in grads.items()}))
         outs.append(res)
     for (bce0, g0), (bce1, g1) in zip(*outs):
         assert bce0 == pytest.approx(bce1, rel=1e-6)
         for k in g0:
             scale = max(1e-6, float(g0[k].abs().max()))
-            # (opt-in split products: the numerators' last-bit differences pass through products that carry ~16 significant bits)
             np.testing.assert_allclose(g1[k].numpy(), g0[k].numpy(), rtol=0,
-                                       atol=(5e-5 if split_products() else 2e-5) * scale + softmax_side_floor(k, g0, 1e-9),
+                                       atol=2e-5 * scale + softmax_side_floor(k, g0, 1e-9),
                                        err_msg=f"{k} train={train}")
 
 
@@ -2325,3 +2261,43 @@ def test_per_field_sort_equals_the_device_wide_sort(B):
                                                    status1.data_ptr(), st), "rows_sort_fields")
         assert torch.equal(got_rows_m, want_rows_m) and int(status1.item()) == int(status0.item()) == 1, dt
         assert torch.equal(out_r, ref_r) and torch.equal(out_s, ref_s), dt
+
+
+@pytest.mark.parametrize("W,n,vocab", [(1, 1000, 50), (2, 5, 3), (4, 70000, 1 << 20), (8, 65536, 400), (8, 65536, 1 << 22), (64, 3000, 97),
+                                       (3, 1, 5)])
+def test_merge_of_sorted_runs_equals_the_stable_sort(W, n, vocab):
+    """satrans_embed_merge_runs (the owner form's sort of what W ranks sent an owner: W sorted runs, ONE ranking launch) against
+    torch's stable sort and satrans_embed_sort of the same list: ascending rows, equal rows in position order (rank-major).  Empty
+    runs, runs of one element, heavy duplication across runs.  And satrans_embed_inverse_positions against index_put."""
+    import ctypes as C
+    from satrans_amd import native as N
+    lib = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(W * 1000 + n)
+    cuts = torch.sort(torch.randint(0, n + 1, (W - 1,), generator=g))[0].tolist() if W > 1 else []
+    starts = [0] + cuts + [n]
+    if W > 2:
+        starts[2] = starts[1]                                    # an empty run
+    ids = torch.randint(0, vocab, (n,), generator=g, dtype=torch.int64)
+    for q in range(W):
+        ids[starts[q]:starts[q + 1]] = torch.sort(ids[starts[q]:starts[q + 1]])[0]
+    ids_d = ids.to(torch.int32).to(DEV)
+    want_rows, want_src = torch.sort(ids, stable=True)
+    out_r, out_s = torch.full((n,), -1, dtype=torch.int32, device=DEV), torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    N.check(lib.satrans_embed_merge_runs(ids_d.data_ptr(), n, (C.c_int64 * (W + 1))(*starts), W, out_r.data_ptr(), out_s.data_ptr(), st),
+            "merge_runs")
+    assert torch.equal(out_r.cpu().long(), want_rows) and torch.equal(out_s.cpu().long(), want_src)
+    ws = torch.empty(int(lib.satrans_embed_sort_workspace_bytes(n, vocab)), dtype=torch.uint8, device=DEV)
+    ref_r, ref_s = torch.empty_like(out_r), torch.empty_like(out_s)
+    N.check(lib.satrans_embed_sort(ids_d.data_ptr(), n, vocab, ref_r.data_ptr(), ref_s.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                   None, st), "sort")
+    assert torch.equal(out_r, ref_r) and torch.equal(out_s, ref_s)
+    inv = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    N.check(lib.satrans_embed_inverse_positions(out_s.data_ptr(), n, inv.data_ptr(), st), "inverse_positions")
+    want_inv = torch.empty(n, dtype=torch.int64)
+    want_inv[want_src] = torch.arange(n)
+    assert torch.equal(inv.cpu().long(), want_inv)
+    # boundaries that do not cover the list are refused
+    bad = list(starts)
+    bad[-1] = n + 1
+    assert lib.satrans_embed_merge_runs(ids_d.data_ptr(), n, (C.c_int64 * (W + 1))(*bad), W, out_r.data_ptr(), out_s.data_ptr(), st) != 0

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-o=gpurun_out/r04z; mkdir -p $o
+o=gpurun_out/r05_final; mkdir -p $o
 python -m pytest tests -m gpu -q > $o/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $o/pytest.log
 python bench.py > $o/bench_default.json 2> $o/bench_default.err; echo "bench rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/ks -o p -- python3 bench.py --train-only --steps 25 --warmup 5 --no-phase-timing > $o/ks.log 2>&1
@@ -12,6 +12,5 @@ python tools/pmc_summary.py gpurun_out/pmc aliccp > $o/pmc_summary.json 2> $o/pm
 rm -rf gpurun_out/pmc
 python bench.py --config alimama --train-only > $o/bench_alimama.json 2>/dev/null
 SATRANS_FORCE_EXCHANGE=1 python bench.py --train-only > $o/bench_owner.json 2>/dev/null
-SATRANS_PRODUCTS=split python bench.py --train-only > $o/bench_split.json 2>/dev/null
 python tools/stamps.py > $o/stamps.txt 2>&1
 head -c 600 $o/bench_default.json

@@ -33,70 +33,91 @@ def run_owner(N, steps=12, warmup=4, B=8192):
     model.to("cuda:0"); model.device = "cuda:0"
     eng = model._require_engine()
     model.train()
-    X, y = bench.synth_batches((steps + warmup) * B, 100)
+    n_steps = steps + warmup
+    X, y = bench.synth_batches(n_steps * B, 100)
     Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
-    bounds = eng._owner_ranges(N)
+    parallel.world_size = lambda: N
+    parallel.rank = lambda: 0
+    parallel.exchange_enabled = lambda: True
+    parallel.prefetch_group = lambda: None
+    eng._owner_world = N                       # (no process group here: skip the first-step flush + group creation)
+    bounds = eng._owner_ranges(N, B)
     lo, hi = bounds[0], bounds[1]
-    others = []
+    others = [[] for _ in range(n_steps)]
     if N > 1:                                   # rows of the other ranks' batches that fall into slice 0, per step, rank-major
-        Xo, _ = bench.synth_batches((steps + warmup) * B * (N - 1), 777)
+        Xo, _ = bench.synth_batches(n_steps * B * (N - 1), 777)
         Xo = torch.from_numpy(Xo).cuda().long()
         big = eng.row_span[:, 0] >= eng.small_rows
         off = eng.row_span[big, 0][None, :]
-        rows_o = (Xo[:, eng.cols.long()[big]] + off).to(torch.int32).reshape(steps + warmup, N - 1, -1)
-        for i in range(steps + warmup):
-            per = []
+        rows_o = (Xo[:, eng.cols.long()[big]] + off).to(torch.int32).reshape(n_steps, N - 1, -1)
+        for i in range(n_steps):
             for r in range(N - 1):
                 v = rows_o[i, r]
-                v = torch.sort(v[(v >= lo) & (v < hi)])[0]
-                per.append(v)
-            others.append(per)
-    state = {"i": 0, "send": None}
+                others[i].append(torch.sort(v[(v >= lo) & (v < hi)])[0])
     arena = model.embedding_arena
-    parallel.world_size = lambda: N
-    parallel.rank = lambda: 0
-    parallel.exchange_enabled = lambda: N > 1
+    calls = {"ids": 0, "last_ids": None}
 
-    def gather_counts(c):
-        c = c.to(torch.int64).cpu()
-        out = torch.zeros(N, N, dtype=torch.int64)
-        out[0] = c
-        for r in range(1, N):
-            out[r, 0] = others[state["i"]][r - 1].numel()
-        return out
+    # the epoch plan (what `fit` builds with ONE all-gather per epoch): this rank's split sizes from its own batches, the other
+    # ranks' from the stand-in lists - with a plan the id exchange of step t + 1 is prefetched under step t
+    def fake_all_gather(out, inp):
+        out.zero_()
+        out[:inp.numel()] = inp
+        o = out.reshape(N, n_steps, N)
+        for i in range(n_steps):
+            for r in range(1, N):
+                o[r, i, 0] = others[i][r - 1].numel()
+    parallel._all_gather = fake_all_gather
+    eng.plan_owner_counts(Xd, None, B)
 
-    def all_to_all_rows(inp, send, recv, name):
+    def all_to_all_rows(inp, send, recv, name, out=None, group=None):
+        n_recv = int(sum(recv))
+        dst = out[:n_recv] if out is not None else torch.empty((n_recv,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
         if name == "all_to_all_row_ids_i32":            # my slice-0 segment + what the other ranks ask owner 0 for
-            state["ids"] = inp
-            return torch.cat([inp[:send[0]]] + others[state["i"]])
-        if name == "all_to_all_rows_f32":               # values for every id I asked for (the other owners' answers: an arena read)
-            return arena[state["ids"].long()]
-        n_recv = sum(recv)                              # gradient rows: mine for slice 0 + as many rows as the others send
-        reps = -(-n_recv // max(inp.shape[0], 1))
-        return inp.repeat(reps, 1)[:n_recv].contiguous()
+            k = calls["ids"]
+            calls["ids"] += 1
+            calls["last_ids"] = inp
+            dst.copy_(torch.cat([inp[:send[0]]] + others[k]))
+        elif name == "all_to_all_rows_f32":             # values for every id I asked for (the other owners' answers: an arena read)
+            torch.index_select(arena, 0, calls["cur_ids"].long(), out=dst)
+        else:                                           # gradient rows: mine for slice 0 + as many rows as the others send
+            reps = -(-n_recv // max(inp.shape[0], 1))
+            dst.copy_(inp.repeat(reps, 1)[:n_recv])
+        return dst
 
-    parallel.gather_counts, parallel.all_to_all_rows = gather_counts, all_to_all_rows
+    parallel.all_to_all_rows = all_to_all_rows
     parallel.all_reduce_flat = lambda flat: None
     parallel.broadcast_slice = lambda t, src: None
     parallel.all_reduce_scalars = lambda t: t
     eng.timers = None
+
+    def step(i):
+        n_s = B * eng.F_small
+        j = (i + 1) % n_steps
+        calls["cur_ids"] = None
+        ws = eng.train_workspace(B, 1, False)
+        # (the ids this rank asks for: the large-table part of its sorted rows - read when the values come back)
+        class _Late:
+            def long(self_):
+                return ws["sorted_rows"][n_s:].long()
+        calls["cur_ids"] = _Late()
+        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B], next_X=Xd[j * B:(j + 1) * B] if i + 1 < n_steps else None)
+
     for i in range(warmup):
-        state["i"] = i
-        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+        step(i)
     eng.flush_lazy(sync=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        state["i"] = i
-        eng.timers = {} if i == warmup + steps - 1 else None
-        eng.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
-    ph = eng.phase_ms()
+    for i in range(warmup, n_steps):
+        eng.timers = {} if i == n_steps - 2 else None
+        step(i)
+        if i == n_steps - 2:
+            ph = eng.phase_ms()
     eng.timers = None
     eng.flush_lazy(sync=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     print(f"owner form, N={N}: {ms:.3f} ms/step per rank (no communication; the slice flush of the {steps} steps included) -> "
-          f"{N * B / ms / 1e3:.2f} M samples/s if comm were free; phases of the last step: " +
+          f"{N * B / ms / 1e3:.2f} M samples/s if comm were free; phases of one step: " +
           ", ".join(f"{k} {v:.3f}" for k, v in ph.items()))
 
 
@@ -147,4 +168,4 @@ if __name__ == "__main__":
     if args and args[0] == "--mode":
         mode, args = args[1], args[2:]
     for n in ([int(a) for a in args] or [1, 2, 4, 8]):
-        (run_owner if mode == "owner" and n > 1 else run)(n)
+        (run_owner if mode == "owner" else run)(n)

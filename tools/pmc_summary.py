@@ -75,5 +75,5 @@ res = {k: out[k] for k in sorted(keep)}
 # provenance: the hash of the kernel SOURCES (two builds of the same sources give different .so bytes) and the bench config
 res["_source_sha256"] = native.source_hash()
 res["_config"] = sys.argv[2] if len(sys.argv) > 2 else "aliccp"
-res["_products"] = "split" if native.lib().satrans_get_product_mode() == 1 else "f32"   # (SATRANS_PRODUCTS of the profiled run = of this process)
+res["_products"] = "f32"
 print(json.dumps(res, indent=1))
