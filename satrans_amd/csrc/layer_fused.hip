@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             // SAVE: the normalised MetaNet rows and their 1 / std go to the backward of this step as well (it then skips the two W2
             // products and the LayerNorm statistics of its recomputation): [sorted position][field][role][D] behind the attention
             // state, then 1 / std [sorted position][field][role]
-            constexpr bool ZSAVE = SAVE;
+            constexpr bool ZSAVE = SAVE && MOD == 0;
             float zsave[KT][4];
             float* save_z = nullptr;
             float* save_r = nullptr;
@@ -545,7 +545,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     float* st_inv = take(ntask_max);                  // 1 / sum_j exp(s_ij - max_i)
     uint32_t* st_keep = (uint32_t*)take(ntask_max);   // bit j: attention-dropout keep flag of (i, j)   (F <= 32)
     float* sP = take(ntask_max * F);                  // exp(s_ij - max_i), the un-normalised softmax numerators
-    float* sDS = take(ntask_max * F);                 // dP_ij, then dS_ij (phases D, E)
+    // dP_ij, then dS_ij (phases D, E); SAVE: first the staging area of the tile's dy rows and saved attention outputs (2 T F D)
+    float* sDS = take(SAVE ? max(ntask_max * F, 2 * Tsamp * F * D) : ntask_max * F);
     // HEADF: head weights [F][D], the tile's token dots, per-sample dense terms / loss / dlogit, per-lane head-gradient sums
     float* s_wh = HEADF ? take(F * D + kHeadDenseMax) : nullptr;
     float* s_dot = HEADF ? take(64) : nullptr;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     float* s_fin = HEADF ? take(2 * 64) : nullptr;                       // kernel end: loss / dlogit sums per sample slot
     float* s_hw = HEADF ? take(kFusedBlock * 4 * KT) : nullptr;          // 4 KT floats per lane: dW_head of the lane's (field, features)
     float* s_hwd = HEADF ? take(64 * kHeadDenseMax) : nullptr;           // dW of the dense columns per sample slot
-    static_assert(!HEADF || (!SAVE && MOD == 0), "fused head: recomputing backward of a MetaNet layer");
+    static_assert(!HEADF || !SAVE, "fused head: the recomputing backward (the last layer has no forward launch to save anything)");
 
     const WorkRange wr = work_range(a.seg, a.S, Tsamp, gridDim.x, blockIdx.x);
     const bool idle = wr.g0 >= wr.g1;      // no tile for this workgroup: only its zero slab is due
@@ -602,7 +603,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // into LDS, issued at the top of the tile and complete by the end of phase A - instead of a recomputation
     const int HF = H * F;
     constexpr bool has_save = SAVE;
-    constexpr bool has_zsave = SAVE;                   // ... and the normalised MetaNet rows with their 1 / std
+    constexpr bool has_zsave = SAVE && MOD == 0;       // ... and the normalised MetaNet rows with their 1 / std
+    // the MetaNet's hidden rows relu(z0 W1) are computed where phase F needs them: always with the saved rows (phase A has no use
+    // for them then), and - recomputed, 2 x 32 more MFMAs per tile - in the one instantiation that otherwise spills 64 registers
+    // (separate Q / K tables with the head fused in: 192 accumulator registers)
+    constexpr bool rehidden = has_zsave || (HEADF && !SAME);
     const float* save_inv = a.attn_save + (size_t)a.B * F * HF;
     const float* save_keep = save_inv + (size_t)a.B * HF;
     const float* save_o = save_keep + (size_t)a.B * HF;
@@ -827,6 +832,17 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                        (token_keep_bits<KT>(key_o, f, D, g4, dc.thresh) << 16);
 
         STAMP(0);
+        // out = in x weight along the forward direction of an image; the MetaNet's hidden rows relu(in W1)
+        auto fwd_w2 = [&](float* img, const float (&in_)[UT][4], float (&out_)[KT][4]) {
+            chain<UT, KT, LD>(img + lo_d, in_, out_);
+        };
+        auto hidden = [&](float* img, const float (&in_)[KT][4], float (&out_)[UT][4]) {
+            chain<KT, UT, LU>(img + lo_u, in_, out_);
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out_[t][r] = fmaxf(out_[t][r], 0.f);
+        };
         // ================= phase A: forward chain ====================================================================
         if (has_tile) {
 #pragma unroll
@@ -834,22 +850,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[t][r] = x_next[t][r];
             float v[KT][4], q[KT][4], k[KT][4];
-            // out = in x weight along the forward direction of an image
-            auto fwd_w1 = [&](float* img, const float (&in_)[KT][4], float (&out_)[UT][4]) {
-                chain<KT, UT, LU>(img + lo_u, in_, out_);
-            };
-            auto fwd_w2 = [&](float* img, const float (&in_)[UT][4], float (&out_)[KT][4]) {
-                chain<UT, KT, LD>(img + lo_d, in_, out_);
-            };
             chain<KT, KT, LD>(wq + lo_d, x, q0);
             chain<KT, KT, LD>(wk + lo_d, x, k0);
             chain<KT, KT, LD>(wv + lo_d, x, v);
             if (mlp_q) {
-                fwd_w1(w1q, q0, hq);
-#pragma unroll
-                for (int t = 0; t < UT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hq[t][r] = fmaxf(hq[t][r], 0.f);
+                // (saved rows: the hidden rows are only needed by phase F, which computes them itself - 2 x 16 registers less to
+                //  carry through the attention phases)
+                if (!has_zsave) hidden(w1q, q0, hq);
                 if (has_zsave) {      // the forward of this step left the normalised rows: no W2 product, no statistics
 #pragma unroll
                     for (int t = 0; t < KT; ++t)
@@ -888,11 +895,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 }
             }
             if (mlp_k) {
-                fwd_w1(w1k, k0, hk);
-#pragma unroll
-                for (int t = 0; t < UT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hk[t][r] = fmaxf(hk[t][r], 0.f);
+                if (!has_zsave) hidden(w1k, k0, hk);
                 if (has_zsave) {
 #pragma unroll
                     for (int t = 0; t < KT; ++t)
@@ -1282,8 +1285,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
             auto metanet_bwd = [&](float (&gout)[KT][4], const float (&zh)[KT][4], float rstd, const float* gam,
                                    float (&ag)[KT][4], float (&ab)[KT][4], int kshift, float (&h)[UT][4],
-                                   const float (&in0)[KT][4], const float* w2T, const float* w1T,
+                                   const float (&in0)[KT][4], const float* w2T, const float* w1T, float* w1f,
                                    f32x4 (&acc_w1)[KT][UT], f32x4 (&acc_w2)[UT][KT]) {
+                if (rehidden) hidden(w1f, in0, h);                              // (phase A skipped it, or its copy was let go)
                 layer_norm_bwd<KT>(gout, zh, rstd, gam, g4, ag, ab);            // gout = dz
                 float dm[KT][4];
 #pragma unroll
@@ -1375,14 +1379,14 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     for (int r = 0; r < 4; ++r) gq[t][r] = back[t][r];
             }
             if (mlp_q)
-                metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, 0, hq, q0, w2qT, w1qT, acc_w1q, acc_w2q);
+                metanet_bwd(gq, zhq, rstd_q, lnq_g, agq, abq, 0, hq, q0, w2qT, w1qT, w1q, acc_w1q, acc_w2q);
             if (mlp_k) {
                 if constexpr (SHLN)   // one table and one LayerNorm: both roles add into the same accumulators
-                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agq, abq, 8, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agq, abq, 8, hk, k0, w2kT, w1kT, w1k, acc_w1q, acc_w2q);
                 else if constexpr (SAME)
-                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1q, acc_w2q);
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, w1k, acc_w1q, acc_w2q);
                 else
-                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, acc_w1k, acc_w2k);
+                    metanet_bwd(gk, zhk, rstd_k, lnk_g, agk, abk, 8, hk, k0, w2kT, w1kT, w1k, acc_w1k, acc_w2k);
             }
 
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
@@ -1823,7 +1827,9 @@ static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same
     const int64_t mlp = (int64_t)D * LU + (int64_t)U * LD;
     // (fused head: head weights, token dots, dense terms, final sums, per-lane and per-slot gradient sums - the kernel's take() calls)
     const int64_t hd = head ? r4((int64_t)F * D + kHeadDenseMax) + 64 + 64 + 128 + (int64_t)kFusedBlock * 4 * (D / 16) + 64 * kHeadDenseMax : 0;
-    return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + 2 * r4(tasks * F) + hd + 64;
+    // (the dS cache doubles as the staging area of the saved-attention hand-over: dy rows + attention outputs of a tile)
+    const int64_t ds = std::max<int64_t>(tasks * F, 2 * (int64_t)T * F * D);
+    return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + r4(tasks * F) + r4(ds) + hd + 64;
 }
 
 // MetaNet width the fused kernels are INSTANTIATED with for an embedding dim (U = 2 D; forward-only D = 64: 16).  With a MetaNet
@@ -1897,9 +1903,11 @@ extern "C" int satrans_layer_fwd_fused(const satrans_layer_desc* d, float* y, fl
     // D = 32: one 12-wave workgroup per CU (three waves per SIMD at <= 168 VGPRs, one copy of the weight images in LDS for
     // ten samples per tile) beats two 4-wave workgroups (two waves per SIMD) by 11 % (0.275 vs 0.309 ms per step)
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
-    if (mod && d->D == 32) return mod == 1 ? launch_fwd_w<32, 64, 4, 12, 1>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 2>(d, y, att, stream);
-    if (mod) return mod == 1 ? launch_fwd_w<16, 32, 2, kFusedWaves, 1>(d, y, att, stream) : launch_fwd_w<16, 32, 2, kFusedWaves, 2>(d, y, att, stream);
     const bool save = d->attn_save && d->D == 32 && d->F <= 32 && satrans_layer_attn_save_floats_fused(d) > 0;   // (as the backward decides)
+    if (mod && d->D == 32)
+        return mod == 1 ? (save ? launch_fwd_w<32, 64, 4, 12, 1, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 1>(d, y, att, stream))
+                        : (save ? launch_fwd_w<32, 64, 4, 12, 2, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12, 2>(d, y, att, stream));
+    if (mod) return mod == 1 ? launch_fwd_w<16, 32, 2, kFusedWaves, 1>(d, y, att, stream) : launch_fwd_w<16, 32, 2, kFusedWaves, 2>(d, y, att, stream);
     if (d->D == 32) return save ? launch_fwd_w<32, 64, 4, 12, 0, true>(d, y, att, stream) : launch_fwd_w<32, 64, 4, 12>(d, y, att, stream);
     if (d->D == 16) return launch_fwd<16, 32, 2>(d, y, att, stream);
     return launch_fwd<64, 16, 4>(d, y, att, stream);
@@ -1913,18 +1921,15 @@ extern "C" int satrans_layer_bwd_fused_supported(const satrans_layer_desc* d) {
 
 extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc* d) {
     FusedBwdPlan p;
-    // built for the (32, 64, 4) MetaNet shape with one shared table
+    // built for the (32, 64, 4) MetaNet shape, one generated-weight table for both roles or one each (flag 'pos')
     if (!d || !fused_bwd_plan(d, p)) return 0;
-    {
-        const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
-        if (!(d->D == 32 && d->U == 64 && same) || (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) ||
-            !(d->flags & (SATRANS_META_Q | SATRANS_META_K)))
-            return 0;
-    }
+    // (gate / bilinear: the attention state alone - they have no MetaNet rows; their layout reserves the slots all the same)
+    const bool alt = d->flags & (SATRANS_GATE | SATRANS_BILINEAR);
+    if (d->D != 32 || (!alt && (d->U != 64 || !(d->flags & (SATRANS_META_Q | SATRANS_META_K))))) return 0;
     const int64_t HF = (int64_t)d->H * d->F;
     // the forward saves from its register-resident score row (F <= 32), the backward copies the numerators 16 bytes at a time
-    // ... and stages the tile's dy and saved output rows in the dS cache (T H F F floats): H F >= 2 D
-    if (d->F > 32 || (d->F * HF) % 4 != 0 || HF < 2 * d->D) return 0;
+    // (and stages the tile's dy and saved output rows in the dS cache: fused_bwd_lds_floats sizes it for both uses)
+    if (d->F > 32 || (d->F * HF) % 4 != 0) return 0;
     // numerators [B][F][HF] | 1 / sum [B][HF] | keep words [B][HF] | attention output [B][F][D] | normalised MetaNet rows
     // [B][F][role][D] | their 1 / std [B][F][role]
     return (int64_t)d->B * (d->F * HF + 2 * HF + (int64_t)d->F * d->D + (int64_t)d->F * (2 * d->D + 2));
@@ -1973,7 +1978,13 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
     // the AliCCP field count as a compile-time constant: -11 % (0.868 -> 0.777 ms over three layers).  The same for the 16
     // fields of the Alimama `sota-pos` shape (separate Q / K tables) spills 34 VGPRs and gains nothing: not instantiated.
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
-    if (mod == 1)
+    const bool save = d->D == 32 && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0;
+    if (mod && save)
+        rc = mod == 1 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 1, true>(d, p, dy, dx, slabs, stream)
+                              : launch_bwd<32, 64, 4, false, false, 0, 1, true>(d, p, dy, dx, slabs, stream))
+                      : (same ? launch_bwd<32, 64, 4, true, false, 0, 2, true>(d, p, dy, dx, slabs, stream)
+                              : launch_bwd<32, 64, 4, false, false, 0, 2, true>(d, p, dy, dx, slabs, stream));
+    else if (mod == 1)
         rc = d->D == 32 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 1>(d, p, dy, dx, slabs, stream)
                                 : launch_bwd<32, 64, 4, false, false, 0, 1>(d, p, dy, dx, slabs, stream))
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 1>(d, p, dy, dx, slabs, stream)
@@ -1983,9 +1994,11 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
                                 : launch_bwd<32, 64, 4, false, false, 0, 2>(d, p, dy, dx, slabs, stream))
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
                                 : launch_bwd<16, 32, 2, false, false, 0, 2>(d, p, dy, dx, slabs, stream));
-    else if (d->D == 32 && same && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0)
-        rc = d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, true>(d, p, dy, dx, slabs, stream)
-                                   : launch_bwd<32, 64, 4, true, false, 0, 0, true>(d, p, dy, dx, slabs, stream);
+    else if (save)
+        rc = !same ? (d->F == 15 ? launch_bwd<32, 64, 4, false, false, 15, 0, true>(d, p, dy, dx, slabs, stream)
+                                 : launch_bwd<32, 64, 4, false, false, 0, 0, true>(d, p, dy, dx, slabs, stream))      // flag 'pos': one table per role
+             : d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, true>(d, p, dy, dx, slabs, stream)
+                                     : launch_bwd<32, 64, 4, true, false, 0, 0, true>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream)
@@ -2014,7 +2027,6 @@ extern "C" int satrans_head_reduce_partials(const float* partial, int nblk, int 
 extern "C" int satrans_layer_bwd_head_fused_supported(const satrans_layer_desc* d, const satrans_head_desc* h) {
     FusedBwdPlan p;
     if (!d || !h) return 0;
-    if (d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) return 0;
     if (!(d->D == 32 || d->D == 16)) return 0;
     if (h->n_dense < 0 || h->n_dense > kHeadDenseMax) return 0;
     return fused_bwd_plan(d, p, true) ? 1 : 0;
@@ -2047,11 +2059,23 @@ extern "C" int satrans_layer_bwd_head_launch_fused(const satrans_layer_desc* d, 
     const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
     constexpr bool f_const = true;
     int rc;
-    if (d->D == 32 && same && d->F == 19 && f_const)
+    const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
+    if (mod == 1)
+        rc = d->D == 32 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                                : launch_bwd<32, 64, 4, false, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd))
+                        : (same ? launch_bwd<16, 32, 2, true, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                                : launch_bwd<16, 32, 2, false, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd));
+    else if (mod == 2)
+        rc = d->D == 32 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 2, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                                : launch_bwd<32, 64, 4, false, false, 0, 2, false, true>(d, p, nullptr, dx, slabs, stream, &hd))
+                        : (same ? launch_bwd<16, 32, 2, true, false, 0, 2, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                                : launch_bwd<16, 32, 2, false, false, 0, 2, false, true>(d, p, nullptr, dx, slabs, stream, &hd));
+    else if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
     else if (d->D == 32)
         rc = same ? launch_bwd<32, 64, 4, true, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
-                  : launch_bwd<32, 64, 4, false, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+             : d->F == 15 ? launch_bwd<32, 64, 4, false, false, 15, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                          : launch_bwd<32, 64, 4, false, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
     else
         rc = same ? launch_bwd<16, 32, 2, true, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
                   : launch_bwd<16, 32, 2, false, false, 0, 0, false, true>(d, p, nullptr, dx, slabs, stream, &hd);

@@ -699,13 +699,14 @@ def test_training_mode_gradients_match_oracle_with_same_masks(name):
 
 @pytest.mark.parametrize("loss", ["binary_crossentropy", "mse", "mae"])
 @pytest.mark.parametrize("train", [False, True])
-@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_qkv", "small_pos_dense", "small_relu", "small_k"])
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos", "small_qkv", "small_pos_dense", "small_relu", "small_k", "small_gate",
+                                  "small_bilinear"])
 def test_fused_last_layer_and_head_equal_the_separate_calls(name, train, loss):
     """satrans_layer_bwd_head (last layer forward + head + loss + backward in one launch; the default of a training step) against
     satrans_layer_fwd + satrans_head_loss + satrans_layer_bwd on the same batch, weights and dropout counters: probabilities,
     loss and every gradient.  The two differ only in the order the logit's F x D terms are added (token dots summed per sample
     against a lane-strided sum), i.e. by fp32 rounding of the logit.  Covers dense columns (Alimama), D = 16, separate Q / K
-    tables ('pos'), ReLU output, one modulated role, and the three losses of compile()."""
+    tables ('pos'), ReLU output, one modulated role, flags gate / bilinear, and the three losses of compile()."""
     c = Case(name)
     out = []
     for fuse in (True, False):
@@ -1919,8 +1920,11 @@ def test_table_classes_on_one_rank_match_reference_golden(monkeypatch, lazy, sma
         assert float(err.max()) <= 2.0 * lr * steps + 1e-6, (k, float(err.max()))
 
 
-def test_size_independent_properties_at_the_baseline_batch():
-    """BASELINE configs[1] shape at the full batch (8192 x 19 fields, D=32, 3 layers, 4 heads, full-size tables), where
+@pytest.mark.parametrize("config", ["aliccp", "alimama"])
+def test_size_independent_properties_at_the_baseline_batch(config):
+    """BASELINE configs[1] shape at the full batch (8192 x 19 fields, D=32, 3 layers, 4 heads, full-size tables) and configs[3]
+    (Alimama shape: 15 sparse fields + a dense column, flag sota-pos - separate Q / K generated tables per layer, the
+    launch_bwd<32,64,4,false,...> instantiations with the saved-attention hand-over and the fused head), where
     the CPU oracle is too slow to be the checker: properties that hold at any size.
       * the gather is a copy: bit-exact against torch indexing of the arena;
       * a sample's output does not depend on its batch-mates (scenario bucketing, tiling, work distribution):
@@ -1929,11 +1933,12 @@ def test_size_independent_properties_at_the_baseline_batch():
         parameter, table and optimizer-visible quantity (dropout on)."""
     import bench
     B = 8192
-    X, y = bench.synth_batches(3 * B, 11)
+    cfg = bench.make_config(config)
+    X, y = bench.synth_batches(3 * B, 11, cfg=cfg)
     Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
 
     def fresh():
-        m = bench.build_model("cpu", 0.005)
+        m = bench.build_model("cpu", cfg["lr"], cfg=cfg)
         m.to(DEV)
         m.device = DEV
         return m
@@ -1943,8 +1948,9 @@ def test_size_independent_properties_at_the_baseline_batch():
     eng = m1._require_engine()
     p = m1(Xd[:B])
     # gather: layer input = arena rows
-    rows = (Xd[:B].long() + eng.row_span[:, 0][None, :])
+    rows = (Xd[:B, :len(cfg["fields"])].long() + eng.row_span[:, 0][None, :])
     assert torch.equal(eng.layer_outputs(B)[0], m1.embedding_arena[rows])
+    assert not eng._ws[B]["generic"], "the fused kernels were expected to take this shape"
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
     assert torch.equal(m1(Xd[:B][perm]), p[perm]), "a sample's output depends on the order of the batch"
     assert torch.equal(m1(Xd[:1000]), p[:1000]), "a sample's output depends on the batch size"
@@ -1954,6 +1960,8 @@ def test_size_independent_properties_at_the_baseline_batch():
         e = m._require_engine()
         for i in range(3):
             e.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+        assert e._ws[B]["fuse_head"] and all(t is not None for t in e._ws[B]["attn_save"][:-1]), \
+            "the step was expected to run the fused last layer and the saved-attention hand-over"
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         return sd, float(e.epoch_sums()[0])
 
@@ -2023,7 +2031,7 @@ def test_ragged_batches_gradients_match_the_oracle(name, B):
 
 
 def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=False, ref64=False, grad_tol=2e-4, kink_frac=0.0,
-                                    meta_mode='QK'):
+                                    meta_mode='QK', flag='sota'):
     from satrans_amd import SATrans, SparseFeat
     rng = np.random.RandomState(D + F)
     fields = [f"f{i}" for i in range(F)]
@@ -2032,7 +2040,7 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
     cols = [SparseFeat(f, vocabulary_size=vocab[f] + 1, embedding_dim=D) for f in fields]
     torch.manual_seed(3)
     model = SATrans(cols, cols, [fields[0]], [3], att_layer_num=0, domain_att_layer_num=L, att_head_num=H, use_linear=False,
-                    use_dnn=False, meta_mode=meta_mode, meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag='sota')
+                    use_dnn=False, meta_mode=meta_mode, meta_dnn_hidden_units=(U, D), seed='1021', device='cpu', flag=flag)
     with torch.no_grad():                                  # weights far enough from zero for every gradient to matter
         for k, p in model.named_parameters():
             if "embedding" in k:
@@ -2044,7 +2052,7 @@ def _synthetic_shape_against_oracle(D, H, U, F, generic, B=21, L=2, int_ids=Fals
     X = np.stack([rng.randint(1 if f == fields[0] else 0, vocab[f], size=B) for f in fields], axis=1).astype(np.float32)
     y = (rng.rand(B) < 0.4).astype(np.float32)
     spec = O.PathSpec(sparse=[(f, i) for i, f in enumerate(fields)], dense=[], domain_cols=[0], embedding_dim=D, head_num=H,
-                      layer_num=L, flag='sota', meta_mode=meta_mode, meta_units=[D, U, D])
+                      layer_num=L, flag=flag, meta_mode=meta_mode, meta_units=[D, U, D])
     Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
     Xg = Xt.long() if int_ids else Xt                     # the id matrix as the kernels get it (int64: SATRANS_ID_I64)
     if ref64:                                             # the oracle in fp64: the difference is then the kernels' rounding alone
@@ -2164,14 +2172,17 @@ def test_fused_kernels_on_field_counts_without_a_golden_case(F, B):
     _synthetic_shape_against_oracle(32, 4, 64, F, generic=False, B=B)
 
 
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
 @pytest.mark.parametrize("train", [False, True])
-def test_saved_attention_backward_equals_the_recomputing_one(train):
+def test_saved_attention_backward_equals_the_recomputing_one(train, name):
     """Saved attention (the default; engine.save_attention = False recomputes; include/satrans_hip.h: satrans_layer_desc.attn_save): the
     forward leaves softmax numerators, 1 / sum, dropout keep words and the attention output per sorted sample position, the
     backward copies them straight into LDS (global_load_lds) instead of running its attention-forward phase.  Same mathematics: every gradient
     within rounding of the recomputing backward (the saved numerators come from the forward kernel's q / k, the recomputed
-    ones from the backward's - equal up to the last bit), on the golden batch and on a ragged one that leaves partial tiles."""
-    c = Case("aliccp_sota")
+    ones from the backward's - equal up to the last bit), on the golden batch and on a ragged one that leaves partial tiles.
+    `alimama_sota_pos`: separate Q / K generated tables per layer (flag 'pos'), 15 fields (H F < 2 D: the staging area of the hand-over
+    is larger than the dS cache it shares LDS with)."""
+    c = Case(name)
     outs = []
     for save in (False, True):
         model = build_model(c, DEV)
@@ -2301,3 +2312,12 @@ def test_merge_of_sorted_runs_equals_the_stable_sort(W, n, vocab):
     bad = list(starts)
     bad[-1] = n + 1
     assert lib.satrans_embed_merge_runs(ids_d.data_ptr(), n, (C.c_int64 * (W + 1))(*bad), W, out_r.data_ptr(), out_s.data_ptr(), st) != 0
+
+
+@pytest.mark.parametrize("F", [15, 19, 32])
+@pytest.mark.parametrize("flag", ["sota-gate", "sota-bilinear", "sota-pos"])
+def test_fused_variants_at_embedding_dim_32_against_the_oracle(flag, F):
+    """flags gate / bilinear / pos at D = 32, H = 4 (the shape the fused kernels hand the attention state over at, and run the
+    last layer with the head fused in): logits and every gradient against the oracle, evaluation and training mode (masks
+    replayed).  The golden gate / bilinear cases are D = 16, which has neither."""
+    _synthetic_shape_against_oracle(32, 4, 64, F, generic=False, B=33, L=3, flag=flag)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.." || exit 1
 for round in $(seq 1 ${ROUNDS:-3}); do
   for lib in "" tools/experiments/_variants/lib_*.so; do
     [ -n "$lib" ] && [ ! -f "$lib" ] && continue
-    r=$(SATRANS_LIB_PATH=${lib:+$PWD/$lib} python bench.py --steps ${STEPS:-40} --warmup 5 --train-only 2>/dev/null | tail -1 | python -c "
+    r=$(SATRANS_LIB_PATH=${lib:+$PWD/$lib} python bench.py ${BENCH_ARGS:-} --steps ${STEPS:-40} --warmup 5 --train-only 2>/dev/null | tail -1 | python -c "
 import json,sys,os
 d=json.loads(sys.stdin.read()); k=d['kernels']
 names=os.environ.get('PHASES','layer_fwd,layer_bwd,layer_bwd_head,adam_touched,lazy_flush,lazy_replay,layer_bwd_reduce').split(',')
