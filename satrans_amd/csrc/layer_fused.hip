@@ -468,6 +468,24 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
         _Pragma("unroll 1") for (int VAR = 0; VAR < F; VAR += 4) BODY(VAR);                                      \
     }
 
+// The same loop as a two-stage software pipeline (field count a constant): the LDS reads of chunk c + 1 are issued before chunk c
+// is computed - at one wave per SIMD nothing else hides an LDS round trip (five chunks, two passes: ten of them per phase).
+#define ATTN_PIPE(BUFT, LOAD, COMP)                                                            \
+    {                                                                                          \
+        BUFT buf_a, buf_b;                                                                     \
+        LOAD(0, buf_a);                                                                        \
+        _Pragma("unroll") for (int c0_ = 0; c0_ < FT; c0_ += 8) {                              \
+            if (c0_ + 4 < FT) LOAD(c0_ + 4, buf_b);                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            COMP(c0_, buf_a);                                                                  \
+            if (c0_ + 4 < FT) {                                                                \
+                if (c0_ + 8 < FT) LOAD(c0_ + 8, buf_a);                                        \
+                __builtin_amdgcn_sched_barrier(0);                                             \
+                COMP(c0_ + 4, buf_b);                                                          \
+            }                                                                                  \
+        }                                                                                      \
+    }
+
 // FT: the field count as a constant (0 = a.F).  MOD: 0 MetaNet (or nothing), 1 flag 'gate', 2 flag 'bilinear'.
 // token-contraction products (weight gradients) with conflict-free operand reads
 #define WGRAD wgrad_r4
@@ -488,6 +506,11 @@ struct FusedHeadArgs {
     float *prob, *logit;       // [B]
     float* partial;            // [G][F D + n_dense + 2]: per-workgroup g_w | g_b | loss (rows of head_reduce_kernel)
 };
+#ifdef SATRANS_ATTN_PIPE
+constexpr bool kAttnPipe = true;
+#else
+constexpr bool kAttnPipe = false;
+#endif
 constexpr int kHeadDenseMax = 2;      // dense columns the fused head carries (Alimama: 1); more -> the separate head launches
 template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, bool SAVE = false, bool HEADF = false>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
@@ -1182,54 +1205,70 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const uint32_t keep = st_keep[task];
             const float scale = dc.scale;
             float dot = 0.f;
-            auto chunk3 = [&](const int j0) {
-                f32x2 vr[4][d / 2];
-                float pj[4], dp[4];
+            struct Rows3 { f32x2 vr[4][d / 2]; float pj[4]; };
+            auto load3 = [&](const int j0, Rows3& c) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
-                    pj[u] = prow[j * HF];
-                    load_row<d>(vbase + (size_t)j * LD, vr[u]);
+                    c.pj[u] = prow[j * HF];
+                    load_row<d>(vbase + (size_t)j * LD, c.vr[u]);
                 }
+            };
+            auto comp3 = [&](const int j0, Rows3& c) {
+                float dp[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + u;
-                    dp[u] = dot_row<d>(gi, vr[u]);
+                    dp[u] = dot_row<d>(gi, c.vr[u]);
                     dp[u] = ((keep >> (j & 31)) & 1u) ? dp[u] * scale : 0.f;
-                    pj[u] = j < F ? pj[u] * inv : 0.f;
-                    dot = fmaf(pj[u], dp[u], dot);
+                    const float pj = j < F ? c.pj[u] * inv : 0.f;
+                    dot = fmaf(pj, dp[u], dot);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (j0 + u < F) drow[j0 + u] = dp[u];
             };
-            ATTN_CHUNKS(j0, chunk3, true);
+            auto chunk3 = [&](const int j0) {
+                Rows3 c;
+                load3(j0, c);
+                comp3(j0, c);
+            };
+            if constexpr (kAttnPipe && FT != 0 && SAME) ATTN_PIPE(Rows3, load3, comp3)
+            else ATTN_CHUNKS(j0, chunk3, true);
             f32x2 dq[d / 2];
 #pragma unroll
             for (int e = 0; e < d / 2; ++e) dq[e] = f32x2{0.f, 0.f};
-            auto chunk4 = [&](const int j0) {
-                f32x2 kr[4][d / 2];
-                float pj[4], ds[4];
+            struct Rows4 { f32x2 kr[4][d / 2]; float pj[4], ds[4]; };
+            auto load4 = [&](const int j0, Rows4& c) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = min(j0 + u, F - 1);
-                    pj[u] = prow[j * HF];
-                    ds[u] = drow[j];
-                    load_row<d>(kbase + (size_t)j * LD, kr[u]);
+                    c.pj[u] = prow[j * HF];
+                    c.ds[u] = drow[j];
+                    load_row<d>(kbase + (size_t)j * LD, c.kr[u]);
                 }
+            };
+            auto comp4 = [&](const int j0, Rows4& c) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = j0 + u;
-                    pj[u] = j < F ? pj[u] * inv : 0.f;
-                    ds[u] = pj[u] * (ds[u] - dot) * inv_sqrt_d;
-                    pj[u] = ((keep >> (j & 31)) & 1u) ? pj[u] * scale : 0.f;
-                    axpy_row<d>(ds[u], kr[u], dq);
+                    c.pj[u] = j < F ? c.pj[u] * inv : 0.f;
+                    c.ds[u] = c.pj[u] * (c.ds[u] - dot) * inv_sqrt_d;
+                    c.pj[u] = ((keep >> (j & 31)) & 1u) ? c.pj[u] * scale : 0.f;
+                    axpy_row<d>(c.ds[u], c.kr[u], dq);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < F) { drow[j0 + u] = ds[u]; prow[(j0 + u) * HF] = pj[u]; }
+                    if (j0 + u < F) { drow[j0 + u] = c.ds[u]; prow[(j0 + u) * HF] = c.pj[u]; }
             };
-            ATTN_CHUNKS(j0, chunk4, true);
+            auto chunk4 = [&](const int j0) {
+                Rows4 c;
+                load4(j0, c);
+                comp4(j0, c);
+            };
+            // (pipelined: chunk c + 1 reads its own rows of the two caches, chunk c writes its own - disjoint)
+            if constexpr (kAttnPipe && FT != 0 && SAME) ATTN_PIPE(Rows4, load4, comp4)
+            else ATTN_CHUNKS(j0, chunk4, true);
             store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
         }
         lds_barrier();
@@ -1245,25 +1284,32 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float* gbase = so + (size_t)(tls * F) * LD + h * d;
             const float* dcol = sDS + (size_t)((tls * H + h) * F) * F + j;
             const float* pcol = sP + (size_t)tls * F * HF + (size_t)j * HF + h * F;      // the P of (query i, key j) at pcol[i]
-            auto chunk5 = [&](const int i0) {
-                f32x2 qr[4][d / 2], gr[4][d / 2];
-                float ds[4], pm[4];
+            struct Rows5 { f32x2 qr[4][d / 2], gr[4][d / 2]; float ds[4], pm[4]; };
+            auto load5 = [&](const int i0, Rows5& c) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int i = min(i0 + u, F - 1);
-                    ds[u] = dcol[(size_t)i * F];
-                    pm[u] = pcol[i];
-                    load_row<d>(qbase + (size_t)i * LD, qr[u]);
-                    load_row<d>(gbase + (size_t)i * LD, gr[u]);
+                    c.ds[u] = dcol[(size_t)i * F];
+                    c.pm[u] = pcol[i];
+                    load_row<d>(qbase + (size_t)i * LD, c.qr[u]);
+                    load_row<d>(gbase + (size_t)i * LD, c.gr[u]);
                 }
+            };
+            auto comp5 = [&](const int i0, Rows5& c) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const bool real = i0 + u < F;
-                    axpy_row<d>(real ? ds[u] : 0.f, qr[u], dk);
-                    axpy_row<d>(real ? pm[u] : 0.f, gr[u], dv);
+                    axpy_row<d>(real ? c.ds[u] : 0.f, c.qr[u], dk);
+                    axpy_row<d>(real ? c.pm[u] : 0.f, c.gr[u], dv);
                 }
             };
-            ATTN_CHUNKS(i0, chunk5, true);
+            auto chunk5 = [&](const int i0) {
+                Rows5 c;
+                load5(i0, c);
+                comp5(i0, c);
+            };
+            if constexpr (kAttnPipe && FT != 0 && SAME) ATTN_PIPE(Rows5, load5, comp5)
+            else ATTN_CHUNKS(i0, chunk5, true);
             store_row<d>(sk + (size_t)(tls * F + j) * LD + h * d, dk, 1.0f);
             store_row<d>(sv + (size_t)(tls * F + j) * LD + h * d, dv, 1.0f);
         }

@@ -1,3 +1,8 @@
+#!/bin/bash
+# The round's records, taken ONCE on the final sources: GPU test suite, default bench line, rocprofv3 kernel stats + one step's
+# timeline, PMC passes, the other configurations (Alimama / gate / bilinear / one rank through RCCL), the N-rank compute emulation,
+# phase stamps.  Output under gpurun_out/r05_final; copy what is to be kept into profiles/.
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 o=gpurun_out/r05_final; mkdir -p $o
 python -m pytest tests -m gpu -q > $o/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $o/pytest.log
@@ -11,6 +16,9 @@ bash tools/pmc_passes.sh > $o/pmc.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc aliccp > $o/pmc_summary.json 2> $o/pmc_summary.err
 rm -rf gpurun_out/pmc
 python bench.py --config alimama --train-only > $o/bench_alimama.json 2>/dev/null
+python bench.py --flag sota-gate --train-only > $o/bench_gate.json 2>/dev/null
+python bench.py --flag sota-bilinear --train-only > $o/bench_bilinear.json 2>/dev/null
 SATRANS_FORCE_EXCHANGE=1 python bench.py --train-only > $o/bench_owner.json 2>/dev/null
+python tools/fake_world.py 1 2 4 8 > $o/fake_world_owner.txt 2>/dev/null
 python tools/stamps.py > $o/stamps.txt 2>&1
 head -c 600 $o/bench_default.json

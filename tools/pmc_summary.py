@@ -25,7 +25,7 @@ def canonical(name):
     if not m:
         return short[:64], None
     args = [a.strip() for a in m.group(2).split(",")]
-    if m.group(1) == "layer_bwd_fused_kernel" and len(args) >= 10 and args[9] == "true":
+    if m.group(1) == "layer_bwd_fused_kernel" and len(args) >= 9 and args[8] == "true":
         return "layer_bwd_fused_kernel[head]", short
     return m.group(1), short
 
