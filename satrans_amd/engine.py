@@ -4,13 +4,15 @@ Owns the per-batch-size workspaces, launches the kernels through the C ABI (satr
 current HIP stream, and keeps the optimizer state.  PyTorch is used here for device memory, streams and the
 [S, P] scenario tables (a handful of tiny ops on S <= a few rows); every per-sample computation is a HIP kernel.
 
-Step anatomy (one training step, single GPU):
-    bucket scenarios -> gather rows -> L x layer_fwd -> head (+BCE, +dlogit) -> L x layer_bwd
-    -> scenario-table backward (tiny) -> sort gathered rows -> Adam on touched rows
-    -> streaming Adam on every other row (+ regulariser sum) -> flat Adam on the dense parameters
-With torch.distributed initialised (one process per GPU, RCCL), the dense gradients are all-reduced (SUM, the loss
-is a sum over samples) and the (row id, gradient row) pairs are all-gathered before the sort, so every rank
-applies the identical update in the identical order (satrans_amd/parallel.py).
+Step anatomy (one training step, one GPU):
+    launch stream   replay of the batch's postponed row updates -> scenario tables -> L-1 x layer_fwd (layer 0 reads its tokens
+                    from the arena: the gather fused in) -> last layer + head + loss + their backward (ONE launch) -> L-1 x
+                    layer_bwd -> touched-row Adam chain -> regulariser partial sums
+    tail stream     slab reduction of all layers -> scenario-table backward -> flat Adam -> next step's gradient clear
+    side stream     (lowest priority) the NEXT batch's ids -> rows + per-field sort, scenario bucketing
+With torch.distributed initialised (one process per GPU, RCCL) the step takes the row-ownership form (_train_step_owner, DESIGN.md
+6): ids to the rows' owners a step ahead on the side stream, current rows back in front of layer 0, gradient rows to the owners
+behind the last backward kernel, ONE all-reduce (SUM: the loss is a sum over samples) of the dense gradients on the tail stream.
 """
 from __future__ import annotations
 

@@ -6,11 +6,15 @@ The reference's only parallelism is an optional single-process `torch.nn.DataPar
 loss is a SUM over samples, gradients are summed onto one device.  The same semantics here, one exchange step
 per iteration:
 
-  * dense parameters (~0.15-0.28 M floats, latency-bound): ONE all_reduce(SUM) of the flat gradient buffer;
-  * embedding gradients: all_gather of the (arena row id int32, gradient row D x fp32) pairs each rank produced
-    (B*F pairs, ~10.6 MB at B=4096).  Every rank then sorts and applies the SAME merged list in the SAME order
-    (rank-major, then position), so the replicas stay bit-identical without ever moving a table-sized buffer.
-    The regulariser gradient 2*l2*p is identical on every rank and is added locally, after the exchange.
+  * dense parameters and the SMALL embedding tables (replicated on every rank): ONE all_reduce(SUM) of the flat gradient buffer
+    (2.8 MB at AliCCP size), the same dense step on every rank;
+  * LARGE embedding tables, row-ownership form (default): every rank owns a slice of the rows - values, Adam moments, the lazy
+    optimizer's bookkeeping - and three uneven all-to-alls per step move row ids to their owners (a step ahead, on a process group
+    of its own: `prefetch_group`), current rows back, gradient rows to the owners (`all_to_all_rows`; engine._train_step_owner);
+  * LARGE tables, replicated form (SATRANS_DP_MODE=replicated, round 2): all_gather of the (arena row id int32, gradient row
+    D x fp32) pairs each rank produced; every rank sorts and applies the SAME merged list in the SAME order (rank-major, then
+    position), so the replicas stay bit-identical without ever moving a table-sized buffer.
+The regulariser gradient 2*l2*p needs no exchange: it is a function of the row itself and is added where the row is stepped.
 """
 from __future__ import annotations
 
