@@ -236,7 +236,7 @@ LAYER_PHASES = ("layer_fwd_gather", "layer_fwd", "layer_bwd_head", "layer_bwd") 
 
 
 def read_dispatch_ms(lib):
-    """Mean duration of the fused layer kernels' dispatches since the last read (satrans_kernel_timing: HIP events that the
+    """Median duration of the fused layer kernels' dispatches since the last read (satrans_kernel_timing: HIP events that the
     dispatch packet itself signals with its begin / end timestamps - the kernel alone, on the stream it runs on): phase name -> ms.
     A step's launches arrive in order [layer 0 forward, other forwards ..., last layer + head, backward L-2 .. 0]."""
     import ctypes as C
@@ -248,7 +248,8 @@ def read_dispatch_ms(lib):
         name = {1: "layer_bwd", 2: "layer_bwd_head"}.get(k) or ("layer_fwd_gather" if prev != 0 else "layer_fwd")
         acc.setdefault(name, []).append(ms[i])
         prev = k
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    med = lambda v: sorted(v)[len(v) // 2] if len(v) % 2 else 0.5 * (sorted(v)[len(v) // 2 - 1] + sorted(v)[len(v) // 2])
+    return {k: med(v) for k, v in acc.items()}          # (median, as the recorded-event phases: engine.phase_ms)
 
 
 def launch_ranks(n: int) -> int:

@@ -246,9 +246,15 @@ class PathEngine:
         return PathEngine._Phase(self, name)
 
     def phase_ms(self) -> Dict[str, float]:
-        """Mean milliseconds per occurrence of every timed phase (synchronises)."""
+        """MEDIAN milliseconds per occurrence of every timed phase (synchronises).  The median, not the mean: a handful of samples
+        per phase, and one of them regularly catches a hiccup (a first-touch page fault, an allocator call) that says nothing
+        about the phase."""
         torch.cuda.synchronize(self.dev)
-        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in (self.timers or {}).items()}
+        out = {}
+        for k, v in (self.timers or {}).items():
+            ts = sorted(a.elapsed_time(b) for a, b in v)
+            out[k] = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+        return out
 
     def workspace(self, B: int) -> dict:
         ws = self._ws.get(B)

@@ -144,6 +144,12 @@ def prefetch_group():
     global _PREFETCH_GROUP
     if _PREFETCH_GROUP is None and dist.is_available() and dist.is_initialized():
         _PREFETCH_GROUP = dist.new_group()
+        if dist.get_backend() == "nccl" and torch.cuda.is_available():
+            # RCCL creates a communicator at the group's FIRST collective (a blocking rendezvous of all ranks): do that here, with
+            # nothing else in flight, rather than in the middle of a step beside the default group's collectives
+            warm = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(warm, group=_PREFETCH_GROUP)
+            torch.cuda.synchronize()
     return _PREFETCH_GROUP
 
 
