@@ -28,6 +28,20 @@ from . import native as N
 from .inputs import split_columns
 
 
+# The step's helper streams, ONE set per device for the whole process.  HIP maps every stream it creates onto one of
+# GPU_MAX_HW_QUEUES hardware queues in creation order, and streams that share a queue serialise: a second engine that created
+# streams of its own found them on the queues of the first one's - its every launch waited ~30 us behind packets that were not
+# its business (tools/fake_world.py with several rank counts in one process: every second run 30 % slower, whatever its N).
+_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _shared_stream(dev, kind: str, make):
+    key = (str(dev), kind)
+    if key not in _STREAMS:
+        _STREAMS[key] = make()
+    return _STREAMS[key]
+
+
 class PathEngine:
     def __init__(self, model):
         self.lib = N.lib()
@@ -944,7 +958,7 @@ class PathEngine:
         if side_tail and d_descs:
             main = torch.cuda.current_stream(self.dev)
             if self._side_tail is None:
-                self._side_tail = torch.cuda.Stream(self.dev)
+                self._side_tail = _shared_stream(self.dev, "tail", lambda: torch.cuda.Stream(self.dev))
             self._side_tail.wait_event(fork)
             with torch.cuda.stream(self._side_tail):
                 if clear_late and not precleared:
@@ -977,23 +991,19 @@ class PathEngine:
         created by libsatrans_hip.so - which is linked against the HIP runtime this process already uses - and wrapped for torch:
         when its kernels and the launch stream's become ready together, the launch stream's are dispatched first.  Lives as long
         as the engine (destroyed in __del__)."""
-        handle = C.c_void_p()
-        with torch.cuda.device(self.dev):
-            rc = self.lib.satrans_stream_create_low_priority(C.byref(handle))
-        if rc == 0 and handle.value:
-            self._low_prio_handle = handle.value
-            return torch.cuda.ExternalStream(handle.value, device=self.dev)
+        def make():
+            handle = C.c_void_p()
+            with torch.cuda.device(self.dev):
+                rc = self.lib.satrans_stream_create_low_priority(C.byref(handle))
+            if rc == 0 and handle.value:
+                return torch.cuda.ExternalStream(handle.value, device=self.dev)      # (lives as long as the process: _STREAMS)
+            return None
+        st = _shared_stream(self.dev, "low_priority", make)
+        if st is not None:
+            return st
         # no priorities on this device / runtime: an early fork would race the last backward kernel for the CUs - fork behind it
         self.prep_early = False
-        return torch.cuda.Stream(self.dev)
-
-    def __del__(self):
-        h, self._low_prio_handle = getattr(self, "_low_prio_handle", None), None
-        if h:
-            try:
-                self.lib.satrans_stream_destroy(C.c_void_p(h))
-            except Exception:
-                pass
+        return _shared_stream(self.dev, "side", lambda: torch.cuda.Stream(self.dev))
 
     def _prepare_async(self, X_next, ws_cur_B, fork=None, defer_bucket=False):
         """Everything of a step that depends on nothing but its id matrix - ids -> arena rows, the per-field sort of the rows,
@@ -1010,7 +1020,8 @@ class PathEngine:
         alt = ws["prep_alt"]
         main = torch.cuda.current_stream(self.dev)
         if self._side is None:
-            self._side = self._low_priority_stream() if self.prep_early else torch.cuda.Stream(self.dev)
+            self._side = self._low_priority_stream() if self.prep_early else \
+                _shared_stream(self.dev, "side", lambda: torch.cuda.Stream(self.dev))
         if fork is None:
             fork = torch.cuda.Event()
             fork.record(main)
@@ -1166,7 +1177,7 @@ class PathEngine:
             use_side = self.overlap
             if use_side:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(self.dev)
+                    self._side = _shared_stream(self.dev, "side", lambda: torch.cuda.Stream(self.dev))
                 ready = torch.cuda.Event()
                 ready.record(main)
                 self._side.wait_event(ready)
