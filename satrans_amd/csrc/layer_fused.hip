@@ -73,7 +73,9 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
     W.w1k = same_tab ? W.w1q : take(SZ_W1);
     W.w2k = same_tab ? W.w2q : take(SZ_W2);
     W.lnq_g = take(D); W.lnq_b = take(D); W.lnk_g = take(D); W.lnk_b = take(D); W.ln_g = take(D); W.ln_b = take(D);
-    const int rows = ((Tsamp * F + 15) >> 4) << 4;
+    // (+ 3: the attention phase reads keys in chunks of four without clamping the last chunk - rows past a sample's F-th belong to
+    //  the next sample or to the zero-initialised / stale tail of the buffer: finite values that meet a weight of exactly 0)
+    const int rows = ((Tsamp * F + 3 + 15) >> 4) << 4;
     float* sq = take(rows * LD);
     float* sk = take(rows * LD);
     float* sv = take(rows * LD);
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
         if (mlp_q) { W.lnq_g[i] = a.lnq_g[i]; W.lnq_b[i] = a.lnq_b[i]; }
         if (mlp_k) { W.lnk_g[i] = a.lnk_g[i]; W.lnk_b[i] = a.lnk_b[i]; }
     }
+    for (int i = threadIdx.x; i < 3 * rows * LD; i += blockDim.x) sq[i] = 0.f;      // (q, k, v rows: finite from the start, see `rows`)
 
     const int wl = n;  // per-lane offset inside an image: row 4g, column n
     const float* wq_l = W.wq + g4 * LD + wl;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 if (4 * c < F) {
                     f32x2 kr[4][d / 2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) load_row<d>(kbase + (size_t)min(4 * c + u, F - 1) * LD, kr[u]);
+                    for (int u = 0; u < 4; ++u) load_row<d>(kbase + (size_t)(4 * c + u) * LD, kr[u]);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float s_ = 4 * c + u < F ? dot_row<d>(qi, kr[u]) * sc_scale : -INFINITY;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 if (4 * c < F) {
                     f32x2 vr[4][d / 2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) load_row<d>(vbase + (size_t)min(4 * c + u, F - 1) * LD, vr[u]);
+                    for (int u = 0; u < 4; ++u) load_row<d>(vbase + (size_t)(4 * c + u) * LD, vr[u]);
                     const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)c, dc.thresh) : 0xFu;
                     keepw &= ~((~kb & 0xFu) << (4 * c));
 #pragma unroll
@@ -1809,7 +1812,7 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_all_kernel(ReduceLayers
 
 static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
-    const int64_t rows = (((int64_t)T * F + 15) / 16) * 16;
+    const int64_t rows = (((int64_t)T * F + 3 + 15) / 16) * 16;      // (as the kernel: three rows of slack behind the last sample)
     const int64_t dd = (int64_t)D * LD;
     const int64_t mlp = (int64_t)D * LU + (int64_t)U * LD;
     return 4 * dd + (same_tab ? 1 : 2) * mlp + 6 * D + 4 * rows * LD + 64;
