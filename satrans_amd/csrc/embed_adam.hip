@@ -171,6 +171,85 @@ __global__ void mark_heads_kernel(const int32_t* __restrict__ sorted_rows, int64
     atomicOr(&touched[r >> 5], 1u << (r & 31));
 }
 
+// Second level: a run that crosses chunk boundaries is the ordered sum  trail(c0) + lead(c0+1) + ... + lead(c1).
+// One lane group per SUPERCHUNK of kSuper chunks walks its chunks once: runs that end inside the superchunk take their
+// optimizer step in the finish body; what crosses a superchunk boundary leaves a record of the same shape one level up (lead/trail
+// partial sums, flags as for chunks), which the spans body finishes.  A row gathered by every sample of every
+// rank (small-vocabulary fields: runs of tens of thousands of positions) thus costs kSuper + run/(kChunk*kSuper)
+// dependent steps instead of run/kChunk.
+// The walk runs at the tail of the chunk kernel wherever a workgroup's 256 / LPR chunks are whole superchunks (D <= 64: the
+// records it reads were written by the same workgroup, one barrier earlier) - one dependent launch less in the chain - and as
+// its own launch otherwise (D = 128).  (No __restrict__ here: in the fused form these are the arrays the chunk phase wrote.)
+constexpr int kSuper = 16;
+template <int LPR>
+__device__ __forceinline__ void touched_super_body(int64_t group, int q, int64_t chunks, const float4* partial, const int32_t* info,
+                                                   const int32_t* trail_row, float4* partial2, int32_t* info2, int32_t* trail_row2,
+                                                   float4* done_sum, int32_t* done_row) {
+    const int64_t c0 = group * kSuper;
+    if (c0 < chunks) {
+        const int64_t c1 = min(chunks, c0 + (int64_t)kSuper);
+        // flags and lead partials of all chunks first (independent loads, issued together; a lead slot that was not written
+        // this step holds stale numbers, which are read but never used)
+        int f[kSuper];
+        float4 lead[kSuper];
+#pragma unroll
+        for (int u = 0; u < kSuper; ++u) f[u] = c0 + u < c1 ? info[c0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kSuper; ++u)
+            lead[u] = c0 + u < c1 ? partial[((c0 + u) * 2 + 0) * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool open = f[0] & 2, is_lead = open;
+        int flags2 = open ? 2 : 0;
+        int32_t row = -1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kSuper; ++u) {
+            const int64_t c = c0 + u;
+            int32_t ended = -1;
+            if (f[u] & 2) {
+                const float4 g = lead[u];
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+                if (f[u] & 4) {
+                    if (is_lead) {
+                        partial2[(group * 2 + 0) * LPR + q] = acc;
+                        flags2 |= 4;
+                    } else {            // a run that ended in chunk c: its step is taken by the parallel finish body
+                        done_sum[c * LPR + q] = acc;
+                        ended = row;
+                    }
+                    open = false;
+                    is_lead = false;
+                }
+            }
+            if (f[u] & 1) {
+                acc = partial[(c * 2 + 1) * LPR + q];
+                row = trail_row[c];
+                open = true;
+                is_lead = false;
+            }
+            if (q == 0 && c < c1) done_row[c] = ended;
+        }
+        if (open) {
+            if (is_lead) {
+                partial2[(group * 2 + 0) * LPR + q] = acc;
+            } else {
+                partial2[(group * 2 + 1) * LPR + q] = acc;
+                flags2 |= 1;
+                if (q == 0) trail_row2[group] = row;
+            }
+        }
+        if (q == 0) info2[group] = flags2;
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void touched_super_kernel(int64_t chunks, const float4* partial, const int32_t* info,
+                                                           const int32_t* trail_row, float4* partial2, int32_t* info2,
+                                                           int32_t* trail_row2, float4* done_sum, int32_t* done_row) {
+    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
+    touched_super_body<LPR>(((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR, threadIdx.x % LPR, chunks, partial, info, trail_row, partial2,
+                            info2, trail_row2, done_sum, done_row);
+}
+
 // Per-chunk bookkeeping for segments that cross chunk boundaries.
 //   info bit0: the chunk's LAST piece starts here and continues into the next chunk (a "trail" piece)
 //   info bit1: the chunk's FIRST piece continues a segment from the previous chunk (a "lead" piece)
@@ -180,9 +259,11 @@ template <int LPR>
 __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict__ P, float4* __restrict__ M,
                                                             float4* __restrict__ V, const int32_t* __restrict__ sorted_rows,
                                                             const int32_t* __restrict__ src, int64_t n,
-                                                            const float4* __restrict__ gemb, float4* __restrict__ partial,
-                                                            int32_t* __restrict__ info, int32_t* __restrict__ trail_row,
-                                                            float4* __restrict__ rowsum, int32_t* __restrict__ head_of) {
+                                                            const float4* __restrict__ gemb, float4* partial,
+                                                            int32_t* info, int32_t* trail_row,
+                                                            float4* __restrict__ rowsum, int32_t* __restrict__ head_of,
+                                                            float4* partial2, int32_t* info2, int32_t* trail_row2,
+                                                            float4* done_sum, int32_t* done_row) {
     __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
     const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
     const int q = threadIdx.x % LPR;
@@ -245,6 +326,15 @@ __global__ __launch_bounds__(256) void touched_chunks_kernel(float4* __restrict_
         flush(next_row != cur);
         if (q == 0) info[group] = flags;
     }
+    // the superchunk walk over this workgroup's own chunk records (see touched_super_body)
+    constexpr int kGroups = 256 / LPR;
+    if constexpr (kGroups % kSuper == 0) {
+        __syncthreads();
+        const int sg = threadIdx.x / LPR;
+        if (sg < kGroups / kSuper)
+            touched_super_body<LPR>((int64_t)blockIdx.x * (kGroups / kSuper) + sg, q, (n + kChunk - 1) / kChunk, partial, info, trail_row,
+                                    partial2, info2, trail_row2, done_sum, done_row);
+    }
 }
 
 // Adam on every row whose run was complete inside one chunk: one lane group per sorted position.
@@ -276,80 +366,6 @@ __device__ __forceinline__ void touched_apply_body(int64_t bid, double* s_red, f
     }
     const double total = block_sum(reg, s_red);
     if (threadIdx.x == 0) reg_partials[bid] = total;
-}
-
-// Second level: a run that crosses chunk boundaries is the ordered sum  trail(c0) + lead(c0+1) + ... + lead(c1).
-// One lane group per SUPERCHUNK of kSuper chunks walks its chunks once: runs that end inside the superchunk take their
-// optimizer step here; what crosses a superchunk boundary leaves a record of the same shape one level up (lead/trail
-// partial sums, flags as for chunks), which the spans kernel below finishes.  A row gathered by every sample of every
-// rank (small-vocabulary fields: runs of tens of thousands of positions) thus costs kSuper + run/(kChunk*kSuper)
-// dependent steps instead of run/kChunk.
-constexpr int kSuper = 16;
-template <int LPR>
-__global__ __launch_bounds__(256) void touched_super_kernel(int64_t chunks,
-                                                           const float4* __restrict__ partial,
-                                                           const int32_t* __restrict__ info,
-                                                           const int32_t* __restrict__ trail_row,
-                                                           float4* __restrict__ partial2, int32_t* __restrict__ info2,
-                                                           int32_t* __restrict__ trail_row2,
-                                                           float4* __restrict__ done_sum, int32_t* __restrict__ done_row) {
-    __builtin_amdgcn_s_setprio(3);      // (ahead of the side stream's next-batch kernels when they share a SIMD: 71 -> 62 us for the touched-row chain)
-    const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
-    const int q = threadIdx.x % LPR;
-    const int64_t c0 = group * kSuper;
-    if (c0 < chunks) {
-        const int64_t c1 = min(chunks, c0 + (int64_t)kSuper);
-        // flags and lead partials of all chunks first (independent loads, issued together; a lead slot that was not written
-        // this step holds stale numbers, which are read but never used)
-        int f[kSuper];
-        float4 lead[kSuper];
-#pragma unroll
-        for (int u = 0; u < kSuper; ++u) f[u] = c0 + u < c1 ? info[c0 + u] : 0;
-#pragma unroll
-        for (int u = 0; u < kSuper; ++u)
-            lead[u] = c0 + u < c1 ? partial[((c0 + u) * 2 + 0) * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        bool open = f[0] & 2, is_lead = open;
-        int flags2 = open ? 2 : 0;
-        int32_t row = -1;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < kSuper; ++u) {
-            const int64_t c = c0 + u;
-            int32_t ended = -1;
-            if (f[u] & 2) {
-                const float4 g = lead[u];
-                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-                if (f[u] & 4) {
-                    if (is_lead) {
-                        partial2[(group * 2 + 0) * LPR + q] = acc;
-                        flags2 |= 4;
-                    } else {            // a run that ended in chunk c: its step is taken by the parallel finish kernel
-                        done_sum[c * LPR + q] = acc;
-                        ended = row;
-                    }
-                    open = false;
-                    is_lead = false;
-                }
-            }
-            if (f[u] & 1) {
-                acc = partial[(c * 2 + 1) * LPR + q];
-                row = trail_row[c];
-                open = true;
-                is_lead = false;
-            }
-            if (q == 0 && c < c1) done_row[c] = ended;
-        }
-        if (open) {
-            if (is_lead) {
-                partial2[(group * 2 + 0) * LPR + q] = acc;
-            } else {
-                partial2[(group * 2 + 1) * LPR + q] = acc;
-                flags2 |= 1;
-                if (q == 0) trail_row2[group] = row;
-            }
-        }
-        if (q == 0) info2[group] = flags2;
-    }
 }
 
 // the runs the superchunk kernel finished, one lane group per chunk (at most one run ends in a chunk that began in an earlier one)
@@ -1139,10 +1155,6 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
     off = (off + 3) & ~(int64_t)3;                     // keep the run sums 16-byte aligned
     float4* rowsum = (float4*)(partial_ws + off);
     int32_t* head_of = (int32_t*)(partial_ws + off + n * D);
-    DISPATCH_LPR(D, (touched_chunks_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
-                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, src, n, (const float4*)gemb, partial, info,
-                        trail_row, rowsum, head_of)));
-    SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
     const int64_t supers = ceil_div(chunks, kSuper);
     int64_t off2 = off + n * D + n;
     off2 = (off2 + 3) & ~(int64_t)3;
@@ -1155,9 +1167,15 @@ static int run_touched(float* arena, float* m, float* v, int D, const int32_t* s
     float4* done_sum = (float4*)(partial_ws + off3);
     int32_t* done_row = (int32_t*)(partial_ws + off3 + chunks * D);
     double* reg_c = reg_b + cblocks;
-    DISPATCH_LPR(D, (touched_super_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
-                        chunks, (const float4*)partial, info, trail_row, partial2, info2, trail_row2, done_sum, done_row)));
-    SATRANS_CHECK_LAUNCH("touched_super_kernel");
+    DISPATCH_LPR(D, (touched_chunks_kernel<LPR><<<(unsigned)cblocks, 256, 0, stream>>>(
+                        (float4*)arena, (float4*)m, (float4*)v, sorted_rows, src, n, (const float4*)gemb, partial, info,
+                        trail_row, rowsum, head_of, partial2, info2, trail_row2, done_sum, done_row)));
+    SATRANS_CHECK_LAUNCH("touched_chunks_kernel");
+    if ((256 / (D / 4)) % kSuper != 0) {      // (D = 128: a workgroup holds half a superchunk)
+        DISPATCH_LPR(D, (touched_super_kernel<LPR><<<(unsigned)sblocks, 256, 0, stream>>>(
+                            chunks, (const float4*)partial, info, trail_row, partial2, info2, trail_row2, done_sum, done_row)));
+        SATRANS_CHECK_LAUNCH("touched_super_kernel");
+    }
     DISPATCH_LPR(D, (touched_step_kernel<LPR><<<(unsigned)(sblocks + cblocks + blocks), 256, 0, stream>>>(
                         sblocks, cblocks, (float4*)arena, (float4*)m, (float4*)v, k, (float4*)G, last, t, sorted_rows, n,
                         (const float4*)rowsum, head_of, reg_a, chunks, (const float4*)done_sum, done_row, reg_b, supers,
