@@ -483,7 +483,9 @@ int satrans_embed_lazy_mark(const int32_t* sorted_rows, int64_t n, int32_t* last
  * square root and the division written out as correctly rounded fma sequences (embed_adam.hip); this call counts the results
  * that differ from the IEEE operations: mode 0 = square root over the floats with bit patterns [first, first + count),
  * restricted to the operand range of the packed path; mode 1 = division over `count` pseudo-random pairs (seed `first`) of that
- * range.  *mismatches is HOST memory.  Used by tests/test_gpu_parity.py (every float of the range for mode 0). */
+ * range; mode 2 / 3 = the same two operations BELOW that range through their exact power-of-two scaling (every positive float
+ * under 2^-100, subnormals included; numerators from the smallest subnormal to 2^-80 and signed zeros).  *mismatches is HOST
+ * memory.  Used by tests/test_gpu_parity.py (every float of the range for modes 0 and 2). */
 int satrans_debug_check_packed_math(int mode, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream);
 
 /* Dense materialisation of the embedding gradient (debug / parity tests only):

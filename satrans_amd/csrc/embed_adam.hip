@@ -573,6 +573,36 @@ __device__ __forceinline__ f32x2 pk_div_rn(f32x2 a, f32x2 b) {
     return pk_fma(d, r, q);
 }
 
+// ---- the same two operations below the packed range -------------------------------------------------------------------------
+// A row nobody gathers decays under the regulariser: |p| and exp_avg fall by a decade every ~60 steps, leave the packed range
+// after ~500 steps, pass through the subnormals and end at zero, exp_avg_sq follows over tens of thousands of steps.  These are
+// most rows of a long run, and the scalar path costs them 2-3x (measured: the flush of 6.57 M rows went from 9.4 to 15 ms once
+// 69 % of the elements had left the range).  Powers of two bring such operands into the packed range and the results back
+// exactly:
+//   sqrt: v in [2^-149, 2^-100) times 2^64 is in [2^-85, 2^-36); the root comes back by 2^-32 and is never subnormal;
+//   a / den: |a| in [2^-149, 2^-80) times 2^69 is in [2^-80, 2^-11); the quotient comes back by 2^-69, exactly as long as it is
+//   normal (scaled quotient >= 2^-57) - otherwise `redo` asks the caller for the IEEE division of that element;
+//   a = +-0 over a positive denominator is a itself (the sequence would return +0 for -0).
+__device__ __forceinline__ f32x2 pk_sqrt_ext(f32x2 v) {
+    const bool sx = v.x < kPkVLo, sy = v.y < kPkVLo;
+    const f32x2 up = {sx ? 0x1p64f : 1.0f, sy ? 0x1p64f : 1.0f};
+    const f32x2 dn = {sx ? 0x1p-32f : 1.0f, sy ? 0x1p-32f : 1.0f};
+    return pk_mul(pk_sqrt_rn(pk_mul(v, up)), dn);
+}
+
+__device__ __forceinline__ f32x2 pk_div_ext(f32x2 a, f32x2 den, bool& redo_x, bool& redo_y) {
+    const bool sx = fabsf(a.x) < kPkALo, sy = fabsf(a.y) < kPkALo;
+    const f32x2 up = {sx ? 0x1p69f : 1.0f, sy ? 0x1p69f : 1.0f};
+    const f32x2 dn = {sx ? 0x1p-69f : 1.0f, sy ? 0x1p-69f : 1.0f};
+    const f32x2 qs = pk_div_rn(pk_mul(a, up), den);
+    f32x2 q = pk_mul(qs, dn);
+    redo_x = sx && a.x != 0.f && !(fabsf(qs.x) >= 0x1p-57f);
+    redo_y = sy && a.y != 0.f && !(fabsf(qs.y) >= 0x1p-57f);
+    q.x = a.x == 0.f ? a.x : q.x;
+    q.y = a.y == 0.f ? a.y : q.y;
+    return q;
+}
+
 // sqrt(v) / bc2_sqrt + eps of adam_core for one element (the division by the per-step constant, see there)
 __device__ __forceinline__ float denom_of(float root, double rbc2, float eps) {
     return __fadd_rn((float)__dmul_rn((double)root, rbc2), eps);
@@ -596,19 +626,76 @@ __device__ __forceinline__ void adam_step4(f32x2 (&p)[2], f32x2 (&m)[2], f32x2 (
     const float amax = fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(a[0].x), fabsf(a[0].y)), fabsf(a[1].x)), fabsf(a[1].y));
     // NaNs drop out of min / max, and a NaN operand gives NaN on either path
     const bool packed = vmin >= kPkVLo && vmax <= kPkVHi && amin >= kPkALo && amax <= kPkAHi && k.eps >= kPkEpsLo;
-    if (packed) {
+    // The path is chosen per WAVE (a vote), so that a wave runs one of them:
+    //  1. the packed sequences when every element of every lane is inside their range (196 ns per step and SIMD);
+    //  2. the same with ONE power of two per lane on the numerators (a row decays as a whole: its four elements of a lane are
+    //     scaled by 2^69 together when the largest is below 2^-60) and zero numerators passed through - rows that are decaying
+    //     or have decayed to zero, mixed with live ones (~1.2x);
+    //  3. the element-wise scaling of pk_sqrt_ext / pk_div_ext when every element is at least inside the extended range (second
+    //     moments down to the smallest subnormal, lanes whose elements are far apart) (~1.5x);
+    //  4. adam_core's IEEE operations otherwise (huge values, NaN, a zero second moment under a non-zero numerator, a tiny eps).
+    if (__all(packed)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const f32x2 root = pk_sqrt_rn(v[u]);
             const f32x2 den = {denom_of(root.x, rbc2, k.eps), denom_of(root.y, rbc2, k.eps)};
             p[u] = pk_add(p[u], pk_div_rn(a[u], den));
         }
-    } else {
+        return;
+    }
+    // (0. a wave of rows that have decayed to zero: p + (+-0) is all there is to compute)
+    if (__all(a[0].x == 0.f && a[0].y == 0.f && a[1].x == 0.f && a[1].y == 0.f)) {
+        p[0] = pk_add(p[0], a[0]);
+        p[1] = pk_add(p[1], a[1]);
+        return;
+    }
+    const bool lane_small = amax < 0x1p-60f;
+    auto lane_ok = [&](float a_) { return lane_small || a_ == 0.f || fabsf(a_) >= kPkALo; };
+    const bool by_lane = vmin >= kPkVLo && vmax <= kPkVHi && amax <= kPkAHi && k.eps >= kPkEpsLo && lane_ok(a[0].x) &&
+                         lane_ok(a[0].y) && lane_ok(a[1].x) && lane_ok(a[1].y);
+    if (__all(by_lane)) {
+        const f32x2 up = pk_set(lane_small ? 0x1p69f : 1.0f), dn = pk_set(lane_small ? 0x1p-69f : 1.0f);
+        f32x2 q[2], den[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            p[u].x = __fadd_rn(p[u].x, __fdiv_rn(a[u].x, denom_of(sqrtf(v[u].x), rbc2, k.eps)));
-            p[u].y = __fadd_rn(p[u].y, __fdiv_rn(a[u].y, denom_of(sqrtf(v[u].y), rbc2, k.eps)));
+            const f32x2 root = pk_sqrt_rn(v[u]);
+            den[u] = f32x2{denom_of(root.x, rbc2, k.eps), denom_of(root.y, rbc2, k.eps)};
+            q[u] = pk_mul(pk_div_rn(pk_mul(a[u], up), den[u]), dn);
         }
+        // the way back is exact while the quotient is normal: scaled numerators are >= 2^-80, so denominators up to 2^-23
+        // (eps + a small root: the decayed rows) are safe; a scaled lane with a larger one divides in IEEE
+        if (lane_small && fmaxf(fmaxf(den[0].x, den[0].y), fmaxf(den[1].x, den[1].y)) > 0x1p-23f) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) q[u] = f32x2{__fdiv_rn(a[u].x, den[u].x), __fdiv_rn(a[u].y, den[u].y)};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            q[u].x = a[u].x == 0.f ? a[u].x : q[u].x;        // (+-0 over a positive denominator is itself; the sequence returns +0)
+            q[u].y = a[u].y == 0.f ? a[u].y : q[u].y;
+            p[u] = pk_add(p[u], q[u]);
+        }
+        return;
+    }
+    auto ext_ok = [&](float a_, float v_) { return a_ == 0.f || (fabsf(a_) <= kPkAHi && v_ > 0.f && v_ <= kPkVHi); };
+    const bool extended = ext_ok(a[0].x, v[0].x) && ext_ok(a[0].y, v[0].y) && ext_ok(a[1].x, v[1].x) && ext_ok(a[1].y, v[1].y) &&
+                          k.eps >= kPkEpsLo;
+    if (__all(extended)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x2 root = pk_sqrt_ext(v[u]);
+            const f32x2 den = {denom_of(root.x, rbc2, k.eps), denom_of(root.y, rbc2, k.eps)};
+            bool redo_x, redo_y;
+            f32x2 q = pk_div_ext(a[u], den, redo_x, redo_y);
+            if (redo_x) q.x = __fdiv_rn(a[u].x, den.x);
+            if (redo_y) q.y = __fdiv_rn(a[u].y, den.y);
+            p[u] = pk_add(p[u], q);
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        p[u].x = __fadd_rn(p[u].x, __fdiv_rn(a[u].x, denom_of(sqrtf(v[u].x), rbc2, k.eps)));
+        p[u].y = __fadd_rn(p[u].y, __fdiv_rn(a[u].y, denom_of(sqrtf(v[u].y), rbc2, k.eps)));
     }
 }
 
@@ -701,7 +788,36 @@ __global__ __launch_bounds__(256) void lazy_flush_kernel(float4* __restrict__ P,
 __global__ void packed_math_check_kernel(int mode, uint64_t first, uint64_t count, unsigned long long* __restrict__ bad) {
     unsigned long long mine = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (mode == 0) {
+        if (mode == 2) {
+            // the scaled square root: every positive float below the packed range, subnormals included
+            const float x = __uint_as_float((uint32_t)(first + i));
+            if (!(x > 0.f && x < kPkVLo)) continue;
+            const f32x2 r = pk_sqrt_ext(f32x2{x, x});
+            const float want = (float)sqrt((double)x);
+            mine += (__float_as_uint(r.x) != __float_as_uint(want)) + (__float_as_uint(r.y) != __float_as_uint(want));
+        } else if (mode == 3) {
+            // the scaled division: numerators of both signs from the smallest subnormal to 2^-80 (exponent field uniform over
+            // 0 .. 47, a zero field being the subnormals), denominators over the packed range; the elements it hands back
+            // (`redo`) take the IEEE division as in adam_step4
+            uint64_t z = (first + i) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            uint64_t w = (z + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+            w ^= w >> 29;
+            const uint32_t ea = (uint32_t)((w >> 8) % 48u);
+            const uint32_t eb = 127 - 30 + (uint32_t)((w >> 20) % 68u);
+            float a = __uint_as_float(((uint32_t)(w & 1u) << 31) | (ea << 23) | (uint32_t)(z & 0x7FFFFFu));
+            if ((w >> 40) % 64u == 0) a = __uint_as_float((uint32_t)(w & 1u) << 31);      // (signed zeros now and then)
+            const float b = __uint_as_float((eb << 23) | (uint32_t)((z >> 23) & 0x7FFFFFu));
+            bool rx, ry;
+            f32x2 q = pk_div_ext(f32x2{a, -a}, f32x2{b, b}, rx, ry);
+            if (rx) q.x = __fdiv_rn(a, b);
+            if (ry) q.y = __fdiv_rn(-a, b);
+            const float want = (float)((double)a / (double)b);
+            mine += __float_as_uint(__fdiv_rn(a, b)) != __float_as_uint(want);
+            mine += (__float_as_uint(q.x) != __float_as_uint(want)) + (__float_as_uint(q.y) != __float_as_uint(-want));
+        } else if (mode == 0) {
             const float x = __uint_as_float((uint32_t)(first + i));
             if (!(x >= kPkVLo && x <= kPkVHi)) continue;
             const f32x2 r = pk_sqrt_rn(f32x2{x, x});
@@ -1370,7 +1486,7 @@ extern "C" int satrans_embed_lazy_flush(float* arena, float* m, float* v, int32_
 // pairs from seed `first`) against the IEEE operations; *mismatches (host) receives the count.
 extern "C" int satrans_debug_check_packed_math(int mode, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SATRANS_REQUIRE((mode == 0 || mode == 1) && mismatches, SATRANS_E_BADARG, "check_packed_math: bad arguments");
+    SATRANS_REQUIRE(mode >= 0 && mode <= 3 && mismatches, SATRANS_E_BADARG, "check_packed_math: bad arguments");
     unsigned long long* dev = nullptr;
     SATRANS_REQUIRE(hipMalloc(&dev, sizeof(unsigned long long)) == hipSuccess, SATRANS_E_LAUNCH, "check_packed_math: hipMalloc");
     (void)hipMemsetAsync(dev, 0, sizeof(unsigned long long), stream);

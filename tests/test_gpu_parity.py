@@ -1482,31 +1482,66 @@ def test_packed_replay_arithmetic_is_the_ieee_arithmetic():
     for seed in (0, 1 << 40):
         N.check(lib.satrans_debug_check_packed_math(1, seed, 1 << 32, C.byref(bad), st), "packed division")
         assert bad.value == 0, f"{bad.value} quotients are not correctly rounded"
+    # below the packed range (rows that decay under the regulariser): the same sequences behind exact power-of-two scaling -
+    # EVERY positive float under 2^-100, subnormals included, and 2^33 numerator / denominator pairs with numerators from the
+    # smallest subnormal to 2^-80 and signed zeros
+    N.check(lib.satrans_debug_check_packed_math(2, 0, lo + 1000, C.byref(bad), st), "scaled sqrt")
+    assert bad.value == 0, f"{bad.value} scaled square roots are not correctly rounded"
+    for seed in (0, 1 << 40):
+        N.check(lib.satrans_debug_check_packed_math(3, seed, 1 << 32, C.byref(bad), st), "scaled division")
+        assert bad.value == 0, f"{bad.value} scaled quotients are not correctly rounded"
 
 
+@pytest.mark.parametrize("state", ["edge", "decayed"])
 @pytest.mark.parametrize("D", [16, 32, 64])
-def test_lazy_flush_equals_streaming_steps_on_edge_values(D):
+def test_lazy_flush_equals_streaming_steps_on_edge_values(D, state):
     """Kernel level: K regulariser-only steps through the streaming kernel (one launch per step) and one flush (and one
-    replay of a row list) must leave identical bits - on ordinary table values and on the values that take the scalar path
-    of the packed replay (zeros, subnormals, 1e-30, 1e20, negative zero) mixed into the same lanes."""
+    replay of a row list) must leave identical bits - `edge`: on ordinary table values and on the values that take the scalar
+    path of the packed replay (zeros, subnormals, 1e-30, 1e20, negative zero) mixed into the same lanes; `decayed`: on the state
+    of rows nobody gathers (magnitudes log-uniform from 1e-8 down through the subnormals to exact zeros of both signs, second
+    moments down to subnormals and zero, whole rows of zeros, a few ordinary rows in between), over enough steps for values to
+    cross from the packed range into the scaled one, into the subnormals and to zero."""
     import ctypes as C
     import math
     from satrans_amd import native as N
     lib = N.lib()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(17 + D)
-    R, K = 4099, 13
+    R, K = (4099, 13) if state == "edge" else (4099, 61)
     lr, b1, b2, eps, l2 = 0.005, 0.9, 0.999, 1e-8, 1e-5
     P = torch.randn(R, D, generator=g) * 1e-4
     M = torch.randn(R, D, generator=g) * 1e-9
     V = torch.rand(R, D, generator=g) * 1e-17
     odd = torch.tensor([0.0, -0.0, 1e-45, 3e-39, 1e-30, -1e-30, 1e20, -3e18, 1.0, 1e-12], dtype=torch.float32)
     pick = torch.randint(0, odd.numel(), (R, D), generator=g)
-    where = torch.rand(R, D, generator=g) < 0.05
-    P = torch.where(where, odd[pick], P)
-    M = torch.where(torch.rand(R, D, generator=g) < 0.03, torch.zeros(()), M)
-    V = torch.where(torch.rand(R, D, generator=g) < 0.03, odd[pick].abs() ** 2, V)
-    V = torch.where(torch.isfinite(V), V, torch.full((), 1e30))
+    if state == "edge":
+        where = torch.rand(R, D, generator=g) < 0.05
+        P = torch.where(where, odd[pick], P)
+        M = torch.where(torch.rand(R, D, generator=g) < 0.03, torch.zeros(()), M)
+        V = torch.where(torch.rand(R, D, generator=g) < 0.03, odd[pick].abs() ** 2, V)
+        V = torch.where(torch.isfinite(V), V, torch.full((), 1e30))
+    else:
+        def tiny(lo_exp, hi_exp):       # +-10^u, u uniform in [lo_exp, hi_exp]: float32 rounds what is below its range to subnormals / zero
+            u = torch.rand(R, D, generator=g, dtype=torch.float64) * (hi_exp - lo_exp) + lo_exp
+            sign = torch.where(torch.rand(R, D, generator=g) < 0.5, -1.0, 1.0).double()
+            return (sign * torch.pow(torch.tensor(10.0, dtype=torch.float64), u)).to(torch.float32)
+        ordinary = (torch.rand(R, 1, generator=g) < 0.1).expand(R, D)          # every tenth row stays an ordinary row
+        zero_row = (torch.rand(R, 1, generator=g) < 0.2).expand(R, D) & ~ordinary
+        zero_row = zero_row.clone()
+        zero_row[1000:1400] = True              # (whole waves of rows that have decayed to zero)
+        ordinary = ordinary.clone()
+        ordinary[1000:1400] = False
+        ordinary[2000:2200] = True              # (and whole waves of ordinary rows)
+        P = torch.where(ordinary, P, tiny(-46.0, -8.0))
+        M = torch.where(ordinary, M, tiny(-47.0, -13.0))
+        V = torch.where(ordinary, V, tiny(-46.0, -17.0).abs())
+        signed_zero = torch.where(torch.rand(R, D, generator=g) < 0.5, torch.tensor(-0.0), torch.tensor(0.0))
+        P = torch.where(zero_row, signed_zero, P)
+        M = torch.where(zero_row, torch.where(torch.rand(R, D, generator=g) < 0.5, torch.tensor(-0.0), torch.tensor(0.0)), M)
+        M = torch.where(torch.rand(R, D, generator=g) < 0.05, signed_zero, M)
+        # (a zero second moment under a non-zero first one sends its whole wave to the IEEE path: rare, so that most waves take
+        #  the scaled sequences)
+        V = torch.where(torch.rand(R, D, generator=g) < 1e-4, torch.zeros(()), V)
     f32 = lambda x: float(np.float32(x))
     table = torch.tensor([(0.0, 1.0)] + [(f32(lr / (1.0 - b1 ** s)), 1.0 / f32(math.sqrt(1.0 - b2 ** s))) for s in range(1, K + 1)],
                          dtype=torch.float64, device=DEV)
