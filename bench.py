@@ -576,7 +576,7 @@ def main():
     gather_fused = "layer_fwd_gather" in phases or "layer_fwd_gather" in dispatch
     count = {"layer_fwd": n_sep - (1 if gather_fused else 0), "layer_fwd_gather": 1, "layer_bwd": n_sep, "layer_bwd_head": 1,
              "lazy_flush": n_flush / K}  # launches per step (the flush runs every
-    #                                   SATRANS_LAZY_FLUSH_EVERY = 64 steps and once more at the end of the timed region)
+    #                                   SATRANS_LAZY_FLUSH_EVERY = 32 steps and once more at the end of the timed region)
 
     def table(ph, count=count, disp=None):
         # `disp`: phase -> the kernel's own duration (events signalled by the dispatch, read_dispatch_ms): the fused layer kernels,

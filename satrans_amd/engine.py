@@ -183,7 +183,7 @@ class PathEngine:
         # end, predict, state_dict).  The total arithmetic is the same either way (every row-step is executed exactly once,
         # at replay or at flush time), but a row that waits 1,000 steps for its next gather is replayed as ONE lane's chain of
         # 1,000 dependent steps inside the step that gathers it, while the flush runs the same steps with every lane busy.
-        self.flush_every = int(os.environ.get("SATRANS_LAZY_FLUSH_EVERY", "64"))
+        self.flush_every = int(os.environ.get("SATRANS_LAZY_FLUSH_EVERY", "32"))
         self._since_flush = 0
         # Several ranks: "owner" (default) = every rank owns a contiguous 1/N slice of the large tables' rows and is the only one
         # to step them (per-rank optimizer work and traffic independent of N); "replicated" = round 2's exchange, every rank
