@@ -495,8 +495,8 @@ def main():
                                     "ms_per_step": round(sus_ph.get("lazy_flush", 0.0) / max(1, eng.flush_every), 4),
                                     "launches_timed": n_fl,
                                     "note": "a flush replays flush_every postponed steps of every row not gathered since (the "
-                                            "headline's one flush replays its K = 20 steps: a third of the work per launch, the "
-                                            "same work per step)"},
+                                            f"headline's one flush replays its K = {K} steps, this one {eng.flush_every}: the same work "
+                                            "per step)"},
                      "note": "same step as `value`, lazy flush inside the timed region, one rank; phases sampled every 50th step "
                              "(a row's postponed optimizer steps are replayed when it is next gathered: the replay chains are "
                              "longer here than in the 20-step headline)"}
