@@ -1464,6 +1464,38 @@ def test_lazy_adam_is_bitwise_the_streaming_adam():
     assert reg_l == pytest.approx(reg_d, rel=1e-6)      # lazy sums p^2 per element in fp32 before going to double
 
 
+def test_lazy_adam_stays_bitwise_the_streaming_adam_while_rows_decay():
+    """700 steps over two small batches: the rows they never gather decay under the regulariser out of the packed range of the
+    replay (|lr * exp_avg| < 2^-80 after ~500 steps) and on towards the subnormals - the regime of most rows of a long run.
+    Tables and moments of the lazy form (periodic flushes, replays before every gather) must stay EXACTLY those of the
+    every-step streaming kernel, and the decayed regime must actually have been reached."""
+    c = Case("aliccp_sota")
+    rng = np.random.RandomState(23)
+    B, steps = 8, 700
+    Xs = [np.stack([rng.randint(1 if f == "301" else 0, v - 1, size=B) for f, v in zip(c.meta["fields"], c.meta["vocab"])],
+                   axis=1).astype(np.float32) for _ in range(2)]
+    ys = [(rng.rand(B) < 0.3).astype(np.float32) for _ in range(2)]
+    Xd = [torch.from_numpy(x).to(DEV) for x in Xs]
+    yd = [torch.from_numpy(v).to(DEV) for v in ys]
+    results = []
+    for lazy in (True, False):
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy")
+        model.train()
+        eng = model._require_engine()
+        eng.lazy, eng.overlap = lazy, False
+        for i in range(steps):
+            eng.train_step(Xd[i % 2], yd[i % 2])
+        eng.flush_lazy()
+        results.append((model.embedding_arena.detach().cpu(), eng.adam_m.cpu(), eng.adam_v.cpu()))
+    (p_l, m_l, v_l), (p_d, m_d, v_d) = results
+    for a, b, what in ((p_l, p_d, "p"), (m_l, m_d, "m"), (v_l, v_d, "v")):
+        same = a.view(torch.int32) == b.view(torch.int32)
+        assert bool(same.all()), f"{what}: {int((~same).sum())} elements differ between the lazy and the streaming form"
+    decayed = ((0.005 * m_d).abs() < 2.0 ** -80) & (m_d != 0)
+    assert float(decayed.float().mean()) > 0.2, "the run did not reach the decayed regime it is meant to cover"
+
+
 def test_packed_replay_arithmetic_is_the_ieee_arithmetic():
     """The replay / flush kernels run their square root and division as packed fma sequences (embed_adam.hip).  They must be
     the correctly rounded operations: the square root is compared with the fp32 rounding of the fp64 square root (correct, as
