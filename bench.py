@@ -158,10 +158,17 @@ def cpu_baseline(state, X, y, batch, lr, flag='sota', timed=10, warm=2, timed_ve
 
     torch.set_num_threads(min(ncpu, 32))
     one()                                                                          # allocates Adam state
-    sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+    # candidates: 8 ... 64 threads (the step is bound by the table sweeps of dense Adam + L2, i.e. by memory bandwidth: on a
+    # 256-core host the all-cores candidate ran 69.8 s per step against 1.8 s at 16 threads and was 209 of the bench's 278 s,
+    # VERDICT r05); a candidate whose FIRST step is already twice the best median so far is abandoned after that step
+    sweep, abandoned = {}, {}
+    for th in sorted({t for t in (8, 16, 32, 64, min(ncpu, 64)) if t <= ncpu}):
         torch.set_num_threads(th)
-        sweep[th] = sorted(one() for _ in range(3))[1]
+        first = one()
+        if sweep and first > 2.0 * min(sweep.values()):
+            abandoned[th] = first
+            continue
+        sweep[th] = sorted([first, one(), one()])[1]
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     for _ in range(max(0, warm - 1)):
@@ -171,7 +178,7 @@ def cpu_baseline(state, X, y, batch, lr, flag='sota', timed=10, warm=2, timed_ve
     med = lambda v: v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
     return dict(value=batch / med(t_plain), value_verbose1=batch / med(t_verb), threads=best, timed=timed,
                 timed_verbose=timed_verbose, sweep_s_per_step={str(k): round(v, 3) for k, v in sweep.items()},
-                steps_used=cursor[0])
+                sweep_abandoned_after_one_step={str(k): round(v, 3) for k, v in abandoned.items()}, steps_used=cursor[0])
 
 
 def gather_microbench(eng, Xd, B, F, D, launches=48):
@@ -252,6 +259,48 @@ def read_dispatch_ms(lib):
     return {k: med(v) for k, v in acc.items()}          # (median, as the recorded-event phases: engine.phase_ms)
 
 
+OTHER_CONFIGS = (          # name, extra arguments, time limit in seconds
+    ("configs[3] alimama sota-pos", ["--config", "alimama"], 240),
+    ("configs[1] flag sota-gate", ["--flag", "sota-gate"], 240),
+    ("configs[1] skewed ids", ["--ids", "skewed"], 240),
+    ("configs[4] c5 at 100 M rows", ["--config", "c5", "--with-gather"], 600),
+)
+
+
+def other_configs():
+    """`python bench.py <variant> --train-only --steps 20 --warmup 5` as a CHILD process per variant (started, never exec'ed; this
+    process keeps its GPU context and waits), each line reduced to {metric, value, ms_per_step, roofline {kernel, bound, frac,
+    launch_ms}, kernels ms per launch, gather (configs[4])}.  A variant that fails or overruns its limit is reported as such."""
+    import subprocess
+    res = {}
+    for name, extra, limit in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "20", "--warmup", "5", "--train-only",
+               "--no-other-configs"] + extra
+        t0 = time.time()
+        try:
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True)
+            line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            if cp.returncode != 0 or not line:
+                res[name] = {"error": f"rc {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
+                continue
+            d = json.loads(line[-1])
+            r = d.get("roofline") or {}
+            rec = {"metric": d["metric"], "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                   "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                   "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_ms",
+                                                       "launches_per_step", "traffic", "traffic_source")},
+                   "kernels_ms_per_launch": {k: v["ms_per_launch"] for k, v in (d.get("kernels") or {}).items()},
+                   "wall_s": round(time.time() - t0, 1), "cmd": " ".join(["python", "bench.py"] + cmd[2:])}
+            if d.get("gather"):
+                rec["gather"] = d["gather"]
+            res[name] = rec
+        except subprocess.TimeoutExpired:
+            res[name] = {"error": f"no line within {limit} s"}
+        except Exception as ex:                                                     # never take the headline line down
+            res[name] = {"error": repr(ex)[:300]}
+    return res
+
+
 def launch_ranks(n: int) -> int:
     """Start `n` ranks of this script on the GPUs of this node (one process per GPU, RCCL) and wait for them."""
     import socket
@@ -297,6 +346,9 @@ def main():
     ap.add_argument("--flag", default=None, help="SATrans flag (reference main.py --flag); 'sota-pos' = the positional variant")
     ap.add_argument("--ids", choices=["uniform", "skewed"], default="uniform",
                     help="id distribution of the synthetic batches (uniform = HBM worst case, the reported configuration)")
+    ap.add_argument("--with-gather", action="store_true", help="with --train-only: also run the gather probes (the c5 line of other_configs)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` object (configs[3], gate, skewed ids, configs[4]: one child process each)")
     args = ap.parse_args()
     import satrans_amd  # noqa: F401  (before the first GPU call: its import sets the HIP runtime's stream-queue default)
     global CFG
@@ -666,7 +718,7 @@ def main():
 
     # ---- the gather on its own: achieved HBM GB/s at the training batch and at the reference's prediction batch
     #      (main.py:353 predicts with 4 x batch_size), a different id batch for every launch -----------------------------
-    gather = gather_microbench(eng, Xd, B, F, D) if not args.train_only else None
+    gather = gather_microbench(eng, Xd, B, F, D) if (not args.train_only or args.with_gather) else None
     fwd_ms = {**dispatch, **phases}
     if gather is not None and gather_fused and "layer_fwd" in fwd_ms:
         # In the training step no gather kernel runs: layer 0 reads its B x F rows (128-byte random reads) straight from the arena.
@@ -788,6 +840,13 @@ def main():
                          f"`value_verbose1` = median of {r['timed_verbose']} steps with the per-step sklearn log_loss + "
                          f"roc_auc_score of fit(verbose=1), what reference main.py runs); {time.time() - t_cpu:.0f}s wall"}
 
+    # ---- the other BASELINE configs and variants on the same clock: one child process each (a fresh engine, nothing shared with
+    #      this one), 20 timed steps after 5, train-only; this process only relays a compact record of each line ---------------
+    others = None
+    if world == 1 and not args.train_only and not args.no_other_configs and args.config == "aliccp" and args.flag == "sota" \
+            and args.ids == "uniform":
+        others = other_configs()
+
     value = world * B * K / elapsed
     out = {
         "metric": ("training samples/sec (AliCCP-shaped, emb=32, 3L/4H, meta_mode=QK)" if args.config == "aliccp" else
@@ -811,7 +870,7 @@ def main():
         "fit_samples_per_s": fit_leg["samples_per_s"] if fit_leg else None, "fit": fit_leg,
         "phase_sum_ms_per_step": round(phase_sum, 4), "phase_sum_frac_of_step": round(phase_sum / (elapsed / K * 1e3), 4),
         "roofline": roofline, "kernels": kernels, "kernels_serial": kernels_serial, "gather": gather,
-        "forward_only": forward_only, "forward_only_bf16": forward_bf16, "cpu_baseline": cpu,
+        "forward_only": forward_only, "forward_only_bf16": forward_bf16, "cpu_baseline": cpu, "other_configs": others,
         "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms], "collectives": collectives,
     }
     sys.stdout.flush()

@@ -29,6 +29,11 @@ import torch.nn as nn
 from .callbacks import CallbackList, History
 from .inputs import DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, split_columns
 
+# _READ_ONLY_FILTER: torch.from_numpy on a read-only memory map of an HDF5 column (h5lite) warns that the array "is not
+# writable"; the upload only reads it.  Installed ONCE, here, for that one message: warnings.catch_warnings() swaps the
+# process-global filter list and is not thread-safe, and the upload runs in a worker thread beside user callbacks.
+warnings.filterwarnings("ignore", message="The given NumPy array is not writable", category=UserWarning)
+
 
 # tables of at most this many rows (and this many in total) form the "small" class of the optimizer
 SMALL_TABLE_ROWS = 16384
@@ -398,9 +403,7 @@ class BaseModel(nn.Module):
                 block = block.astype(np.float32)                  # (numpy's rounding, as the host path)
             elif block.dtype.kind == "u" and block.dtype.itemsize > 1:
                 block = block.astype(np.int64)                    # (torch has no wide unsigned tensors to upload)
-            with warnings.catch_warnings():                       # (a read-only memory map of an HDF5 column is only read)
-                warnings.simplefilter("ignore", UserWarning)
-                data[:, j:j + w] = torch.from_numpy(block).to(self.device)
+            data[:, j:j + w] = torch.from_numpy(block).to(self.device)      # (read-only memory maps: _READ_ONLY_FILTER above)
             j += w
         return data
 

@@ -644,14 +644,17 @@ __device__ __forceinline__ void adam_step4(f32x2 (&p)[2], f32x2 (&m)[2], f32x2 (
         return;
     }
     // (0. a wave of rows that have decayed to zero: p + (+-0) is all there is to compute)
-    if (__all(a[0].x == 0.f && a[0].y == 0.f && a[1].x == 0.f && a[1].y == 0.f)) {
+    // (only over a POSITIVE denominator is +-0 / den = +-0: eps = 0 with a zero second moment is 0 / 0 = NaN in adam_core and in
+    //  torch, and a NaN second moment is a NaN there - `v >= 0` is false for a NaN; both fall through to the IEEE tier)
+    const bool v_sane = v[0].x >= 0.f && v[0].y >= 0.f && v[1].x >= 0.f && v[1].y >= 0.f;
+    if (__all(k.eps > 0.f && v_sane && a[0].x == 0.f && a[0].y == 0.f && a[1].x == 0.f && a[1].y == 0.f)) {
         p[0] = pk_add(p[0], a[0]);
         p[1] = pk_add(p[1], a[1]);
         return;
     }
     const bool lane_small = amax < 0x1p-60f;
     auto lane_ok = [&](float a_) { return lane_small || a_ == 0.f || fabsf(a_) >= kPkALo; };
-    const bool by_lane = vmin >= kPkVLo && vmax <= kPkVHi && amax <= kPkAHi && k.eps >= kPkEpsLo && lane_ok(a[0].x) &&
+    const bool by_lane = v_sane && vmin >= kPkVLo && vmax <= kPkVHi && amax <= kPkAHi && k.eps >= kPkEpsLo && lane_ok(a[0].x) &&
                          lane_ok(a[0].y) && lane_ok(a[1].x) && lane_ok(a[1].y);
     if (__all(by_lane)) {
         const f32x2 up = pk_set(lane_small ? 0x1p69f : 1.0f), dn = pk_set(lane_small ? 0x1p-69f : 1.0f);
@@ -676,7 +679,7 @@ __device__ __forceinline__ void adam_step4(f32x2 (&p)[2], f32x2 (&m)[2], f32x2 (
         }
         return;
     }
-    auto ext_ok = [&](float a_, float v_) { return a_ == 0.f || (fabsf(a_) <= kPkAHi && v_ > 0.f && v_ <= kPkVHi); };
+    auto ext_ok = [&](float a_, float v_) { return (a_ == 0.f && v_ >= 0.f) || (fabsf(a_) <= kPkAHi && v_ > 0.f && v_ <= kPkVHi); };
     const bool extended = ext_ok(a[0].x, v[0].x) && ext_ok(a[0].y, v[0].y) && ext_ok(a[1].x, v[1].x) && ext_ok(a[1].y, v[1].y) &&
                           k.eps >= kPkEpsLo;
     if (__all(extended)) {

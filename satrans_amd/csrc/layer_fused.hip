@@ -514,6 +514,22 @@ constexpr bool kAttnPipe = true;
 #else
 constexpr bool kAttnPipe = false;
 #endif
+// Attention backward on the matrix pipe (round 6): v_mfma_f32_4x4x1_16b_f32 is sixteen INDEPENDENT 4 x 4 rank-1 updates per
+// instruction - block b multiplies the A values of lanes 4b..4b+3 with the B values of the same four lanes - at the rate of the
+// other f32 shapes (8.8 cycles per instruction, one accumulator or several: tools/microbench/mfma_4x4.hip).  With one lane per
+// (sample, head, query row), rows padded to a multiple of 4 so that a block = four consecutive rows of one (sample, head):
+//   B = the lane's OWN operand (its go row, its dS row), A = shared rows addressed by lane & 3 -> register r of the lane is
+//   element (key 4 jb + r) of ITS row of dP^T, or feature pair r of ITS dq row: the F = 19, d = 8 products run without
+//   padding to a 16 x 16 tile (which wastes 2.8 x on the F side and 2 x on the d side) and the softmax backward between them
+//   stays lane-local exactly as in the wavefront arm.  -DSATRANS_ATTN_LANE builds that arm instead (the ablation).
+#ifdef SATRANS_ATTN_LANE
+constexpr bool kAttnMfma = false;
+#else
+constexpr bool kAttnMfma = true;
+#endif
+__device__ __forceinline__ f32x4 mfma_b16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
 constexpr int kHeadDenseMax = 2;      // dense columns the fused head carries (Alimama: 1); more -> the separate head launches
 template <int D, int U, int H, bool SAME, bool TR, int FT = 0, int MOD = 0, bool SAVE = false, bool HEADF = false>
 __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans_layer_desc a, int Tsamp,
@@ -527,6 +543,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     static_assert(KT <= 2, "the cached dropout keep flags hold 8 bits per site");
     static_assert(64 * H <= kFusedBlock, "one attention task per thread: a tile holds at most 64 tokens x H heads");
     constexpr int SZ_DD = D * LD, SZ_W1 = D * LU, SZ_W2 = U * LD;
+    // the matrix-pipe arm of phases D / E: field count a constant, rows padded to FP, one lane per padded (sample, head, row)
+    constexpr int FP = (FT + 3) & ~3, NJB = FP / 4;
+    constexpr bool MFA = kAttnMfma && FT != 0 && d == 8 && (64 / (FT ? FT : 64)) * H * FP <= kFusedBlock;
     extern __shared__ __align__(16) float lds[];
     const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -572,7 +591,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     uint32_t* st_keep = (uint32_t*)take(ntask_max);   // bit j: attention-dropout keep flag of (i, j)   (F <= 32)
     float* sP = take(ntask_max * F);                  // exp(s_ij - max_i), the un-normalised softmax numerators
     // dP_ij, then dS_ij (phases D, E); SAVE: first the staging area of the tile's dy rows and saved attention outputs (2 T F D)
-    float* sDS = take(SAVE ? max(ntask_max * F, 2 * Tsamp * F * D) : ntask_max * F);
+    // (matrix-pipe arm: dS transposed and padded, [sample, head][key][query row padded to FP] - phase D writes one float per key,
+    //  phase E reads its key's row 16 bytes at a time)
+    float* sDS = take(max(SAVE ? max(ntask_max * F, 2 * Tsamp * F * D) : ntask_max * F, MFA ? Tsamp * H * FP * FP : 0));
     // HEADF: head weights [F][D], the tile's token dots, per-sample dense terms / loss / dlogit, per-lane head-gradient sums
     float* s_wh = HEADF ? take(F * D + kHeadDenseMax) : nullptr;
     float* s_dot = HEADF ? take(64) : nullptr;
@@ -622,6 +643,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // (sample, head, row) of this thread's attention task - the same in every tile and every attention phase
     const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
+    // matrix-pipe arm: (sample, head, padded row) of this lane; lanes beyond the tile's samples address the last sample
+    constexpr int FPd = MFA ? FP : 1;
+    const int m_ls_raw = (int)threadIdx.x / (H * FPd), m_rem = (int)threadIdx.x - m_ls_raw * H * FPd;
+    const int m_h = m_rem / FPd, m_i = m_rem - m_h * FPd, m_sub = lane & 3;      // (H FP and FP are multiples of 4: m_i & 3 = lane & 3)
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);
     // a.attn_save: the forward of this step left the attention's softmax numerators [p][j][H F], 1 / sum [p][H F], keep words
@@ -1196,6 +1221,81 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // pass 1: dP_ij = (go_i . v_j) * mask_ij staged in the task's row of the dS cache, dot_i = sum_j P_ij dP_ij;
         // pass 2: dS_ij = P_ij (dP_ij - dot_i) / sqrt(d) replaces it, the numerator cache row becomes P_ij * mask_ij
         //         (the coefficient of dv_j), dq_i = sum_j dS_ij k_j.
+        if constexpr (MFA) {
+          // ---- matrix-pipe arm.  Every lane of a wave that holds a sample of the tile runs the products (the A operands are
+          //      shared rows addressed by lane & 3, whatever the lane's own row); only the stores are predicated. -------------
+          if (64 * wave < nS * H * FP) {
+            const int tls = min(m_ls_raw, Tsamp - 1), h = m_h;
+            const int iq = min(m_i, FT - 1);                       // a padding row computes a copy of the last real row, stores nothing
+            const bool own = m_ls_raw < nS && m_i < FT;
+            const int told = tls * HF + h * FT + iq;                // this row in the forward's (unpadded) task numbering
+            // dP^T block jb: register r = dP[i][4 jb + r] = sum_e v[4 jb + r][e] go[i][e]
+            float ge[d];
+            {
+                const float* gr = so + (size_t)(tls * FT + iq) * LD + h * d;
+                const float4 g0 = *reinterpret_cast<const float4*>(gr), g1 = *reinterpret_cast<const float4*>(gr + 4);
+                ge[0] = g0.x; ge[1] = g0.y; ge[2] = g0.z; ge[3] = g0.w; ge[4] = g1.x; ge[5] = g1.y; ge[6] = g1.z; ge[7] = g1.w;
+            }
+            float va[NJB][d];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {
+                const float* vr = sv + (size_t)min(tls * FT + 4 * jb + m_sub, ROWS - 1) * LD + h * d;
+                const float4 v0 = *reinterpret_cast<const float4*>(vr), v1 = *reinterpret_cast<const float4*>(vr + 4);
+                va[jb][0] = v0.x; va[jb][1] = v0.y; va[jb][2] = v0.z; va[jb][3] = v0.w;
+                va[jb][4] = v1.x; va[jb][5] = v1.y; va[jb][6] = v1.z; va[jb][7] = v1.w;
+            }
+            float* prow = sP + (size_t)tls * FT * HF + (h * FT + iq);
+            float pn[FT];
+#pragma unroll
+            for (int j = 0; j < FT; ++j) pn[j] = prow[j * HF];
+            const float inv = st_inv[told];
+            const uint32_t keep = st_keep[told];
+            const float scale = dc.scale;
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 dp[NJB];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) dp[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < d; ++e)
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) dp[jb] = mfma_b16(va[jb][e], ge[e], dp[jb]);
+            // the K / Q feature pairs of phase D's second product: lane & 3 picks the pair, issued here, under the softmax arithmetic
+            f32x2 kp[FT];
+            {
+                const float* kb = sk + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
+#pragma unroll
+                for (int j = 0; j < FT; ++j) kp[j] = *reinterpret_cast<const f32x2*>(kb + (size_t)j * LD);
+            }
+            float dsv[FT];
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                const float dpj = ((keep >> j) & 1u) ? dp[j >> 2][j & 3] * scale : 0.f;
+                pn[j] *= inv;
+                dot = fmaf(pn[j], dpj, dot);
+                dsv[j] = dpj;
+            }
+            float* dsT = sDS + (size_t)((tls * H + h) * FP) * FP + m_i;        // dS[i][j] at dsT[j FP]
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                dsv[j] = pn[j] * (dsv[j] - dot) * inv_sqrt_d;
+                const float pm = ((keep >> j) & 1u) ? pn[j] * scale : 0.f;
+                if (own) { dsT[j * FP] = dsv[j]; prow[j * HF] = pm; }
+            }
+            // dq[i][2 r], dq[i][2 r + 1] = sum_j k[j][h d + 2 r (+ 1)] dS[i][j]
+            f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                qa = mfma_b16(kp[j].x, dsv[j], qa);
+                qb = mfma_b16(kp[j].y, dsv[j], qb);
+            }
+            if (own) {
+                float* qr = sg + (size_t)(tls * FT + m_i) * LD + h * d;
+                *reinterpret_cast<float4*>(qr) = make_float4(qa[0], qb[0], qa[1], qb[1]);
+                *reinterpret_cast<float4*>(qr + 4) = make_float4(qa[2], qb[2], qa[3], qb[3]);
+            }
+          }
+        } else
         if (const int task = threadIdx.x; task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
             const int tls = t0_ls, h = t0_h, i = t0_i;
             f32x2 gi[d / 2];
@@ -1278,6 +1378,54 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 
         STAMP(4);
         // ================= phase E: by columns: dk_j = sum_i dS_ij q_i, dv_j = sum_i P_ij mask_ij go_i (in place of k_j, v_j)
+        if constexpr (MFA) {
+          // ---- matrix-pipe arm: the lane's row is now KEY j; B = its own column of dS / of the masked probabilities (read as
+          //      rows of the transposed caches), A = the q / go feature pairs picked by lane & 3 -------------------------------
+          if (64 * wave < nS * H * FP) {
+            const int tls = min(m_ls_raw, Tsamp - 1), h = m_h;
+            const int jk = min(m_i, FT - 1);
+            const bool own = m_ls_raw < nS && m_i < FT;
+            float dsc[FP], pmc[FT];
+            {
+                const float* dr_ = sDS + (size_t)((tls * H + h) * FP + jk) * FP;
+#pragma unroll
+                for (int ib = 0; ib < NJB; ++ib) {
+                    const float4 t = *reinterpret_cast<const float4*>(dr_ + 4 * ib);
+                    dsc[4 * ib] = t.x; dsc[4 * ib + 1] = t.y; dsc[4 * ib + 2] = t.z; dsc[4 * ib + 3] = t.w;
+                }
+                const float* pc = sP + (size_t)tls * FT * HF + (size_t)jk * HF + h * FT;
+#pragma unroll
+                for (int i = 0; i < FT; ++i) pmc[i] = pc[i];
+            }
+            f32x2 qp[FT], gp[FT];
+            {
+                const float* qb_ = sq + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
+                const float* gb_ = so + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    qp[i] = *reinterpret_cast<const f32x2*>(qb_ + (size_t)i * LD);
+                    gp[i] = *reinterpret_cast<const f32x2*>(gb_ + (size_t)i * LD);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 ka = {0.f, 0.f, 0.f, 0.f}, kb2 = {0.f, 0.f, 0.f, 0.f}, va2 = {0.f, 0.f, 0.f, 0.f}, vb2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < FT; ++i) {
+                ka = mfma_b16(qp[i].x, dsc[i], ka);
+                kb2 = mfma_b16(qp[i].y, dsc[i], kb2);
+                va2 = mfma_b16(gp[i].x, pmc[i], va2);
+                vb2 = mfma_b16(gp[i].y, pmc[i], vb2);
+            }
+            if (own) {
+                float* kr = sk + (size_t)(tls * FT + m_i) * LD + h * d;
+                float* vr = sv + (size_t)(tls * FT + m_i) * LD + h * d;
+                *reinterpret_cast<float4*>(kr) = make_float4(ka[0], kb2[0], ka[1], kb2[1]);
+                *reinterpret_cast<float4*>(kr + 4) = make_float4(ka[2], kb2[2], ka[3], kb2[3]);
+                *reinterpret_cast<float4*>(vr) = make_float4(va2[0], vb2[0], va2[1], vb2[1]);
+                *reinterpret_cast<float4*>(vr + 4) = make_float4(va2[2], vb2[2], va2[3], vb2[3]);
+            }
+          }
+        } else
         if (const int task = threadIdx.x; task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
             const int tls = t0_ls, h = t0_h, j = t0_i;
             f32x2 dk[d / 2], dv[d / 2];
@@ -1877,7 +2025,8 @@ static int64_t fused_bwd_lds_floats(int T, int F, int D, int U, int H, bool same
     // (fused head: head weights, token dots, dense terms, final sums, per-lane and per-slot gradient sums - the kernel's take() calls)
     const int64_t hd = head ? r4((int64_t)F * D + kHeadDenseMax) + 64 + 64 + 128 + (int64_t)kFusedBlock * 4 * (D / 16) + 64 * kHeadDenseMax : 0;
     // (the dS cache doubles as the staging area of the saved-attention hand-over: dy rows + attention outputs of a tile)
-    const int64_t ds = std::max<int64_t>(tasks * F, 2 * (int64_t)T * F * D);
+    const int64_t FP = (F + 3) & ~3;       // (the matrix-pipe arm of the attention backward keeps dS padded: [T H][FP][FP])
+    const int64_t ds = std::max<int64_t>(std::max<int64_t>(tasks * F, 2 * (int64_t)T * F * D), (int64_t)T * H * FP * FP);
     return copies * 4 * dd + (same_tab ? 1 : 2) * copies * mlp + 6 * D + 5 * 64 * LD + 2 * r4(tasks) + r4(tasks * F) + r4(ds) + hd + 64;
 }
 

@@ -202,6 +202,11 @@ class PathEngine:
         self.fuse_head = True
         # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
         self.prefetch = True
+        # owner form, several ranks: the NEXT batch's id exchange a step ahead, on a process group of its own
+        # (_prepare_owner_async).  SATRANS_OWNER_PREFETCH=0 (or engine.owner_prefetch = False, the same on every rank) routes the
+        # id exchange back through the step itself on the default group: one communicator, one issue order - the fallback
+        # should two communicators ever misbehave on a node
+        self.owner_prefetch = os.environ.get("SATRANS_OWNER_PREFETCH", "1") != "0"
         # phases that `phase()` does not bracket with recorded events even while `timers` is set (bench.py: the fused layer kernels,
         # whose own durations come from satrans_kernel_timing without a marker in the queue)
         self.untimed_phases = frozenset()
@@ -990,7 +995,7 @@ class PathEngine:
         """A HIP stream of the lowest priority the device offers (torch only hands out priorities <= 0, i.e. normal and above),
         created by libsatrans_hip.so - which is linked against the HIP runtime this process already uses - and wrapped for torch:
         when its kernels and the launch stream's become ready together, the launch stream's are dispatched first.  Lives as long
-        as the engine (destroyed in __del__)."""
+        as the process (kept in the module-wide _STREAMS table, shared by every engine on the device; never destroyed)."""
         def make():
             handle = C.c_void_p()
             with torch.cuda.device(self.dev):
@@ -1346,6 +1351,8 @@ class PathEngine:
             self.flush_lazy()
             self._owner_bounds = None
             self._owner_world = world
+        if self.owner_prefetch:
+            parallel.prefetch_group()                  # (collective, idempotent: every rank plans its epoch here)
         inner = torch.tensor(self._owner_ranges(world, batch_size)[1:-1], dtype=torch.int64, device=self.dev)
         n = ids.shape[0]
         steps = (n - 1) // batch_size + 1
@@ -1447,13 +1454,21 @@ class PathEngine:
                 "satrans_embed_inverse_positions")
         return dict(ow=ow, send=send, recv=recv, n_recv=n_recv, B=B, half=half)
 
-    def _prepare_owner_async(self, X_next, world, bt):
+    def _prepare_owner_async(self, X_next, world, bt, after=None):
         """The id exchange of the NEXT step on the side stream, behind that batch's sort (_prepare_async), on a process group of
         its own (parallel.prefetch_group) - issued by the host AFTER this step's gradient collectives, so that every rank issues
         its collectives in the same order.  Only with an epoch plan (the split sizes are then known without a read-back)."""
         from . import parallel
         prep = self._prep
         if prep is None or prep.get("owner") is not None or self._side is None:
+            return
+        group = parallel._PREFETCH_GROUP               # (read only: created in front of the step, _train_step_owner)
+        if not self.owner_prefetch or group is None:
+            if prep["done"] is None:                   # no exchange ahead: only the deferred bucketing is left to do
+                with torch.cuda.stream(self._side):
+                    self._bucket(prep["X"], self.train_workspace(prep["B"], 1, False)["prep_alt"])
+                    prep["done"] = torch.cuda.Event()
+                    prep["done"].record(self._side)
             return
         B = prep["B"]
         ws = self.train_workspace(B, 1, False)        # (the NEXT batch's workspace: a ragged last batch has one of its own)
@@ -1462,8 +1477,17 @@ class PathEngine:
         with torch.cuda.stream(self._side):
             if counts is not None:
                 half = 1 - ws.get("_own_half", 0)
+                # Two communicators: RCCL kernels of different communicators must reach the device in the same order on every
+                # rank, and host issue order alone does not give that (the side stream starts where a rank-local event fires).
+                # The exchange therefore waits for THIS step's gradient collectives (events behind the gradient-row all-to-all on
+                # the launch stream and behind the all-reduce on the tail stream): on every rank the default group's collectives
+                # of step t are complete before the prefetch group's collective of step t + 1 can start, and the next step's
+                # first default-group collective (the row answer) waits for this exchange - one total order, never two
+                # communicators' kernels in flight at once.
+                for ev in after or ():
+                    self._side.wait_event(ev)
                 with self.phase("owner_ids_next"):
-                    own = self._owner_exchange_ids(ws, half, ws["prep_alt"], counts, B, group=parallel.prefetch_group())
+                    own = self._owner_exchange_ids(ws, half, ws["prep_alt"], counts, B, group=group)
                 own["done"] = torch.cuda.Event()
                 own["done"].record(self._side)
                 prep["owner"] = own
@@ -1506,7 +1530,10 @@ class PathEngine:
             self.flush_lazy()                         # (first owner-form step: everything current and identical everywhere)
             self._owner_bounds = None
             self._owner_world = world
-            parallel.prefetch_group()                 # (collective: every rank is here)
+        if self.owner_prefetch and parallel._PREFETCH_GROUP is None:
+            # created and warmed HERE, in front of every collective of the step and with nothing in flight (collective: every
+            # rank takes its first owner-form step at the same point of the program) - never lazily under the side stream
+            parallel.prefetch_group()
         bounds = self._owner_ranges(world, B)
         if "xg" not in ws:
             ws["xg"] = torch.empty(n_loc, D, dtype=torch.float32, device=self.dev)
@@ -1523,6 +1550,14 @@ class PathEngine:
         if not prepared:
             if own is not None:
                 main.wait_event(own["done"])      # (the discarded exchange still owns its half of the buffers)
+                if world > 1:
+                    # The id exchange of the batch named with `next_X` is already done - by EVERY rank, on the prefetch group.
+                    # Replacing it here means one more default-group all-to-all that only the ranks whose hint was wrong would
+                    # enter: a hang, not a slow path.  The decision cannot be rank-local, so it is an error.
+                    raise RuntimeError("train_step (owner form, several ranks): this batch is not the one the previous step named "
+                                       "with next_X, and that batch's id exchange has already run on every rank.  Pass the tensor "
+                                       "of the next call as next_X on every rank (fit does), or no next_X at all, or set "
+                                       "SATRANS_OWNER_PREFETCH=0.")
             own = None
             N.check(lib.satrans_gather_fwd(arena, self.row_span.data_ptr(), self.cols.data_ptr(), X.data_ptr(),
                                            N.id_dtype_of(X), X.stride(0), B, self.F, D, None, ws["rows"].data_ptr(),
@@ -1588,6 +1623,8 @@ class PathEngine:
                 N.check(lib.satrans_embed_pack_rows(big_src.data_ptr(), n_b, gemb.data_ptr(), D, ws["packed_o"].data_ptr(), st),
                         "satrans_embed_pack_rows(grads)")
             recv_g = parallel.all_to_all_rows(ws["packed_o"][:n_b], send, recv, "all_to_all_grad_rows_f32", out=ow["vals"])
+        ev_grads = torch.cuda.Event()
+        ev_grads.record(main)                         # (the launch stream has waited for the collective: it is complete here)
         # ---- 5. small tables + dense parameters, tail stream (beside 4): ordered sums, ONE all-reduce, dense steps --------------
         with (torch.cuda.stream(tail) if tail is not None else contextlib.nullcontext()):
             st_t = self._stream()
@@ -1597,6 +1634,8 @@ class PathEngine:
                                                            ws["partial_ws"].data_ptr(), ws["reg_unused"].data_ptr(),
                                                            self.g_small.data_ptr(), st_t), "satrans_embed_segment_sums")
             parallel.all_reduce_flat(self.g_exchange)
+            ev_reduce = torch.cuda.Event()
+            ev_reduce.record(torch.cuda.current_stream(self.dev))
             if self.small_rows > 0:
                 with self.phase("adam_small"):
                     N.check(lib.satrans_embed_adam_rows(arena, am, av, self.last_step.data_ptr(), 0, self.small_rows, D,
@@ -1618,7 +1657,7 @@ class PathEngine:
                     self._precleared[0].record(tail)
         # (the next batch's id exchange: issued behind this step's two gradient collectives - the same order on every rank)
         if hook is not None:
-            self._prepare_owner_async(next_X, world, bt)
+            self._prepare_owner_async(next_X, world, bt, after=(ev_grads, ev_reduce))
         if n_recv:
             with self.phase("adam_touched"):
                 N.check(lib.satrans_embed_adam_touched(arena, am, av, D, ow["sorted"].data_ptr(), ow["src"].data_ptr(), n_recv,

@@ -1524,7 +1524,7 @@ def test_packed_replay_arithmetic_is_the_ieee_arithmetic():
         assert bad.value == 0, f"{bad.value} scaled quotients are not correctly rounded"
 
 
-@pytest.mark.parametrize("state", ["edge", "decayed"])
+@pytest.mark.parametrize("state", ["edge", "decayed", "eps0"])
 @pytest.mark.parametrize("D", [16, 32, 64])
 def test_lazy_flush_equals_streaming_steps_on_edge_values(D, state):
     """Kernel level: K regulariser-only steps through the streaming kernel (one launch per step) and one flush (and one
@@ -1532,15 +1532,17 @@ def test_lazy_flush_equals_streaming_steps_on_edge_values(D, state):
     path of the packed replay (zeros, subnormals, 1e-30, 1e20, negative zero) mixed into the same lanes; `decayed`: on the state
     of rows nobody gathers (magnitudes log-uniform from 1e-8 down through the subnormals to exact zeros of both signs, second
     moments down to subnormals and zero, whole rows of zeros, a few ordinary rows in between), over enough steps for values to
-    cross from the packed range into the scaled one, into the subnormals and to zero."""
+    cross from the packed range into the scaled one, into the subnormals and to zero; `eps0`: the decayed state with eps = 0,
+    where a zero second moment under a zero numerator is 0 / 0 = NaN in the streaming kernel (and in torch.optim.Adam): the
+    shortcuts of the lazy kernels for zero numerators must not hide it."""
     import ctypes as C
     import math
     from satrans_amd import native as N
     lib = N.lib()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(17 + D)
-    R, K = (4099, 13) if state == "edge" else (4099, 61)
-    lr, b1, b2, eps, l2 = 0.005, 0.9, 0.999, 1e-8, 1e-5
+    R, K = (4099, 13) if state == "edge" else (4099, 61 if state == "decayed" else 9)
+    lr, b1, b2, eps, l2 = 0.005, 0.9, 0.999, (0.0 if state == "eps0" else 1e-8), 1e-5
     P = torch.randn(R, D, generator=g) * 1e-4
     M = torch.randn(R, D, generator=g) * 1e-9
     V = torch.rand(R, D, generator=g) * 1e-17
@@ -2039,6 +2041,54 @@ def test_size_independent_properties_at_the_baseline_batch(config):
     assert loss1 == loss2
     for k in sd1:
         assert torch.equal(sd1[k], sd2[k]), f"run-to-run difference in {k}"
+
+
+def test_skewed_ids_at_the_baseline_batch_are_reproducible_and_lazy_equals_streaming():
+    """The full batch (8192 x 19, full-size tables) with SKEWED ids - log-uniform ranks, P(id) ~ 1 / (id + 1): what real CTR ids
+    look like - so that hot rows appear thousands of times in one batch: runs of thousands of positions through
+    the ordered segmented sums (touched_chunks, the superchunk walk) and replays of rows gathered every step.  Properties:
+      * the gather is a copy (bit-exact against torch indexing);
+      * two training runs from one seed leave identical bits (fixed-order reductions over the long runs);
+      * the lazy optimizer form leaves the bits of the every-step streaming kernel, tables and both moments."""
+    import bench
+    B, steps = 8192, 4
+    cfg = bench.make_config("aliccp")
+    X, y = bench.synth_batches(steps * B, 29, ids="skewed", cfg=cfg)
+    Xd, yd = torch.from_numpy(X).to(DEV), torch.from_numpy(y).to(DEV)
+    # the premise: hot rows - the most frequent row of the largest table fills hundreds of positions of ONE batch
+    col = X[:B, cfg["fields"].index("205")].astype(np.int64)
+    assert np.bincount(col).max() > 300, "the skewed batches are expected to repeat their hot rows hundreds of times"
+
+    def run(lazy):
+        m = bench.build_model("cpu", cfg["lr"], cfg=cfg)
+        m.to(DEV)
+        m.device = DEV
+        e = m._require_engine()
+        m.eval()
+        m(Xd[:B])
+        rows = (Xd[:B, :len(cfg["fields"])].long() + e.row_span[:, 0][None, :])
+        assert torch.equal(e.layer_outputs(B)[0], m.embedding_arena[rows])
+        m.train()
+        e.lazy = lazy
+        for i in range(steps):
+            e.train_step(Xd[i * B:(i + 1) * B], yd[i * B:(i + 1) * B])
+        e.flush_lazy()
+        return ({k: v.detach().clone() for k, v in m.state_dict().items()}, e.adam_m.clone(), e.adam_v.clone(),
+                float(e.epoch_sums()[0]))
+
+    sd1, m1, v1, loss1 = run(True)
+    sd2, m2, v2, loss2 = run(True)
+    assert loss1 == loss2
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), f"run-to-run difference in {k}"
+    assert torch.equal(m1, m2) and torch.equal(v1, v2)
+    del sd2, m2, v2
+    sd3, m3, v3, loss3 = run(False)
+    assert loss1 == loss3
+    for k in sd1:
+        assert torch.equal(sd1[k].view(torch.int32) if sd1[k].dtype == torch.float32 else sd1[k],
+                           sd3[k].view(torch.int32) if sd3[k].dtype == torch.float32 else sd3[k]), f"lazy and streaming differ in {k}"
+    assert torch.equal(m1, m3) and torch.equal(v1, v3)
 
 
 def test_vocabulary_above_2_pow_24_uses_integer_ids():
