@@ -68,9 +68,13 @@ def make_config(name, table_rows=None):
 
 CFG = make_config("aliccp")
 
-PMC_SUMMARY = "r05_pmc_summary.json"   # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py)
+# profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py; configs[4]: tools/pmc_c5.sh +
+# pmc_c5_summary.py - there a "launch" is the chain of launches that makes one layer's forward / backward)
+PMC_SUMMARIES = {"aliccp": "r06_pmc_summary.json", "c5": "r06_c5_pmc_summary.json"}
+PMC_SUMMARY = PMC_SUMMARIES["aliccp"]
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
+BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 
 
 def synth_batches(n_rows, seed, ids="uniform", cfg=None):
@@ -694,6 +698,22 @@ def main():
     # of another configuration is reported as such, never as this run's traffic; a phase made of many kernels has none.
     if roofline and not one_kernel:
         roofline["traffic_source"] = "none: the phase is a chain of launches (general path); see profiles/ for per-kernel stats"
+        try:
+            from satrans_amd import native as _native
+            name = PMC_SUMMARIES.get(args.config)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            key = {"layer_bwd": "layer_bwd_chain", "layer_fwd": "layer_fwd_chain", "layer_fwd_gather": "layer_fwd_chain"}[dominant]
+            if pmc.get("_source_sha256") != _native.source_hash():
+                roofline["traffic_source"] = (f"stale: profiles/{name} was taken on other kernel sources "
+                                              f"({str(pmc.get('_source_sha256'))[:12]} vs {_native.source_hash()[:12]})")
+            elif args.flag == CFG["flag"] and not CFG.get("scaled"):
+                roofline["traffic"] = int(pmc[key]["bytes_per_launch"])
+                roofline["traffic_ratio_min"] = round(roofline["traffic"] / roofline["algorithmic_bytes_min"], 3)
+                roofline["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc of these kernel sources, 2 x FETCH_SIZE + WRITE_SIZE summed "
+                                              f"over the launches of one layer's chain (activations live in HBM between the launches of "
+                                              f"the general path, so the ratio to x + dy + dx is the price of not fusing)")
+        except (OSError, KeyError, TypeError):
+            pass
     elif roofline:
         try:
             from satrans_amd import native as _native
@@ -753,7 +773,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        forward_only = {"batch": nb, "ms_per_batch": round(ms, 4), "samples_per_s": round(nb / (ms / 1e3), 1)}
+        fl = L * fwd_flops * (nb / B) / 1e12                                      # all layers of the evaluation forward, TFLOP
+        forward_only = {"batch": nb, "ms_per_batch": round(ms, 4), "samples_per_s": round(nb / (ms / 1e3), 1),
+                        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": round(fl / (ms / 1e3), 2), "peak": FP32_PEAK_TFLOPS,
+                                     "frac": round(fl / (ms / 1e3) / FP32_PEAK_TFLOPS, 4),
+                                     "note": "whole evaluation forward (gather + L layer launches + head) between two events"}}
         model.train()
     except Exception as ex:
         print(f"[bench] forward-only timing skipped: {ex}", file=sys.stderr)
@@ -782,7 +806,18 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        fl = L * fwd_flops * (nb / B) / 1e12
+        # which pipe bounds it: 12 F D^2 of the 12 F D^2 + 2 F^2 D MACs per sample and layer run as bf16 MFMA (16 x the fp32 rate),
+        # the attention dots, softmax and LayerNorms stay fp32 VALU - the fp32 vector pipe is the bound, so the fraction is quoted
+        # against BOTH peaks: the kernel's fp32 work against the fp32 peak, all of its work against the bf16 dense peak
+        fl32 = L * 2.0 * (2 * F * F * D) * nb / 1e12
         forward_bf16 = {"dtype": "bf16", "batch": nb, "ms_per_batch": round(ms, 4), "samples_per_s": round(nb / (ms / 1e3), 1),
+                        "roofline": {"bound": "valu-f32 (attention, softmax, LayerNorm); products on bf16 mfma", "unit": "TFLOP/s",
+                                     "achieved": round(fl / (ms / 1e3), 2), "peak": BF16_PEAK_TFLOPS,
+                                     "frac": round(fl / (ms / 1e3) / BF16_PEAK_TFLOPS, 4),
+                                     "fp32_part_achieved": round(fl32 / (ms / 1e3), 2), "fp32_peak": FP32_PEAK_TFLOPS,
+                                     "fp32_part_frac": round(fl32 / (ms / 1e3) / FP32_PEAK_TFLOPS, 4),
+                                     "equivalent_frac_of_fp32_peak": round(fl / (ms / 1e3) / FP32_PEAK_TFLOPS, 4)},
                         "logit_max_abs_err_vs_fp32_kernels": float((lb16 - l32).abs().max()),
                         "note": "evaluation forward only; products bf16 x bf16 -> fp32 (v_mfma_f32_16x16x32_bf16), LayerNorm / "
                                 "softmax / attention dots fp32; training stays fp32"}

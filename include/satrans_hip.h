@@ -30,7 +30,8 @@ extern "C" {
 /* 4: satrans_layer_desc gained the trailing `attn_save` field and satrans_set_layer_bwd8 left the library (round 3; the number
  *    was bumped one round late); round 4 added satrans_layer_bwd_head (a new entry point, no struct changed).  A caller built against an
  *    older header passes a shorter struct: satrans_abi_version() must be compared with this constant before any other call. */
-#define SATRANS_ABI_VERSION 5
+/* 6: satrans_adam_hparams gained the trailing `arith` field (round 6). */
+#define SATRANS_ABI_VERSION 6
 
 /* error codes */
 #define SATRANS_OK 0
@@ -375,11 +376,16 @@ int64_t satrans_head_scratch_floats(int B, int FD, int n_dense);
  * Optimizer: torch.optim.Adam semantics (reference main.py:343) with the L2 regulariser of
  * meta_basemodel.py:577-593 folded in as its gradient 2*l2*p.
  * ---------------------------------------------------------------------------------------------- */
+#define SATRANS_ADAM_EXACT 0   /* torch.optim.Adam's fp32 operations bit for bit (correctly rounded sqrt and divisions) */
+#define SATRANS_ADAM_FAST  1   /* hardware sqrt / reciprocal: each update within 3.2e-7 relative of the exact one, ~2.5x fewer
+                                  instructions; every kernel form (streaming, gathered rows, lazy replay / flush) runs the
+                                  SAME sequence, so the forms still agree bit for bit with each other */
 typedef struct satrans_adam_hparams {
     float lr_over_bc1;  /* lr / (1 - beta1^t)                */
     float bc2_sqrt;     /* sqrt(1 - beta2^t)                 */
     float beta1, beta2, eps;
     float l2;           /* l2_reg_embedding (0 for flat dense parameters) */
+    int32_t arith;      /* SATRANS_ADAM_EXACT / SATRANS_ADAM_FAST (ABI 6) */
 } satrans_adam_hparams;
 
 /* Flat parameter vector (everything that is not an embedding table): p,g,m,v [n]. */

@@ -31,6 +31,8 @@ constexpr int kStreamBlocks = 2048;  // upper bound of the streaming grid = slot
 struct AdamK {
     float neg_step, w1, beta2, w2, eps, l2x2, l2;
     double rbc2;   // 1 / (double)bc2_sqrt, see adam_core
+    float rbc2f;   // ... rounded to fp32: the fast arithmetic's factor
+    int fast;      // satrans_adam_hparams.arith: 0 = torch's operations bit for bit, 1 = hardware sqrt / reciprocal (adam_core)
 };
 
 __host__ inline AdamK make_adamk(const satrans_adam_hparams& h) {
@@ -43,6 +45,8 @@ __host__ inline AdamK make_adamk(const satrans_adam_hparams& h) {
     k.eps = h.eps;
     k.l2 = h.l2;
     k.l2x2 = 2.0f * h.l2;
+    k.rbc2f = (float)k.rbc2;
+    k.fast = h.arith == SATRANS_ADAM_FAST ? 1 : 0;
     return k;
 }
 
@@ -63,8 +67,26 @@ __device__ __forceinline__ void adam_core(float& p, float& m, float& v, float g,
     p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step, m), denom));     // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// The FAST arithmetic (satrans_adam_hparams.arith = SATRANS_ADAM_FAST, the engine's default since round 6): the moments as
+// above, the update through the hardware's square root and reciprocal as they are (v_sqrt_f32, v_rcp_f32: 1 ulp each; a
+// subnormal second moment counts as zero, < 1e-19 against eps) and one multiply by the fp32 reciprocal of bc2_sqrt:
+//     denom = fma(sqrt_hw(v), rbc2f, eps);   p = fma(neg_step * m, rcp_hw(denom), p)
+// Relative error of ONE update against torch's correctly rounded operations <= 2^-21.6 (3 roundings of half an ulp and two
+// 1-ulp instructions), i.e. <= 3.2e-7 * |update| <= 3.2e-7 * lr per element and step - measured drift in INTEGRATION.md 4.
+// The same instruction sequence in every kernel form (streaming, gathered rows, lazy replay / flush: packed fp32 operations
+// are IEEE per element), so the forms still leave identical bits.  ~2.5x fewer VALU cycles per element-step than the
+// correctly rounded sequences the exact form needs (its flush sits on their instruction floor: profiles/r05_valu_rates.txt).
+__device__ __forceinline__ void adam_core_fast(float& p, float& m, float& v, float g, float neg_step, float rbc2f, float w1,
+                                               float beta2, float w2, float eps) {
+    m = fmaf(w1, __fsub_rn(g, m), m);
+    v = fmaf(__fmul_rn(w2, g), g, __fmul_rn(v, beta2));
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(v), rbc2f, eps);
+    p = fmaf(__fmul_rn(neg_step, m), __builtin_amdgcn_rcpf(denom), p);
+}
+
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, const AdamK& k) {
-    adam_core(p, m, v, g, k.neg_step, k.rbc2, k.w1, k.beta2, k.w2, k.eps);
+    if (k.fast) adam_core_fast(p, m, v, g, k.neg_step, k.rbc2f, k.w1, k.beta2, k.w2, k.eps);      // (uniform: a scalar branch)
+    else adam_core(p, m, v, g, k.neg_step, k.rbc2, k.w1, k.beta2, k.w2, k.eps);
 }
 
 __device__ __forceinline__ double adam4(float4& p, float4& m, float4& v, float4 g, const AdamK& k) {
@@ -504,9 +526,11 @@ __global__ void pack_rows_kernel(const int32_t* __restrict__ src, int64_t n, con
 // ---------------------------------------------------------------------------------------------------------
 struct LazyK {
     float w1, beta2, w2, eps, l2x2, l2;
+    int fast;
 };
 __host__ inline LazyK make_lazyk(const satrans_adam_hparams& h) {
     LazyK k;
+    k.fast = h.arith == SATRANS_ADAM_FAST ? 1 : 0;
     k.w1 = (float)(1.0 - (double)h.beta1);
     k.beta2 = h.beta2;
     k.w2 = (float)(1.0 - (double)h.beta2);
@@ -702,6 +726,23 @@ __device__ __forceinline__ void adam_step4(f32x2 (&p)[2], f32x2 (&m)[2], f32x2 (
     }
 }
 
+// The same step in the FAST arithmetic (adam_core_fast, four elements): one path for every value - no range votes, no scaling.
+__device__ __forceinline__ void adam_step4_fast(f32x2 (&p)[2], f32x2 (&m)[2], f32x2 (&v)[2], f32x2 (&sq)[2], float neg_step,
+                                                float rbc2f, const LazyK& k) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        sq[u] = pk_fma(p[u], p[u], sq[u]);
+        const f32x2 g = pk_add(pk_set(0.f), pk_mul(pk_set(k.l2x2), p[u]));
+        m[u] = pk_fma(pk_set(k.w1), pk_sub(g, m[u]), m[u]);
+        v[u] = pk_fma(pk_mul(pk_set(k.w2), g), g, pk_mul(v[u], pk_set(k.beta2)));
+        const f32x2 a = pk_mul(pk_set(neg_step), m[u]);
+        const f32x2 root = {__builtin_amdgcn_sqrtf(v[u].x), __builtin_amdgcn_sqrtf(v[u].y)};
+        const f32x2 den = pk_fma(root, pk_set(rbc2f), pk_set(k.eps));
+        const f32x2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        p[u] = pk_fma(a, r, p[u]);
+    }
+}
+
 // four elements per lane; steps (from, to] ; table[s] = (lr / (1 - beta1^s) as fp32, 1 / (double)fp32(sqrt(1 - beta2^s))) as doubles
 __device__ __forceinline__ double replay_element4(float4& P4, float4& M4, float4& V4, int from, int to,
                                                   const double2* __restrict__ table, const LazyK& k) {
@@ -710,9 +751,16 @@ __device__ __forceinline__ double replay_element4(float4& P4, float4& M4, float4
     // blocks and steps stay in double
     f32x2 p[2] = {{P4.x, P4.y}, {P4.z, P4.w}}, m[2] = {{M4.x, M4.y}, {M4.z, M4.w}}, v[2] = {{V4.x, V4.y}, {V4.z, V4.w}};
     f32x2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int s = from + 1; s <= to; ++s) {
-        const double2 hp = table[s];
-        adam_step4(p, m, v, sq, -(float)hp.x, hp.y, k);
+    if (k.fast) {
+        for (int s = from + 1; s <= to; ++s) {
+            const double2 hp = table[s];
+            adam_step4_fast(p, m, v, sq, -(float)hp.x, (float)hp.y, k);
+        }
+    } else {
+        for (int s = from + 1; s <= to; ++s) {
+            const double2 hp = table[s];
+            adam_step4(p, m, v, sq, -(float)hp.x, hp.y, k);
+        }
     }
     P4 = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
     M4 = make_float4(m[0].x, m[0].y, m[1].x, m[1].y);

@@ -527,6 +527,14 @@ constexpr bool kAttnMfma = false;
 #else
 constexpr bool kAttnMfma = true;
 #endif
+// Diagnostic build only (-DSATRANS_DIAG_SKIP=mask): the backward kernel WITHOUT its phase D (1) / E (2) / B (4) bodies - wrong
+// results, the same launch otherwise: the kernel's duration with a phase removed is that phase's cost without the stamps'
+// own perturbation (tools/experiments/r06_phase_cost.sh).  Never compiled into the shipped library.
+#ifdef SATRANS_DIAG_SKIP
+constexpr int kDiagSkip = SATRANS_DIAG_SKIP;
+#else
+constexpr int kDiagSkip = 0;
+#endif
 __device__ __forceinline__ f32x4 mfma_b16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
@@ -544,8 +552,11 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     static_assert(64 * H <= kFusedBlock, "one attention task per thread: a tile holds at most 64 tokens x H heads");
     constexpr int SZ_DD = D * LD, SZ_W1 = D * LU, SZ_W2 = U * LD;
     // the matrix-pipe arm of phases D / E: field count a constant, rows padded to FP, one lane per padded (sample, head, row)
-    constexpr int FP = (FT + 3) & ~3, NJB = FP / 4;
-    constexpr bool MFA = kAttnMfma && FT != 0 && d == 8 && (64 / (FT ? FT : 64)) * H * FP <= kFusedBlock;
+    // Lanes: a wave holds SHW = 64 / FP whole (sample, head) groups of FP lanes (F = 19: 3 groups of 20, four lanes spare; F = 15:
+    // 4 of 16), so that no group straddles two waves - everything phases D and E exchange about a (sample, head) stays inside one
+    // wave, and E follows D behind a wave-local wait instead of a workgroup barrier.
+    constexpr int FP = (FT + 3) & ~3, NJB = FP / 4, SHW = FT ? 64 / (FP ? FP : 1) : 1;
+    constexpr bool MFA = kAttnMfma && FT != 0 && d == 8 && (64 / (FT ? FT : 64)) * H <= kFusedWaves * SHW;
     extern __shared__ __align__(16) float lds[];
     const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -644,9 +655,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     const int t0_ls = (int)threadIdx.x / (H * F), t0_rem = (int)threadIdx.x - t0_ls * H * F;
     const int t0_h = t0_rem / F, t0_i = t0_rem - t0_h * F;
     // matrix-pipe arm: (sample, head, padded row) of this lane; lanes beyond the tile's samples address the last sample
+    // (the spare lanes of a wave repeat the first rows of its last group: same operands, same results, same addresses)
     constexpr int FPd = MFA ? FP : 1;
-    const int m_ls_raw = (int)threadIdx.x / (H * FPd), m_rem = (int)threadIdx.x - m_ls_raw * H * FPd;
-    const int m_h = m_rem / FPd, m_i = m_rem - m_h * FPd, m_sub = lane & 3;      // (H FP and FP are multiples of 4: m_i & 3 = lane & 3)
+    const int m_grp = lane / FPd, m_sh = wave * SHW + min(m_grp, SHW - 1);
+    const int m_ls_raw = m_sh / H, m_h = m_sh - m_ls_raw * H, m_i = lane - m_grp * FPd, m_sub = lane & 3;      // (FP is a multiple of 4: m_i & 3 = lane & 3)
+    auto ld_pair = [](const float* p_) -> f32x2 { return *reinterpret_cast<const f32x2*>(p_); };      // (a feature pair of a row)
+    // (round 6, measured on one box: keeping the compiler from pairing these reads into ds_read2_b64 - half the LDS rate per
+    //  byte - or pinning the reads ahead of the products with scheduling barriers moves the kernel by < 1 %: left to the compiler)
     const FusedDrop dc = fused_drop(a);
     const float inv_sqrt_d = 1.0f / sqrtf((float)d);
     // a.attn_save: the forward of this step left the attention's softmax numerators [p][j][H F], 1 / sum [p][H F], keep words
@@ -788,9 +803,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
           const int first_ = lo + tile_ * Tsamp;
           return a.order[first_ + (tok < min(Tsamp, hi - first_) * F ? ls_tok : 0)];
       };
-      auto task_sample_of = [&](int tile_) {
+      auto task_sample_of = [&](int tile_) {      // (the sample of this lane's attention row in phase B: its dropout key)
           const int first_ = lo + tile_ * Tsamp;
-          return a.order[first_ + min(t0_ls, min(Tsamp, hi - first_) - 1)];
+          return a.order[first_ + min(MFA ? m_ls_raw : t0_ls, min(Tsamp, hi - first_) - 1)];
       };
       // row of a.x that holds this lane's input row: the position b F + f itself, or - gather fused in - the id stored there
       // (the raw loaded id travels to the point of use: any arithmetic on it right here - a sign extension - would be a wait
@@ -810,8 +825,43 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
           for (int k_ = 0; k_ < KT; ++k_) cb_next[k_] = a.order[first_ + min(((int)threadIdx.x + kFusedBlock * k_) / per4, last_)];
       };
+      // The hand-over of a tile (saved attention: softmax numerators, 1 / sum, keep words into their caches; the tile's dy rows
+      // [sample][F][D] and saved attention outputs, unpadded, into the dS cache, which phase C reads once) is copied straight
+      // into LDS, 16 bytes per lane, at the TOP of the tile (the caches are dead since the barrier behind the previous phase E)
+      // and waited for at the end of phase A; the first tile of a scenario range: in front of the loop.
+      // (Round 6 tried the copy for tile t + 1 at the start of tile t's phase F, a whole phase ahead of its use: +7.5 us per
+      //  launch, 186 against 178.5 - an LDS-DMA piece costs 100-185 cycles to issue inside a phase that is busy with matrix
+      //  products and LDS reads, eleven pieces per wave and tile; at the top of the tile nothing else is in flight.)
+      auto handover_copy = [&](int tile_) {
+          const int first_ = lo + tile_ * Tsamp;
+          const int nS_ = min(Tsamp, hi - first_);
+#pragma unroll
+          for (int k_ = 0; k_ < KT; ++k_) {
+              const int c = (int)threadIdx.x + kFusedBlock * k_;
+              const int ls_ = c / per4;
+              if (c < nS_ * per4) {
+                  __builtin_amdgcn_global_load_lds(dy + (size_t)cb_next[k_] * F * D + 4 * (c - ls_ * per4),
+                                                   (lds_ptr)(sDS + 4 * (kFusedBlock * k_ + 64 * wave)), 16, 0, 0);
+                  __builtin_amdgcn_global_load_lds(save_o + (size_t)first_ * F * D + 4 * c,
+                                                   (lds_ptr)(sDS + Tsamp * F * D + 4 * (kFusedBlock * k_ + 64 * wave)), 16, 0, 0);
+              }
+          }
+          const int n4 = nS_ * F * HF / 4;
+          const float* gp = a.attn_save + (size_t)first_ * F * HF;
+          for (int c0 = 0; c0 < n4; c0 += kFusedBlock) {
+              const int c = c0 + (int)threadIdx.x;
+              if (c < n4) __builtin_amdgcn_global_load_lds(gp + 4 * c, (lds_ptr)(sP + 4 * (c0 + 64 * wave)), 16, 0, 0);
+          }
+          if ((int)threadIdx.x < nS_ * HF) {
+              __builtin_amdgcn_global_load_lds(save_inv + (size_t)first_ * HF + threadIdx.x, (lds_ptr)(st_inv + 64 * wave), 4, 0, 0);
+              __builtin_amdgcn_global_load_lds(save_keep + (size_t)first_ * HF + threadIdx.x, (lds_ptr)(st_keep + 64 * wave), 4, 0, 0);
+          }
+      };
       int b_next = sample_of(t0), tb_next = task_sample_of(t0);
-      if (has_save) copy_samples_of(t0);
+      if (has_save) {
+          copy_samples_of(t0);
+          handover_copy(t0);      // (the caches are dead: the previous range ended on the barrier behind its last phase F)
+      }
       int xrow_next = row_of(t0, b_next);
       load_frag<KT>(a.x + (size_t)xrow_next * D + g4, x_next);
       // saved MetaNet rows: zh of both roles and their 1 / std of this lane's token, straight by sorted position - fetched where
@@ -836,32 +886,10 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         const int tile_n = min(tile + 1, t1 - 1);
         b_next = sample_of(tile_n);
         tb_next = task_sample_of(tile_n);
-        if (has_save) {      // (the caches are dead since the previous tile's phase E; nothing touches them before this tile's phase C)
-            // dy rows [sample of the tile][F][D] and the saved attention outputs, unpadded, into the dS cache (dead until phase D;
-            // phase C reads each row once: bank conflicts do not matter)
-#pragma unroll
-            for (int k_ = 0; k_ < KT; ++k_) {
-                const int c = (int)threadIdx.x + kFusedBlock * k_;
-                const int ls_ = c / per4;
-                if (c < nS * per4) {
-                    __builtin_amdgcn_global_load_lds(dy + (size_t)cb_next[k_] * F * D + 4 * (c - ls_ * per4),
-                                                     (lds_ptr)(sDS + 4 * (kFusedBlock * k_ + 64 * wave)), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(save_o + (size_t)first * F * D + 4 * c,
-                                                     (lds_ptr)(sDS + Tsamp * F * D + 4 * (kFusedBlock * k_ + 64 * wave)), 16, 0, 0);
-                }
-            }
-            copy_samples_of(tile_n);
-            const int n4 = nS * F * HF / 4;
-            const float* gp = a.attn_save + (size_t)first * F * HF;
-            for (int c0 = 0; c0 < n4; c0 += kFusedBlock) {
-                const int c = c0 + (int)threadIdx.x;
-                if (c < n4) __builtin_amdgcn_global_load_lds(gp + 4 * c, (lds_ptr)(sP + 4 * (c0 + 64 * wave)), 16, 0, 0);
-            }
-            if ((int)threadIdx.x < nS * HF) {
-                __builtin_amdgcn_global_load_lds(save_inv + (size_t)first * HF + threadIdx.x, (lds_ptr)(st_inv + 64 * wave), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(save_keep + (size_t)first * HF + threadIdx.x, (lds_ptr)(st_keep + 64 * wave), 4, 0, 0);
-            }
-        }
+        // (saved attention: this tile's hand-over, see handover_copy; the sample indices of the NEXT tile's dy rows are fetched
+        //  here, a tile ahead of the copy that needs them)
+        if (has_save && tile > t0) handover_copy(tile);
+        if (has_save) copy_samples_of(tile_n);
         // HEADF: the sample's label and dense columns, consumed in phase C - issued here, raw (see the load pipeline above)
         float label_pre = 0.f, dense_pre[kHeadDenseMax] = {0.f, 0.f};
         if constexpr (HEADF) {
@@ -999,6 +1027,90 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // Scores are staged in the task's row of the numerator cache (pre-scaled by log2(e)/sqrt(d)), keys in chunks of
         // four with all loads of a chunk issued before its results are stored; padding keys of the last chunk read the
         // last real row and are masked arithmetically.
+        if constexpr ((kDiagSkip & 4) != 0) {
+        } else if constexpr (MFA && !has_save) {
+          // ---- matrix-pipe arm (see phase D): S^T blocks from the key rows picked by lane & 3 and the lane's own query row, the
+          //      softmax lane-local on the 4 NJB accumulator registers, o = P V from the value feature pairs picked by lane & 3 ----
+          if ((wave * SHW) / H < nS) {
+            const int tls = min(m_ls_raw, Tsamp - 1), h = m_h;
+            const int iq = min(m_i, FT - 1);
+            const bool own = m_ls_raw < nS && m_i < FT && m_grp < SHW;
+            const int told = tls * HF + h * FT + iq;
+            float qe[d];
+            {
+                const float* qr = sq + (size_t)(tls * FT + iq) * LD + h * d;
+                const float4 q0_ = *reinterpret_cast<const float4*>(qr), q1_ = *reinterpret_cast<const float4*>(qr + 4);
+                qe[0] = q0_.x; qe[1] = q0_.y; qe[2] = q0_.z; qe[3] = q0_.w; qe[4] = q1_.x; qe[5] = q1_.y; qe[6] = q1_.z; qe[7] = q1_.w;
+            }
+            float ka[NJB][d];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {
+                const float* kr = sk + (size_t)min(tls * FT + 4 * jb + m_sub, ROWS - 1) * LD + h * d;
+                const float4 k0_ = *reinterpret_cast<const float4*>(kr), k1_ = *reinterpret_cast<const float4*>(kr + 4);
+                ka[jb][0] = k0_.x; ka[jb][1] = k0_.y; ka[jb][2] = k0_.z; ka[jb][3] = k0_.w;
+                ka[jb][4] = k1_.x; ka[jb][5] = k1_.y; ka[jb][6] = k1_.z; ka[jb][7] = k1_.w;
+            }
+            f32x2 vp[FT];
+            {
+                const float* vb = sv + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
+#pragma unroll
+                for (int j = 0; j < FT; ++j) vp[j] = ld_pair(vb + (size_t)j * LD);
+            }
+            f32x4 sc4[NJB];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) sc4[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < d; ++e)
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) sc4[jb] = mfma_b16(ka[jb][e], qe[e], sc4[jb]);
+            const float sc_scale = inv_sqrt_d * kLog2e;
+            float ex[FT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                ex[j] = sc4[j >> 2][j & 3] * sc_scale;
+                mx = fmaxf(mx, ex[j]);
+            }
+            const uint32_t skey = drop_sample_key(dc.key[kSiteAttn], (uint32_t)tb0);
+            const uint32_t block0 = drop_attn_elem(h, FT, iq, 0) >> 2;
+            // (every lane writes: a padding / spare lane holds a copy of a real row - same values to the same addresses -, and
+            //  the slots of a sample the tile does not have belong to nobody.  A branch around the stores would also make the
+            //  compiler drain the LDS queue in front of every product that follows.)
+            float* prow = sP + (size_t)tls * FT * HF + (h * FT + iq);
+            float sum = 0.f;
+            uint32_t keep = 0xFFFFFFFFu;
+            f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {
+                const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)jb, dc.thresh) : 0xFu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 4 * jb + r;
+                    if (j < FT) {
+                        ex[j] = __builtin_amdgcn_exp2f(ex[j] - mx);
+                        sum += ex[j];
+                        float pe = ex[j];
+                        if (dc.on) {
+                            const bool kp = (kb >> r) & 1u;
+                            pe = kp ? ex[j] * dc.scale : 0.f;
+                            keep = kp ? keep : keep & ~(1u << j);
+                        }
+                        oa = mfma_b16(vp[j].x, pe, oa);
+                        ob = mfma_b16(vp[j].y, pe, ob);
+                        prow[j * HF] = ex[j];
+                    }
+                }
+            }
+            const float inv = 1.0f / sum;
+            st_inv[told] = inv;
+            st_keep[told] = keep;
+            if (own) {
+                float* orow = so + (size_t)(tls * FT + m_i) * LD + h * d;
+                *reinterpret_cast<float4*>(orow) = make_float4(oa[0] * inv, ob[0] * inv, oa[1] * inv, ob[1] * inv);
+                *reinterpret_cast<float4*>(orow + 4) = make_float4(oa[2] * inv, ob[2] * inv, oa[3] * inv, ob[3] * inv);
+            }
+          }
+        } else
         if (const int task = threadIdx.x; !has_save && task < nS * H * F) {      // (at most 64 H <= 256 tasks per tile: one per thread)
             const int tls = t0_ls, h = t0_h, i = t0_i;
             const int tb = tb0;
@@ -1221,13 +1333,14 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         // pass 1: dP_ij = (go_i . v_j) * mask_ij staged in the task's row of the dS cache, dot_i = sum_j P_ij dP_ij;
         // pass 2: dS_ij = P_ij (dP_ij - dot_i) / sqrt(d) replaces it, the numerator cache row becomes P_ij * mask_ij
         //         (the coefficient of dv_j), dq_i = sum_j dS_ij k_j.
-        if constexpr (MFA) {
+        if constexpr ((kDiagSkip & 1) != 0) {
+        } else if constexpr (MFA) {
           // ---- matrix-pipe arm.  Every lane of a wave that holds a sample of the tile runs the products (the A operands are
-          //      shared rows addressed by lane & 3, whatever the lane's own row); only the stores are predicated. -------------
-          if (64 * wave < nS * H * FP) {
+          //      shared rows addressed by lane & 3, whatever the lane's own row). ---------------------------------------------
+          if ((wave * SHW) / H < nS) {
             const int tls = min(m_ls_raw, Tsamp - 1), h = m_h;
-            const int iq = min(m_i, FT - 1);                       // a padding row computes a copy of the last real row, stores nothing
-            const bool own = m_ls_raw < nS && m_i < FT;
+            const int iq = min(m_i, FT - 1);                       // a padding row computes a copy of the last real row
+            const bool own = m_ls_raw < nS && m_i < FT && m_grp < SHW;
             const int told = tls * HF + h * FT + iq;                // this row in the forward's (unpadded) task numbering
             // dP^T block jb: register r = dP[i][4 jb + r] = sum_e v[4 jb + r][e] go[i][e]
             float ge[d];
@@ -1251,7 +1364,6 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             const float inv = st_inv[told];
             const uint32_t keep = st_keep[told];
             const float scale = dc.scale;
-            __builtin_amdgcn_sched_barrier(0);
             f32x4 dp[NJB];
 #pragma unroll
             for (int jb = 0; jb < NJB; ++jb) dp[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1259,12 +1371,12 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             for (int e = 0; e < d; ++e)
 #pragma unroll
                 for (int jb = 0; jb < NJB; ++jb) dp[jb] = mfma_b16(va[jb][e], ge[e], dp[jb]);
-            // the K / Q feature pairs of phase D's second product: lane & 3 picks the pair, issued here, under the softmax arithmetic
+            // the K feature pairs of the second product (lane & 3 picks the pair): in flight under the softmax arithmetic
             f32x2 kp[FT];
             {
                 const float* kb = sk + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
 #pragma unroll
-                for (int j = 0; j < FT; ++j) kp[j] = *reinterpret_cast<const f32x2*>(kb + (size_t)j * LD);
+                for (int j = 0; j < FT; ++j) kp[j] = ld_pair(kb + (size_t)j * LD);
             }
             float dsv[FT];
             float dot = 0.f;
@@ -1275,19 +1387,18 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                 dot = fmaf(pn[j], dpj, dot);
                 dsv[j] = dpj;
             }
+            // dq[i][2 r], dq[i][2 r + 1] = sum_j k[j][h d + 2 r (+ 1)] dS[i][j]; dS and the masked probabilities go to the caches as
+            // they are made (every lane stores, no branch: see phase B), between the products
             float* dsT = sDS + (size_t)((tls * H + h) * FP) * FP + m_i;        // dS[i][j] at dsT[j FP]
+            f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < FT; ++j) {
                 dsv[j] = pn[j] * (dsv[j] - dot) * inv_sqrt_d;
                 const float pm = ((keep >> j) & 1u) ? pn[j] * scale : 0.f;
-                if (own) { dsT[j * FP] = dsv[j]; prow[j * HF] = pm; }
-            }
-            // dq[i][2 r], dq[i][2 r + 1] = sum_j k[j][h d + 2 r (+ 1)] dS[i][j]
-            f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < FT; ++j) {
                 qa = mfma_b16(kp[j].x, dsv[j], qa);
                 qb = mfma_b16(kp[j].y, dsv[j], qb);
+                dsT[j * FP] = dsv[j];
+                prow[j * HF] = pm;
             }
             if (own) {
                 float* qr = sg + (size_t)(tls * FT + m_i) * LD + h * d;
@@ -1374,18 +1485,29 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             else ATTN_CHUNKS(j0, chunk4, true);
             store_row<d>(sg + (size_t)(tls * F + i) * LD + h * d, dq, 1.0f);
         }
-        lds_barrier();
+        // (matrix-pipe arm: phase E reads of the caches only what its own wave wrote in phase D, and rewrites of the k / v rows only
+        //  the (sample, head) column slices its own wave has finished reading: a wave-local wait, no workgroup barrier)
+        if constexpr (MFA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else lds_barrier();
 
         STAMP(4);
         // ================= phase E: by columns: dk_j = sum_i dS_ij q_i, dv_j = sum_i P_ij mask_ij go_i (in place of k_j, v_j)
-        if constexpr (MFA) {
+        if constexpr ((kDiagSkip & 2) != 0) {
+        } else if constexpr (MFA) {
           // ---- matrix-pipe arm: the lane's row is now KEY j; B = its own column of dS / of the masked probabilities (read as
           //      rows of the transposed caches), A = the q / go feature pairs picked by lane & 3 -------------------------------
-          if (64 * wave < nS * H * FP) {
+          if ((wave * SHW) / H < nS) {
             const int tls = min(m_ls_raw, Tsamp - 1), h = m_h;
             const int jk = min(m_i, FT - 1);
-            const bool own = m_ls_raw < nS && m_i < FT;
+            const bool own = m_ls_raw < nS && m_i < FT && m_grp < SHW;
             float dsc[FP], pmc[FT];
+            f32x2 qp[FT], gp[FT];
+            const float* qb_ = sq + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
+            const float* gb_ = so + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
+            // The LDS queue of a wave counts 15 reads at most and waits by count: of the 53 reads of this phase the first product
+            // needs 24, and a wait for them is only expressible while fewer than 16 younger ones are in flight.  So: its own
+            // operands + the 10 of the masked probabilities, half of the first product, the go pairs, its other half, the second
+            // product - every wait a counted one, every read a product or more ahead of its use.
             {
                 const float* dr_ = sDS + (size_t)((tls * H + h) * FP + jk) * FP;
 #pragma unroll
@@ -1393,26 +1515,30 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                     const float4 t = *reinterpret_cast<const float4*>(dr_ + 4 * ib);
                     dsc[4 * ib] = t.x; dsc[4 * ib + 1] = t.y; dsc[4 * ib + 2] = t.z; dsc[4 * ib + 3] = t.w;
                 }
+#pragma unroll
+                for (int i = 0; i < FT; ++i) qp[i] = ld_pair(qb_ + (size_t)i * LD);
+            }
+            {
                 const float* pc = sP + (size_t)tls * FT * HF + (size_t)jk * HF + h * FT;
 #pragma unroll
                 for (int i = 0; i < FT; ++i) pmc[i] = pc[i];
             }
-            f32x2 qp[FT], gp[FT];
-            {
-                const float* qb_ = sq + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
-                const float* gb_ = so + (size_t)(tls * FT) * LD + h * d + 2 * m_sub;
-#pragma unroll
-                for (int i = 0; i < FT; ++i) {
-                    qp[i] = *reinterpret_cast<const f32x2*>(qb_ + (size_t)i * LD);
-                    gp[i] = *reinterpret_cast<const f32x2*>(gb_ + (size_t)i * LD);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
             f32x4 ka = {0.f, 0.f, 0.f, 0.f}, kb2 = {0.f, 0.f, 0.f, 0.f}, va2 = {0.f, 0.f, 0.f, 0.f}, vb2 = {0.f, 0.f, 0.f, 0.f};
+            constexpr int IH = FT / 2;
 #pragma unroll
-            for (int i = 0; i < FT; ++i) {
+            for (int i = 0; i < IH; ++i) {
                 ka = mfma_b16(qp[i].x, dsc[i], ka);
                 kb2 = mfma_b16(qp[i].y, dsc[i], kb2);
+            }
+#pragma unroll
+            for (int i = 0; i < FT; ++i) gp[i] = ld_pair(gb_ + (size_t)i * LD);
+#pragma unroll
+            for (int i = IH; i < FT; ++i) {
+                ka = mfma_b16(qp[i].x, dsc[i], ka);
+                kb2 = mfma_b16(qp[i].y, dsc[i], kb2);
+            }
+#pragma unroll
+            for (int i = 0; i < FT; ++i) {
                 va2 = mfma_b16(gp[i].x, pmc[i], va2);
                 vb2 = mfma_b16(gp[i].y, pmc[i], vb2);
             }

@@ -65,11 +65,17 @@ __device__ __forceinline__ void chain_bf16(const __bf16* __restrict__ il, const 
     }
 }
 
-template <int D, int U, int H, int WAVES>
+// FT: the field count as a constant (0 = a.F).  With it and d = 8 the attention runs on the matrix pipe as in the fused backward
+// (layer_fused.hip, phases B / D / E): v_mfma_f32_4x4x1_16b_f32, one lane per (sample, head, query row) in whole groups of
+// FP = 4 ceil(F / 4) lanes per wave, S^T = K q from the key rows picked by lane & 3 and the lane's own query row, the softmax
+// lane-local on the accumulator registers, o = P V from the value feature pairs picked by lane & 3 - fp32 throughout.  With
+// the products on the bf16 pipe the attention is ~2/3 of this kernel, so this is where its time goes.
+template <int D, int U, int H, int WAVES, int FT = 0>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_bf16_kernel(satrans_layer_desc a, int Tsamp, float* __restrict__ y) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, KD = D + 8, KU = U + 8;
+    constexpr bool MFA = FT != 0 && d == 8;
     extern __shared__ __align__(16) float lds[];
-    const int F = a.F;
+    const int F = FT ? FT : a.F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4, g4 = 4 * g;
     const bool meta_q = a.flags & SATRANS_META_Q, meta_k = a.flags & SATRANS_META_K;
@@ -166,7 +172,68 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_bf16_kernel(satrans_laye
         // ---- phase 2: attention in fp32, one lane per (sample, head, query row)  (satrans.py:75-90) -------------------
         // two passes over the keys in chunks of four (maximum of the scaled scores, then exp2 / sum / PV with the scores
         // recomputed); padding keys of the last chunk read the last real row and are masked
-        {
+        if constexpr (MFA) {
+          constexpr int FP = (FT + 3) & ~3, NJB = FP / 4, SHW = 64 / FP;      // SHW whole (sample, head) groups per wave
+          const int grp = lane / FP, m_i = lane - grp * FP, sub = lane & 3;   // (FP is a multiple of 4: m_i & 3 = lane & 3)
+          const float sc_scale = inv_sqrt_d * kLog2e;
+          const int ngrp = nS * H;
+          for (int g0 = wave * SHW; g0 < ngrp; g0 += WAVES * SHW) {           // (wave-uniform: every lane runs the products)
+            // spare lanes of the wave and groups beyond the tile repeat a real group: same operands, nothing stored
+            const int sh = min(g0 + min(grp, SHW - 1), ngrp - 1);
+            const bool own = grp < SHW && g0 + grp < ngrp && m_i < FT;
+            const int ls = sh / H, h = sh - ls * H, iq = min(m_i, FT - 1);
+            float* qrow = sq + (size_t)(ls * FT + iq) * LD + h * d;
+            float qe[d];
+            {
+                const float4 q0_ = *reinterpret_cast<const float4*>(qrow), q1_ = *reinterpret_cast<const float4*>(qrow + 4);
+                qe[0] = q0_.x; qe[1] = q0_.y; qe[2] = q0_.z; qe[3] = q0_.w; qe[4] = q1_.x; qe[5] = q1_.y; qe[6] = q1_.z; qe[7] = q1_.w;
+            }
+            float ka[NJB][d];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {      // (a padding key of the last block reads a row of the buffer: masked below)
+                const float* kr = sk + (size_t)min(ls * FT + 4 * jb + sub, rows - 1) * LD + h * d;
+                const float4 k0_ = *reinterpret_cast<const float4*>(kr), k1_ = *reinterpret_cast<const float4*>(kr + 4);
+                ka[jb][0] = k0_.x; ka[jb][1] = k0_.y; ka[jb][2] = k0_.z; ka[jb][3] = k0_.w;
+                ka[jb][4] = k1_.x; ka[jb][5] = k1_.y; ka[jb][6] = k1_.z; ka[jb][7] = k1_.w;
+            }
+            f32x2 vp[FT];
+            {
+                const float* vb = sv + (size_t)(ls * FT) * LD + h * d + 2 * sub;
+#pragma unroll
+                for (int j = 0; j < FT; ++j) vp[j] = *reinterpret_cast<const f32x2*>(vb + (size_t)j * LD);
+            }
+            f32x4 sc4[NJB];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) sc4[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < d; ++e)
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb)
+                    sc4[jb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ka[jb][e], qe[e], sc4[jb], 0, 0, 0);
+            float ex[FT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                ex[j] = sc4[j >> 2][j & 3] * sc_scale;
+                mx = fmaxf(mx, ex[j]);
+            }
+            float sum = 0.f;
+            f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                ex[j] = __builtin_amdgcn_exp2f(ex[j] - mx);
+                sum += ex[j];
+                oa = __builtin_amdgcn_mfma_f32_4x4x1f32(vp[j].x, ex[j], oa, 0, 0, 0);
+                ob = __builtin_amdgcn_mfma_f32_4x4x1f32(vp[j].y, ex[j], ob, 0, 0, 0);
+            }
+            // the attention output takes the place of this lane's own q row slice (nobody else reads it)
+            const float inv = 1.0f / sum;
+            if (own) {
+                *reinterpret_cast<float4*>(qrow) = make_float4(oa[0] * inv, ob[0] * inv, oa[1] * inv, ob[1] * inv);
+                *reinterpret_cast<float4*>(qrow + 4) = make_float4(oa[2] * inv, ob[2] * inv, oa[3] * inv, ob[3] * inv);
+            }
+          }
+        } else {
           const float sc_scale = inv_sqrt_d * kLog2e;
           for (int task = threadIdx.x; task < nS * H * F; task += 64 * WAVES) {
             const int ls = task / (H * F), rem = task - ls * H * F;
@@ -245,7 +312,7 @@ static int64_t bf16_fwd_lds_bytes(int T, int F, int D, int U, bool same_tab) {
     return 2 * bf + 4 * (6 * D + 3 * rows * LD) + 256;
 }
 
-template <int D, int U, int H, int WAVES>
+template <int D, int U, int H, int WAVES, int FT = 0>
 static int launch_fwd_bf16(const satrans_layer_desc* d, float* y, hipStream_t stream) {
     const bool same_tab = d->tab_q == d->tab_k;
     int best = 0;
@@ -253,21 +320,27 @@ static int launch_fwd_bf16(const satrans_layer_desc* d, float* y, hipStream_t st
     for (int t = 1; t <= 4 * WAVES; ++t) {
         if (bf16_fwd_lds_bytes(t, d->F, D, U, same_tab) > 156 * 1024) break;
         const int tok = t * d->F, ntt = (tok + 15) / 16;
-        const double eff = (double)tok / (16.0 * ntt) * (double)ntt / (double)(ceil_div(ntt, WAVES) * WAVES);
+        double eff = (double)tok / (16.0 * ntt) * (double)ntt / (double)(ceil_div(ntt, WAVES) * WAVES);
+        if (FT != 0) {
+            // matrix-pipe attention: whole rounds of WAVES * (64 / FP) (sample, head) groups; the attention is ~2/3 of the kernel
+            const int per_round = WAVES * (64 / ((FT + 3) & ~3)), groups = t * H;
+            const double eff_att = (double)groups / (double)(ceil_div(groups, per_round) * per_round);
+            eff = 1.0 / (0.35 / eff + 0.65 / eff_att);
+        }
         if (eff >= best_eff) { best_eff = eff; best = t; }
     }
     SATRANS_REQUIRE(best > 0, SATRANS_E_UNSUPPORTED, "layer_fwd(bf16): F=%d does not fit LDS", d->F);
     const size_t lds = (size_t)bf16_fwd_lds_bytes(best, d->F, D, U, same_tab);
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_bf16_kernel<D, U, H, WAVES>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_bf16_kernel<D, U, H, WAVES, FT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(bf16): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
     }
     const int64_t tiles = ceil_div(d->B, best) + d->S;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count()));
-    layer_fwd_bf16_kernel<D, U, H, WAVES><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y);
+    layer_fwd_bf16_kernel<D, U, H, WAVES, FT><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y);
     SATRANS_CHECK_LAUNCH("layer_fwd_bf16_kernel");
     return SATRANS_OK;
 }
@@ -289,6 +362,8 @@ extern "C" int satrans_layer_fwd_bf16(const satrans_layer_desc* d, float* y, voi
                     "layer_fwd(bf16): evaluation forward of (D,U,H) = (32,64,4) or (64,128,4) without gate / bilinear");
     SATRANS_REQUIRE(y, SATRANS_E_BADARG, "layer_fwd(bf16): null output");
     hipStream_t stream = (hipStream_t)stream_;
+    if (d->D == 32 && d->F == 19) return launch_fwd_bf16<32, 64, 4, 12, 19>(d, y, stream);      // AliCCP
+    if (d->D == 32 && d->F == 15) return launch_fwd_bf16<32, 64, 4, 12, 15>(d, y, stream);      // Alimama
     if (d->D == 32) return launch_fwd_bf16<32, 64, 4, 12>(d, y, stream);
     return launch_fwd_bf16<64, 128, 4, 8>(d, y, stream);
 }

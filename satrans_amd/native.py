@@ -23,7 +23,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SATRANS_LIB_PATH") or os.path.join(_HERE, "libsatrans_hip.so")   # (override: kernel experiments)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ID_F32, ID_I32, ID_I64 = 0, 1, 2
 META_Q, META_K, RELU_OUT, NO_RES, TRAIN, GATE, BILINEAR = 1, 2, 4, 8, 16, 32, 64
@@ -78,7 +78,10 @@ class MetaNetDesc(C.Structure):
 class AdamHParams(C.Structure):
     """Mirror of `satrans_adam_hparams`."""
     _fields_ = [("lr_over_bc1", C.c_float), ("bc2_sqrt", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("eps", C.c_float), ("l2", C.c_float)]
+                ("beta2", C.c_float), ("eps", C.c_float), ("l2", C.c_float), ("arith", C.c_int32)]
+
+
+ADAM_EXACT, ADAM_FAST = 0, 1      # satrans_adam_hparams.arith (SATRANS_ADAM_EXACT / SATRANS_ADAM_FAST)
 
 
 # name -> (restype, argtypes); tests/test_host_cpu.py::test_library_exports_every_declared_symbol checks this table against the header

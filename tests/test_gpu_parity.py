@@ -523,10 +523,12 @@ def _adam_reference(p, g, lr, steps_done, m, v):
     return p.detach(), st["exp_avg"], st["exp_avg_sq"]
 
 
-def test_optimizer_kernels_exact():
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_optimizer_kernels_exact(arith):
     """Optimizer kernels in isolation, on gradients that are exact in any summation order (small integers times
     a power of two): flat Adam, touched-row Adam with heavy duplication across chunk boundaries, and the
-    streaming Adam of untouched rows must reproduce torch.optim.Adam + L2 to the last few ulps."""
+    streaming Adam of untouched rows must reproduce torch.optim.Adam + L2 to the last few ulps - in the exact arithmetic and,
+    inside the same bounds (its own is 3.2e-7 of the update), in the fast one; whichever path a row takes, the bits agree."""
     import ctypes as C
     import math
     from satrans_amd import native as N
@@ -539,6 +541,7 @@ def test_optimizer_kernels_exact():
         h = N.AdamHParams()
         h.lr_over_bc1, h.bc2_sqrt = lr / (1 - b1 ** t), math.sqrt(1 - b2 ** t)
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, eps, l2v
+        h.arith = N.ADAM_FAST if arith == "fast" else N.ADAM_EXACT
         return h
 
     # ---- flat ----
@@ -1433,9 +1436,10 @@ def test_teacher_forced_step_at_the_baseline_batch_on_full_size_tables():
     assert checked_tables == len(bench.ALICCP_FIELDS)
 
 
-def test_lazy_adam_is_bitwise_the_streaming_adam():
+@pytest.mark.parametrize("arith", ["fast", "exact"])
+def test_lazy_adam_is_bitwise_the_streaming_adam(arith):
     """The lazy-exact optimizer path (postponed regulariser-only steps, replayed before a row is gathered and by the
-    flush) must leave EXACTLY the tables, moments and epoch sums of the every-step streaming kernel."""
+    flush) must leave EXACTLY the tables, moments and epoch sums of the every-step streaming kernel - in either arithmetic."""
     c = Case("aliccp_sota")
     rng = np.random.RandomState(11)
     B, steps = 64, 9
@@ -1448,7 +1452,7 @@ def test_lazy_adam_is_bitwise_the_streaming_adam():
         model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy")
         model.train()
         eng = model._require_engine()
-        eng.lazy, eng.overlap = lazy, False
+        eng.lazy, eng.overlap, eng.adam_arith = lazy, False, arith
         eng.reset_epoch_sums()
         for i, (xb, yb) in enumerate(zip(Xs, ys)):
             eng.train_step(torch.from_numpy(xb).to(DEV), torch.from_numpy(yb).to(DEV))
@@ -1524,9 +1528,10 @@ def test_packed_replay_arithmetic_is_the_ieee_arithmetic():
         assert bad.value == 0, f"{bad.value} scaled quotients are not correctly rounded"
 
 
+@pytest.mark.parametrize("arith", ["exact", "fast"])
 @pytest.mark.parametrize("state", ["edge", "decayed", "eps0"])
 @pytest.mark.parametrize("D", [16, 32, 64])
-def test_lazy_flush_equals_streaming_steps_on_edge_values(D, state):
+def test_lazy_flush_equals_streaming_steps_on_edge_values(D, state, arith):
     """Kernel level: K regulariser-only steps through the streaming kernel (one launch per step) and one flush (and one
     replay of a row list) must leave identical bits - `edge`: on ordinary table values and on the values that take the scalar
     path of the packed replay (zeros, subnormals, 1e-30, 1e20, negative zero) mixed into the same lanes; `decayed`: on the state
@@ -1584,6 +1589,7 @@ def test_lazy_flush_equals_streaming_steps_on_edge_values(D, state):
         h = N.AdamHParams()
         h.lr_over_bc1, h.bc2_sqrt = lr / (1 - b1 ** t), math.sqrt(1 - b2 ** t)
         h.beta1, h.beta2, h.eps, h.l2 = b1, b2, eps, l2
+        h.arith = N.ADAM_FAST if arith == "fast" else N.ADAM_EXACT       # (every form runs the same sequence in either arithmetic)
         return h
 
     Ps, Ms, Vs = (x.clone().to(DEV) for x in (P, M, V))

@@ -14,9 +14,9 @@ rm -rf $o/ks
 bash tools/pmc_passes.sh > $o/pmc.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc aliccp > $o/pmc_summary.json 2> $o/pmc_summary.err
 rm -rf gpurun_out/pmc
-# the default bench line AFTER the counter passes: bench.py takes roofline.traffic from profiles/r05_pmc_summary.json and refuses a
+# the default bench line AFTER the counter passes: bench.py takes roofline.traffic from profiles/r06_pmc_summary.json and refuses a
 # summary of other kernel sources (on the GPU box this copy only lives for the call; copy it into profiles/ here as well)
-cp $o/pmc_summary.json profiles/r05_pmc_summary.json
+cp $o/pmc_summary.json profiles/r06_pmc_summary.json
 python bench.py > $o/bench_default.json 2> $o/bench_default.err; echo "bench rc=$?"
 python bench.py --config alimama --train-only > $o/bench_alimama.json 2>/dev/null
 python bench.py --flag sota-gate --train-only > $o/bench_gate.json 2>/dev/null
