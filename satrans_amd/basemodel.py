@@ -610,6 +610,8 @@ class BaseModel(nn.Module):
                     self.train()
             if bar is not None:
                 bar.close()
+            if shuffle and epoch + 1 < epochs and not self.stop_training:
+                self._speculate_epoch_order(sample_num)      # (host work under the device's queued tail, before the first read-back)
             engine.raise_if_bad_ids()
             bce_sum, reg_sum = engine.epoch_sums()
             epoch_logs = {"loss": (bce_sum + reg_sum) / sample_num}
@@ -679,10 +681,30 @@ class BaseModel(nn.Module):
             return None
         torch.empty((), dtype=torch.int64).random_()
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        spec, self._order_spec = getattr(self, "_order_spec", None), None
+        if spec is not None and spec[0] == seed and spec[1] == n:
+            perm = spec[2]                 # drawn ahead from the seed this point was going to produce (_speculate_epoch_order)
+        else:
+            gen = torch.Generator()
+            gen.manual_seed(seed)
+            perm = torch.randperm(n, generator=gen)
+        return perm if on_host else perm.to(self.device)
+
+    def _speculate_epoch_order(self, n: int) -> None:
+        """The NEXT epoch's permutation, drawn while the device still works off the tail of this epoch's launch queue (the host
+        runs ~0.3 ms per step ahead of it and would otherwise sit in the epoch's first read-back).  The permutation is a function
+        of the seed that the global generator's next-but-one draw yields: that draw is PEEKED (state saved, two draws, state
+        restored - the generator is left exactly as it was), the 11 ns / row randperm runs on a private generator, and
+        `_epoch_order` uses the result only if its own, real draws - after the epoch-end and epoch-begin callbacks, where the
+        reference's DataLoader draws - produce the same seed.  A callback that reseeds or consumes the generator in between simply
+        makes the speculation miss.  (A 17 ms serial bubble per 1.6 M rows and epoch, 9 % of a warm epoch, before.)"""
+        state = torch.get_rng_state()
+        torch.empty((), dtype=torch.int64).random_()
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        torch.set_rng_state(state)
         gen = torch.Generator()
         gen.manual_seed(seed)
-        perm = torch.randperm(n, generator=gen)
-        return perm if on_host else perm.to(self.device)
+        self._order_spec = (seed, n, torch.randperm(n, generator=gen))
 
     def evaluate(self, x, y, batch_size=256):
         """Metric name -> value on (x, y); models/meta_basemodel.py:387-399."""

@@ -2303,7 +2303,11 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
     // fields of the Alimama `sota-pos` shape (separate Q / K tables) spills 34 VGPRs and gains nothing: not instantiated.
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
     const bool save = d->D == 32 && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0;
-    if (mod && save)
+    // (gate / bilinear at the AliCCP field count: the field count a constant, hence the matrix-pipe attention arm - round 6)
+    if (mod && save && same && d->F == 19 && f_const)
+        rc = mod == 1 ? launch_bwd<32, 64, 4, true, false, 19, 1, true>(d, p, dy, dx, slabs, stream)
+                      : launch_bwd<32, 64, 4, true, false, 19, 2, true>(d, p, dy, dx, slabs, stream);
+    else if (mod && save)
         rc = mod == 1 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 1, true>(d, p, dy, dx, slabs, stream)
                               : launch_bwd<32, 64, 4, false, false, 0, 1, true>(d, p, dy, dx, slabs, stream))
                       : (same ? launch_bwd<32, 64, 4, true, false, 0, 2, true>(d, p, dy, dx, slabs, stream)
@@ -2384,7 +2388,10 @@ extern "C" int satrans_layer_bwd_head_launch_fused(const satrans_layer_desc* d, 
     constexpr bool f_const = true;
     int rc;
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
-    if (mod == 1)
+    if (mod && d->D == 32 && same && d->F == 19 && f_const)
+        rc = mod == 1 ? launch_bwd<32, 64, 4, true, false, 19, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
+                      : launch_bwd<32, 64, 4, true, false, 19, 2, false, true>(d, p, nullptr, dx, slabs, stream, &hd);
+    else if (mod == 1)
         rc = d->D == 32 ? (same ? launch_bwd<32, 64, 4, true, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd)
                                 : launch_bwd<32, 64, 4, false, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd))
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 1, false, true>(d, p, nullptr, dx, slabs, stream, &hd)

@@ -253,3 +253,36 @@ def test_hdf5_reader_on_a_file_written_by_libhdf5():
     assert f.base == 512 and f.keys("/") == ["testdouble"]
     a = f.dataset("/testdouble")
     assert a.dtype == np.float64 and np.allclose(np.asarray(a).ravel(), np.pi / 4 * np.arange(9))
+
+
+def test_speculative_epoch_order_is_the_order_the_loader_draws():
+    """fit() draws the NEXT epoch's permutation while the device drains the current one (basemodel._speculate_epoch_order).  The
+    speculation must leave the global generator untouched, must be what `_epoch_order` would have drawn (= what the reference's
+    DataLoader(shuffle=True) draws: one base-seed draw, one sampler-seed draw, randperm on that seed), and must be dropped when
+    something consumes or reseeds the generator in between (a callback)."""
+    model = build_model(Case("small_qkv"), "cpu")
+    n = 1000
+
+    def loader_order():                                    # torch.utils.data.DataLoader(range(n), shuffle=True) order, first epoch
+        import torch.utils.data as tud
+        return torch.tensor(list(iter(tud.DataLoader(range(n), batch_size=n, shuffle=True)))[0])
+
+    torch.manual_seed(77)
+    want1 = loader_order()
+    want2 = loader_order()
+    torch.manual_seed(77)
+    got1 = model._epoch_order(n, True, on_host=True)
+    state = torch.get_rng_state()
+    model._speculate_epoch_order(n)
+    assert torch.equal(torch.get_rng_state(), state), "the speculation must leave the global generator as it was"
+    spec_perm = model._order_spec[2]
+    got2 = model._epoch_order(n, True, on_host=True)
+    assert got2 is spec_perm, "the speculated permutation is the one used when nothing touched the generator"
+    assert torch.equal(got1, want1) and torch.equal(got2, want2)
+    # a callback reseeds between the epochs: the speculation misses and the order is the reseeded one
+    model._speculate_epoch_order(n)
+    torch.manual_seed(5)
+    want3 = loader_order()
+    torch.manual_seed(5)
+    got3 = model._epoch_order(n, True, on_host=True)
+    assert torch.equal(got3, want3) and model._order_spec is None
