@@ -376,6 +376,84 @@ __global__ __launch_bounds__(1024) void gen_slot_reduce_kernel(const float* __re
     }
 }
 
+// ---- all reductions of one layer's backward in ONE launch (round 6) -------------------------------------------------------------
+// A layer backward of the general path makes 9 weight-gradient partial sets and 2 gamma / beta slot sets; reducing each behind its
+// product was 11 launches of ~9-16 us with nothing else to run (66 per step at configs[4]).  With a partial region of its own
+// per product the reductions have no order among each other (every one adds into its own destination), so they are collected
+// and run as blockIdx.z of one launch at the end of the layer - the same sums in the same order, bit for bit.
+struct ReduceJob {
+    const float* partial;
+    float* dst;
+    const int32_t* seg;
+    int64_t dst_seg_stride;
+    int chunks, count, F, chunk_rows, chunk_stride, segs, kind;      // kind 0: gen_tn_reduce, 1: gen_slot_reduce (chunks = gridx, segs = S)
+};
+constexpr int kMaxReduceJobs = 24;
+struct ReduceJobs {
+    ReduceJob j[kMaxReduceJobs];
+};
+struct ReduceDefer {          // host side: the jobs collected so far and the partial region they carve their buffers from
+    ReduceJobs jobs;
+    int n = 0;
+    float* part = nullptr;
+    int64_t used = 0, cap = 0;
+    float* take(int64_t floats) {
+        float* r = part + used;
+        used += (floats + 3) & ~(int64_t)3;
+        return used <= cap ? r : nullptr;
+    }
+};
+
+__global__ __launch_bounds__(1024) void gen_multi_reduce_kernel(ReduceJobs jobs) {
+    constexpr int G = 32;
+    __shared__ float s_part[G][32];
+    const ReduceJob& jb = jobs.j[blockIdx.z];
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + lane;
+    if (blockIdx.x * 32 >= jb.count) return;
+    float t = 0.f;
+    if (jb.kind == 0) {
+        const int s = blockIdx.y;
+        if (s >= jb.segs) return;
+        const int used = jb.seg ? (int)(((int64_t)(jb.seg[s + 1] - jb.seg[s]) * jb.F + jb.chunk_rows - 1) / jb.chunk_rows) : jb.chunks;
+        const int share = (used + G - 1) / G;
+        const int c0 = grp * share, c1 = min(used, c0 + share);
+        if (e < jb.count) {
+            const int stride = jb.chunk_stride ? jb.chunk_stride : jb.count;
+            const float* p = jb.partial + (size_t)s * jb.chunks * stride + e;
+#pragma unroll 4
+            for (int c = c0; c < c1; ++c) t += p[(size_t)c * stride];
+        }
+        s_part[grp][lane] = t;
+        __syncthreads();
+        if (grp == 0 && e < jb.count) {
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < G; ++k) r += s_part[k][lane];
+            jb.dst[(size_t)s * jb.dst_seg_stride + e] += r;
+        }
+    } else {
+        if (blockIdx.y != 0) return;
+        int running = 0;
+        for (int s = 0; s < jb.segs; ++s) {
+            const int used = (int)(((int64_t)(jb.seg[s + 1] - jb.seg[s]) * jb.F + jb.chunk_rows - 1) / jb.chunk_rows);
+            if (e < jb.count) {
+                const float* p = jb.partial + (size_t)s * jb.chunks * jb.count + e;
+                for (int c = (grp - running % G + G) % G; c < used; c += G) t += p[(size_t)c * jb.count];
+            }
+            running += used;
+        }
+        s_part[grp][lane] = t;
+        __syncthreads();
+        if (grp == 0 && e < jb.count) {
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < G; ++k) r += s_part[k][lane];
+            jb.dst[e] += r;
+        }
+    }
+}
+
 // rows in scenario-sorted order <- the layer input in the caller's order (or the arena rows of the fused gather), and back
 __global__ void gen_permute_in_kernel(satrans_layer_desc a, const float* __restrict__ src, float* __restrict__ dst, bool is_x) {
     const int q4 = a.D >> 2;
@@ -1363,14 +1441,18 @@ static GenLayout gen_layout(const satrans_layer_desc* d) {
     L.dr = take(L.nd); L.du = take(L.nd); L.go = take(L.nd); L.dq = take(L.nd); L.dk = take(L.nd); L.dv = take(L.nd);
     L.dt = take(L.nd); L.dm = take(L.nd); L.dh = take(L.nu);
     const int64_t chunks = ceil_div(N, kTnRows) + d->S;
-    // per chunk: one [K][N] partial of the largest product, or the three [D][D] partials of the fan product (dWq, dWk, dWv)
-    L.part_floats = std::max<int64_t>((int64_t)d->S * chunks * std::max<int64_t>((int64_t)d->D * std::max(d->U, d->D), 1),
-                                      chunks * 3 * (int64_t)d->D * d->D);
-    L.part = take(L.part_floats);
+    // Partial sums of the weight-gradient products.  One region per product of a layer backward (their reductions run as ONE
+    // launch at the end of the layer, gen_multi_reduce_kernel): dWo [D][D]; per role dW2 [U][D] and dW1 [D][U] per scenario; the
+    // three [D][D] of dWq / dWk / dWv; the gamma / beta partials of up to three LayerNorm backward launches and of the two fused
+    // MetaNet backward launches.  (gate / bilinear reduce behind each product and reuse the head of the region.)
+    const int64_t Ue = std::max(d->U, d->D);
+    L.mn_slots = ceil_div(N, kG2Rows) * std::max(d->S, 1);                 // gamma / beta partials of the fused MetaNet backward
     L.ln_blocks = std::min<int64_t>(1024, ceil_div(N, 256 / (d->D / 4)));
+    L.part_floats = chunks * ((int64_t)d->D * d->D + 4 * (int64_t)d->S * d->D * Ue + 3 * (int64_t)d->D * d->D) +
+                    3 * (L.ln_blocks * 2 * d->D + 4) + 2 * (L.mn_slots * 2 * d->D + 4) + 64;
+    L.part = take(L.part_floats);
     L.ln_part = take(L.ln_blocks * 2 * d->D);
     L.modfull = take((d->flags & (SATRANS_GATE | SATRANS_BILINEAR)) ? (int64_t)d->S * d->D * d->D : 0);   // gate / bilinear: z^T g per scenario
-    L.mn_slots = ceil_div(N, kG2Rows) * std::max(d->S, 1);                 // gamma / beta partials of the fused MetaNet backward
     L.mn_part = take(L.mn_slots * 2 * d->D);
     L.scratch_total = o;
     return L;
@@ -1427,8 +1509,10 @@ static int gen_gemm(hipStream_t st, int batch, const float* const* A, const floa
 }
 
 // dst[s] += A^T G over segment s (seg == nullptr: one segment); dst_seg_stride between the segments' outputs
+// `defer`: the product writes its partials into a region of its own and its reduction joins the layer's ONE reduction launch
+// (gen_multi_reduce_kernel) instead of following the product
 static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int32_t* seg, int S, int M, int F, int K, int N,
-                       float* partial, float* dst, int64_t dst_seg_stride) {
+                       float* partial, float* dst, int64_t dst_seg_stride, ReduceDefer* defer = nullptr) {
     const int segs = seg ? S : 1;
     const int chunks = (int)ceil_div(M, kTnRows);
     SATRANS_REQUIRE(K % 16 == 0 && N % 16 == 0 && K >= 16 && N >= 16 && K <= 128 && N <= 128, SATRANS_E_UNSUPPORTED,
@@ -1441,10 +1525,18 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
         const float* Ap = A + 64 * h;
         float* dp = dst + (size_t)64 * h * N;
         const size_t lds = sizeof(float) * (size_t)Kp * N;
+        if (defer) {
+            partial = defer->take((int64_t)segs * chunks * Kp * N);
+            SATRANS_REQUIRE(partial && defer->n < kMaxReduceJobs, SATRANS_E_LAUNCH, "general path: deferred reductions out of room");
+        }
         if (Kp <= 64 && N <= 64) gen_gemm_tn_kernel<1, 1><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
         else if (Kp <= 64) gen_gemm_tn_kernel<1, 2><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
         else gen_gemm_tn_kernel<2, 1><<<grid, 256, lds, st>>>(Ap, G, seg, M, F, Kp, N, K, partial);
         SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel");
+        if (defer) {
+            defer->jobs.j[defer->n++] = ReduceJob{partial, dp, seg, dst_seg_stride, chunks, Kp * N, F, kTnRows, 0, segs, 0};
+            continue;
+        }
         gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)Kp * N, 32), (unsigned)segs), 1024, 0, st>>>(partial, chunks, Kp * N, dp,
                                                                                                           dst_seg_stride, seg, F, kTnRows);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
@@ -1452,13 +1544,37 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
     return SATRANS_OK;
 }
 
+// the collected reductions of a layer backward, one launch
+static int gen_run_deferred(hipStream_t st, ReduceDefer& defer) {
+    if (defer.n == 0) return SATRANS_OK;
+    int bx = 1, by = 1;
+    for (int i = 0; i < defer.n; ++i) {
+        bx = std::max(bx, (int)ceil_div(defer.jobs.j[i].count, 32));
+        by = std::max(by, defer.jobs.j[i].kind == 0 ? defer.jobs.j[i].segs : 1);
+    }
+    gen_multi_reduce_kernel<<<dim3((unsigned)bx, (unsigned)by, (unsigned)defer.n), 1024, 0, st>>>(defer.jobs);
+    SATRANS_CHECK_LAUNCH("gen_multi_reduce_kernel");
+    defer.n = 0;
+    return SATRANS_OK;
+}
+
 // dst_i += A^T G_i for three gradient tensors of width N = K = D <= 64 over the same rows A (see gen_gemm_tn_kernel, FAN)
-static int gen_gemm_tn_fan(hipStream_t st, const float* A, const float* const* G, int M, int D, float* partial, float* const* dst) {
+static int gen_gemm_tn_fan(hipStream_t st, const float* A, const float* const* G, int M, int D, float* partial, float* const* dst,
+                           ReduceDefer* defer = nullptr) {
     SATRANS_REQUIRE(D % 16 == 0 && D >= 16 && D <= 64, SATRANS_E_UNSUPPORTED, "general-path fan weight gradient: D = %d", D);
     const int chunks = (int)ceil_div(M, kTnRows);
     const size_t lds = sizeof(float) * 3 * (size_t)D * D;
+    if (defer) {
+        partial = defer->take((int64_t)chunks * 3 * D * D);
+        SATRANS_REQUIRE(partial && defer->n + 3 <= kMaxReduceJobs, SATRANS_E_LAUNCH, "general path: deferred reductions out of room");
+    }
     gen_gemm_tn_kernel<1, 3, true><<<dim3((unsigned)chunks, 1), 256, lds, st>>>(A, G[0], nullptr, M, 1, D, D, D, partial, G[1], G[2]);
     SATRANS_CHECK_LAUNCH("gen_gemm_tn_kernel(fan)");
+    if (defer) {
+        for (int w = 0; w < 3; ++w)
+            defer->jobs.j[defer->n++] = ReduceJob{partial + (size_t)w * D * D, dst[w], nullptr, 0, chunks, D * D, 1, kTnRows, 3 * D * D, 1, 0};
+        return SATRANS_OK;
+    }
     for (int w = 0; w < 3; ++w) {
         gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div((int64_t)D * D, 32), 1), 1024, 0, st>>>(partial + (size_t)w * D * D, chunks, D * D,
                                                                                              dst[w], 0, nullptr, 1, kTnRows, 3 * D * D);
@@ -1585,17 +1701,23 @@ static int gen_ln_fwd(hipStream_t st, const satrans_layer_desc* d, const float* 
 
 static int gen_ln_bwd(hipStream_t st, const satrans_layer_desc* d, const GenLayout& L, float* scratch, const float* g, bool g_orig,
                       const float* t, const float* a_pre, const float* gamma, float* dt, float* dm, int site, bool relu,
-                      float* g_gamma_beta, bool relu_post = false, bool norm = true) {
+                      float* g_gamma_beta, bool relu_post = false, bool norm = true, ReduceDefer* defer = nullptr) {
     const int64_t N = (int64_t)d->B * d->F;
     const GenDrop dc = gen_drop(d, site);
     const int tpi = 256 / (d->D / 4);
     const int blocks = (int)L.ln_blocks;
     const int tpb = (int)(ceil_div(ceil_div(N, blocks), tpi) * tpi);
     float* part = scratch + L.ln_part;
+    if (defer && g_gamma_beta && norm) {
+        part = defer->take((int64_t)blocks * 2 * d->D);
+        SATRANS_REQUIRE(part && defer->n < kMaxReduceJobs, SATRANS_E_LAUNCH, "general path: deferred reductions out of room");
+    }
     GEN_LN_DISPATCH(d->D, (gen_ln_bwd_kernel<LPT><<<(unsigned)blocks, 256, 0, st>>>(g, g_orig, t, a_pre, gamma, dt, dm, part, N,
                                                                                    d->F, d->order, dc, relu, tpb, relu_post, norm)));
     SATRANS_CHECK_LAUNCH("gen_ln_bwd_kernel");
-    if (g_gamma_beta && norm) {
+    if (g_gamma_beta && norm && defer) {
+        defer->jobs.j[defer->n++] = ReduceJob{part, g_gamma_beta, nullptr, 0, blocks, 2 * d->D, 0, 1, 0, 1, 0};
+    } else if (g_gamma_beta && norm) {
         gen_tn_reduce_kernel<<<dim3((unsigned)ceil_div(2 * d->D, 32), 1), 1024, 0, st>>>(part, blocks, 2 * d->D, g_gamma_beta, 0, nullptr, 0, 1);
         SATRANS_CHECK_LAUNCH("gen_tn_reduce_kernel");
     }
@@ -1791,9 +1913,16 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     float *dr = scratch + L.dr, *du = scratch + L.du, *go = scratch + L.go, *dq = scratch + L.dq, *dk = scratch + L.dk,
           *dv = scratch + L.dv, *dt = scratch + L.dt, *dm = scratch + L.dm, *dh = scratch + L.dh, *part = scratch + L.part;
     int rc;
+    // (the reductions of this layer's weight-gradient partials: collected, one launch at the end; gate / bilinear read one of
+    //  their reduced products right away and keep the reduce-behind-the-product form)
+    ReduceDefer defer_store;
+    defer_store.part = part;
+    defer_store.cap = L.part_floats;
+    ReduceDefer* defer = (gate || bil) ? nullptr : &defer_store;
     // ---- output block: LayerNorm backward (dy arrives in the caller's sample order), dWo, go = du Wo ----------------------------
-    if ((rc = gen_ln_bwd(st, d, L, scratch, dy, true, saved + L.to, saved + L.u, d->ln_g, dr, du, kSiteOut, relu, g_ln))) return rc;
-    if ((rc = gen_gemm_tn(st, du, saved + L.o, nullptr, 1, M, F, D, D, part, g_wo, 0))) return rc;     // dWo[out][in] += du^T o
+    if ((rc = gen_ln_bwd(st, d, L, scratch, dy, true, saved + L.to, saved + L.u, d->ln_g, dr, du, kSiteOut, relu, g_ln, false, true,
+                         defer))) return rc;
+    if ((rc = gen_gemm_tn(st, du, saved + L.o, nullptr, 1, M, F, D, D, part, g_wo, 0, defer))) return rc;     // dWo[out][in] += du^T o
     {
         const float* A[1] = {du};
         const float* Bw[1] = {d->w_out};
@@ -1813,26 +1942,29 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
         constexpr bool fuse = true;
         if (fuse && gen_metanet_fused_ok(D, U)) {
             // data gradients in one pass (g <- dz0; dm, dh written for the two weight-gradient products), then dW2, dW1
-            float* mn_part = scratch + L.mn_part;
+            float* mn_part = defer ? defer->take(L.mn_slots * 2 * D) : scratch + L.mn_part;
+            SATRANS_REQUIRE(mn_part && (!defer || defer->n < kMaxReduceJobs), SATRANS_E_LAUNCH, "general path: deferred reductions out of room");
             int r = gen_metanet_fused_bwd(st, d, g, t, h, tab, dm, dh, gam, mn_part, site);
             if (r) return r;
-            if (g_ln_role) {
+            if (g_ln_role && defer) {
+                defer->jobs.j[defer->n++] = ReduceJob{mn_part, g_ln_role, d->seg, 0, (int)ceil_div(M, kG2Rows), 2 * D, F, kG2Rows, 0, S, 1};
+            } else if (g_ln_role) {
                 gen_slot_reduce_kernel<<<(unsigned)ceil_div(2 * D, 32), 1024, 0, st>>>(mn_part, (int)ceil_div(M, kG2Rows), S, d->seg, F,
                                                                                     kG2Rows, 2 * D, g_ln_role);
                 SATRANS_CHECK_LAUNCH("gen_slot_reduce_kernel");
             }
-            if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride))) return r;
-            return gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride);
+            if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride, defer))) return r;
+            return gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride, defer);
         }
-        int r = gen_ln_bwd(st, d, L, scratch, g, false, t, nullptr, gam, dt, dm, site, false, g_ln_role);
+        int r = gen_ln_bwd(st, d, L, scratch, g, false, t, nullptr, gam, dt, dm, site, false, g_ln_role, false, true, defer);
         if (r) return r;
         // dW2[u][o] += h^T dm ;  dh = (dm W2^T) * [h > 0] ;  dW1[i][u] += z0^T dh ;  dz0 = dt + dh W1^T
-        if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride))) return r;
+        if ((r = gen_gemm_tn(st, h, dm, d->seg, S, M, F, U, D, part, g_tab + (size_t)D * U, d->tab_stride, defer))) return r;
         const float* A1[1] = {dm};
         const float* B1[1] = {tab + (size_t)D * U};
         float* C1[1] = {dh};
         if ((r = gen_gemm<true, 3>(st, 1, A1, B1, C1, d->seg, S, M, F, D, U, D, d->tab_stride, h))) return r;
-        if ((r = gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride))) return r;
+        if ((r = gen_gemm_tn(st, z0, dh, d->seg, S, M, F, D, U, part, g_tab, d->tab_stride, defer))) return r;
         const float* A2[1] = {dh};
         const float* B2[1] = {tab};
         float* C2[1] = {g};                  // g <- dt + dh W1^T
@@ -1871,12 +2003,13 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     if (D <= 64) {
         const float* gs[3] = {dq, dk, dv};
         float* dsts[3] = {g_wq, g_wk, g_wv};
-        if ((rc = gen_gemm_tn_fan(st, xs, gs, M, D, part, dsts))) return rc;
+        if ((rc = gen_gemm_tn_fan(st, xs, gs, M, D, part, dsts, defer))) return rc;
     } else {
-        if ((rc = gen_gemm_tn(st, xs, dq, nullptr, 1, M, F, D, D, part, g_wq, 0))) return rc;
-        if ((rc = gen_gemm_tn(st, xs, dk, nullptr, 1, M, F, D, D, part, g_wk, 0))) return rc;
-        if ((rc = gen_gemm_tn(st, xs, dv, nullptr, 1, M, F, D, D, part, g_wv, 0))) return rc;
+        if ((rc = gen_gemm_tn(st, xs, dq, nullptr, 1, M, F, D, D, part, g_wq, 0, defer))) return rc;
+        if ((rc = gen_gemm_tn(st, xs, dk, nullptr, 1, M, F, D, D, part, g_wk, 0, defer))) return rc;
+        if ((rc = gen_gemm_tn(st, xs, dv, nullptr, 1, M, F, D, D, part, g_wv, 0, defer))) return rc;
     }
+    if (defer && (rc = gen_run_deferred(st, *defer))) return rc;
     {
         const float* grads[3] = {dq, dk, dv};
         const float* ws[3] = {d->w_query, d->w_key, d->w_value};

@@ -553,15 +553,24 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
 
     def after_step(self, fn, *tensors) -> None:
         """Launches that only READ what the step just produced - the probabilities of `last_prob()`, the labels: `fit`'s per-step
-        metrics - go on the stream of the step's tail kernels (reduction, scenario-table backward, flat Adam), beside the
-        touched-row chain, instead of between two steps of the launch stream.  `fn()` is called with that stream current;
+        metrics - go on a stream of their own that starts behind the step's last backward kernel, beside the tail kernels
+        (reduction, scenario-table backward, flat Adam) and the touched-row chain, instead of between two steps of the launch
+        stream.  `fn()` is called with that stream current;
         `tensors` are the caller's operands, kept from being recycled while that stream uses them.  The next launch that
         overwrites the probabilities waits for it (`_join_prob_readers`).  Without such a stream (several ranks, the fused head
         switched off) `fn()` simply runs on the launch stream."""
-        st = self._side_tail
-        if st is None or getattr(self, "_flat_done", None) is None or not self.side_tail:
+        fork = getattr(self, "_last_fork", None)
+        if self._side_tail is None or getattr(self, "_flat_done", None) is None or not self.side_tail or fork is None:
             fn()
             return
+        # A stream of its own that starts where the tail stream starts - right behind the last backward kernel - so that the
+        # launch runs in the seam between two steps, where the CUs are idle (the touched-row chain, the reduction and the
+        # scenario-table backward are small).  Queued BEHIND the tail stream's kernels (round 5) the one-workgroup metrics kernel
+        # of `fit` (57 us, ~75 KB of LDS: no room beside a layer kernel's workgroup) was still running when the next step's first
+        # layer kernel started: one of that persistent kernel's 256 workgroups waited for its CU and the whole launch ended
+        # ~44 us late - fit(verbose=1) ran at 0.9975 ms per step against 0.9535 with verbose=0 (profiles/r06_fit_epoch.txt).
+        st = _shared_stream(self.dev, "reader", lambda: torch.cuda.Stream(self.dev))
+        st.wait_event(fork)
         with torch.cuda.stream(st):
             fn()
             self._prob_read = torch.cuda.Event()
@@ -955,6 +964,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
             fork.record(torch.cuda.current_stream(self.dev))
         if after_layers is not None:
             after_layers(fork)
+        self._last_fork = fork            # (after_step: readers of this step's probabilities start here too)
         # train_step (side_tail): the reduction and the scenario-table backward feed only the flat Adam launch at the very end of
         # the step, while the five touched-row launches that come first need only the last backward kernel's dx.  On a stream of
         # their own (NOT the next-batch stream: queued behind each other the two made the next step wait, which is what the first
