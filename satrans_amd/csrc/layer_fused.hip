@@ -669,6 +669,16 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // into LDS, issued at the top of the tile and complete by the end of phase A - instead of a recomputation
     const int HF = H * F;
     constexpr bool has_save = SAVE;
+    // REGH: the saved attention goes straight from HBM into the registers of the lanes that use it - the token lane's dy row and
+    // saved attention output (issued at the top of the tile, used in phase C), the attention lane's softmax numerators, 1 / sum and
+    // keep word (issued at the start of phase C, used in phase D) - instead of through LDS by eleven LDS-DMA pieces per wave and
+    // tile: a piece costs 100-185 cycles to issue, a plain 16-byte load a few, and the LDS reads of the staged copies go too.
+    // (The matrix-pipe arm only: its attention lanes are known per wave.)
+#ifdef SATRANS_HANDOVER_LDS
+    constexpr bool REGH = false;
+#else
+    constexpr bool REGH = SAVE && MFA;
+#endif
     constexpr bool has_zsave = SAVE && MOD == 0;       // ... and the normalised MetaNet rows with their 1 / std
     // the MetaNet's hidden rows relu(z0 W1) are computed where phase F needs them: always with the saved rows (phase A has no use
     // for them then), and - recomputed, 2 x 32 more MFMAs per tile - in the one instantiation that otherwise spills 64 registers
@@ -858,7 +868,7 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
           }
       };
       int b_next = sample_of(t0), tb_next = task_sample_of(t0);
-      if (has_save) {
+      if (has_save && !REGH) {
           copy_samples_of(t0);
           handover_copy(t0);      // (the caches are dead: the previous range ended on the barrier behind its last phase F)
       }
@@ -888,8 +898,15 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         tb_next = task_sample_of(tile_n);
         // (saved attention: this tile's hand-over, see handover_copy; the sample indices of the NEXT tile's dy rows are fetched
         //  here, a tile ahead of the copy that needs them)
-        if (has_save && tile > t0) handover_copy(tile);
-        if (has_save) copy_samples_of(tile_n);
+        if (has_save && !REGH && tile > t0) handover_copy(tile);
+        if (has_save && !REGH) copy_samples_of(tile_n);
+        // REGH: this token's upstream gradient row and saved attention output, consumed in phase C (padding lanes read the tile's
+        // first token and are masked where the rows are consumed)
+        float gy_reg[KT][4], o_reg[KT][4];
+        if constexpr (REGH) {
+            load_frag<KT>(dy + ((size_t)b * F + f) * D + g4, gy_reg);
+            load_frag<KT>(save_o + ((size_t)first * F + (valid ? tok : 0)) * D + g4, o_reg);
+        }
         // HEADF: the sample's label and dense columns, consumed in phase C - issued here, raw (see the load pipeline above)
         float label_pre = 0.f, dense_pre[kHeadDenseMax] = {0.f, 0.f};
         if constexpr (HEADF) {
@@ -1014,10 +1031,22 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             store_frag<KT>(my_k, k);
             store_frag<KT>(my_v, v);
         }
-        if (has_save) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the caches have landed in LDS
+        if (has_save && !REGH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the caches have landed in LDS
         lds_barrier();
 
         STAMP(1);
+        // REGH: this attention lane's softmax numerators (own query row, all keys), 1 / sum and keep word: issued here, a phase C
+        // ahead of phase D (a lane of a sample the tile does not have reads the tile's last sample: its results are not stored)
+        float p_reg[FT ? FT : 1], inv_reg = 0.f;
+        uint32_t keep_reg = 0;
+        if constexpr (REGH) {
+            const int tls_g = min(m_ls_raw, nS - 1), iq_g = min(m_i, FT - 1);
+            const float* pb = a.attn_save + ((size_t)(first + tls_g) * FT) * HF + m_h * FT + iq_g;
+#pragma unroll
+            for (int j = 0; j < FT; ++j) p_reg[j] = pb[(size_t)j * HF];
+            inv_reg = save_inv[(size_t)(first + tls_g) * HF + m_h * FT + iq_g];
+            keep_reg = __float_as_uint(save_keep[(size_t)(first + tls_g) * HF + m_h * FT + iq_g]);
+        }
         // the upstream gradient rows of phase C: issued here, a phase ahead (HBM latency under the attention forward); padding
         // lanes read a real row (sample 0 of the tile, field 0) and are masked where the rows are consumed
         float gy_pre[KT][4];
@@ -1208,7 +1237,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         const float* staged = sDS + ((size_t)(valid ? ls_tok : 0) * F + f) * D + g4;      // (saved attention: this token's dy row)
         if (has_tile) {
             float o[KT][4], u[KT][4];
-            if (has_save) {
+            if constexpr (REGH) {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][r] = valid ? o_reg[t][r] : 0.f;
+                store_frag<KT>(my_o, o);          // (dWo below reads the wave's o rows from LDS)
+            } else if (has_save) {
                 load_frag<KT>(staged + Tsamp * F * D, o, valid);
                 store_frag<KT>(my_o, o);          // (dWo below reads the wave's o rows from LDS)
             } else {
@@ -1307,8 +1342,8 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
 #pragma unroll
             for (int t = 0; t < KT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gy[t][r] = valid ? gy_pre[t][r] : 0.f;
-            if (has_save) load_frag<KT>(staged, gy, valid);
+                for (int r = 0; r < 4; ++r) gy[t][r] = valid ? (REGH ? gy_reg[t][r] : gy_pre[t][r]) : 0.f;
+            if (has_save && !REGH) load_frag<KT>(staged, gy, valid);
         }
         if (has_tile) {
             layer_norm_bwd<KT>(gy, zh, rstd_o, ln_g, g4, agl, abl);          // gy is now dr
@@ -1360,9 +1395,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             float* prow = sP + (size_t)tls * FT * HF + (h * FT + iq);
             float pn[FT];
 #pragma unroll
-            for (int j = 0; j < FT; ++j) pn[j] = prow[j * HF];
-            const float inv = st_inv[told];
-            const uint32_t keep = st_keep[told];
+            for (int j = 0; j < FT; ++j) pn[j] = REGH ? p_reg[j] : prow[j * HF];
+            const float inv = REGH ? inv_reg : st_inv[told];
+            const uint32_t keep = REGH ? keep_reg : st_keep[told];
             const float scale = dc.scale;
             f32x4 dp[NJB];
 #pragma unroll

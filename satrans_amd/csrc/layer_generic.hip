@@ -1545,15 +1545,32 @@ static int gen_gemm_tn(hipStream_t st, const float* A, const float* G, const int
 }
 
 // the collected reductions of a layer backward, one launch
+// Jobs that add into the SAME destination (one generated-weight table for the Q and the K role: both roles' dW1 / dW2 and
+// LayerNorm gradients accumulate into one buffer) must keep their order and may not run side by side: a job whose destination
+// an earlier job of the launch already has goes to the next launch (two launches per layer then, the roles in their old order).
 static int gen_run_deferred(hipStream_t st, ReduceDefer& defer) {
-    if (defer.n == 0) return SATRANS_OK;
-    int bx = 1, by = 1;
-    for (int i = 0; i < defer.n; ++i) {
-        bx = std::max(bx, (int)ceil_div(defer.jobs.j[i].count, 32));
-        by = std::max(by, defer.jobs.j[i].kind == 0 ? defer.jobs.j[i].segs : 1);
+    bool done[kMaxReduceJobs] = {};
+    int left = defer.n;
+    while (left > 0) {
+        ReduceJobs pass;
+        int np = 0, bx = 1, by = 1;
+        for (int i = 0; i < defer.n; ++i) {
+            if (done[i]) continue;
+            bool clash = false;
+            for (int k = 0; k < np; ++k) clash = clash || pass.j[k].dst == defer.jobs.j[i].dst;
+            // (a later job with the same destination as a POSTPONED one must wait as well: order is by first come)
+            for (int k = 0; k < i; ++k) clash = clash || (!done[k] && defer.jobs.j[k].dst == defer.jobs.j[i].dst);
+            if (clash) continue;
+            pass.j[np++] = defer.jobs.j[i];
+            bx = std::max(bx, (int)ceil_div(defer.jobs.j[i].count, 32));
+            by = std::max(by, defer.jobs.j[i].kind == 0 ? defer.jobs.j[i].segs : 1);
+        }
+        for (int i = 0, k = 0; i < defer.n && k < np; ++i)
+            if (!done[i] && pass.j[k].partial == defer.jobs.j[i].partial) { done[i] = true; ++k; }
+        left -= np;
+        gen_multi_reduce_kernel<<<dim3((unsigned)bx, (unsigned)by, (unsigned)np), 1024, 0, st>>>(pass);
+        SATRANS_CHECK_LAUNCH("gen_multi_reduce_kernel");
     }
-    gen_multi_reduce_kernel<<<dim3((unsigned)bx, (unsigned)by, (unsigned)defer.n), 1024, 0, st>>>(defer.jobs);
-    SATRANS_CHECK_LAUNCH("gen_multi_reduce_kernel");
     defer.n = 0;
     return SATRANS_OK;
 }
