@@ -47,7 +47,15 @@ static KernelTimer g_ktimer;
 // pays nothing for the other two).  Every product runs on v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain).
 // SAVE: leave the attention's numerators / statistics / output (and the normalised MetaNet rows) in a.attn_save for the backward
 // of this step
-template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, bool SAVE = false>
+// Diagnostic build only (-DSATRANS_DIAG_FWDSAVE=mask): the training forward WITHOUT the stores of its hand-over's numerators (1),
+// normalised MetaNet rows (2), 1 / sum + keep word + attention output (4) - what each part of the hand-over costs this kernel.
+#ifdef SATRANS_DIAG_FWDSAVE
+constexpr int kDiagFwdSave = SATRANS_DIAG_FWDSAVE;
+#else
+constexpr int kDiagFwdSave = 0;
+#endif
+// PROW: the hand-over's numerators as padded rows (see the store below)
+template <int D, int U, int H, int WAVES = kFusedWaves, int MOD = 0, bool SAVE = false, bool PROW = false>
 __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_layer_desc a, int Tsamp,
                                                                       float* __restrict__ y, float* __restrict__ att) {
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, LU = U + 4;
@@ -192,7 +200,8 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             float* save_r = nullptr;
             if constexpr (ZSAVE) {
                 const size_t pos = (size_t)(first + ls) * F + f;
-                float* z_all = a.attn_save + (size_t)a.B * ((size_t)F * H * F + 2 * H * F + (size_t)F * D);
+                const size_t p_floats_ = (size_t)a.B * (PROW ? (size_t)H * F * ((F + 3) & ~3) : (size_t)F * H * F);
+                float* z_all = a.attn_save + p_floats_ + (size_t)a.B * (2 * H * F + (size_t)F * D);
                 save_z = z_all + pos * 2 * D + g4;
                 save_r = z_all + (size_t)a.B * F * 2 * D + pos * 2;
             }
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 float h[UT][4], o[KT][4];
                 metanet_frag<D, U>(w1q_l, w2q_l, W.lnq_g, W.lnq_b, g4, dc, kSiteMetaQ,
                                    drop_sample_key(dc.key[kSiteMetaQ], (uint32_t)b), f, q, h, o, mean, rstd, ZSAVE ? zsave : nullptr);
-                if (ZSAVE && valid) {
+                if (ZSAVE && !(kDiagFwdSave & 2) && valid) {
                     store_frag<KT>(save_z, zsave);
                     if (g == 0) save_r[0] = rstd;
                 }
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                 float h[UT][4], o[KT][4];
                 metanet_frag<D, U>(w1k_l, w2k_l, W.lnk_g, W.lnk_b, g4, dc, kSiteMetaK,
                                    drop_sample_key(dc.key[kSiteMetaK], (uint32_t)b), f, k, h, o, mean, rstd, ZSAVE ? zsave : nullptr);
-                if (ZSAVE && valid) {
+                if (ZSAVE && !(kDiagFwdSave & 2) && valid) {
                     store_frag<KT>(save_z + D, zsave);
                     if (g == 0) save_r[1] = rstd;
                 }
@@ -275,8 +284,14 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
             // a.attn_save: what the backward of this step would recompute, per SORTED sample position p = first + ls (the layout
             // the backward tiles walk): numerators [p][j][H F], then 1 / sum [p][H F], keep word [p][H F], attention output
             // [p][F][D]; lanes of one sample are consecutive tasks, so every store instruction writes runs of up to H F floats
-            const int HF = H * F;
-            float* save_p = SAVE ? a.attn_save + (size_t)(first + ls) * F * HF + rem : nullptr;
+            // PROW (the backward will take the hand-over straight into registers, fused_save_rows): the numerators as one
+            // padded ROW per (position, head, query row), [p][H][F][FP], FP = 4 ceil(F / 4): five 16-byte stores per lane instead
+            // of nineteen 4-byte ones (the scattered stores were 6 of this kernel's 83 us), and 16-byte loads in the backward.
+            const int HF = H * F, FPs = (F + 3) & ~3;
+            const size_t p_floats = (size_t)a.B * (PROW ? (size_t)H * F * FPs : (size_t)F * HF);
+            float* save_p = !SAVE ? nullptr
+                            : PROW ? a.attn_save + (((size_t)(first + ls) * H + h) * F + i) * FPs
+                                        : a.attn_save + (size_t)(first + ls) * F * HF + rem;
             uint32_t keepw = 0xFFFFFFFFu;
 #pragma unroll
             for (int c = 0; c < kRowChunks; ++c) {
@@ -286,20 +301,25 @@ __global__ __launch_bounds__(64 * WAVES) void layer_fwd_fused_kernel(satrans_lay
                     for (int u = 0; u < 4; ++u) load_row<d>(vbase + (size_t)(4 * c + u) * LD, vr[u]);
                     const uint32_t kb = dc.on ? drop_keep4(skey, block0 + (uint32_t)c, dc.thresh) : 0xFu;
                     keepw &= ~((~kb & 0xFu) << (4 * c));
+                    float ex4[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float ex = __builtin_amdgcn_exp2f(sc[4 * c + u] - mx);
+                        ex4[u] = ex;
                         sum += ex;
-                        if (SAVE && 4 * c + u < F) save_p[(size_t)(4 * c + u) * HF] = ex;
+                        if (SAVE && !(kDiagFwdSave & 1) && !PROW && 4 * c + u < F) save_p[(size_t)(4 * c + u) * HF] = ex;
                         float pe = ex;
                         if (dc.on) pe = (kb >> u) & 1u ? ex * dc.scale : 0.f;
                         sc[4 * c + u] = pe;
                         axpy_row<d>(pe, vr[u], oacc);
                     }
+                    // (keys beyond F carry exp2(-inf) = 0: the row's padding)
+                    if (SAVE && !(kDiagFwdSave & 1) && PROW)
+                        *reinterpret_cast<float4*>(save_p + 4 * c) = make_float4(ex4[0], ex4[1], ex4[2], ex4[3]);
                 }
             }
-            if constexpr (SAVE) {
-                float* inv_all = a.attn_save + (size_t)a.B * F * HF;
+            if constexpr (SAVE && !(kDiagFwdSave & 4)) {
+                float* inv_all = a.attn_save + p_floats;
                 float* keep_all = inv_all + (size_t)a.B * HF;
                 float* o_all = keep_all + (size_t)a.B * HF;
                 const size_t t_ = (size_t)(first + ls) * HF + rem;
@@ -684,7 +704,9 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
     // for them then), and - recomputed, 2 x 32 more MFMAs per tile - in the one instantiation that otherwise spills 64 registers
     // (separate Q / K tables with the head fused in: 192 accumulator registers)
     constexpr bool rehidden = has_zsave || (HEADF && !SAME);
-    const float* save_inv = a.attn_save + (size_t)a.B * F * HF;
+    // (written so that the instantiations without the register hand-over keep the expression - and the code - they had:
+    //  tools/experiments/README.md, round 6, "a codegen-fragile instantiation")
+    const float* save_inv = REGH ? a.attn_save + (size_t)a.B * H * F * FP : a.attn_save + (size_t)a.B * F * HF;
     const float* save_keep = save_inv + (size_t)a.B * HF;
     const float* save_o = save_keep + (size_t)a.B * HF;
     const float* save_z = save_o + (size_t)a.B * F * D;
@@ -1037,13 +1059,16 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
         STAMP(1);
         // REGH: this attention lane's softmax numerators (own query row, all keys), 1 / sum and keep word: issued here, a phase C
         // ahead of phase D (a lane of a sample the tile does not have reads the tile's last sample: its results are not stored)
-        float p_reg[FT ? FT : 1], inv_reg = 0.f;
+        float p_reg[FT ? FP : 1], inv_reg = 0.f;
         uint32_t keep_reg = 0;
         if constexpr (REGH) {
             const int tls_g = min(m_ls_raw, nS - 1), iq_g = min(m_i, FT - 1);
-            const float* pb = a.attn_save + ((size_t)(first + tls_g) * FT) * HF + m_h * FT + iq_g;
+            const float* pb = a.attn_save + (((size_t)(first + tls_g) * H + m_h) * FT + iq_g) * FP;      // [p][H][F][FP]: this lane's row
 #pragma unroll
-            for (int j = 0; j < FT; ++j) p_reg[j] = pb[(size_t)j * HF];
+            for (int jb = 0; jb < NJB; ++jb) {
+                const float4 t4 = *reinterpret_cast<const float4*>(pb + 4 * jb);
+                p_reg[4 * jb] = t4.x; p_reg[4 * jb + 1] = t4.y; p_reg[4 * jb + 2] = t4.z; p_reg[4 * jb + 3] = t4.w;
+            }
             inv_reg = save_inv[(size_t)(first + tls_g) * HF + m_h * FT + iq_g];
             keep_reg = __float_as_uint(save_keep[(size_t)(first + tls_g) * HF + m_h * FT + iq_g]);
         }
@@ -2119,6 +2144,22 @@ __global__ __launch_bounds__(32 * kRG) void fused_reduce_all_kernel(ReduceLayers
 // host side
 // -------------------------------------------------------------------------------------------------------------------
 
+// The field count the fused backward is instantiated with for this layer (0: the runtime-F instantiation).  With a constant the
+// backward runs the matrix-pipe attention arm and takes the hand-over straight into registers (REGH) - and the forward then
+// writes the numerators as padded rows: ONE predicate for both launchers.
+static int fused_bwd_ft(const satrans_layer_desc* d) {
+    if (d->D != 32 || d->H != 4) return 0;
+    const bool same = d->tab_q == d->tab_k && d->lnq_g == d->lnk_g && d->lnq_b == d->lnk_b;
+    const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
+    if (mod) return same && d->F == 19 ? 19 : 0;
+    return same ? (d->F == 19 ? 19 : 0) : (d->F == 15 ? 15 : 0);
+}
+#ifdef SATRANS_HANDOVER_LDS
+static bool fused_save_rows(const satrans_layer_desc* d) { return false; }
+#else
+static bool fused_save_rows(const satrans_layer_desc* d) { return kAttnMfma && fused_bwd_ft(d) != 0; }
+#endif
+
 static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     const int LD = D + 4, LU = U + 4;
     const int64_t rows = (((int64_t)T * F + 3 + 15) / 16) * 16;      // (as the kernel: three rows of slack behind the last sample)
@@ -2127,8 +2168,10 @@ static int64_t fused_fwd_lds_floats(int T, int F, int D, int U, bool same_tab) {
     return 4 * dd + (same_tab ? 1 : 2) * mlp + 6 * D + 4 * rows * LD + 64;
 }
 
-template <int D, int U, int H, int WAVES, int MOD = 0, bool SAVE = false>
+template <int D, int U, int H, int WAVES, int MOD = 0, bool SAVE = false, bool PROW = false>
 static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipStream_t stream) {
+    if constexpr (SAVE && !PROW && D == 32)
+        if (fused_save_rows(d)) return launch_fwd_w<D, U, H, WAVES, MOD, SAVE, true>(d, y, att, stream);
     const bool same_tab = d->tab_q == d->tab_k;
     // samples per tile: as many as keep `per_cu` workgroups per CU, preferring tiles that fill their 16-token MFMA rows
     int best = 0;
@@ -2147,7 +2190,7 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const size_t lds = (size_t)fused_fwd_lds_floats(best, d->F, D, U, same_tab) * 4;
     static size_t attr_set = 0;
     if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE>,
+        hipError_t e = hipFuncSetAttribute((const void*)layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE, PROW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         SATRANS_REQUIRE(e == hipSuccess, SATRANS_E_LAUNCH, "layer_fwd(fused): LDS attribute: %s", hipGetErrorString(e));
         attr_set = lds;
@@ -2156,10 +2199,10 @@ static int launch_fwd_w(const satrans_layer_desc* d, float* y, float* att, hipSt
     const int per_cu = lds * 2 <= (size_t)160 * 1024 ? 2 : 1;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count() * per_cu));
     if (KernelTimer::Pair* tp = g_ktimer.next(0))      // (satrans_kernel_timing: the dispatch's own begin / end timestamps)
-        hipExtLaunchKernelGGL((layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE>), dim3(gx), dim3(64 * WAVES), lds, stream,
+        hipExtLaunchKernelGGL((layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE, PROW>), dim3(gx), dim3(64 * WAVES), lds, stream,
                               tp->start, tp->stop, 0, *d, best, y, att);
     else
-    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
+    layer_fwd_fused_kernel<D, U, H, WAVES, MOD, SAVE, PROW><<<gx, 64 * WAVES, lds, stream>>>(*d, best, y, att);
     SATRANS_CHECK_LAUNCH("layer_fwd_fused_kernel");
     return SATRANS_OK;
 }
@@ -2291,7 +2334,9 @@ extern "C" int64_t satrans_layer_attn_save_floats_fused(const satrans_layer_desc
     if (d->F > 32 || (d->F * HF) % 4 != 0) return 0;
     // numerators [B][F][HF] | 1 / sum [B][HF] | keep words [B][HF] | attention output [B][F][D] | normalised MetaNet rows
     // [B][F][role][D] | their 1 / std [B][F][role]
-    return (int64_t)d->B * (d->F * HF + 2 * HF + (int64_t)d->F * d->D + (int64_t)d->F * (2 * d->D + 2));
+    // (numerators: [B][F][HF], or - register hand-over - padded rows [B][H][F][FP]: sized for the larger)
+    const int64_t FPs = (d->F + 3) & ~3;
+    return (int64_t)d->B * ((int64_t)d->H * d->F * FPs + 2 * HF + (int64_t)d->F * d->D + (int64_t)d->F * (2 * d->D + 2));
 }
 
 extern "C" int64_t satrans_layer_bwd_slab_floats_fused(const satrans_layer_desc* d) {
@@ -2339,7 +2384,8 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
     const int mod = (d->flags & SATRANS_GATE) ? 1 : ((d->flags & SATRANS_BILINEAR) ? 2 : 0);
     const bool save = d->D == 32 && d->attn_save && satrans_layer_attn_save_floats_fused(d) > 0;
     // (gate / bilinear at the AliCCP field count: the field count a constant, hence the matrix-pipe attention arm - round 6)
-    if (mod && save && same && d->F == 19 && f_const)
+    const int ft = fused_bwd_ft(d);      // (the predicate the forward's hand-over layout follows: fused_save_rows)
+    if (mod && save && ft == 19)
         rc = mod == 1 ? launch_bwd<32, 64, 4, true, false, 19, 1, true>(d, p, dy, dx, slabs, stream)
                       : launch_bwd<32, 64, 4, true, false, 19, 2, true>(d, p, dy, dx, slabs, stream);
     else if (mod && save)
@@ -2358,10 +2404,10 @@ extern "C" int satrans_layer_bwd_launch_fused(const satrans_layer_desc* d, const
                         : (same ? launch_bwd<16, 32, 2, true, false, 0, 2>(d, p, dy, dx, slabs, stream)
                                 : launch_bwd<16, 32, 2, false, false, 0, 2>(d, p, dy, dx, slabs, stream));
     else if (save)
-        rc = !same ? (d->F == 15 ? launch_bwd<32, 64, 4, false, false, 15, 0, true>(d, p, dy, dx, slabs, stream)
-                                 : launch_bwd<32, 64, 4, false, false, 0, 0, true>(d, p, dy, dx, slabs, stream))      // flag 'pos': one table per role
-             : d->F == 19 && f_const ? launch_bwd<32, 64, 4, true, false, 19, 0, true>(d, p, dy, dx, slabs, stream)
-                                     : launch_bwd<32, 64, 4, true, false, 0, 0, true>(d, p, dy, dx, slabs, stream);
+        rc = !same ? (ft == 15 ? launch_bwd<32, 64, 4, false, false, 15, 0, true>(d, p, dy, dx, slabs, stream)
+                               : launch_bwd<32, 64, 4, false, false, 0, 0, true>(d, p, dy, dx, slabs, stream))      // flag 'pos': one table per role
+             : ft == 19 ? launch_bwd<32, 64, 4, true, false, 19, 0, true>(d, p, dy, dx, slabs, stream)
+                        : launch_bwd<32, 64, 4, true, false, 0, 0, true>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32 && same && d->F == 19 && f_const)
         rc = launch_bwd<32, 64, 4, true, false, 19>(d, p, dy, dx, slabs, stream);
     else if (d->D == 32) rc = same ? launch_bwd<32, 64, 4, true, false>(d, p, dy, dx, slabs, stream)

@@ -263,6 +263,9 @@ struct FusedDrop {
 __device__ __forceinline__ FusedDrop fused_drop(const satrans_layer_desc& a) {
     FusedDrop dc;
     dc.on = (a.flags & SATRANS_TRAIN) && a.drop_p > 0.f;
+#ifdef SATRANS_DIAG_NODROP      // diagnostic build only: what the dropout hashing and masking cost (results are then those of p = 0)
+    dc.on = false;
+#endif
     dc.scale = dc.on ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     dc.thresh = drop_threshold(a.drop_p);
     for (int s = 0; s < 4; ++s) dc.key[s] = drop_site_key(a.seed, a.step, a.layer, s);
