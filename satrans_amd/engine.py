@@ -194,11 +194,14 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         self.fuse_head = True
         # train_step(next_X=...): the next batch's ids -> rows, sort and bucketing on a side stream under this step's tail
         self.prefetch = True
-        # owner form, several ranks: the NEXT batch's id exchange a step ahead, on a process group of its own
-        # (_prepare_owner_async).  SATRANS_OWNER_PREFETCH=0 (or engine.owner_prefetch = False, the same on every rank) routes the
-        # id exchange back through the step itself on the default group: one communicator, one issue order - the fallback
-        # should two communicators ever misbehave on a node
-        self.owner_prefetch = os.environ.get("SATRANS_OWNER_PREFETCH", "1") != "0"
+        # owner form, several ranks: where the id exchange of a batch runs.  Default (round 6): inside the step, on the default
+        # process group - one communicator, one issue order, nothing to deadlock, and on the one setting this
+        # tooling can measure (one rank through RCCL) also the fastest: 1.084 ms/step against 1.20 with round 5's exchange a
+        # step ahead on a second communicator and 1.91 with that exchange ordered behind the step's gradient collectives by
+        # events (profiles/bench_r06_owner_form_one_rank_rccl*.json).  SATRANS_OWNER_PREFETCH=1 (or engine.owner_prefetch =
+        # True, the same on every rank) selects the ordered a-step-ahead form (_prepare_owner_async) - what an 8-GPU node
+        # would have to arbitrate, which no box available to this repository can.
+        self.owner_prefetch = os.environ.get("SATRANS_OWNER_PREFETCH", "0") == "1"
         # arithmetic of the embedding tables' Adam update (satrans_adam_hparams.arith): "fast" = hardware sqrt / reciprocal, every
         # update within 3.2e-7 relative of torch's; "exact" = torch.optim.Adam's fp32 operations bit for bit
         # (SATRANS_ADAM_ARITH=exact).  Either way the streaming, gathered-row and lazy forms leave identical bits.

@@ -1797,7 +1797,8 @@ def _dp_fit_worker(rank, world, port, name, out_dir, mode):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["SATRANS_SMALL_TABLE_ROWS"] = "20"
-    os.environ["SATRANS_DP_MODE"] = mode
+    os.environ["SATRANS_DP_MODE"] = mode.split("+")[0]
+    os.environ["SATRANS_OWNER_PREFETCH"] = "1" if mode.endswith("+prefetch") else "0"      # (the id exchange a step ahead, or in the step)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         c = Case(name)
@@ -1836,11 +1837,11 @@ def test_two_rank_fit_plans_the_owner_exchange_per_epoch(tmp_path):
     name = "aliccp_sota"
     c = Case(name)
     res = {}
-    for mode in ("owner", "replicated"):
+    for mode in ("owner", "owner+prefetch", "replicated"):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        out = tmp_path / mode
+        out = tmp_path / mode.replace("+", "_")
         out.mkdir()
         mp.spawn(_dp_fit_worker, args=(2, port, name, str(out), mode), nprocs=2, join=True)
         r0, r1 = torch.load(out / "fit0.pt"), torch.load(out / "fit1.pt")
@@ -1850,6 +1851,9 @@ def test_two_rank_fit_plans_the_owner_exchange_per_epoch(tmp_path):
         res[mode] = r0
     steps = (c.X.shape[0] // 2 - 1) // 10 + 1
     assert res["owner"]["__plan__"].tolist() == [steps, steps], "the epoch plan was not consumed step by step"
+    assert res["owner+prefetch"]["__plan__"].tolist() == [steps, steps]
+    for k, v in res["owner"].items():                            # where the id exchange runs changes nothing of the result
+        assert torch.equal(v, res["owner+prefetch"][k]), f"the exchange a step ahead changed {k}"
     assert int(res["owner"]["__plans__"]) == 2 and res["replicated"]["__plan__"].tolist() == [-1, -1]
     np.testing.assert_allclose(res["owner"]["__loss__"].numpy(), res["replicated"]["__loss__"].numpy(), rtol=1e-6)
     gold = c.arrays("grad")
