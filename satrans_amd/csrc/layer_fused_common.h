@@ -174,6 +174,11 @@ __device__ __forceinline__ void wgrad_r4(const float* al, const float* gl, f32x4
 #pragma unroll
         for (int nt = 0; nt < NT_; ++nt) gv[ks][nt] = gl[ks * LDG + 16 * nt];
     }
+#ifndef SATRANS_EXP_WGRAD_NOSB
+    // (as in `chain`: without it hipcc sinks every step's operand reads to their products - read, wait for everything, four MFMAs,
+    //  eight times over: round 6 found that stream in the dW1 products of phase F)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
