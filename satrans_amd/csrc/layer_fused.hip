@@ -1681,7 +1681,20 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         if (dc.on) mk = (keepbits >> (kshift + 4 * t + r)) & 1u ? dc.scale : 0.f;
                         dm[t][r] = gout[t][r] * mk;
                     }
+                // Order (round 6): a weight-gradient product reads back from LDS what this wave has just stored, and at one wave per
+                // SIMD nothing hides that store -> load round trip - except the chain that does not depend on it.  So: store the
+                // operands of dW2, run dh = dm W2^T (registers + weights only), THEN the dW2 products; store the operands of dW1,
+                // run back = dh W1^T, THEN the dW1 products.  (-DSATRANS_EXP_WGRAD_INORDER: the products right behind their stores.)
+#ifdef SATRANS_EXP_WGRAD_INORDER
+                constexpr bool kLate = false;
+#else
+                constexpr bool kLate = true;
+#endif
                 // dW2[u][o] += h^T dm : h goes to the q (and o) rows of this tile, dm to the dq rows
+                auto dw2_products = [&]() {
+                    WGRAD<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
+                    if constexpr (HB == 2) WGRAD<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
+                };
                 {
                     float part[KT][4];
 #pragma unroll
@@ -1697,18 +1710,22 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, dm);
-                    WGRAD<NB, KT, 0, 0, LD, LD>(wg_q, wg_g, acc_w2);
-                    if constexpr (HB == 2) WGRAD<NB, KT, NB, 0, LD, LD>(wg_o, wg_g, acc_w2);
+                    if constexpr (!kLate) dw2_products();
                 }
                 // dh = (dm W2^T) * [h > 0]
                 float dh[UT][4];
                 if constexpr (TR) chain<KT, UT, LU>(w2T + lo_u, dm, dh);
                 else chain_t<KT, UT, LD>(w2T + lt_d, dm, dh);              // w2T is then the forward image W2 [U][LD]
+                if constexpr (kLate) dw2_products();
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dh[t][r] = h[t][r] > 0.f ? dh[t][r] : 0.f;
                 // dW1[i][u] += in0^T dh : in0 to the dq rows, dh to the q (and o) rows
+                auto dw1_products = [&]() {
+                    WGRAD<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
+                    if constexpr (HB == 2) WGRAD<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
+                };
                 {
                     float part[KT][4];
 #pragma unroll
@@ -1724,13 +1741,13 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
                         store_frag<KT>(my_o, part);
                     }
                     store_frag<KT>(my_g, in0, valid);
-                    WGRAD<KT, NB, 0, 0, LD, LD>(wg_g, wg_q, acc_w1);
-                    if constexpr (HB == 2) WGRAD<KT, NB, 0, NB, LD, LD>(wg_g, wg_o, acc_w1);
+                    if constexpr (!kLate) dw1_products();
                 }
                 // gradient of the MetaNet input: dz + dh W1^T
                 float back[KT][4];
                 if constexpr (TR) chain<UT, KT, LD>(w1T + lo_d, dh, back);
                 else chain_t<UT, KT, LU>(w1T + lt_u, dh, back);            // ... the forward image W1 [D][LU]
+                if constexpr (kLate) dw1_products();
 #pragma unroll
                 for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -1773,33 +1790,42 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             }
 
             // projections: dW{q,k,v}[i][o] += x^T g ; dx = dr + gq Wq^T + gk Wk^T + gv Wv^T
+            // (the same interleaving as in metanet_bwd: the back-projection of a gradient - registers and weights only - runs between
+            //  the LDS stores of that gradient's rows and the weight-gradient product that reads them back)
+            float gv[KT][4], back[KT][4];
+            auto back_dd = [&](float* img, const float (&in_)[KT][4], float (&out_)[KT][4]) {
+                if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
+                else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
+            };
+            auto add_back = [&]() {
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            };
+#ifdef SATRANS_EXP_WGRAD_INORDER
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
             store_frag<KT>(my_o, gk);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
-            float gv[KT][4], back[KT][4];
             load_frag<KT>(my_v, gv, valid);
-            auto back_dd = [&](float* img, const float (&in_)[KT][4], float (&out_)[KT][4]) {
-                if constexpr (TR) chain<KT, KT, LD>(img + lo_d, in_, out_);
-                else chain_t<KT, KT, LD>(img + lt_d, in_, out_);
-            };
-            back_dd(wqT, gq, back);
-#pragma unroll
-            for (int t = 0; t < KT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
-            back_dd(wkT, gk, back);
-#pragma unroll
-            for (int t = 0; t < KT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
-            back_dd(wvT, gv, back);
-#pragma unroll
-            for (int t = 0; t < KT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dr[t][r] += back[t][r];
+            back_dd(wqT, gq, back); add_back();
+            back_dd(wkT, gk, back); add_back();
+            back_dd(wvT, gv, back); add_back();
+#else
+            store_frag<KT>(my_q, x, valid);
+            store_frag<KT>(my_o, gq);
+            load_frag<KT>(my_v, gv, valid);                                    // (the value gradients: rows phase E left in LDS)
+            back_dd(wvT, gv, back); add_back();
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
+            store_frag<KT>(my_o, gk);
+            back_dd(wqT, gq, back); add_back();
+            WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
+            back_dd(wkT, gk, back); add_back();
+#endif
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
         lds_barrier();
