@@ -154,6 +154,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.loss_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.reg_sum = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.reg_roll = torch.zeros(1, dtype=torch.float64, device=self.dev)     # the rolling flush's share (its own stream)
         self.adam_t = 0
         self.adam_m = self.adam_v = None
         self.flat_m = self.flat_v = self.flat_g = None
@@ -177,6 +178,12 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         # 1,000 dependent steps inside the step that gathers it, while the flush runs the same steps with every lane busy.
         self.flush_every = int(os.environ.get("SATRANS_LAZY_FLUSH_EVERY", "32"))
         self._since_flush = 0
+        # One rank, lazy form: instead of ONE launch over all rows every `flush_every` steps (2.6 ms at 6.57 M rows, on the launch
+        # stream), every step brings 1/flush_every of the rows up to the PREVIOUS step on a lowest-priority stream forked behind
+        # its last backward kernel (_roll_flush): the same row-steps, executed underneath the step's small tail kernels.
+        self.rolling_flush = os.environ.get("SATRANS_ROLLING_FLUSH", "0") == "1"
+        self._roll = None
+        self._roll_done = None
         # Several ranks: "owner" (default) = every rank owns a contiguous 1/N slice of the large tables' rows and is the only one
         # to step them (per-rank optimizer work and traffic independent of N); "replicated" = round 2's exchange, every rank
         # applies every rank's updates (satrans_amd/parallel.py).
@@ -783,15 +790,17 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
 
     def reset_epoch_sums(self):
         self._join_flat()          # (a pipelined step's slab reduction adds to loss_sum on the tail stream)
+        self._join_roll()
         self.loss_sum.zero_()
         self.reg_sum.zero_()
         self.reg_small.zero_()
+        self.reg_roll.zero_()
 
     def epoch_sums(self):
         """(sum of this rank's sample losses, sum over the epoch's steps of the regulariser l2 * |tables|^2).  Collective in
         the owner form of several ranks: a rank accumulates the regulariser of the rows it owns, the total is their sum."""
         self.flush_lazy()          # the regulariser sums of postponed steps belong to this epoch
-        reg = self.reg_sum
+        reg = self.reg_sum + self.reg_roll       # (flush_lazy joined the rolling flush's stream)
         if self._owner_world:
             from . import parallel
             reg = parallel.all_reduce_scalars(self.reg_sum.clone()) + self.reg_small
@@ -1005,7 +1014,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                 and X.dtype in (torch.float32, torch.int32, torch.int64) and not self.multi and self.lazy
                 and self._sort_fields is not None and B <= 8192 and self.fuse_gather and not self.force_split)
 
-    def _low_priority_stream(self):
+    def _low_priority_stream(self, name: str = "low_priority"):
         """A HIP stream of the lowest priority the device offers (torch only hands out priorities <= 0, i.e. normal and above),
         created by libsatrans_hip.so - which is linked against the HIP runtime this process already uses - and wrapped for torch:
         when its kernels and the launch stream's become ready together, the launch stream's are dispatched first.  Lives as long
@@ -1017,8 +1026,8 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
             if rc == 0 and handle.value:
                 return torch.cuda.ExternalStream(handle.value, device=self.dev)      # (lives as long as the process: _STREAMS)
             return None
-        st = _shared_stream(self.dev, "low_priority", make)
-        if st is not None:
+        st = _shared_stream(self.dev, name, make)
+        if st is not None or name != "low_priority":
             return st
         # no priorities on this device / runtime: an early fork would race the last backward kernel for the CUs - fork behind it
         self.prep_early = False
@@ -1329,6 +1338,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         stale replicas it raises instead of starting a collective the other ranks never join (a rank-0-only
         checkpoint in the middle of an epoch would hang); `model.synchronize()` on every rank first makes it legal."""
         self._join_flat()
+        self._join_roll()
         if self.lazy and self._lazy_pending:
             m = self.m
             h = self._hparams(m.l2_reg_embedding) if self.adam_t > 0 else None
@@ -1362,6 +1372,49 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                                                   self._flush_reg.data_ptr(), st), "satrans_embed_lazy_flush")
         N.check(self.lib.satrans_sum_f64(self._flush_reg.data_ptr(), self._flush_reg.numel(), self.reg_sum.data_ptr(),
                                          1, st), "satrans_sum_f64")
+
+    def _join_roll(self):
+        """The launch stream waits for the rolling flush of the previous step (it writes table rows and their `last_step`)."""
+        if self._roll_done is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._roll_done)
+            self._roll_done = None
+
+    def _roll_flush(self, fork) -> bool:
+        """Rolling form of the periodic flush (one rank, lazy): slice `adam_t mod flush_every` of the rows is brought up to step
+        adam_t - 1 on a lowest-priority stream that starts at `fork` (behind the last backward kernel of step adam_t).  The target
+        is the step BEFORE the one whose touched-row launch runs beside it: the rows of that launch were replayed to adam_t - 1 at
+        the head of the step, so the flush kernel skips them (`last_step >= target`: neither read nor written) and the two never
+        meet on a row.  The next reader or writer of any row - the next step's replay, flush_lazy() - waits for `_roll_done`.
+        Same row-steps as the one-launch flush, each executed once, so the tables stay the same bits."""
+        target = self.adam_t - 1
+        if target < 1 or fork is None:
+            return False
+        if self._roll is None:
+            self._roll = self._low_priority_stream("roll")
+            if self._roll is None:
+                self.rolling_flush = False
+                return False
+            self._roll_reg = torch.zeros(self._flush_reg.numel(), dtype=torch.float64, device=self.dev)
+        m, n_sl = self.m, self.flush_every
+        s = self.adam_t % n_sl
+        lo, hi = self.total_rows * s // n_sl, self.total_rows * (s + 1) // n_sl
+        if hi <= lo:
+            return True
+        h = self._hparams(m.l2_reg_embedding)
+        table = self._table(self.adam_t)               # (built / patched on the launch stream, in front of `fork`)
+        self._roll.wait_event(fork)
+        with torch.cuda.stream(self._roll):
+            st = self._stream()
+            with self.phase("lazy_flush_roll"):
+                N.check(self.lib.satrans_embed_lazy_flush(m.embedding_arena[lo:].data_ptr(), self.adam_m[lo:].data_ptr(),
+                                                          self.adam_v[lo:].data_ptr(), self.last_step[lo:].data_ptr(), hi - lo,
+                                                          self.D, target, table.data_ptr(), C.byref(h), 0,
+                                                          self._roll_reg.data_ptr(), st), "satrans_embed_lazy_flush")
+            N.check(self.lib.satrans_sum_f64(self._roll_reg.data_ptr(), self._roll_reg.numel(), self.reg_roll.data_ptr(), 1, st),
+                    "satrans_sum_f64")
+            self._roll_done = torch.cuda.Event()
+            self._roll_done.record(self._roll)
+        return True
 
     # ------------------------------------------------------------------------------------------------
     # inspection for the parity tests: one forward+backward, gradients by state_dict key (dense tables)

@@ -39,6 +39,7 @@ class LocalStepMixin:
         h_emb = self._hparams(l2)
         # ---- 2. lazy form: replay the postponed steps of exactly these rows up to t-1, so that the gather reads current
         #         values (small-table rows are always current: they take a dense step every step) --------------------------
+        self._join_roll()
         if self.lazy and self.adam_t > 1:
             with self.phase("lazy_replay"):
                 self._replay_rows(ws["sorted_rows"], n_loc, ws["replay_reg"], None)
@@ -77,6 +78,7 @@ class LocalStepMixin:
             hook = lambda fork: self._prepare_async(next_X, B, fork)
         gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook,
                              side_tail=self.side_tail and not split)
+        rolled = self.lazy and self.rolling_flush and self.flush_every > 1 and not split and self._roll_flush(self._last_fork)
 
         # ---- 5. small tables (forced table classes only): ordered segmented sums into their dense gradient, dense step ----------
         if n_s > 0:
@@ -134,5 +136,7 @@ class LocalStepMixin:
         else:
             with self.phase("adam_flat"):
                 self._flat_step(h_flat, ws, st)
-        if self.lazy and self.flush_every and self._since_flush >= self.flush_every:
+        if rolled:
+            self._since_flush = 0          # (every row is at most flush_every steps behind by construction)
+        elif self.lazy and self.flush_every and self._since_flush >= self.flush_every:
             self.flush_lazy()

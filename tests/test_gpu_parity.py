@@ -1468,6 +1468,46 @@ def test_lazy_adam_is_bitwise_the_streaming_adam(arith):
     assert reg_l == pytest.approx(reg_d, rel=1e-6)      # lazy sums p^2 per element in fp32 before going to double
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_rolling_flush_is_bitwise_the_streaming_adam(pipelined):
+    """The rolling form of the periodic flush (engine._roll_flush: a slice of the rows per step, on its own lowest-priority
+    stream, beside the step's touched-row launch) leaves EXACTLY the tables, moments and epoch sums of the every-step streaming
+    kernel - 43 steps with a slice count of 8 (every row rolled five times), a mid-run evaluation, with and without the
+    announced next batch."""
+    c = Case("aliccp_sota")
+    rng = np.random.RandomState(12)
+    B, steps = 64, 43
+    Xs = [torch.from_numpy(np.stack([rng.randint(1 if f == "301" else 0, v - 1, size=B)
+                                     for f, v in zip(c.meta["fields"], c.meta["vocab"])], axis=1).astype(np.float32)).to(DEV)
+          for _ in range(steps)]
+    ys = [torch.from_numpy((rng.rand(B) < 0.3).astype(np.float32)).to(DEV) for _ in range(steps)]
+    results = []
+    for form in ("rolling", "streaming"):
+        model = build_model(c, DEV)
+        model.compile(torch.optim.Adam(model.parameters(), lr=0.005), "binary_crossentropy")
+        model.train()
+        eng = model._require_engine()
+        eng.lazy, eng.overlap = form == "rolling", False
+        eng.rolling_flush, eng.flush_every = form == "rolling", 8
+        eng.reset_epoch_sums()
+        rolled = 0
+        for i in range(steps):
+            eng.train_step(Xs[i], ys[i], next_X=Xs[i + 1] if pipelined and i + 1 < steps else None)
+            rolled += eng._roll_done is not None
+            if i == 20:
+                model.eval(); model(Xs[i]); model.train()
+        if form == "rolling":
+            assert rolled >= steps - 2 and getattr(eng, "flush_count", 0) <= 2, (rolled, getattr(eng, "flush_count", 0))
+        bce, reg = eng.epoch_sums()
+        results.append((sd_to_cpu(model), eng.adam_m.cpu(), eng.adam_v.cpu(), bce, reg))
+    (sd_l, m_l, v_l, bce_l, reg_l), (sd_d, m_d, v_d, bce_d, reg_d) = results
+    for k in sd_d:
+        assert torch.equal(sd_l[k], sd_d[k]), k
+    assert torch.equal(m_l, m_d) and torch.equal(v_l, v_d)
+    assert bce_l == bce_d
+    assert reg_l == pytest.approx(reg_d, rel=1e-6)
+
+
 def test_lazy_adam_stays_bitwise_the_streaming_adam_while_rows_decay():
     """700 steps over two small batches: the rows they never gather decay under the regulariser out of the packed range of the
     replay (|lr * exp_avg| < 2^-80 after ~500 steps) and on towards the subnormals - the regime of most rows of a long run.
