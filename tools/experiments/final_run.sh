@@ -29,7 +29,7 @@ cp $(find $o/ks5 -name "*kernel_stats.csv" | head -1) $o/c5_kernel_stats.csv
 rm -rf $o/ks5
 python bench.py --flag sota-bilinear --train-only > $o/bench_bilinear.json 2>/dev/null
 SATRANS_FORCE_EXCHANGE=1 python bench.py --train-only > $o/bench_owner.json 2>/dev/null
-SATRANS_FORCE_EXCHANGE=1 SATRANS_OWNER_PREFETCH=0 python bench.py --train-only > $o/bench_owner_noprefetch.json 2>/dev/null
+SATRANS_FORCE_EXCHANGE=1 SATRANS_OWNER_PREFETCH=1 python bench.py --train-only > $o/bench_owner_prefetch.json 2>/dev/null
 SATRANS_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --train-only --steps 10 --warmup 3 > $o/bench_two_ranks_one_gpu_gloo.json 2> $o/bench_two_ranks.err; echo "two ranks rc=$?"
 python tools/fake_world.py 1 2 4 8 > $o/fake_world_owner.txt 2>/dev/null
 python tools/experiments/r06_fit_epoch.py > $o/fit_epoch.txt 2>/dev/null
