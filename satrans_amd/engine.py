@@ -181,7 +181,10 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         # One rank, lazy form: instead of ONE launch over all rows every `flush_every` steps (2.6 ms at 6.57 M rows, on the launch
         # stream), every step brings 1/flush_every of the rows up to the PREVIOUS step on a lowest-priority stream forked behind
         # its last backward kernel (_roll_flush): the same row-steps, executed underneath the step's small tail kernels.
-        self.rolling_flush = os.environ.get("SATRANS_ROLLING_FLUSH", "0") == "1"
+        # Values: "0" off; "tail" fork behind the step's last backward kernel; "step" fork behind the step's replay launch (the slice
+        # has the whole step's layer kernels to hide under: pays where those are ordinary grids - the general path).
+        self.rolling_flush = {"1": "tail", "0": ""}.get(os.environ.get("SATRANS_ROLLING_FLUSH", "0"),
+                                                        os.environ.get("SATRANS_ROLLING_FLUSH", "0"))
         self._roll = None
         self._roll_done = None
         # Several ranks: "owner" (default) = every rank owns a contiguous 1/N slice of the large tables' rows and is the only one

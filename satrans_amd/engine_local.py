@@ -45,6 +45,12 @@ class LocalStepMixin:
                 self._replay_rows(ws["sorted_rows"], n_loc, ws["replay_reg"], None)
         elif self.lazy:
             ws["replay_reg"].zero_()
+        rolling = self.rolling_flush if self.lazy and self.flush_every > 1 and not split else ""
+        rolled = False
+        if rolling == "step":
+            fork = torch.cuda.Event()
+            fork.record(main)
+            rolled = self._roll_flush(fork)
         # ---- 3. streaming form of the dense step: every other row takes its regulariser-only step now, on a side stream
         #         underneath the forward ---------------------------------------------------------------------------------------
         side_done = None
@@ -78,7 +84,8 @@ class LocalStepMixin:
             hook = lambda fork: self._prepare_async(next_X, B, fork)
         gemb = self.backward(X, y, ws, rows_ready=True, bucket_ready=prepared, after_layers=hook,
                              side_tail=self.side_tail and not split)
-        rolled = self.lazy and self.rolling_flush and self.flush_every > 1 and not split and self._roll_flush(self._last_fork)
+        if rolling and rolling != "step":
+            rolled = self._roll_flush(self._last_fork)
 
         # ---- 5. small tables (forced table classes only): ordered segmented sums into their dense gradient, dense step ----------
         if n_s > 0:

@@ -1468,10 +1468,11 @@ def test_lazy_adam_is_bitwise_the_streaming_adam(arith):
     assert reg_l == pytest.approx(reg_d, rel=1e-6)      # lazy sums p^2 per element in fp32 before going to double
 
 
+@pytest.mark.parametrize("mode", ["tail", "step"])
 @pytest.mark.parametrize("pipelined", [False, True])
-def test_rolling_flush_is_bitwise_the_streaming_adam(pipelined):
+def test_rolling_flush_is_bitwise_the_streaming_adam(pipelined, mode):
     """The rolling form of the periodic flush (engine._roll_flush: a slice of the rows per step, on its own lowest-priority
-    stream, beside the step's touched-row launch) leaves EXACTLY the tables, moments and epoch sums of the every-step streaming
+    stream, forked behind the step's last backward kernel - "tail" - or behind its replay launch - "step") leaves EXACTLY the tables, moments and epoch sums of the every-step streaming
     kernel - 43 steps with a slice count of 8 (every row rolled five times), a mid-run evaluation, with and without the
     announced next batch."""
     c = Case("aliccp_sota")
@@ -1488,7 +1489,7 @@ def test_rolling_flush_is_bitwise_the_streaming_adam(pipelined):
         model.train()
         eng = model._require_engine()
         eng.lazy, eng.overlap = form == "rolling", False
-        eng.rolling_flush, eng.flush_every = form == "rolling", 8
+        eng.rolling_flush, eng.flush_every = mode if form == "rolling" else "", 8
         eng.reset_epoch_sums()
         rolled = 0
         for i in range(steps):
