@@ -529,22 +529,25 @@ class BaseModel(nn.Module):
             fused_buf = None
             if verbose > 0 and self.metrics and device_metrics and str(self.device).startswith("cuda"):
                 fused_buf = torch.full((steps_per_epoch, 2), float("nan"), dtype=torch.float64, device=self.device)
-            order = self._epoch_order(sample_num, shuffle, on_host=upload is not None)
+            # (resident dataset: the order is drawn by a worker thread and handed out head first - the first chunk of steps starts
+            #  while the rest of the permutation is still being drawn, sampler.AsyncOrder)
+            order = self._epoch_order(sample_num, shuffle, on_host=True, lazy=not stream)
             if upload is not None:
                 upload.join()
                 upload = None
                 if "error" in box:
                     raise box["error"]
                 data, labels = box["data"], box["labels"]
-                order = order.to(self.device) if order is not None else None
             engine.reset_epoch_sums()
             if not stream and torch.is_tensor(data):
-                engine.plan_owner_counts(data, order, batch_size)      # several ranks, owner form: the epoch's exchange sizes at once
+                # several ranks, owner form: the epoch's exchange sizes at once (the one consumer that needs the whole order now)
+                whole = order.full() if order is not None and engine.plans_owner_counts() else None
+                engine.plan_owner_counts(data, whole, batch_size)
             feeder = None
             if stream:
                 from .pipeline import HostBatchFeeder
                 feeder = iter(HostBatchFeeder(host_ids, y, batch_size, self.device,
-                                              order.cpu().numpy() if order is not None else None, host_dense))
+                                              order.numpy() if order is not None else None, host_dense))
             iterator = range(steps_per_epoch)
             bar = None
             if verbose == 1:
@@ -565,7 +568,7 @@ class BaseModel(nn.Module):
                 c = step_ // chunk_steps
                 if chunk["id"] != c:
                     c_lo = c * chunk_steps * batch_size
-                    idx = order[c_lo:min(sample_num, c_lo + chunk_steps * batch_size)]
+                    idx = order.rows(c_lo, min(sample_num, c_lo + chunk_steps * batch_size))
                     chunk.update(id=c, lo=c_lo, data=data.index_select(0, idx), labels=labels.index_select(0, idx))
                 return chunk["data"][lo_ - chunk["lo"]:hi_ - chunk["lo"]], chunk["labels"][lo_ - chunk["lo"]:hi_ - chunk["lo"]]
 
@@ -672,22 +675,23 @@ class BaseModel(nn.Module):
                 f"this rank ({sample_num}, {batch_size}). Give every rank an equally long shard (drop or pad the tail) "
                 f"and the same batch_size.")
 
-    def _epoch_order(self, n: int, shuffle: bool, on_host: bool = False) -> Optional[torch.Tensor]:
+    def _epoch_order(self, n: int, shuffle: bool, on_host: bool = False, lazy: bool = False):
         """Sample order of one epoch.  With shuffle the permutation is drawn the way
         torch.utils.data.DataLoader(shuffle=True) draws it for the reference (one base-seed draw by the loader
         iterator, one seed draw by RandomSampler, then randperm with that seed), so the same torch seed yields
-        the same batches."""
+        the same batches.  The permutation itself comes from satrans_amd/sampler.py: torch.randperm's result bit for bit, drawn
+        faster; `lazy`: a sampler.AsyncOrder - a worker thread draws it, its head is usable before its tail exists."""
         if not shuffle:
             return None
+        from . import sampler
         torch.empty((), dtype=torch.int64).random_()
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         spec, self._order_spec = getattr(self, "_order_spec", None), None
-        if spec is not None and spec[0] == seed and spec[1] == n:
-            perm = spec[2]                 # drawn ahead from the seed this point was going to produce (_speculate_epoch_order)
-        else:
-            gen = torch.Generator()
-            gen.manual_seed(seed)
-            perm = torch.randperm(n, generator=gen)
+        ahead = spec[2] if spec is not None and spec[0] == seed and spec[1] == n else None
+        # (`ahead`: drawn ahead from the seed this point was going to produce, _speculate_epoch_order)
+        if lazy:
+            return sampler.AsyncOrder(seed, n, self.device, ready=ahead)
+        perm = ahead if ahead is not None else sampler.randperm(seed, n)
         return perm if on_host else perm.to(self.device)
 
     def _speculate_epoch_order(self, n: int) -> None:
@@ -702,9 +706,8 @@ class BaseModel(nn.Module):
         torch.empty((), dtype=torch.int64).random_()
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         torch.set_rng_state(state)
-        gen = torch.Generator()
-        gen.manual_seed(seed)
-        self._order_spec = (seed, n, torch.randperm(n, generator=gen))
+        from . import sampler
+        self._order_spec = (seed, n, sampler.randperm(seed, n))
 
     def evaluate(self, x, y, batch_size=256):
         """Metric name -> value on (x, y); models/meta_basemodel.py:387-399."""

@@ -53,6 +53,11 @@ class OwnerStepMixin:
             self._owner_bounds = (world, bounds)
         return bounds
 
+    def plans_owner_counts(self) -> bool:
+        """Whether plan_owner_counts would plan anything (fit() only waits for the whole sample order when it does)."""
+        from . import parallel
+        return bool(parallel.exchange_enabled() and self.dp_mode == "owner" and self.lazy and self.F_small < self.F)
+
     def plan_owner_counts(self, ids: torch.Tensor, order: Optional[torch.Tensor], batch_size: int) -> None:
         """Owner form, optional: the per-step all-to-all split sizes of a whole epoch in ONE pass and ONE read-back, for callers
         that know the epoch's batches ahead (`fit`: the resident id matrix [N, C] and the epoch's sample order).  Without a plan
@@ -61,7 +66,7 @@ class OwnerStepMixin:
         from . import parallel
         self._owner_plan = None
         world = parallel.world_size()
-        if not (parallel.exchange_enabled() and self.dp_mode == "owner" and self.lazy and self.F_small < self.F):
+        if not self.plans_owner_counts():
             return
         if ids.dtype not in (torch.float32, torch.int32, torch.int64) or ids.dim() != 2:
             return

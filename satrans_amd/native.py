@@ -90,6 +90,7 @@ SIGNATURES = {
     "satrans_abi_version": (C.c_int, []),
     "satrans_stream_create_low_priority": (C.c_int, [C.POINTER(C.c_void_p)]),
     "satrans_stream_destroy": (C.c_int, [C.c_void_p]),
+    "satrans_host_randperm": (C.c_int, [C.c_uint64, C.c_int64, _vp, _vp]),
     "satrans_kernel_timing": (C.c_int, [C.c_int]),
     "satrans_kernel_timing_read": (C.c_int, [_vp, _vp, C.c_int]),
     "satrans_bucket_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),

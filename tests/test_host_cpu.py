@@ -286,3 +286,37 @@ def test_speculative_epoch_order_is_the_order_the_loader_draws():
     torch.manual_seed(5)
     got3 = model._epoch_order(n, True, on_host=True)
     assert torch.equal(got3, want3) and model._order_spec is None
+
+
+def test_host_randperm_is_torch_randperm_and_its_head_is_final_before_its_tail():
+    """satrans_host_randperm (csrc/host_sampler.hip) must return torch.randperm's permutation bit for bit - it replaces the draw
+    of the reference's RandomSampler - for seeds above 2**32 (torch seeds its Mersenne Twister with the low 32 bits), around the
+    block size of its look-ahead, and for the trivial sizes; sampler.AsyncOrder must hand out the same rows, head first, and
+    through the loader-order draws of `_epoch_order(lazy=True)` the order of DataLoader(shuffle=True)."""
+    from satrans_amd import sampler
+    assert sampler.native_ok(), "the library's pass no longer reproduces torch.randperm on this torch version"
+    for seed in (0, 1, 5489, 2 ** 31 + 7, 2 ** 40 + 3, 2 ** 63 - 1):
+        for n in (0, 1, 2, 3, 63, 64, 65, 66, 127, 128, 129, 130, 1000, 65537, 200001):
+            gen = torch.Generator()
+            gen.manual_seed(seed)
+            want = torch.randperm(n, generator=gen)
+            got = sampler.randperm(seed, n)
+            assert got.dtype == torch.int64 and torch.equal(got, want), (seed, n)
+    n = 300001
+    gen = torch.Generator()
+    gen.manual_seed(2 ** 35 + 11)
+    want = torch.randperm(n, generator=gen)
+    order = sampler.AsyncOrder(2 ** 35 + 11, n, "cpu")
+    head = order.rows(0, 4096)                      # (possibly while the worker is still drawing the tail)
+    assert torch.equal(head, want[:4096])
+    assert torch.equal(order.rows(4096, 70000), want[4096:70000])
+    assert torch.equal(order.full(), want) and torch.equal(order.rows(250000, n), want[250000:])
+    assert torch.equal(sampler.AsyncOrder(3, n, "cpu", ready=want).rows(5, 9), want[5:9])     # a permutation drawn ahead
+    # through the model: the two generator draws of the loader, then the permutation
+    import torch.utils.data as tud
+    model = build_model(Case("small_qkv"), "cpu")
+    torch.manual_seed(123)
+    loader = torch.tensor(list(iter(tud.DataLoader(range(5000), batch_size=5000, shuffle=True)))[0])
+    torch.manual_seed(123)
+    lazy = model._epoch_order(5000, True, on_host=True, lazy=True)
+    assert torch.equal(lazy.rows(0, 100), loader[:100]) and torch.equal(lazy.full(), loader)
