@@ -585,8 +585,9 @@ def main():
                        "warm_epoch": {"wall_s": round(warm, 3), "samples_per_s": round(n_fit * B / warm, 1),
                                       "note": "a two-epoch fit minus the one-epoch fit: an epoch over the already resident dataset"},
                        "epoch_loss": float(hist.history["loss"][-1]) if hist.history.get("loss") else None,
-                       "note": "model.fit(x=dict, y, batch_size, epochs=1, verbose=1, shuffle=True): host packing + upload of "
-                               "the epoch's rows, per-epoch shuffle, per-step train metrics (binary_crossentropy, auc), History"}
+                       "note": "model.fit(x=dict, y, batch_size, epochs=1, verbose=1, shuffle=True): upload of the dataset's columns, the "
+                               "epoch's shuffle order (the reference loader's permutation), per-step train metrics "
+                               "(binary_crossentropy, auc), History"}
             model.train()
         except Exception as ex:
             print(f"[bench] fit leg skipped: {ex}", file=sys.stderr)
