@@ -53,6 +53,13 @@ extern "C" {
 #define SATRANS_TRAIN 16    /* apply the four dropouts (p = drop_p)                                    */
 #define SATRANS_GATE 32     /* flag 'gate': q,k *= 2*vec instead of the MetaNet,   satrans.py:61-62,68-69 */
 #define SATRANS_BILINEAR 64 /* flag 'bilinear': per-head q_h @ M[s,h],             satrans.py:79-81     */
+/* General path only (satrans_layer_fwd_generic / satrans_layer_bwd_generic; every other entry point refuses them): a stack of
+ * layers (satrans.py:236-239: `for layer in self.domain_int_layers`) keeps its activations in the scenario-sorted order of
+ * d->order between its layers instead of changing the order at both ends of every layer.
+ *   X_SORTED  x (and, in the backward, dx) are rows [position in d->order][F][D]; x is not copied: the backward reads d->x again
+ *   Y_SORTED  y (and, in the backward, dy) likewise */
+#define SATRANS_X_SORTED 128
+#define SATRANS_Y_SORTED 256
 
 const char* satrans_last_error(void);
 int satrans_abi_version(void);

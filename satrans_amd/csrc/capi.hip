@@ -91,6 +91,8 @@ int satrans_set_layer_impl(int impl) {
 int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* stream) {
     int rc = satrans_layer_validate(d, "layer_fwd");
     if (rc) return rc;
+    SATRANS_REQUIRE(!(d->flags & (SATRANS_X_SORTED | SATRANS_Y_SORTED)), SATRANS_E_UNSUPPORTED,
+                    "layer_fwd: SATRANS_X_SORTED / SATRANS_Y_SORTED are flags of the general path (satrans_layer_fwd_generic)");
     if (satrans_layer_impl() == 0 && satrans_layer_fused_supported(d)) return satrans_layer_fwd_fused(d, y, att, stream);
     return satrans_layer_fwd_lds(d, y, att, stream);
 }
@@ -119,6 +121,8 @@ int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, f
                       void* stream) {
     int rc = satrans_layer_validate(d, "layer_bwd");
     if (rc) return rc;
+    SATRANS_REQUIRE(!(d->flags & (SATRANS_X_SORTED | SATRANS_Y_SORTED)), SATRANS_E_UNSUPPORTED,
+                    "layer_bwd: SATRANS_X_SORTED / SATRANS_Y_SORTED are flags of the general path (satrans_layer_bwd_generic)");
     if (satrans_layer_impl() == 0 && satrans_layer_bwd_fused_supported(d))
         return satrans_layer_bwd_fused(d, dy, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
     return satrans_layer_bwd_lds(d, dy, dx, slabs, g_wq, g_wk, g_wv, g_wo, g_ln, g_lnq, g_lnk, g_tab_q, g_tab_k, stream);
@@ -127,6 +131,7 @@ int satrans_layer_bwd(const satrans_layer_desc* d, const float* dy, float* dx, f
 // the last layer of a training step with the head fused in: fused kernels only (layer_fused.hip)
 int satrans_layer_bwd_head_supported(const satrans_layer_desc* d, const satrans_head_desc* h) {
     if (!d || !h || satrans_layer_validate(d, "layer_bwd_head")) return 0;
+    if (d->flags & (SATRANS_X_SORTED | SATRANS_Y_SORTED)) return 0;
     return satrans_layer_impl() == 0 && satrans_layer_fused_supported(d) && satrans_layer_bwd_head_fused_supported(d, h);
 }
 

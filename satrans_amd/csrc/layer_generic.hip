@@ -1844,10 +1844,17 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
     const int B = d->B, F = d->F, D = d->D, U = d->U, H = d->H, S = d->S, M = B * F;
     const bool meta_q = d->flags & SATRANS_META_Q, meta_k = d->flags & SATRANS_META_K;
     const bool relu = d->flags & SATRANS_RELU_OUT, use_res = !(d->flags & SATRANS_NO_RES);
-    float *xs = saved + L.xs, *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
+    // SATRANS_X_SORTED: the input IS the scenario-sorted rows (the previous layer of a stack left them so: SATRANS_Y_SORTED
+    // there) - no copy, the backward reads d->x again; else the rows are brought into that order (or gathered: layer 0)
+    const bool x_sorted = d->flags & SATRANS_X_SORTED, y_sorted = d->flags & SATRANS_Y_SORTED;
+    SATRANS_REQUIRE(!(x_sorted && d->x_rows), SATRANS_E_BADARG, "layer_fwd(generic): SATRANS_X_SORTED with a fused gather");
+    float *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
+    const float* xs = x_sorted ? d->x : saved + L.xs;
     int rc;
-    gen_permute_in_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, nullptr, xs, true);
-    SATRANS_CHECK_LAUNCH("gen_permute_in_kernel");
+    if (!x_sorted) {
+        gen_permute_in_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, nullptr, saved + L.xs, true);
+        SATRANS_CHECK_LAUNCH("gen_permute_in_kernel");
+    }
     {   // satrans.py:55-57
         const float* A[3] = {xs, xs, xs};
         const float* Bw[3] = {d->w_query, d->w_key, d->w_value};
@@ -1906,7 +1913,7 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
         const float* Bw[1] = {d->w_out};
         float* C[1] = {saved + L.u};
         if ((rc = gen_gemm<true, 0>(st, 1, A, Bw, C, nullptr, 1, M, F, D, D, D, 0))) return rc;
-        if ((rc = gen_ln_fwd(st, d, saved + L.u, use_res ? xs : nullptr, saved + L.to, y, true, d->ln_g, d->ln_b, kSiteOut, relu)))
+        if ((rc = gen_ln_fwd(st, d, saved + L.u, use_res ? xs : nullptr, saved + L.to, y, !y_sorted, d->ln_g, d->ln_b, kSiteOut, relu)))
             return rc;
     }
     return SATRANS_OK;
@@ -1922,12 +1929,15 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     const int B = d->B, F = d->F, D = d->D, U = d->U, H = d->H, S = d->S, M = B * F;
     const bool meta_q = d->flags & SATRANS_META_Q, meta_k = d->flags & SATRANS_META_K;
     const bool relu = d->flags & SATRANS_RELU_OUT, use_res = !(d->flags & SATRANS_NO_RES);
-    const float *xs = saved + L.xs, *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
+    // (SATRANS_X_SORTED / SATRANS_Y_SORTED as in the forward: x, dx / dy in scenario-sorted order - nothing to permute)
+    const bool x_sorted = d->flags & SATRANS_X_SORTED, y_sorted = d->flags & SATRANS_Y_SORTED;
+    SATRANS_REQUIRE(!(x_sorted && d->x_rows), SATRANS_E_BADARG, "layer_bwd(generic): SATRANS_X_SORTED with a fused gather");
+    const float *xs = x_sorted ? d->x : saved + L.xs, *q0 = saved + L.q0, *k0 = saved + L.k0, *v = saved + L.v;
     const bool gate = d->flags & SATRANS_GATE, bil = d->flags & SATRANS_BILINEAR;
     const bool q_mod = bil || meta_q, k_mod = !bil && meta_k;
     const float* q = q_mod ? saved + L.q : q0;
     const float* k = k_mod ? saved + L.k : k0;
-    float *dr = scratch + L.dr, *du = scratch + L.du, *go = scratch + L.go, *dq = scratch + L.dq, *dk = scratch + L.dk,
+    float *dr = x_sorted ? dx : scratch + L.dr, *du = scratch + L.du, *go = scratch + L.go, *dq = scratch + L.dq, *dk = scratch + L.dk,
           *dv = scratch + L.dv, *dt = scratch + L.dt, *dm = scratch + L.dm, *dh = scratch + L.dh, *part = scratch + L.part;
     int rc;
     // (the reductions of this layer's weight-gradient partials: collected, one launch at the end; gate / bilinear read one of
@@ -1937,7 +1947,7 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     defer_store.cap = L.part_floats;
     ReduceDefer* defer = (gate || bil) ? nullptr : &defer_store;
     // ---- output block: LayerNorm backward (dy arrives in the caller's sample order), dWo, go = du Wo ----------------------------
-    if ((rc = gen_ln_bwd(st, d, L, scratch, dy, true, saved + L.to, saved + L.u, d->ln_g, dr, du, kSiteOut, relu, g_ln, false, true,
+    if ((rc = gen_ln_bwd(st, d, L, scratch, dy, !y_sorted, saved + L.to, saved + L.u, d->ln_g, dr, du, kSiteOut, relu, g_ln, false, true,
                          defer))) return rc;
     if ((rc = gen_gemm_tn(st, du, saved + L.o, nullptr, 1, M, F, D, D, part, g_wo, 0, defer))) return rc;     // dWo[out][in] += du^T o
     {
@@ -2041,8 +2051,10 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
             }
         }
     }
-    gen_permute_out_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, dr, dx);
-    SATRANS_CHECK_LAUNCH("gen_permute_out_kernel");
+    if (!x_sorted) {      // (sorted input: the sums above went straight into dx)
+        gen_permute_out_kernel<<<(unsigned)ceil_div((int64_t)M * (D / 4), 256), 256, 0, st>>>(*d, dr, dx);
+        SATRANS_CHECK_LAUNCH("gen_permute_out_kernel");
+    }
     return SATRANS_OK;
 }
 

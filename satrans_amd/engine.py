@@ -183,6 +183,8 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         # its last backward kernel (_roll_flush): the same row-steps, executed underneath the step's small tail kernels.
         # Values: "0" off; "tail" fork behind the step's last backward kernel; "step" fork behind the step's replay launch (the slice
         # has the whole step's layer kernels to hide under: pays where those are ordinary grids - the general path).
+        # General path (configs[4]): SATRANS_GEN_SORTED=0 restores the order change at both ends of every layer
+        self.sorted_acts = os.environ.get("SATRANS_GEN_SORTED", "1") != "0"
         self.rolling_flush = {"1": "tail", "0": ""}.get(os.environ.get("SATRANS_ROLLING_FLUSH", "0"),
                                                         os.environ.get("SATRANS_ROLLING_FLUSH", "0"))
         self._roll = None
@@ -444,12 +446,14 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
             self._grad_view("qkvid_embeddings.weight").data_ptr() if self.pos else None, self.L, st),
                 "satrans_scenario_inputs_bwd")
 
-    def _layer_desc(self, ws, l, B, x, tabs, training, fuse=False, attn_save=False) -> N.LayerDesc:
+    def _layer_desc(self, ws, l, B, x, tabs, training, fuse=False, attn_save=False, sorted_io=False) -> N.LayerDesc:
         m = self.m
         lay = m.domain_int_layers[l]
         d = N.LayerDesc()
         d.B, d.F, d.D, d.H, d.U, d.S = B, self.F, self.D, self.H, self.U, self.S
         d.flags = self.flags | (N.TRAIN if training else 0)
+        if sorted_io:      # general path, training step: interior activations (and their gradients) stay scenario-sorted
+            d.flags |= (N.X_SORTED if l > 0 else 0) | (N.Y_SORTED if l < self.L - 1 else 0)
         d.layer = l
         d.drop_p = self.drop_p
         d.seed, d.step = self.drop_seed, self.drop_step & 0xFFFFFFFF
@@ -533,13 +537,14 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                 "satrans_bucket_scenarios")
 
     def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False, n_layers=None,
-                     bucket_ready=False):
+                     bucket_ready=False, sorted_io=False):
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         if not bucket_ready:
             self._bucket(X, ws)
         fuse = self.fuse_gather or self._x_src is not None
         ws["acts0_of"] = None if fuse else X
+        ws["acts_sorted"] = bool(sorted_io)
         if not (fuse and rows_ready):
             with self.phase("gather_fwd"):
                 N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
@@ -549,7 +554,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         self._last_X = X
         self._stepped_since_forward = False
         for l in range(self.L if n_layers is None else n_layers):
-            desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn)
+            desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn, sorted_io=sorted_io)
             att = att_list[l].data_ptr() if att_list is not None else None
             # (layer 0 reads its tokens straight from the embedding arena - the gather fused in: its own phase name, so that what
             #  the random row reads cost shows next to the other layers' time)
@@ -705,7 +710,16 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                                                 self.D, ws["acts"][0].data_ptr(), ws["rows"].data_ptr(),
                                                 self.status.data_ptr(), self._stream()), "satrans_gather_fwd")
             ws["acts0_of"] = X
-        return [a.clone() for a in ws["acts"]]
+        acts = [a.clone() for a in ws["acts"]]
+        if ws.get("acts_sorted"):
+            # a training step of the general path left the interior activations in scenario-sorted order (sorted position p holds
+            # sample order[p]): hand them out in the caller's order like every other
+            order = ws["order"].long()
+            for l in range(1, self.L):
+                back = torch.empty_like(acts[l])
+                back[order] = acts[l]
+                acts[l] = back
+        return acts
 
     def raise_if_bad_ids(self):
         if int(self.status.item()) != 0:
@@ -870,8 +884,11 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         tabs = self.scenario_tables(grad=modulated)                           # (HIP kernels: no autograd graph either way)
         g_tabs = self._g_tabs_flat.view(tabs.shape) if modulated else None      # zeroed with flat_g above
         fuse_head = self._fuse_head(X, ws, B)
+        # general path: the layers of the stack hand their activations on in scenario-sorted order, and their gradients back
+        # likewise (no order change at the ends of the interior layers: SATRANS_X_SORTED / SATRANS_Y_SORTED)
+        sorted_io = bool(ws["generic"]) and self.sorted_acts and self.L > 1
         self._run_forward(X, ws, training, tabs.detach(), rows_ready=rows_ready, save_attn=True,
-                          n_layers=self.L - 1 if fuse_head else None, bucket_ready=bucket_ready)
+                          n_layers=self.L - 1 if fuse_head else None, bucket_ready=bucket_ready, sorted_io=sorted_io)
         if not fuse_head:
             with self.phase("head"):
                 self._head(X, ws, y)
@@ -884,7 +901,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         for l in reversed(range(self.L)):
             head_here = fuse_head and l == self.L - 1
             desc = self._layer_desc(ws, l, B, None, tabs.detach(), training, self.fuse_gather or self._x_src is not None,
-                                    attn_save=not head_here)
+                                    attn_save=not head_here, sorted_io=sorted_io)
             lay = f"domain_int_layers.{l}."
             gq = gk = glnq = glnk = None
             if modulated:

@@ -27,6 +27,7 @@ ABI_VERSION = 6
 
 ID_F32, ID_I32, ID_I64 = 0, 1, 2
 META_Q, META_K, RELU_OUT, NO_RES, TRAIN, GATE, BILINEAR = 1, 2, 4, 8, 16, 32, 64
+X_SORTED, Y_SORTED = 128, 256      # general path: activations stay in scenario-sorted order between the layers of a stack
 
 _c_f32p = C.c_void_p
 _vp = C.c_void_p

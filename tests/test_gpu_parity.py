@@ -1241,6 +1241,36 @@ def test_gate_and_bilinear_kernel_families(monkeypatch, name, family):
         N.check(N.lib().satrans_set_layer_impl(0), "set_layer_impl")
 
 
+def test_general_path_sorted_activations_are_the_same_bits():
+    """A training step of the general path keeps the activations of a stack of layers - and their gradients on the way back - in
+    scenario-sorted order between the layers (SATRANS_X_SORTED / SATRANS_Y_SORTED: no order change at the ends of the interior
+    layers).  Same operations on the same values: loss, every gradient and the layer outputs `layer_outputs()` hands out must be
+    the bits of the form that changes the order at both ends of every layer, in evaluation and in training mode."""
+    c = Case("small_d64_u128")
+    res = {}
+    for sorted_acts in (True, False):
+        model = build_model(c, DEV)
+        model.compile("adam", "binary_crossentropy")
+        eng = model._require_engine()
+        eng.sorted_acts = sorted_acts
+        for train in (False, True):
+            model.train(train)
+            eng.drop_step = 40
+            bce, reg, grads = eng.loss_and_grads(c.X.to(DEV), c.y.to(DEV))
+            ws = eng._ws[c.X.shape[0]]
+            assert ws["generic"] and bool(ws.get("acts_sorted")) == (sorted_acts and c.meta["L"] > 1)
+            res[(sorted_acts, train)] = (bce, {k: g.clone() for k, g in grads.items()},
+                                         [a.clone() for a in eng.layer_outputs(c.X.shape[0])[1:]])
+    assert c.meta["L"] > 1, "the case must stack layers for the flags to be exercised"
+    for train in (False, True):
+        (bce_a, g_a, acts_a), (bce_b, g_b, acts_b) = res[(True, train)], res[(False, train)]
+        assert bce_a == bce_b
+        for k in g_b:
+            assert torch.equal(g_a[k], g_b[k]), (train, k)
+        for l, (a, b) in enumerate(zip(acts_a, acts_b)):
+            assert torch.equal(a, b), (train, l)
+
+
 def test_general_path_attention_arms_agree():
     """The two attention arms of the general forward at a configs[4]-class shape (40 fields, head dimension 16): MFMA
     (transposed scores, softmax in the accumulators, P^T fed straight back as the B operand) and one lane per query row -
