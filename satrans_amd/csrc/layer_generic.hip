@@ -664,6 +664,112 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 4 : 2) void gen_metanet_fwd_kern
     }
 }
 
+// ---- Output block forward in one pass (satrans.py:91-99): u = o Wo^T, t = drop(relu?(u)) + x, y = LayerNorm(t) -----------------------
+// The product of gen_gemm_kernel<true, 0> with the LayerNorm launch as its epilogue: a token's D = 16 KJ outputs sit in the
+// four lanes g of one wave (as in gen_metanet_fwd_kernel), so the statistics are two cross-lane adds.  u is written only when the
+// backward needs it (flag `relu`: the mask [u > 0]); t (saved for the backward) and y always; y in the caller's sample order
+// when `y_orig`.  Reads o and x once, writes t and y: 537 MB at the configs[4] shape where the two launches move 940 MB.
+template <int KJ>
+__global__ __launch_bounds__(256) void gen_out_ln_fwd_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                           const float* __restrict__ res, float* __restrict__ u_out,
+                                                           float* __restrict__ t_out, float* __restrict__ y, bool y_orig,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int M, int F, const int32_t* __restrict__ order, GenDrop dc, bool relu) {
+    extern __shared__ __align__(16) float g2_lds[];
+    constexpr int D = KJ * 16;
+    const int64_t row0 = (int64_t)blockIdx.x * kG2Rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int RS = g2_row_slots(D) * 4, PL = g2_plane_floats(D, D);
+    g2_stage<true>(W, D, D, D, g2_lds, RS, PL);            // B(k, nn) = Wo[nn][k]
+    __syncthreads();
+    const float* bt = g2_lds + g * PL + n * RS;
+    float4 a[KJ], an[KJ];
+    auto load_rows = [&](int64_t g0, float4 (&dst)[KJ]) {
+        const int64_t row = g0 + n;
+        if (row < M) {
+            const float4* src = reinterpret_cast<const float4*>(A + row * D + 4 * g);
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) dst[j] = src[4 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) dst[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int64_t wave_row0 = row0 + 16 * wave;
+    const int64_t tile_hi = min((int64_t)M, row0 + kG2Rows);
+    if (wave_row0 < tile_hi) load_rows(wave_row0, a);
+    for (int64_t g0 = wave_row0; g0 < tile_hi; g0 += 64) {
+        const int64_t row = g0 + n;
+        const bool live = row < M;
+        const int64_t rr = live ? row : 0;
+        const int pos = (int)(rr / F), f = (int)(rr - (int64_t)pos * F);
+        const int b = order[pos];      // (loaded BEFORE the next group's rows are requested: loads return in order)
+        float4 rs[KJ];
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn)
+            rs[jn] = res ? *reinterpret_cast<const float4*>(res + rr * D + 16 * jn + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool more = g0 + 64 < tile_hi;
+        if (more) load_rows(g0 + 64, an);
+        const uint32_t skey = dc.on ? drop_sample_key(dc.key, (uint32_t)b) : 0u;
+        float v[KJ][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = bt + 16 * jn * RS;
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const float4 bb = *reinterpret_cast<const float4*>(bp + 4 * j);
+                acc = mfma4(bb.x, a[j].x, acc);
+                acc = mfma4(bb.y, a[j].y, acc);
+                acc = mfma4(bb.z, a[j].z, acc);
+                acc = mfma4(bb.w, a[j].w, acc);
+            }
+            const int c = 16 * jn + 4 * g;
+            if (live && u_out) *reinterpret_cast<float4*>(u_out + row * D + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            const uint32_t kb = dc.on ? drop_keep4(skey, (uint32_t)(f * D + c) >> 2, dc.thresh) : 0xFu;
+            const float zr[4] = {rs[jn].x, rs[jn].y, rs[jn].z, rs[jn].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[e];
+                if (relu) x = fmaxf(x, 0.f);
+                if (dc.on) x = (kb >> e) & 1u ? x * dc.scale : 0.f;
+                x += zr[e];
+                v[jn][e] = x;
+                sum += x;
+            }
+            if (live) *reinterpret_cast<float4*>(t_out + row * D + c) = make_float4(v[jn][0], v[jn][1], v[jn][2], v[jn][3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int jn = 0; jn < KJ; ++jn)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q = fmaf(v[jn][e] - mean, v[jn][e] - mean, q);
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / D) + 1e-6f);
+        if (live) {
+            const int64_t dst = y_orig ? (int64_t)b * F + f : row;
+#pragma unroll
+            for (int jn = 0; jn < KJ; ++jn) {
+                const int c = 16 * jn + 4 * g;
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt4 = *reinterpret_cast<const float4*>(beta + c);
+                *reinterpret_cast<float4*>(y + dst * D + c) =
+                    make_float4((v[jn][0] - mean) * rstd * gm.x + bt4.x, (v[jn][1] - mean) * rstd * gm.y + bt4.y,
+                                (v[jn][2] - mean) * rstd * gm.z + bt4.z, (v[jn][3] - mean) * rstd * gm.w + bt4.w);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) a[j] = an[j];
+        }
+    }
+}
+
 // ---- MetaNet backward, the data-gradient chain in one pass: LayerNorm backward -> dm = mask(dt) -> dh = (dm W2^T) [h > 0] ->
 // dz = dt + dh W1^T, with the same chaining as the forward kernel (dm tiles are the second operand of the contraction over D, dh
 // tiles of the contraction over U).  dm and dh are written out because the weight-gradient products (dW2 = h^T dm, dW1 = z^T dh)
@@ -1671,6 +1777,31 @@ static int gen_metanet_fused_fwd(hipStream_t st, const satrans_layer_desc* d, co
     return SATRANS_OK;
 }
 
+// the fused output block (gen_out_ln_fwd_kernel): D in {16, 32, 64} (a token's row in the four lanes g of one wave, <= 16 registers);
+// -DSATRANS_EXP_NO_OUT_LN: the product and the LayerNorm as two launches, as before
+static bool gen_out_ln_fused_ok(int D) {
+#ifdef SATRANS_EXP_NO_OUT_LN
+    return false;
+#else
+    return D == 16 || D == 32 || D == 64;
+#endif
+}
+static int gen_out_ln_fused_fwd(hipStream_t st, const satrans_layer_desc* d, const float* o, const float* w, const float* res, float* u,
+                                float* t, float* y, bool y_orig, bool relu) {
+    const int M = d->B * d->F, D = d->D;
+    const GenDrop dc = gen_drop(d, kSiteOut);
+    const unsigned grid = (unsigned)ceil_div(M, kG2Rows);
+    const size_t lds = sizeof(float) * 4 * (size_t)g2_plane_floats(D, D);
+#define GEN_OUT_CASE(KJ_)                                                                                                        \
+    gen_out_ln_fwd_kernel<KJ_><<<grid, 256, lds, st>>>(o, w, res, u, t, y, y_orig, d->ln_g, d->ln_b, M, d->F, d->order, dc, relu);
+    if (D == 64) { GEN_OUT_CASE(4) }
+    else if (D == 32) { GEN_OUT_CASE(2) }
+    else { GEN_OUT_CASE(1) }
+#undef GEN_OUT_CASE
+    SATRANS_CHECK_LAUNCH("gen_out_ln_fwd_kernel");
+    return SATRANS_OK;
+}
+
 static int gen_metanet_fused_bwd(hipStream_t st, const satrans_layer_desc* d, float* g, const float* t, const float* h, const float* tab,
                                  float* dm, float* dh, const float* gam, float* part, int site) {
     const int M = d->B * d->F, D = d->D, U = d->U;
@@ -1908,6 +2039,10 @@ extern "C" int satrans_layer_fwd_generic(const satrans_layer_desc* d, float* y, 
     }
     if ((rc = gen_attention_fwd(st, d, q, k, v, saved + L.o, reinterpret_cast<float2*>(saved + L.st), att,   // satrans.py:75-90
                                 1.0f / sqrtf((float)(D / H))))) return rc;
+    if (gen_out_ln_fused_ok(D)) {   // satrans.py:91-99 in one launch (u only kept when the backward needs its sign: flag `relu`)
+        return gen_out_ln_fused_fwd(st, d, saved + L.o, d->w_out, use_res ? xs : nullptr, relu ? saved + L.u : nullptr, saved + L.to, y,
+                                    !y_sorted, relu);
+    }
     {   // satrans.py:91-99
         const float* A[1] = {saved + L.o};
         const float* Bw[1] = {d->w_out};
