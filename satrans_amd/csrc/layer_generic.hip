@@ -2082,6 +2082,8 @@ extern "C" int satrans_layer_bwd_generic(const satrans_layer_desc* d, const floa
     defer_store.cap = L.part_floats;
     ReduceDefer* defer = (gate || bil) ? nullptr : &defer_store;
     // ---- output block: LayerNorm backward (dy arrives in the caller's sample order), dWo, go = du Wo ----------------------------
+    // (the same fusion in this direction - LayerNorm backward + mask as the prologue of go = du Wo, one launch for two - was built
+    //  and measured in round 6: 2.22 against 2.22-2.25 ms per layer backward, inside the run-to-run noise; not kept)
     if ((rc = gen_ln_bwd(st, d, L, scratch, dy, !y_sorted, saved + L.to, saved + L.u, d->ln_g, dr, du, kSiteOut, relu, g_ln, false, true,
                          defer))) return rc;
     if ((rc = gen_gemm_tn(st, du, saved + L.o, nullptr, 1, M, F, D, D, part, g_wo, 0, defer))) return rc;     // dWo[out][in] += du^T o
