@@ -199,6 +199,11 @@ __global__ __launch_bounds__(256) void gen_gemm_sum_kernel(GemmBatch gb, int nsr
                 }
                 *reinterpret_cast<float4*>(C + row * N + 16 * jn + 4 * g) = v;
             }
+#ifndef SATRANS_EXP_SUM_NOSB
+            // (the weight fragments of later tiles stay behind this tile: hoisted, all 12 KJ reads of a row group held 320 registers
+            //  - one wave per SIMD; with the barrier 2-3 waves, profiles/r06_c5_fusions.txt)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if (more) {
 #pragma unroll
