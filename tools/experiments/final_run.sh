@@ -18,6 +18,10 @@ bash tools/pmc_passes.sh > $o/pmc.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc aliccp > $o/pmc_summary.json 2> $o/pmc_summary.err
 rm -rf gpurun_out/pmc
 cp $o/pmc_summary.json profiles/r06_pmc_summary.json
+PMC_OUT=gpurun_out/pmc_alimama PMC_BENCH_ARGS="--config alimama" PMC_ONLY_TRAFFIC=1 bash tools/pmc_passes.sh > $o/pmc_alimama.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_alimama alimama > $o/alimama_pmc_summary.json 2> $o/alimama_pmc_summary.err
+rm -rf gpurun_out/pmc_alimama
+cp $o/alimama_pmc_summary.json profiles/r06_alimama_pmc_summary.json
 bash tools/pmc_c5.sh > $o/pmc_c5.log 2>&1
 python tools/pmc_c5_summary.py gpurun_out/pmc_c5 6 > $o/c5_pmc_summary.json 2> $o/c5_pmc_summary.err
 rm -rf gpurun_out/pmc_c5
