@@ -70,7 +70,8 @@ CFG = make_config("aliccp")
 
 # profiles/: counters of the shipped kernel sources (tools/pmc_passes.sh + pmc_summary.py; configs[4]: tools/pmc_c5.sh +
 # pmc_c5_summary.py - there a "launch" is the chain of launches that makes one layer's forward / backward)
-PMC_SUMMARIES = {"aliccp": "r06_pmc_summary.json", "alimama": "r06_alimama_pmc_summary.json", "c5": "r06_c5_pmc_summary.json"}
+PMC_SUMMARIES = {"aliccp": "r06_pmc_summary.json", "alimama": "r06_alimama_pmc_summary.json", "c5": "r06_c5_pmc_summary.json",
+                 "aliccp:sota-gate": "r06_gate_pmc_summary.json"}      # key: config, or config:flag for a non-default flag
 PMC_SUMMARY = PMC_SUMMARIES["aliccp"]
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy rate
 FP32_PEAK_TFLOPS = 157.3       # dense fp32 (vector = f32-input MFMA) peak
@@ -719,14 +720,15 @@ def main():
         try:
             from satrans_amd import native as _native
             sha = _native.source_hash()
-            PMC_SUMMARY = PMC_SUMMARIES.get(args.config, PMC_SUMMARIES["aliccp"])
+            pmc_key = args.config if args.flag == CFG["flag"] else f"{args.config}:{args.flag}"
+            PMC_SUMMARY = PMC_SUMMARIES.get(pmc_key, PMC_SUMMARIES["aliccp"])
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
             rec = pmc[{"layer_bwd": "layer_bwd_fused_kernel", "layer_bwd_head": "layer_bwd_fused_kernel[head]",
                        "layer_fwd": "layer_fwd_fused_kernel", "layer_fwd_gather": "layer_fwd_fused_kernel @layer0"}.get(dominant, roofline["kernel"])]
             if pmc.get("_source_sha256") != sha:
                 roofline["traffic_source"] = (f"stale: profiles/{PMC_SUMMARY} was taken on other kernel sources "
                                               f"({str(pmc.get('_source_sha256'))[:12]} vs {sha[:12]})")
-            elif pmc.get("_config") != args.config or args.flag != CFG["flag"]:
+            elif pmc.get("_config") != pmc_key:
                 roofline["traffic_source"] = f"none: profiles/{PMC_SUMMARY} is of config {pmc.get('_config')!r}, default flag"
             else:
                 roofline["traffic"] = round((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0)

@@ -22,6 +22,10 @@ PMC_OUT=gpurun_out/pmc_alimama PMC_BENCH_ARGS="--config alimama" PMC_ONLY_TRAFFI
 python tools/pmc_summary.py gpurun_out/pmc_alimama alimama > $o/alimama_pmc_summary.json 2> $o/alimama_pmc_summary.err
 rm -rf gpurun_out/pmc_alimama
 cp $o/alimama_pmc_summary.json profiles/r06_alimama_pmc_summary.json
+PMC_OUT=gpurun_out/pmc_gate PMC_BENCH_ARGS="--flag sota-gate" PMC_ONLY_TRAFFIC=1 bash tools/pmc_passes.sh > $o/pmc_gate.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_gate aliccp:sota-gate > $o/gate_pmc_summary.json 2> $o/gate_pmc_summary.err
+rm -rf gpurun_out/pmc_gate
+cp $o/gate_pmc_summary.json profiles/r06_gate_pmc_summary.json
 bash tools/pmc_c5.sh > $o/pmc_c5.log 2>&1
 python tools/pmc_c5_summary.py gpurun_out/pmc_c5 6 > $o/c5_pmc_summary.json 2> $o/c5_pmc_summary.err
 rm -rf gpurun_out/pmc_c5
