@@ -220,6 +220,13 @@ int satrans_layer_fwd(const satrans_layer_desc* d, float* y, float* att, void* s
  * Built for (D,U,H) = (32,64,4) and (64,128,4). */
 int satrans_layer_fwd_bf16_supported(const satrans_layer_desc* d);
 int satrans_layer_fwd_bf16(const satrans_layer_desc* d, float* y, void* stream);
+/* The whole stack of n layers (satrans.py:236-239: `for layer in self.domain_int_layers`) of an EVALUATION forward as one launch: a
+ * tile's rows stay in LDS between the layers - read from HBM once, written once - and every layer's weight images are staged once
+ * per workgroup; per layer the code of satrans_layer_fwd_bf16, i.e. the same bits.  1 <= n <= 4 layers of D = 32 with one shape,
+ * one set of flags and one scenario bucketing; layer 0 reads its rows as satrans_layer_fwd_bf16 does (fused gather included), the
+ * x / x_rows of the others are ignored.  y: the last layer's output [B][F][D]. */
+int satrans_stack_fwd_bf16_supported(int n, const satrans_layer_desc* const* descs);
+int satrans_stack_fwd_bf16(int n, const satrans_layer_desc* const* descs, float* y, void* stream);
 
 /* General path for shapes the fused kernels are not built for (csrc/layer_generic.hip; first of all BASELINE configs[4]:
  * 64 fields, embedding_dim 64, MetaNet hidden 128): a layer as a short sequence of grouped f32-MFMA GEMM, LayerNorm and

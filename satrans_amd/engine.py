@@ -183,6 +183,8 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         # its last backward kernel (_roll_flush): the same row-steps, executed underneath the step's small tail kernels.
         # Values: "0" off; "tail" fork behind the step's last backward kernel; "step" fork behind the step's replay launch (the slice
         # has the whole step's layer kernels to hide under: pays where those are ordinary grids - the general path).
+        # bf16 evaluation forward: SATRANS_BF16_STACK=0 launches the layers one by one (satrans_layer_fwd_bf16)
+        self.bf16_stack = os.environ.get("SATRANS_BF16_STACK", "1") != "0"
         # General path (configs[4]): SATRANS_GEN_SORTED=0 restores the order change at both ends of every layer
         self.sorted_acts = os.environ.get("SATRANS_GEN_SORTED", "1") != "0"
         self.rolling_flush = {"1": "tail", "0": ""}.get(os.environ.get("SATRANS_ROLLING_FLUSH", "0"),
@@ -553,6 +555,16 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                                                self.status.data_ptr(), st), "satrans_gather_fwd")
         self._last_X = X
         self._stepped_since_forward = False
+        # evaluation on the bf16 pipe: the whole stack as ONE launch where it is built (a tile's rows stay in LDS between the
+        # layers); `layer_outputs()` then only has the last layer's - callers that want every layer's set engine.bf16_stack = False
+        if self.fwd_bf16 and self.bf16_stack and not training and att_list is None and n_layers is None and not ws["generic"] \
+                and 1 < self.L <= 4:
+            descs = [self._layer_desc(ws, l, B, None, tabs, False, fuse) for l in range(self.L)]
+            arr = (C.POINTER(N.LayerDesc) * self.L)(*[C.pointer(d_) for d_ in descs])
+            if lib.satrans_stack_fwd_bf16_supported(self.L, arr):
+                with self.phase("layer_fwd"):
+                    N.check(lib.satrans_stack_fwd_bf16(self.L, arr, ws["acts"][self.L].data_ptr(), st), "satrans_stack_fwd_bf16")
+                return
         for l in range(self.L if n_layers is None else n_layers):
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn, sorted_io=sorted_io)
             att = att_list[l].data_ptr() if att_list is not None else None

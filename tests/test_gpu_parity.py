@@ -942,6 +942,30 @@ def test_bf16_forward_stays_within_bf16_rounding_of_the_reference(name):
 
 
 @pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
+def test_bf16_stack_launch_is_the_layer_launches_bit_for_bit(name):
+    """The bf16 evaluation forward runs the whole stack of layers as ONE launch (satrans_stack_fwd_bf16: a tile's rows stay in LDS
+    between the layers).  Per layer it is the code of satrans_layer_fwd_bf16: logits and probabilities must be the bits of the
+    layer-by-layer launches, on the golden batch, on a ragged one and on a batch larger than a workgroup's tile count."""
+    c = Case(name)
+    model = build_model(c, DEV)
+    model.eval()
+    model.set_forward_precision("bf16")
+    eng = model._require_engine()
+    rng = np.random.RandomState(3)
+    big = torch.from_numpy(np.concatenate([c.X.numpy()[rng.randint(0, c.X.shape[0], size=3000)]], axis=0))
+    for X in (c.X, c.X[:37], big):
+        X = X.to(DEV)
+        outs = {}
+        for stack in (True, False):
+            eng.bf16_stack = stack
+            p = model(X).clone()
+            outs[stack] = (p, eng.last_logit().clone())
+        assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][0], outs[False][0]), X.shape
+    eng.bf16_stack = True
+    model.set_forward_precision("fp32")
+
+
+@pytest.mark.parametrize("name", ["aliccp_sota", "alimama_sota_pos"])
 def test_streamed_input_pipeline_equals_the_resident_dataset(name, tmp_path):
     """fit / predict with the dataset kept on the host and streamed in double-buffered pinned batches (satrans_amd/pipeline.py;
     here from memory-mapped .npy columns, the loader for datasets that should not sit in HBM) against the resident-dataset
