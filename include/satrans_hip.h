@@ -359,6 +359,10 @@ typedef struct satrans_head_desc {
     float* scratch;
 } satrans_head_desc;
 int satrans_layer_bwd_head_supported(const satrans_layer_desc* d, const satrans_head_desc* h);
+/* satrans_stack_fwd_bf16 with the head behind it in the same launch (evaluation: satrans.py:236-255): h->w, h->bias, the dense
+ * columns as above, outputs h->prob [B] and h->logit [B] (optional); labels / loss / gradients of `h` are not used.  A tile holds
+ * whole samples, so the last layer's rows never leave LDS; head_kernel's summation order, i.e. the bits of satrans_head. */
+int satrans_stack_fwd_bf16_head(int n, const satrans_layer_desc* const* descs, const satrans_head_desc* h, void* stream);
 int64_t satrans_layer_bwd_head_scratch_floats(const satrans_layer_desc* d, int n_dense);
 int satrans_layer_bwd_head(const satrans_layer_desc* d, const satrans_head_desc* h, float* dx, float* slabs, float* g_wq,
                            float* g_wk, float* g_wv, float* g_wo, float* g_ln, float* g_lnq, float* g_lnk, float* g_tab_q,

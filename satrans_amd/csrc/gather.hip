@@ -121,19 +121,33 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const void
     const int R = (B + kBucketThreads - 1) / kBucketThreads;
     const int n = SP * R * kBucketWaves;
     bool bad = false;
-    for (int r = 0; r < R; ++r) {
-        const int b = r * kBucketThreads + t;
-        int id = -1;                                   // (beyond B: no scenario)
-        if (b < B) {
-            int64_t v = load_id(X, id_dtype, x_stride, b, col);
-            if (v < 0 || v >= S) { bad = true; v = 0; }
-            id = (int)v;
-            sid[b] = id;
+    // (eight rounds' ids requested together: one workgroup walks the whole batch, and a round that waits for its own strided 4-byte
+    //  loads before the next round asks for its ones took 54 us at the prediction batch of 32,768 - round 6)
+    constexpr int kAhead = 8;
+    for (int r0 = 0; r0 < R; r0 += kAhead) {
+        int64_t v8[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int b = (r0 + u) * kBucketThreads + t;
+            v8[u] = (r0 + u < R && b < B) ? load_id(X, id_dtype, x_stride, b, col) : -1;
         }
 #pragma unroll
-        for (int sc = 0; sc < SP; ++sc) {
-            const uint64_t mask = __ballot(id == sc);
-            if (lane == 0) s_pos[(sc * R + r) * kBucketWaves + w] = __popcll(mask);
+        for (int u = 0; u < kAhead; ++u) {
+            const int r = r0 + u;
+            if (r >= R) break;                         // (uniform)
+            const int b = r * kBucketThreads + t;
+            int id = -1;                               // (beyond B: no scenario)
+            if (b < B) {
+                int64_t v = v8[u];
+                if (v < 0 || v >= S) { bad = true; v = 0; }
+                id = (int)v;
+                sid[b] = id;
+            }
+#pragma unroll
+            for (int sc = 0; sc < SP; ++sc) {
+                const uint64_t mask = __ballot(id == sc);
+                if (lane == 0) s_pos[(sc * R + r) * kBucketWaves + w] = __popcll(mask);
+            }
         }
     }
     if (bad) atomicOr(status, 1);
@@ -159,17 +173,94 @@ __global__ __launch_bounds__(kBucketThreads) void bucket_small_kernel(const void
     }
     __syncthreads();
     if (t <= S) seg[t] = t == S ? B : s_pos[t * R * kBucketWaves];
-    for (int r = 0; r < R; ++r) {
-        const int b = r * kBucketThreads + t;
-        const int id = b < B ? sid[b] : -1;            // (written by this very thread above)
-        uint64_t my_mask = 0;
+    for (int r0 = 0; r0 < R; r0 += kAhead) {
+        int id8[kAhead];
 #pragma unroll
-        for (int sc = 0; sc < SP; ++sc) {
-            const uint64_t mask = __ballot(id == sc);
-            if (id == sc) my_mask = mask;
+        for (int u = 0; u < kAhead; ++u) {
+            const int b = (r0 + u) * kBucketThreads + t;
+            id8[u] = (r0 + u < R && b < B) ? sid[b] : -1;      // (written by this very thread above)
         }
-        if (b < B) order[s_pos[(id * R + r) * kBucketWaves + w] + lanes_below(my_mask)] = b;
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int r = r0 + u;
+            if (r >= R) break;
+            const int b = r * kBucketThreads + t;
+            const int id = id8[u];
+            uint64_t my_mask = 0;
+#pragma unroll
+            for (int sc = 0; sc < SP; ++sc) {
+                const uint64_t mask = __ballot(id == sc);
+                if (id == sc) my_mask = mask;
+            }
+            if (b < B) order[s_pos[(id * R + r) * kBucketWaves + w] + lanes_below(my_mask)] = b;
+        }
     }
+}
+
+// The same stable counting sort for a LARGE batch (the prediction batch of 32,768: one workgroup fetching 32,768 strided ids - a
+// cache line each - is bound by one CU's line rate: 52 us) in two launches of one workgroup per round of 1,024 samples:
+//   bucket_count_kernel    round r: ids -> sid, ballots -> counts[s][r][w]                        (global, SP x R x 16 ints)
+//   bucket_place_kernel    round r: every workgroup scans the (small) count array itself - exclusive prefix in (scenario, round,
+//                          wave) order, exactly bucket_small_kernel's - and places its own samples; workgroup 0 writes seg
+// Same `order`, `seg`, `sid` and status as the one-workgroup kernel, bit for bit.
+template <int SP>
+__global__ __launch_bounds__(kBucketThreads) void bucket_count_kernel(const void* __restrict__ X, int id_dtype, int64_t x_stride,
+                                                                      int col, int B, int S, int32_t* __restrict__ sid,
+                                                                      int32_t* __restrict__ counts, int32_t* __restrict__ status) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, r = blockIdx.x, R = gridDim.x;
+    const int b = r * kBucketThreads + t;
+    int id = -1;
+    if (b < B) {
+        int64_t v = load_id(X, id_dtype, x_stride, b, col);
+        if (v < 0 || v >= S) { atomicOr(status, 1); v = 0; }
+        id = (int)v;
+        sid[b] = id;
+    }
+#pragma unroll
+    for (int sc = 0; sc < SP; ++sc) {
+        const uint64_t mask = __ballot(id == sc);
+        if (lane == 0) counts[(sc * R + r) * kBucketWaves + w] = __popcll(mask);
+    }
+}
+template <int SP>
+__global__ __launch_bounds__(kBucketThreads) void bucket_place_kernel(int B, int S, const int32_t* __restrict__ sid,
+                                                                      const int32_t* __restrict__ counts,
+                                                                      int32_t* __restrict__ order, int32_t* __restrict__ seg) {
+    extern __shared__ int32_t s_pos[];                 // [SP][R][kBucketWaves] counts, then exclusive prefixes
+    __shared__ int32_t s_wave[kBucketWaves];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, r = blockIdx.x, R = gridDim.x;
+    const int n = SP * R * kBucketWaves;
+    for (int k = t; k < n; k += kBucketThreads) s_pos[k] = counts[k];
+    __syncthreads();
+    const int per = (n + kBucketThreads - 1) / kBucketThreads;
+    int32_t mine = 0;
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) mine += s_pos[k];
+    int32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    int32_t run = incl - mine;
+    for (int ww = 0; ww < w; ++ww) run += s_wave[ww];
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) {
+        const int32_t c = s_pos[k];
+        s_pos[k] = run;
+        run += c;
+    }
+    __syncthreads();
+    if (r == 0 && t <= S) seg[t] = t == S ? B : s_pos[t * R * kBucketWaves];
+    const int b = r * kBucketThreads + t;
+    const int id = b < B ? sid[b] : -1;
+    uint64_t my_mask = 0;
+#pragma unroll
+    for (int sc = 0; sc < SP; ++sc) {
+        const uint64_t mask = __ballot(id == sc);
+        if (id == sc) my_mask = mask;
+    }
+    if (b < B) order[s_pos[(id * R + r) * kBucketWaves + w] + lanes_below(my_mask)] = b;
 }
 
 static int bits_for(int64_t n) {  // number of key bits needed for values in [0, n)
@@ -217,6 +308,20 @@ extern "C" int satrans_bucket_scenarios(const void* X, int id_dtype, int64_t x_s
         const int R = (int)ceil_div(B, kBucketThreads);
         const int SP = S <= 4 ? 4 : (S <= 8 ? 8 : 16);
         const size_t lds = (size_t)SP * R * kBucketWaves * sizeof(int32_t);      // <= 64 KB
+        // 16 rounds and more (B > 15,360; 8 scenario rows at most: 32 KB of counts in LDS per workgroup): two launches of R
+        // workgroups (-DSATRANS_EXP_BUCKET_ONE_WG: the one-workgroup kernel at every size)
+#ifndef SATRANS_EXP_BUCKET_ONE_WG
+        if (R >= 16 && SP <= 8 && (int64_t)lds <= workspace_bytes) {
+            int32_t* counts = (int32_t*)workspace;
+#define SATRANS_BUCKET2(SPV)                                                                                                    \
+            bucket_count_kernel<SPV><<<R, kBucketThreads, 0, stream>>>(X, id_dtype, x_stride, col, B, S, sid, counts, status);   \
+            bucket_place_kernel<SPV><<<R, kBucketThreads, lds, stream>>>(B, S, sid, counts, order, seg)
+            if (SP == 4) { SATRANS_BUCKET2(4); } else { SATRANS_BUCKET2(8); }
+#undef SATRANS_BUCKET2
+            SATRANS_CHECK_LAUNCH("bucket_place_kernel");
+            return SATRANS_OK;
+        }
+#endif
 #define SATRANS_BUCKET(SPV)                                                                                                     \
         bucket_small_kernel<SPV><<<1, kBucketThreads, lds, stream>>>(X, id_dtype, x_stride, col, B, S, sid, order, seg, status)
         if (SP == 4) SATRANS_BUCKET(4);

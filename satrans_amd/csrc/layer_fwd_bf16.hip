@@ -312,9 +312,22 @@ struct Bf16Stack {
     satrans_layer_desc d[4];
     int L;
 };
+// ... and the head behind it (satrans.py:244-255: flatten + dense columns + Linear + sigmoid; head.hip's head_kernel): a tile holds
+// whole samples, so the last layer's rows never leave LDS.  One wave per sample, lane i takes the 16-byte chunks i, i + 64, ... of
+// the flattened row in head_kernel's order and the same butterfly sum: the same bits.  prob == nullptr: no head, y is written.
+struct Bf16Head {
+    const float* w;
+    const float* bias;
+    const float* dense;
+    int64_t dense_stride;
+    int32_t dense_col[2];
+    int32_t n_dense;
+    float* prob;
+    float* logit;
+};
 
 template <int D, int U, int H, int WAVES, int FT = 0>
-__global__ __launch_bounds__(64 * WAVES) void stack_fwd_bf16_kernel(Bf16Stack sa, int Tsamp, float* __restrict__ y) {
+__global__ __launch_bounds__(64 * WAVES) void stack_fwd_bf16_kernel(Bf16Stack sa, int Tsamp, float* __restrict__ y, Bf16Head hd) {
     const satrans_layer_desc& a = sa.d[0];      // shape, flags, scenario segments and the input rows: the first layer's
     const int NL = sa.L;
     constexpr int KT = D / 16, UT = U / 16, d = D / H, LD = D + 4, KD = D + 8, KU = U + 8;
@@ -560,10 +573,37 @@ __global__ __launch_bounds__(64 * WAVES) void stack_fwd_bf16_kernel(Bf16Stack sa
                 }
             float mean, rstd;
             layer_norm_frag<KT>(u, ln_g, ln_b, g4, mean, rstd);
-            if (last_l) { if (valid) store_frag<KT>(y + ((size_t)b * F + f) * D + g4, u); }
+            if (last_l && !hd.prob) { if (valid) store_frag<KT>(y + ((size_t)b * F + f) * D + g4, u); }
             else store_frag<KT>(sx + (size_t)tok * LD + g4, u);
         }
         __syncthreads();
+        if (last_l && hd.prob) {
+            const int FD4 = F * (D / 4);
+            const float4* w4 = reinterpret_cast<const float4*>(hd.w);
+            for (int ls = wave; ls < nS; ls += WAVES) {
+                const int b = samp[ls];
+                float acc = 0.f;
+                for (int i = lane; i < FD4; i += 64) {
+                    const int f = i / (D / 4), col = (i - f * (D / 4)) * 4;
+                    const float4 xv = *reinterpret_cast<const float4*>(sx + (size_t)(ls * F + f) * LD + col), wv = w4[i];
+                    acc = fmaf(xv.x, wv.x, acc);
+                    acc = fmaf(xv.y, wv.y, acc);
+                    acc = fmaf(xv.z, wv.z, acc);
+                    acc = fmaf(xv.w, wv.w, acc);
+                }
+                for (int j = lane; j < hd.n_dense; j += 64)
+                    acc = fmaf(hd.dense[(size_t)b * hd.dense_stride + hd.dense_col[j & 1]], hd.w[F * D + j], acc);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                const float z = acc + hd.bias[0];
+                const float pr = 1.0f / (1.0f + expf(-z));
+                if (lane == 0) {
+                    hd.prob[b] = pr;
+                    if (hd.logit) hd.logit[b] = z;
+                }
+            }
+            __syncthreads();      // (the next tile's first layer writes these rows again)
+        }
         }      // layers
       }
     }
@@ -618,7 +658,7 @@ static int64_t bf16_stack_lds_bytes(int NL, int T, int F, int D, int U, bool sam
 }
 
 template <int D, int U, int H, int WAVES, int FT = 0>
-static int launch_stack_bf16(const Bf16Stack& sa, float* y, hipStream_t stream) {
+static int launch_stack_bf16(const Bf16Stack& sa, float* y, const Bf16Head& hd, hipStream_t stream) {
     const satrans_layer_desc* d = &sa.d[0];
     const bool same_tab = d->tab_q == d->tab_k;
     int best = 0;
@@ -647,7 +687,7 @@ static int launch_stack_bf16(const Bf16Stack& sa, float* y, hipStream_t stream) 
     }
     const int64_t tiles = ceil_div(d->B, best) + d->S;
     const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)cu_count()));
-    stack_fwd_bf16_kernel<D, U, H, WAVES, FT><<<gx, 64 * WAVES, lds, stream>>>(sa, best, y);
+    stack_fwd_bf16_kernel<D, U, H, WAVES, FT><<<gx, 64 * WAVES, lds, stream>>>(sa, best, y, hd);
     SATRANS_CHECK_LAUNCH("stack_fwd_bf16_kernel");
     return SATRANS_OK;
 }
@@ -674,18 +714,36 @@ extern "C" int satrans_stack_fwd_bf16_supported(int n, const satrans_layer_desc*
     return bf16_stack_lds_bytes(n, 1, descs[0]->F, 32, 64, same_tab) <= 160 * 1024;
 }
 
-extern "C" int satrans_stack_fwd_bf16(int n, const satrans_layer_desc* const* descs, float* y, void* stream_) {
-    SATRANS_REQUIRE(satrans_stack_fwd_bf16_supported(n, descs), SATRANS_E_UNSUPPORTED,
-                    "stack_fwd(bf16): 1 - 4 evaluation layers of (D,U,H) = (32,64,4), one shape, flags and scenario bucketing");
-    SATRANS_REQUIRE(y, SATRANS_E_BADARG, "stack_fwd(bf16): null output");
-    hipStream_t stream = (hipStream_t)stream_;
+static int stack_fwd_bf16_any(int n, const satrans_layer_desc* const* descs, float* y, const Bf16Head& hd, hipStream_t stream) {
     Bf16Stack sa;
     for (int l = 0; l < 4; ++l) sa.d[l] = *descs[l < n ? l : 0];
     sa.L = n;
     const satrans_layer_desc* d = descs[0];
-    if (d->F == 19) return launch_stack_bf16<32, 64, 4, 12, 19>(sa, y, stream);      // AliCCP
-    if (d->F == 15) return launch_stack_bf16<32, 64, 4, 12, 15>(sa, y, stream);      // Alimama
-    return launch_stack_bf16<32, 64, 4, 12>(sa, y, stream);
+    if (d->F == 19) return launch_stack_bf16<32, 64, 4, 12, 19>(sa, y, hd, stream);      // AliCCP
+    if (d->F == 15) return launch_stack_bf16<32, 64, 4, 12, 15>(sa, y, hd, stream);      // Alimama
+    return launch_stack_bf16<32, 64, 4, 12>(sa, y, hd, stream);
+}
+
+extern "C" int satrans_stack_fwd_bf16(int n, const satrans_layer_desc* const* descs, float* y, void* stream_) {
+    SATRANS_REQUIRE(satrans_stack_fwd_bf16_supported(n, descs), SATRANS_E_UNSUPPORTED,
+                    "stack_fwd(bf16): 1 - 4 evaluation layers of (D,U,H) = (32,64,4), one shape, flags and scenario bucketing");
+    SATRANS_REQUIRE(y, SATRANS_E_BADARG, "stack_fwd(bf16): null output");
+    Bf16Head hd = {};
+    return stack_fwd_bf16_any(n, descs, y, hd, (hipStream_t)stream_);
+}
+
+// ... with the head: h->w [F*D + n_dense], h->bias, h->dense / dense_stride / h_dense_cols (HOST array, n_dense <= 2) as in
+// satrans_layer_bwd_head; outputs h->prob [B] and h->logit [B] (optional).  The last layer's rows are not written anywhere.
+extern "C" int satrans_stack_fwd_bf16_head(int n, const satrans_layer_desc* const* descs, const satrans_head_desc* h, void* stream_) {
+    SATRANS_REQUIRE(satrans_stack_fwd_bf16_supported(n, descs), SATRANS_E_UNSUPPORTED,
+                    "stack_fwd_head(bf16): 1 - 4 evaluation layers of (D,U,H) = (32,64,4), one shape, flags and scenario bucketing");
+    SATRANS_REQUIRE(h && h->w && h->bias && h->prob && h->n_dense >= 0 && h->n_dense <= 2 && (h->n_dense == 0 || (h->dense && h->h_dense_cols)),
+                    SATRANS_E_BADARG, "stack_fwd_head(bf16): bad head operands");
+    Bf16Head hd = {};
+    hd.w = h->w; hd.bias = h->bias; hd.dense = h->dense; hd.dense_stride = h->dense_stride; hd.n_dense = h->n_dense;
+    for (int j = 0; j < h->n_dense; ++j) hd.dense_col[j] = h->h_dense_cols[j];
+    hd.prob = h->prob; hd.logit = h->logit;
+    return stack_fwd_bf16_any(n, descs, nullptr, hd, (hipStream_t)stream_);
 }
 
 extern "C" int satrans_layer_fwd_bf16_supported(const satrans_layer_desc* d) {

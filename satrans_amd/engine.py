@@ -539,7 +539,8 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                 "satrans_bucket_scenarios")
 
     def _run_forward(self, X, ws, training, tabs, att_list=None, rows_ready=False, save_attn=False, n_layers=None,
-                     bucket_ready=False, sorted_io=False):
+                     bucket_ready=False, sorted_io=False, eval_head=False) -> bool:
+        """-> True when the head ran too (`eval_head`: the bf16 evaluation stack with the head behind it in the same launch)."""
         lib, B, st = self.lib, X.shape[0], self._stream()
         idt = N.id_dtype_of(X)
         if not bucket_ready:
@@ -563,8 +564,13 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
             arr = (C.POINTER(N.LayerDesc) * self.L)(*[C.pointer(d_) for d_ in descs])
             if lib.satrans_stack_fwd_bf16_supported(self.L, arr):
                 with self.phase("layer_fwd"):
+                    if eval_head and self.n_dense <= 2:
+                        self._join_prob_readers()
+                        hd = self._head_desc(X, ws, None)
+                        N.check(lib.satrans_stack_fwd_bf16_head(self.L, arr, C.byref(hd), st), "satrans_stack_fwd_bf16_head")
+                        return True
                     N.check(lib.satrans_stack_fwd_bf16(self.L, arr, ws["acts"][self.L].data_ptr(), st), "satrans_stack_fwd_bf16")
-                return
+                return False
         for l in range(self.L if n_layers is None else n_layers):
             desc = self._layer_desc(ws, l, B, None, tabs, training, fuse, attn_save=save_attn, sorted_io=sorted_io)
             att = att_list[l].data_ptr() if att_list is not None else None
@@ -691,8 +697,8 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
                         for _ in range(self.L)]
         if training:
             self.drop_step += 1
-        self._run_forward(X, ws, training, tabs, att_list)
-        self._head(X, ws)
+        if not self._run_forward(X, ws, training, tabs, att_list, eval_head=True):
+            self._head(X, ws)
         if att_list is not None:
             for layer, att in zip(self.m.domain_int_layers, att_list):
                 layer.normalized_att_scores = att

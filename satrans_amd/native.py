@@ -108,6 +108,7 @@ SIGNATURES = {
     "satrans_layer_fwd_bf16": (C.c_int, [C.POINTER(LayerDesc), _vp, _vp]),
     "satrans_stack_fwd_bf16_supported": (C.c_int, [C.c_int, C.POINTER(C.POINTER(LayerDesc))]),
     "satrans_stack_fwd_bf16": (C.c_int, [C.c_int, C.POINTER(C.POINTER(LayerDesc)), _vp, _vp]),
+    "satrans_stack_fwd_bf16_head": (C.c_int, [C.c_int, C.POINTER(C.POINTER(LayerDesc)), C.POINTER(HeadDesc), _vp]),
 "satrans_layer_generic_supported": (C.c_int, [C.POINTER(LayerDesc)]),
     "satrans_layer_generic_saved_floats": (C.c_int64, [C.POINTER(LayerDesc)]),
     "satrans_layer_generic_scratch_floats": (C.c_int64, [C.POINTER(LayerDesc)]),

@@ -767,10 +767,11 @@ def test_kernel_timing_brackets_every_fused_launch_and_changes_no_bit():
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
-@pytest.mark.parametrize("S,B", [(1, 1), (3, 5), (4, 1000), (4, 8192), (16, 8192), (16, 65536), (17, 300), (4, 70000), (4096, 5000)])
+@pytest.mark.parametrize("S,B", [(1, 1), (3, 5), (4, 1000), (4, 8192), (16, 8192), (16, 65536), (17, 300), (4, 70000), (4096, 5000),
+                                 (4, 32768), (3, 16000), (8, 40000), (7, 65536)])
 def test_scenario_bucketing_is_a_stable_sort(S, B):
-    """satrans_bucket_scenarios - one counting-sort launch for S <= 16 scenario rows, the rocPRIM radix sort beyond - against a
-    stable argsort: `order` groups the sample indices by scenario in their original order, seg[s] is where scenario s starts."""
+    """satrans_bucket_scenarios - one counting-sort launch for S <= 16 scenario rows (two launches of one workgroup per 1,024 samples
+    from 16 rounds on, S <= 8: the prediction batch), the rocPRIM radix sort beyond - against a stable argsort: `order` groups the sample indices by scenario in their original order, seg[s] is where scenario s starts."""
     from satrans_amd import native as N
     lib = N.lib()
     rng = np.random.RandomState(S + B)
