@@ -548,6 +548,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         fuse = self.fuse_gather or self._x_src is not None
         ws["acts0_of"] = None if fuse else X
         ws["acts_sorted"] = bool(sorted_io)
+        ws["acts_stacked"] = False
         if not (fuse and rows_ready):
             with self.phase("gather_fwd"):
                 N.check(lib.satrans_gather_fwd(self.m.embedding_arena.data_ptr(), self.row_span.data_ptr(),
@@ -563,6 +564,7 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
             descs = [self._layer_desc(ws, l, B, None, tabs, False, fuse) for l in range(self.L)]
             arr = (C.POINTER(N.LayerDesc) * self.L)(*[C.pointer(d_) for d_ in descs])
             if lib.satrans_stack_fwd_bf16_supported(self.L, arr):
+                ws["acts_stacked"] = True       # (the layers' outputs never left LDS: layer_outputs() re-runs them one by one)
                 with self.phase("layer_fwd"):
                     if eval_head and self.n_dense <= 2:
                         self._join_prob_readers()
@@ -715,6 +717,14 @@ class PathEngine(LocalStepMixin, ReplicatedStepMixin, OwnerStepMixin):
         """[att_input, layer 0 output, ...] of the most recent forward at this batch size (tests, attention dumps).  With the
         gather fused into the first layer `att_input` was never materialised: the standalone gather kernel writes it now."""
         ws = self._ws[B]
+        if ws.get("acts_stacked"):
+            # the last forward ran the whole stack as one launch (bf16 evaluation): the same layers again, one launch each - the same
+            # bits (tests) - so that every layer's output exists
+            keep, self.bf16_stack = self.bf16_stack, False
+            try:
+                self._run_forward(self._last_X, ws, False, self.scenario_tables(grad=False))
+            finally:
+                self.bf16_stack = keep
         if ws.get("acts0_of") is None:
             if getattr(self, "_stepped_since_forward", False):
                 # the gather was fused into layer 0 and the optimizer has since moved the rows it read: a re-gather would

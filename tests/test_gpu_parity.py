@@ -962,7 +962,14 @@ def test_bf16_stack_launch_is_the_layer_launches_bit_for_bit(name):
             p = model(X).clone()
             outs[stack] = (p, eng.last_logit().clone())
         assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][0], outs[False][0]), X.shape
+    # layer_outputs() behind a stacked forward hands out every layer's output (the layers run once more, one launch each)
+    eng.bf16_stack = False
+    model(c.X.to(DEV))
+    want = eng.layer_outputs(c.X.shape[0])
     eng.bf16_stack = True
+    model(c.X.to(DEV))
+    got = eng.layer_outputs(c.X.shape[0])
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
     model.set_forward_precision("fp32")
 
 
