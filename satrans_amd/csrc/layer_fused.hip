@@ -1815,16 +1815,24 @@ __global__ __launch_bounds__(kFusedBlock, 1) void layer_bwd_fused_kernel(satrans
             back_dd(wkT, gk, back); add_back();
             back_dd(wvT, gv, back); add_back();
 #else
+            // (dx is SUMMED in the order q, k, v of every earlier round - the value term is computed first and added last: the
+            //  order of a sum is part of a build's bits, and with the value term first the default bench run ended in its other
+            //  attractor, memorising instead of collapsing onto the base rate: tools/experiments/README.md, round 6)
+            float back_v[KT][4];
             store_frag<KT>(my_q, x, valid);
             store_frag<KT>(my_o, gq);
             load_frag<KT>(my_v, gv, valid);                                    // (the value gradients: rows phase E left in LDS)
-            back_dd(wvT, gv, back); add_back();
+            back_dd(wvT, gv, back_v);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wq);
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_v, acc_wv);
             store_frag<KT>(my_o, gk);
             back_dd(wqT, gq, back); add_back();
             WGRAD<KT, KT, 0, 0, LD, LD>(wg_q, wg_o, acc_wk);
             back_dd(wkT, gk, back); add_back();
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dr[t][r] += back_v[t][r];
 #endif
             if (valid) store_frag<KT>(dx + ((size_t)b * F + f) * D + g4, dr);
         }
